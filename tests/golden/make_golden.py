@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by importing the REFERENCE
+modules (read-only checkout at /root/reference) on CPU, in the build container.
+
+The reference never travels to the GPU box: only the .npz files written here do.
+Large tensors (the 31 M-parameter U-Net weights, the 272 M-parameter generator
+weights) are NOT stored; they are regenerated from a seed by
+``oracle.unet_state_dict`` / ``golden_util.seeded_*`` (our own code) and loaded
+into the reference modules with ``load_state_dict(strict=True)`` -- which also
+checks that our key names and shapes are exactly the reference's.  A checksum
+of every generated tensor is stored so a drift of the PRNG stream is detected.
+
+Usage:  python tests/golden/make_golden.py [--only unet|ops|pix2pix]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+REF = os.environ.get("GENSEG_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+
+from golden_util import (grad_summary, seeded_discriminator_state_dict,  # noqa: E402
+                         seeded_generator_state_dict, tensor_checksum)
+from oracle import oracle  # noqa: E402
+
+torch.set_num_threads(8)
+torch.manual_seed(0)
+
+
+def ref_seg_loss(logits, mask, dice_loss):
+    """train_end2end_jsrt.py:181-183 (classes=1) and the canonical multiclass form."""
+    import torch.nn.functional as F
+    n_classes = logits.shape[1]
+    if n_classes == 1:
+        t = mask.float()
+        bce = torch.nn.BCEWithLogitsLoss()(logits, t)
+        dl = dice_loss(torch.sigmoid(logits.squeeze(1)), t.squeeze(1))
+        return bce, dl
+    m = mask[:, 0].long()
+    ce = torch.nn.CrossEntropyLoss()(logits, m)
+    dl = dice_loss(F.softmax(logits, dim=1).float(),
+                   F.one_hot(m, n_classes).permute(0, 3, 1, 2).float(), multiclass=True)
+    return ce, dl
+
+
+def make_unet(name, n_classes, batch, h, w, seed, mask_mode="ellipse"):
+    from unet import UNet
+    from unet.evaluate import evaluate  # noqa: F401  (import check only)
+    from util.dice_score import dice_loss, dice_coeff, multiclass_dice_coeff
+    import torch.nn.functional as F
+
+    sd = oracle.unet_state_dict(1, n_classes, seed=seed)
+    net = UNet(1, n_classes)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    size = max(h, w)
+    x, mask = oracle.synthetic_batch(batch, size, seed=1234 + seed)
+    x, mask = x[:, :, :h, :w].contiguous(), mask[:, :, :h, :w].contiguous()
+    if mask_mode == "zeros":
+        mask.zero_()
+    elif mask_mode == "ones":
+        mask.fill_(1)
+    logits = net(x)
+    l1, l2 = ref_seg_loss(logits, mask, dice_loss)
+    loss = l1 + l2
+    loss.backward()
+    out = {
+        "n_classes": n_classes, "seed": seed, "x": x.numpy(), "mask": mask.numpy().astype(np.uint8),
+        "logits": logits.detach().numpy(), "loss_ce": l1.item(), "loss_dice": l2.item(), "loss": loss.item(),
+    }
+    for k, p in net.named_parameters():
+        out["gsum/" + k] = grad_summary(p.grad)
+    for k, b in net.named_buffers():
+        if "num_batches" not in k:
+            out["buf/" + k] = b.detach().numpy().copy()
+    for k, v in sd.items():
+        if v.is_floating_point():
+            out["wsum/" + k] = tensor_checksum(v)
+    # eval-mode pass with the *updated* running statistics + the evaluate.py Dice
+    net.eval()
+    with torch.no_grad():
+        lg = net(x)
+        out["logits_eval"] = lg.numpy()
+        if n_classes == 1:
+            pred = (torch.sigmoid(lg) > 0.5).float()
+            out["eval_dice"] = dice_coeff(pred.squeeze(), mask.float().squeeze(), reduce_batch_first=False).item()
+        else:
+            t = F.one_hot(mask[:, 0].long(), n_classes).permute(0, 3, 1, 2).float()
+            p = F.one_hot(lg.argmax(dim=1), n_classes).permute(0, 3, 1, 2).float()
+            out["eval_dice"] = multiclass_dice_coeff(p[:, 1:], t[:, 1:], reduce_batch_first=False).item()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "loss", loss.item(), "logits", tuple(logits.shape))
+
+
+def make_dice_cases():
+    from util.dice_score import dice_coeff, dice_loss, multiclass_dice_coeff
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    p = torch.rand(3, 17, 13, generator=g)
+    t = (torch.rand(3, 17, 13, generator=g) > 0.6).float()
+    out["p"], out["t"] = p.numpy(), t.numpy()
+    out["coeff_rbf_false"] = dice_coeff(p, t, False).item()
+    out["coeff_rbf_true"] = dice_coeff(p, t, True).item()
+    out["loss"] = dice_loss(p, t).item()
+    z = torch.zeros_like(p)
+    out["all_zero_loss"] = dice_loss(z, z).item()                 # dice == 1 -> loss 0
+    out["zero_target_loss"] = dice_loss(p, z).item()
+    out["coeff_2d"] = dice_coeff(p[0], t[0]).item()
+    pm = torch.softmax(torch.randn(2, 3, 9, 11, generator=g), 1)
+    tm = torch.nn.functional.one_hot(torch.randint(0, 3, (2, 9, 11), generator=g), 3).permute(0, 3, 1, 2).float()
+    out["pm"], out["tm"] = pm.numpy(), tm.numpy()
+    out["mc_rbf_false"] = multiclass_dice_coeff(pm, tm, False).item()
+    out["mc_loss"] = dice_loss(pm, tm, multiclass=True).item()
+    # gradient of the loss w.r.t. the probabilities
+    pg = p.clone().requires_grad_(True)
+    dice_loss(pg, t).backward()
+    out["loss_grad_p"] = pg.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "dice_cases.npz"), **out)
+    print("dice_cases done")
+
+
+def make_ops_micro():
+    """Per-op micro fixtures at tiny shapes from the reference's own modules."""
+    from unet.unet_parts import DoubleConv, Down, Up, OutConv
+    from models_pix2pix import networks
+    g = torch.Generator().manual_seed(11)
+    out = {}
+
+    def rnd(*s):
+        return torch.randn(*s, generator=g)
+
+    # DoubleConv / Down / Up (odd sizes -> non-zero F.pad) / OutConv
+    dc = DoubleConv(3, 8)
+    x = rnd(2, 3, 9, 7)
+    dc.train()
+    y = dc(x)
+    for k, v in dc.state_dict().items():
+        out["dc/" + k] = v.numpy().copy()
+    out["dc/x"], out["dc/y"] = x.numpy(), y.detach().numpy()
+    dn = Down(4, 8)
+    x = rnd(2, 4, 11, 9)
+    for k, v in dn.state_dict().items():       # snapshot BEFORE the forward mutates BN buffers
+        out["down/sd/" + k] = v.numpy().copy()
+    out["down/x"], out["down/y"] = x.numpy(), dn(x).detach().numpy()
+    upm = Up(8, 4, bilinear=False)
+    x1, x2 = rnd(2, 8, 4, 3), rnd(2, 4, 9, 7)
+    for k, v in upm.state_dict().items():
+        out["up/sd/" + k] = v.numpy().copy()
+    out["up/x1"], out["up/x2"], out["up/y"] = x1.numpy(), x2.numpy(), upm(x1, x2).detach().numpy()
+    oc = OutConv(8, 2)
+    x = rnd(2, 8, 5, 6)
+    for k, v in oc.state_dict().items():
+        out["outc/sd/" + k] = v.numpy().copy()
+    out["outc/x"], out["outc/y"] = x.numpy(), oc(x).detach().numpy()
+
+    # mixed transposed conv cell (networks.py:486-511) and its exact k=8 merge
+    cell = networks.Cell_upconv(6, 5, bias=True, layer_index=2)
+    arch = 0.3 * rnd(8, 3)
+    networks.upconv_arch.data.copy_(arch)
+    x = rnd(2, 6, 5, 4)
+    for k, v in cell.state_dict().items():
+        out["cell/sd/" + k] = v.numpy().copy()
+    out["cell/arch"], out["cell/x"], out["cell/y"] = arch.numpy(), x.numpy(), cell(x).detach().numpy()
+
+    # GANLoss modes
+    pred = rnd(2, 1, 6, 6)
+    out["gan/pred"] = pred.numpy()
+    for mode in ("vanilla", "lsgan", "wgangp"):
+        crit = networks.GANLoss(mode)
+        out[f"gan/{mode}/real"] = crit(pred, True).item()
+        out[f"gan/{mode}/fake"] = crit(pred, False).item()
+    a, b = rnd(2, 1, 8, 8), rnd(2, 1, 8, 8)
+    out["l1/a"], out["l1/b"], out["l1/y"] = a.numpy(), b.numpy(), torch.nn.L1Loss()(a, b).item()
+    x, t = rnd(2, 1, 8, 8), (rnd(2, 1, 8, 8) > 0).float()
+    out["bce/x"], out["bce/t"] = x.numpy(), t.numpy()
+    out["bce/y"] = torch.nn.BCEWithLogitsLoss()(x, t).item()
+    np.savez_compressed(os.path.join(HERE, "ops_micro.npz"), **out)
+    print("ops_micro done")
+
+
+def make_pix2pix(size=256, batch=2):
+    from models_pix2pix import networks
+    norm = networks.get_norm_layer("batch")
+    G = networks.UnetGenerator(1, 1, 8, 64, norm_layer=norm, use_dropout=True)
+    D = networks.NLayerDiscriminator(2, 64, 3, norm)
+    sdG = seeded_generator_state_dict(seed=21)
+    sdD = seeded_discriminator_state_dict(seed=22)
+    G.load_state_dict(sdG, strict=True)
+    D.load_state_dict(sdD, strict=True)
+    g = torch.Generator().manual_seed(23)
+    arch = 0.5 * torch.randn(8, 3, generator=g)
+    networks.upconv_arch.data.copy_(arch)
+    _, mask = oracle.synthetic_batch(batch, size, seed=77)
+    real_mask = mask.float()
+    real_image = torch.rand(batch, 1, size, size, generator=g)
+    for m in G.modules():                     # dropout p forced to 0
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    out = {"arch": arch.numpy(), "mask": mask.numpy().astype(np.uint8), "real_image": real_image.numpy()}
+    # train-mode generator + discriminator, the two GAN step losses and grads
+    G.train(); D.train()
+    fake = G(real_mask)
+    out["fake_train"] = fake.detach().numpy()
+    crit = networks.GANLoss("vanilla")
+    pred_fake = D(torch.cat((real_mask, fake), 1))
+    out["pred_fake_train"] = pred_fake.detach().numpy()
+    loss_G = crit(pred_fake, True) + torch.nn.L1Loss()(fake, real_image) * 100.0
+    G.zero_grad(); D.zero_grad()
+    if networks.upconv_arch.grad is not None:
+        networks.upconv_arch.grad = None
+    loss_G.backward()
+    out["loss_G"] = loss_G.item()
+    for k, p in G.named_parameters():
+        out["gsumG/" + k] = grad_summary(p.grad)
+    out["arch_grad_G"] = networks.upconv_arch.grad.numpy().copy()
+    for k, b in G.named_buffers():
+        if "num_batches" not in k:
+            out["bufG/" + k] = b.detach().numpy().copy()
+    # D step (fresh modules so BN buffers start from the seeded state)
+    D2 = networks.NLayerDiscriminator(2, 64, 3, norm)
+    D2.load_state_dict(sdD, strict=True)
+    D2.train()
+    pf = D2(torch.cat((real_mask, fake), 1).detach())
+    pr = D2(torch.cat((real_mask, real_image), 1))
+    loss_D = (crit(pf, False) + crit(pr, True)) * 0.5
+    loss_D.backward()
+    out["loss_D"] = loss_D.item()
+    out["pred_real_train"] = pr.detach().numpy()
+    for k, p in D2.named_parameters():
+        out["gsumD/" + k] = grad_summary(p.grad)
+    # eval-mode outputs from the seeded (un-stepped) state
+    G3 = networks.UnetGenerator(1, 1, 8, 64, norm_layer=norm, use_dropout=True)
+    G3.load_state_dict(sdG, strict=True)
+    G3.eval()
+    D3 = networks.NLayerDiscriminator(2, 64, 3, norm)
+    D3.load_state_dict(sdD, strict=True)
+    D3.eval()
+    with torch.no_grad():
+        fe = G3(real_mask)
+        out["fake_eval"] = fe.numpy()
+        out["pred_eval"] = D3(torch.cat((real_mask, fe), 1)).numpy()
+    for k, v in sdD.items():
+        if v.is_floating_point():
+            out["wsumD/" + k] = tensor_checksum(v)
+    for k, v in sdG.items():
+        if v.is_floating_point():
+            out["wsumG/" + k] = tensor_checksum(v)
+    np.savez_compressed(os.path.join(HERE, f"pix2pix_{size}.npz"), **out)
+    print("pix2pix", size, "loss_G", loss_G.item(), "loss_D", loss_D.item())
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    if a.only in ("", "unet"):
+        make_unet("unet_c1_64", 1, 2, 64, 64, seed=1)
+        make_unet("unet_c2_64", 2, 2, 64, 64, seed=2)
+        make_unet("unet_c2_128_b4", 2, 4, 128, 128, seed=3)          # BASELINE config 1
+        make_unet("unet_c1_odd", 1, 2, 70, 52, seed=4)               # non-zero F.pad through Up
+        make_unet("unet_c1_zeros", 1, 2, 32, 32, seed=5, mask_mode="zeros")
+        make_unet("unet_c1_ones", 1, 2, 32, 32, seed=6, mask_mode="ones")
+    if a.only in ("", "ops"):
+        make_dice_cases()
+        make_ops_micro()
+    if a.only in ("", "pix2pix"):
+        make_pix2pix(256, 2)

@@ -1,0 +1,148 @@
+"""Pins the CPU oracle (oracle/oracle.py) against the golden vectors generated
+from the imported reference (tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import (grad_summary, seeded_discriminator_state_dict,
+                         seeded_generator_state_dict, tensor_checksum)
+from oracle import oracle
+
+torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+@pytest.mark.parametrize("name", ["unet_c1_64", "unet_c2_64", "unet_c1_odd", "unet_c1_zeros", "unet_c1_ones",
+                                  "unet_c2_128_b4"])
+def test_unet_step_matches_reference(golden_dir, name):
+    z = load(golden_dir, name)
+    n_classes, seed = int(z["n_classes"]), int(z["seed"])
+    sd = oracle.unet_state_dict(1, n_classes, seed=seed)
+    for k, v in sd.items():                      # PRNG stream drift guard
+        if v.is_floating_point():
+            np.testing.assert_allclose(tensor_checksum(v), z["wsum/" + k], rtol=1e-12, atol=0)
+    x = torch.from_numpy(z["x"])
+    mask = torch.from_numpy(z["mask"].astype(np.int64))
+    logits, loss, grads, updates = oracle.unet_step(sd, x, mask, train=True)
+    assert np.abs(logits.numpy() - z["logits"]).max() < 2e-5
+    assert abs(loss.item() - float(z["loss"])) < 2e-6
+    for k, g in grads.items():
+        ref = z["gsum/" + k]
+        got = grad_summary(g)
+        scale = max(ref[1], 1e-12)               # L2 norm of the reference gradient
+        assert abs(got[1] - ref[1]) / scale < 2e-3, k
+        # sampled elements: a single ReLU/max-pool near-tie flipping (1e-7 relative differences in
+        # the BN reduction order) moves one pixel's contribution, ~1/(N*H*W) of a deep layer's grad
+        assert np.abs(got[2:] - ref[2:]).max() / scale < 2e-2, k
+    for k, v in updates.items():
+        if "num_batches" in k:
+            assert int(v) == 1
+        else:
+            np.testing.assert_allclose(v.numpy(), z["buf/" + k], rtol=2e-4, atol=2e-6)
+    # eval mode with the updated running statistics, and the evaluate.py Dice
+    sd2 = dict(sd)
+    sd2.update(updates)
+    lg = oracle.unet_forward(sd2, x, train=False)
+    assert np.abs(lg.numpy() - z["logits_eval"]).max() < 5e-4 * max(1.0, np.abs(z["logits_eval"]).max())
+    assert abs(oracle.evaluate_dice(lg, mask).item() - float(z["eval_dice"])) < 1e-6
+
+
+def test_dice_cases(golden_dir):
+    z = load(golden_dir, "dice_cases")
+    p, t = torch.from_numpy(z["p"]), torch.from_numpy(z["t"])
+    assert abs(oracle.dice_coeff(p, t, False).item() - float(z["coeff_rbf_false"])) < 1e-7
+    assert abs(oracle.dice_coeff(p, t, True).item() - float(z["coeff_rbf_true"])) < 1e-7
+    assert abs(oracle.dice_loss(p, t).item() - float(z["loss"])) < 1e-7
+    zz = torch.zeros_like(p)
+    assert oracle.dice_loss(zz, zz).item() == float(z["all_zero_loss"]) == 0.0
+    assert abs(oracle.dice_loss(p, zz).item() - float(z["zero_target_loss"])) < 1e-7
+    assert abs(oracle.dice_coeff(p[0], t[0]).item() - float(z["coeff_2d"])) < 1e-7
+    pm, tm = torch.from_numpy(z["pm"]), torch.from_numpy(z["tm"])
+    assert abs(oracle.multiclass_dice_coeff(pm, tm, False).item() - float(z["mc_rbf_false"])) < 1e-7
+    assert abs(oracle.dice_loss(pm, tm, multiclass=True).item() - float(z["mc_loss"])) < 1e-7
+    pg = p.clone().requires_grad_(True)
+    oracle.dice_loss(pg, t).backward()
+    np.testing.assert_allclose(pg.grad.numpy(), z["loss_grad_p"], rtol=1e-5, atol=1e-9)
+
+
+def _sub(z, prefix):
+    return {k[len(prefix):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(prefix)}
+
+
+def test_ops_micro(golden_dir):
+    z = load(golden_dir, "ops_micro")
+    sd = {"m." + k: v for k, v in _sub(z, "dc/").items() if k not in ("x", "y")}
+    y = oracle.double_conv(torch.from_numpy(z["dc/x"]), sd, "m", train=True)
+    # the snapshot was taken after forward (buffers mutated) but train mode ignores buffers
+    assert np.abs(y.numpy() - z["dc/y"]).max() < 1e-5
+    sd = {"d." + k: v for k, v in _sub(z, "down/sd/").items()}
+    y = oracle.down(torch.from_numpy(z["down/x"]), sd, "d", train=True)
+    assert np.abs(y.numpy() - z["down/y"]).max() < 1e-5
+    sd = {"u." + k: v for k, v in _sub(z, "up/sd/").items()}
+    y = oracle.up(torch.from_numpy(z["up/x1"]), torch.from_numpy(z["up/x2"]), sd, "u", train=True)
+    assert np.abs(y.numpy() - z["up/y"]).max() < 1e-5
+    sd = _sub(z, "outc/sd/")
+    y = torch.nn.functional.conv2d(torch.from_numpy(z["outc/x"]), sd["conv.weight"], sd["conv.bias"])
+    assert np.abs(y.numpy() - z["outc/y"]).max() < 1e-6
+    # mixed up-conv cell and its exact k=8 merge
+    sd = {"c." + k: v for k, v in _sub(z, "cell/sd/").items()}
+    arch, x = torch.from_numpy(z["cell/arch"]), torch.from_numpy(z["cell/x"])
+    y = oracle.mixed_upconv(x, sd, "c", arch[2])
+    assert np.abs(y.numpy() - z["cell/y"]).max() < 1e-5
+    Wm, b = oracle.merged_upconv_weight(sd, "c", arch[2])
+    ym = torch.nn.functional.conv_transpose2d(x, Wm, b, stride=2, padding=3)
+    assert np.abs(ym.numpy() - z["cell/y"]).max() < 1e-5
+    pred = torch.from_numpy(z["gan/pred"])
+    for mode in ("vanilla", "lsgan", "wgangp"):
+        assert abs(oracle.gan_loss(pred, True, mode).item() - float(z[f"gan/{mode}/real"])) < 1e-6
+        assert abs(oracle.gan_loss(pred, False, mode).item() - float(z[f"gan/{mode}/fake"])) < 1e-6
+    assert abs(oracle.l1_loss(torch.from_numpy(z["l1/a"]), torch.from_numpy(z["l1/b"])).item() - float(z["l1/y"])) < 1e-7
+    assert abs(oracle.bce_with_logits(torch.from_numpy(z["bce/x"]), torch.from_numpy(z["bce/t"])).item()
+               - float(z["bce/y"])) < 1e-7
+
+
+def test_pix2pix_matches_reference(golden_dir):
+    z = load(golden_dir, "pix2pix_256")
+    sdG = seeded_generator_state_dict(seed=21)
+    sdD = seeded_discriminator_state_dict(seed=22)
+    for k, v in sdD.items():
+        if v.is_floating_point():
+            np.testing.assert_allclose(tensor_checksum(v), z["wsumD/" + k], rtol=1e-12)
+    arch = torch.from_numpy(z["arch"])
+    mask = torch.from_numpy(z["mask"].astype(np.float32))
+    real_image = torch.from_numpy(z["real_image"])
+    with torch.no_grad():
+        fe = oracle.unet_generator_forward(sdG, arch, mask, train=False)
+        assert np.abs(fe.numpy() - z["fake_eval"]).max() < 1e-5
+        fm = oracle.unet_generator_forward(sdG, arch, mask, train=False, merged=True)
+        assert np.abs(fm.numpy() - z["fake_eval"]).max() < 1e-5
+        pe = oracle.nlayer_discriminator_forward(sdD, torch.cat((mask, fe), 1), train=False)
+        assert np.abs(pe.numpy() - z["pred_eval"]).max() < 1e-5
+    # train mode (dropout disabled), GAN step losses
+    pG = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sdG.items()}
+    pD = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sdD.items()}
+    a = arch.clone().requires_grad_(True)
+    fake = oracle.unet_generator_forward(pG, a, mask, train=True)
+    assert np.abs(fake.detach().numpy() - z["fake_train"]).max() < 2e-5
+    pred_fake = oracle.nlayer_discriminator_forward(pD, torch.cat((mask, fake), 1), train=True)
+    assert np.abs(pred_fake.detach().numpy() - z["pred_fake_train"]).max() < 1e-4
+    loss_G = oracle.gan_loss(pred_fake, True) + oracle.l1_loss(fake, real_image) * 100.0
+    assert abs(loss_G.item() - float(z["loss_G"])) < 1e-4
+    leaves = {k: v for k, v in pG.items() if v.requires_grad}
+    grads = torch.autograd.grad(loss_G, list(leaves.values()) + [a])
+    # BatchNorm over 2 samples x 1x1 (innermost block at bs=2) is ill-conditioned: compare against the
+    # gradient's scale, not element-wise relative
+    ag = z["arch_grad_G"]
+    assert np.abs(grads[-1].numpy() - ag).max() < 1e-2 * np.abs(ag).max()
+    for (k, _), g in zip(leaves.items(), grads[:-1]):
+        ref = z["gsumG/" + k]
+        got = grad_summary(g)
+        scale = max(ref[1], 1e-12)
+        assert abs(got[1] - ref[1]) / scale < 1e-2, k
+    loss_D = oracle.discriminator_step_loss(sdG, sdD, arch, mask, real_image)
+    assert abs(loss_D.item() - float(z["loss_D"])) < 1e-5
