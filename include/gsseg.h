@@ -1,0 +1,182 @@
+/*
+ * gsseg.h -- C ABI of libgsseg_hip.so: the MI355X (gfx950) kernels under the
+ * GenSeg segmentation hot path (U-Net / Pix2Pix / Dice+BCE forward + backward).
+ *
+ * The reference (importZL/semantic_segmentation) has no FFI of its own: its
+ * boundary for this path is the Python object model.  Each entry
+ * point below therefore cites the reference *operator call site* whose ATen
+ * kernel(s) it replaces.  The Python package `semantic_segmentation_amd` binds
+ * these with ctypes (semantic_segmentation_amd/_lib.py) and re-creates the
+ * reference's module/function API on top.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch's caching
+ *     allocator); kernels never allocate.  Workspaces are caller supplied.
+ *   - activations / gradients: NHWC, 16-bit (GS_F16 or GS_BF16), with an explicit
+ *     pixel stride (elements) and channel offset so a tensor can be a channel
+ *     slice of a wider concat buffer.  Statistics, losses, weight gradients: fp32.
+ *   - all launches go to `stream` (hipStream_t passed as void*), never synchronise.
+ *   - return 0 on success, negative GsStatus otherwise; gs_last_error() gives text.
+ */
+#ifndef GSSEG_H
+#define GSSEG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_ABI_VERSION 1
+
+enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
+enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
+enum GsAct { GS_ACT_NONE = 0, GS_ACT_RELU = 1, GS_ACT_LEAKY02 = 2, GS_ACT_TANH = 3 };
+
+#define GS_MAX_TAPS 64
+
+/* Geometry of one implicit-GEMM launch.  Logical output grid (N, OHg, OWg); logical pixel
+ * (n, oy, ox) reads input pixel (oy*isy + tap_dy[t], ox*isx + tap_dx[t]) for tap t (zero when
+ * outside [0,IH)x[0,IW)) and writes physical output pixel (oy*osy + ooy, ox*osx + oox) of an
+ * [N, OH, OW] tensor.  This one form covers Conv2d (any k/stride/pad), its data gradient, and
+ * ConvTranspose2d split into stride*stride sub-pixel classes. */
+typedef struct GsConvGeom {
+    int32_t N, IH, IW, Cin, in_pix_stride, in_coff;
+    int32_t OHg, OWg, Cout;
+    int32_t OH, OW, out_pix_stride, out_coff;
+    int32_t isy, isx, osy, osx, ooy, oox;
+    int32_t ntaps;
+    int32_t tap_dy[GS_MAX_TAPS], tap_dx[GS_MAX_TAPS];
+} GsConvGeom;
+
+const char* gs_last_error(void);
+int gs_abi_version(void);
+
+/* ---- MFMA implicit GEMM: nn.Conv2d / ConvTranspose2d forward and data-gradient -------------
+ * replaces F.conv2d / F.conv_transpose2d at unet/unet_parts.py:16,19,53 and
+ * models_pix2pix/networks.py:582,590-602,640-661 (and their autograd dgrad).
+ * x: [N,IH,IW,*] dtype; w: [ntaps][Cout][Cin] dtype (K-major); y: [N,OH,OW,*] dtype.
+ * bias (fp32 [Cout]) may be NULL.  bn_partials (fp32 [gs_conv_igemm_mtiles][2][Cout]) may be NULL;
+ * when given, per-M-tile sums of y and y*y (fp32 accumulators, before rounding, before bias) are
+ * written there for train-mode BatchNorm (unet_parts.py:17,20).  Requires Cin % 8 == 0. */
+int gs_conv_igemm_mtiles(const GsConvGeom* g);
+int gs_conv_igemm(const GsConvGeom* g, const void* x, const void* w, void* y, const float* bias,
+                  float* bn_partials, int act, int dtype, void* stream);
+
+/* ---- MFMA weight gradient -------------------------------------------------------------------
+ * dw[t][co][ci] (fp32, ACCUMULATED with atomics: caller zeroes) += sum over logical pixels of
+ * dy[pix][co] * x[inpix(pix,t)][ci].  `g` describes the forward conv: dy lives on the OUTPUT side
+ * (N,OH,OW,out_pix_stride,out_coff), x on the INPUT side.  Replaces the autograd weight gradient of
+ * the same call sites.  Requires Cin % 8 == 0 and Cout % 8 == 0. */
+int gs_conv_wgrad(const GsConvGeom* g, const void* x, const void* dy, float* dw, int dtype, void* stream);
+
+/* ---- direct (VALU) convolutions for 1..4-channel ends of the nets ----------------------------
+ * gs_conv_smallcin_fwd: x fp32 NCHW [N,Cin,IH,IW] (the image / mask as the loader hands it,
+ *   unet_model.py:27, networks.py:582 outermost, :640) -> y NHWC dtype [N,OH,OW,Cout] (+bias,
+ *   +act, +bn_partials as above; bn tile = 256 output pixels).  w fp32 [Cout][Cin][k][k] (reference layout).
+ * gs_conv_smallcin_wgrad: dw fp32 [Cout][Cin][k][k] += sum dy*x (atomics; caller zeroes). `gscale` multiplies.
+ * gs_conv_smallcin_dgrad: dx fp32 NCHW [N,Cin,IH,IW] = conv_transpose(dy, w)*gscale (overwrites). */
+int gs_conv_smallcin_mtiles(int N, int OH, int OW);
+int gs_conv_smallcin_fwd(const float* x, const float* w, const float* bias, void* y, float* bn_partials,
+                         int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int k, int stride, int pad,
+                         int act, int dtype, void* stream);
+int gs_conv_smallcin_wgrad(const float* x, const void* dy, float* dw, int N, int Cin, int IH, int IW, int Cout,
+                           int OH, int OW, int k, int stride, int pad, float gscale, int dtype, void* stream);
+int gs_conv_smallcin_dgrad(const void* dy, const float* w, float* dx, int N, int Cin, int IH, int IW, int Cout,
+                           int OH, int OW, int k, int stride, int pad, float gscale, int dtype, void* stream);
+
+/* ---- small-Cout head: 1x1 (OutConv, unet_parts.py:71-77) or kxk (PatchGAN last conv, networks.py:661)
+ * x NHWC dtype [N,IH,IW,Cin] -> logits fp32 NCHW [N,Cout,OH,OW], Cout <= 4.  w fp32 [Cout][Cin][k][k].
+ * bwd: dlogits fp32 NCHW (already multiplied by the loss scale) -> dx NHWC dtype; dw/db fp32 accumulate*gscale. */
+int gs_conv_smallcout_fwd(const void* x, const float* w, const float* bias, float* y, int N, int IH, int IW, int Cin,
+                          int Cout, int OH, int OW, int k, int stride, int pad, int dtype, void* stream);
+int gs_conv_smallcout_bwd(const void* x, const float* w, const float* dy, void* dx, float* dw, float* db,
+                          int N, int IH, int IW, int Cin, int Cout, int OH, int OW, int k, int stride, int pad,
+                          float gscale, int dtype, void* stream);
+
+/* ---- train-mode BatchNorm2d split around the convolution (unet_parts.py:17,20; networks.py:584,586)
+ * finalize: reduce [ntiles][2][C] partials -> scale = gamma*rsqrt(var+eps), shift = beta - mean*scale,
+ *   save mean / invstd, update running_mean / running_var (momentum, unbiased var) in place when non-NULL.
+ * eval mode: gs_bn_eval_coeffs builds scale/shift from the running statistics. */
+/* floats a partials buffer must hold for `ntiles` tiles of C channels (includes the reduction scratch) */
+int64_t gs_bn_partials_floats(int ntiles, int C);
+int gs_bn_finalize(const float* partials, int ntiles, int C, double count, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float momentum, float eps,
+                   float* scale, float* shift, float* mean, float* invstd, void* stream);
+int gs_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, float* scale, float* shift, float* mean, float* invstd,
+                      void* stream);
+
+/* apply: z = act(y*scale + shift) (scale/shift NULL -> identity), y dense NHWC [N,H,W,C];
+ * z written with (z_pix_stride, z_coff) -- e.g. straight into the skip half of the concat buffer
+ * (unet_parts.py:67) ; optional 2x2/stride-2 max-pool of z (unet_parts.py:34) to zp [N,H/2,W/2,C] dense;
+ * optional dropout keep-mask (uint8 [N,H,W,C], value scaled by 1/(1-p)) for networks.py:606-607. */
+int gs_bn_act_apply(const void* y, const float* scale, const float* shift, int act, void* z, int z_pix_stride,
+                    int z_coff, void* zp, const uint8_t* keep_mask, float keep_scale, int N, int H, int W, int C,
+                    int dtype, void* stream);
+
+/* backward of  z = act(bn(y)) [-> maxpool]:  dz = dz_a[pix*sa + coff_a + c] (may be NULL) + the
+ * max-pool gradient routed from dzp [N,H/2,W/2,C] (may be NULL; first-max tie rule as ATen).
+ * reduce: partial sums of dzh and dzh*xhat -> [gs_bn_bwd_tiles][2][C];
+ * coeffs: from partials -> dgamma, dbeta (fp32, OVERWRITE, multiplied by gscale) and c1,c2 = sums/count;
+ * apply:  dy = scale*(dzh - c1 - xhat*c2)   (bn==0: dy = dzh, act gradient only). */
+int gs_bn_bwd_tiles(int N, int H, int W);                       /* upper bound, sizes the partials buffer */
+int gs_bn_bwd_tiles_used(int N, int H, int W, int pooled);      /* tiles actually written -> gs_bn_bwd_coeffs */
+int gs_bn_act_bwd_reduce(const void* y, const void* dz_a, int sa, int coff_a, const void* dzp,
+                         const float* scale, const float* shift, const float* mean, const float* invstd, int act,
+                         float* partials, int N, int H, int W, int C, int dtype, void* stream);
+int gs_bn_bwd_coeffs(const float* partials, int ntiles, int C, double count, float gscale, float* dgamma,
+                     float* dbeta, float* c1, float* c2, void* stream);
+int gs_bn_act_bwd_apply(const void* y, const void* dz_a, int sa, int coff_a, const void* dzp,
+                        const float* scale, const float* shift, const float* mean, const float* invstd,
+                        const float* c1, const float* c2, int act, int bn, void* dy, int N, int H, int W, int C,
+                        int dtype, void* stream);
+
+/* per-channel column sums over the sub-rectangle [y0,y0+h) x [x0,x0+w) of a (strided) NHWC tensor
+ * [N,H,W,*]: out[c] (OVERWRITE) = gscale * sum t[pix*s + coff + c]  (bias gradient of ConvTranspose2d,
+ * unet_parts.py:53, excluding the F.pad border of unet_parts.py:59-61).  ws: fp32 [1024*C] workspace. */
+int gs_colsum(const void* t, int pix_stride, int coff, int N, int H, int W, int y0, int x0, int h, int w, int C,
+              float gscale, float* ws, float* out, int dtype, void* stream);
+
+/* ---- weight packing ------------------------------------------------------------------------
+ * Conv2d weight fp32 [Cout][Cin][kh][kw] -> fwd pack [kh*kw][Cout][Cin] and dgrad pack
+ * [kh*kw][Cin][Cout] (tap order unchanged; the host flips taps through the geometry).
+ * transposed=1: ConvTranspose2d weight fp32 [Cin][Cout][kh][kw], same outputs. Either output may be NULL.
+ * unpack: dw fp32 [taps][A][B] -> grad fp32 [A][B][kh][kw] (transposed=0) or [B][A][kh][kw] (1), times gscale,
+ * OVERWRITING grad. */
+int gs_pack_weight(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int taps, int transposed,
+                   int dtype, void* stream);
+int gs_unpack_wgrad(const float* dw, float* grad, int A, int B, int taps, int transposed, float gscale, void* stream);
+
+/* layout helpers: fp32 NCHW <-> 16-bit NHWC */
+int gs_nchw_to_nhwc(const float* src, void* dst, int N, int C, int H, int W, int dst_pix_stride, int dst_coff,
+                    int dtype, void* stream);
+int gs_nhwc_to_nchw(const void* src, int src_pix_stride, int src_coff, float* dst, int N, int C, int H, int W,
+                    float gscale, int dtype, void* stream);
+
+/* ---- losses (train_end2end_jsrt.py:136-138,181-183; util/dice_score.py:5-28; networks.py:263-281)
+ * seg loss forward: logits fp32 NCHW [N,C,H,W], mask uint8 [N,H,W] (class index; {0,1} for C==1).
+ *   C==1: BCEWithLogits(mean) + 1 - dice(sigmoid(x), t) with ONE global sum over the batch;
+ *   C>1 : CrossEntropy(mean) + 1 - dice(softmax(x), onehot(t)) (global sum over N*C*H*W).
+ *   out[0]=loss out[1]=ce/bce out[2]=dice_loss out[3..5]=inter(2*sum p t), sum p, sum t.  ws: fp32 [4*1024].
+ * backward: dlogits fp32 NCHW = dloss/dlogits * gscale * gout[0]  (gout: device scalar, upstream grad). */
+int gs_seg_loss_fwd(const float* logits, const uint8_t* mask, int N, int C, int H, int W, float* ws, float* out,
+                    void* stream);
+int gs_seg_loss_bwd(const float* logits, const uint8_t* mask, const float* out, const float* gout, float gscale,
+                    float* dlogits, int N, int C, int H, int W, void* stream);
+/* generic dice_loss(input, target) on fp32 tensors of n elements, one global sum (dice_score.py:25-28 with
+ * reduce_batch_first=True): out[0]=loss, out[1..3]=inter,sum_p,sum_t.  bwd: dinput = dloss/dinput * gout[0]. */
+int gs_dice_loss_fwd(const float* p, const float* t, int64_t n, float* ws, float* out, void* stream);
+int gs_dice_loss_bwd(const float* t, const float* out, const float* gout, float* dp, int64_t n, void* stream);
+/* mean-reduced elementwise losses: mode 0 = BCEWithLogits vs constant label `cval` (GANLoss vanilla),
+ * 1 = MSE vs constant (lsgan), 2 = mean(x)*cval (wgangp, cval=+-1), 3 = L1 |x - t| (t tensor),
+ * 4 = BCEWithLogits vs tensor t.   out[0] = loss.  bwd: dx = dloss/dx * gout[0] * gscale. */
+int gs_mean_loss_fwd(const float* x, const float* t, float cval, int mode, int64_t n, float* ws, float* out,
+                     void* stream);
+int gs_mean_loss_bwd(const float* x, const float* t, float cval, int mode, int64_t n, const float* gout,
+                     float gscale, float* dx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSSEG_H */

@@ -1,0 +1,560 @@
+// Train-mode BatchNorm split around the MFMA convolutions, fused with the activation, the 2x2 max-pool
+// and the skip-concat write (all HBM-bound: 16-byte vector accesses, one pass per tensor).
+//   forward : conv epilogue -> per-tile partial sums -> gs_bn_finalize -> gs_bn_act_apply
+//   backward: gs_bn_act_bwd_reduce -> gs_bn_bwd_coeffs -> gs_bn_act_bwd_apply
+// Reference semantics: torch.nn.BatchNorm2d(train) + ReLU/LeakyReLU + MaxPool2d(2) + torch.cat
+// (unet/unet_parts.py:17-21,34,67 ; models_pix2pix/networks.py:583-586,606-607,642-657).
+#include "common.hpp"
+
+namespace {
+
+constexpr int RED_SLICES = 64;
+
+// ---- two-stage deterministic reduction of [ntiles][2][C] partials ---------------------------------
+// stage 1: grid (ceil(C/32), nslices); block 256 = 8 tile-lanes x 32 channels -> out1[slice][2][C] (double)
+__global__ __launch_bounds__(256) void reduce_partials_stage1(const float* __restrict__ part, int ntiles, int C,
+                                                              int tiles_per_slice, double* __restrict__ out1) {
+    __shared__ double red[2][8][32];
+    const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    const int t0 = blockIdx.y * tiles_per_slice, t1 = min(ntiles, t0 + tiles_per_slice);
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+        for (int tt = t0 + tl; tt < t1; tt += 8) {
+            s1 += (double)part[((int64_t)tt * 2 + 0) * C + c];
+            s2 += (double)part[((int64_t)tt * 2 + 1) * C + c];
+        }
+    }
+    red[0][tl][cl] = s1;
+    red[1][tl][cl] = s2;
+    __syncthreads();
+    if (tl == 0 && c < C) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { a += red[0][i][cl]; b += red[1][i][cl]; }
+        out1[((int64_t)blockIdx.y * 2 + 0) * C + c] = a;
+        out1[((int64_t)blockIdx.y * 2 + 1) * C + c] = b;
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ s, int nslices, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* running_mean, float* running_var, float momentum, float eps,
+                                   float* scale, float* shift, float* mean_out, float* invstd_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < nslices; ++i) { s1 += s[((int64_t)i * 2 + 0) * C + c]; s2 += s[((int64_t)i * 2 + 1) * C + c]; }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+    const float sc = gm * invstd;
+    scale[c] = sc;
+    shift[c] = bt - (float)mean * sc;
+    mean_out[c] = (float)mean;
+    invstd_out[c] = invstd;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) {
+        const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, float* scale, float* shift, float* mean, float* invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float is = 1.f / sqrtf(rv[c] + eps);
+    const float sc = (gamma ? gamma[c] : 1.f) * is;
+    scale[c] = sc;
+    shift[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
+    mean[c] = rm[c];
+    invstd[c] = is;
+}
+
+__global__ void bn_bwd_coeffs_kernel(const double* __restrict__ s, int nslices, int C, double count, float gscale,
+                                     float* dgamma, float* dbeta, float* c1, float* c2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < nslices; ++i) { s1 += s[((int64_t)i * 2 + 0) * C + c]; s2 += s[((int64_t)i * 2 + 1) * C + c]; }
+    if (dbeta) dbeta[c] = (float)(s1 * gscale);
+    if (dgamma) dgamma[c] = (float)(s2 * gscale);
+    c1[c] = (float)(s1 / count);
+    c2[c] = (float)(s2 / count);
+}
+
+// ---- forward apply -------------------------------------------------------------------------------
+struct ApplyArgs {
+    const unsigned short* y;
+    const float* scale;
+    const float* shift;
+    unsigned short* z;
+    unsigned short* zp;
+    const uint8_t* keep;
+    float keep_scale;
+    int act, N, H, W, C, zs, zc;
+};
+
+template <int DT, bool POOL>
+__global__ __launch_bounds__(256) void bn_act_apply_kernel(const ApplyArgs a) {
+    const int nch = a.C >> 3;
+    const int PH = POOL ? (a.H + 1) / 2 : a.H, PW = POOL ? (a.W + 1) / 2 : a.W;
+    const int64_t total = (int64_t)a.N * PH * PW * nch;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % nch);
+        int64_t pidx = idx / nch;
+        const int px = (int)(pidx % PW); pidx /= PW;
+        const int py = (int)(pidx % PH);
+        const int n = (int)(pidx / PH);
+        const int c0 = ch * 8;
+        float sc[8], sh[8];
+        if (a.scale) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { sc[i] = a.scale[c0 + i]; sh[i] = a.shift[c0 + i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { sc[i] = 1.f; sh[i] = 0.f; }
+        }
+        if (!POOL) {
+            const int64_t pix = ((int64_t)n * a.H + py) * a.W + px;
+            float v[8];
+            unpack8<DT>(*reinterpret_cast<const uint4*>(a.y + pix * a.C + c0), v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = act_fwd(v[i] * sc[i] + sh[i], a.act);
+            if (a.keep) {
+                const uint2 k = *reinterpret_cast<const uint2*>(a.keep + pix * a.C + c0);
+                const unsigned int kw[2] = {k.x, k.y};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] *= ((kw[i >> 2] >> (8 * (i & 3))) & 0xffu) ? a.keep_scale : 0.f;
+            }
+            *reinterpret_cast<uint4*>(a.z + pix * a.zs + a.zc + c0) = pack8<DT>(v);
+        } else {
+            float mx[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mx[i] = -INFINITY;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int yy = 2 * py + dy, xx = 2 * px + dx;
+                    if (yy < a.H && xx < a.W) {
+                        const int64_t pix = ((int64_t)n * a.H + yy) * a.W + xx;
+                        float v[8];
+                        unpack8<DT>(*reinterpret_cast<const uint4*>(a.y + pix * a.C + c0), v);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] = act_fwd(v[i] * sc[i] + sh[i], a.act);
+                        const uint4 pk = pack8<DT>(v);
+                        *reinterpret_cast<uint4*>(a.z + pix * a.zs + a.zc + c0) = pk;
+                        // pool the ROUNDED values: the next layer sees exactly max over the stored z
+                        float r[8];
+                        unpack8<DT>(pk, r);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) mx[i] = fmaxf(mx[i], r[i]);
+                    }
+                }
+            if (py < a.H / 2 && px < a.W / 2) {
+                const int64_t pp = ((int64_t)n * (a.H / 2) + py) * (a.W / 2) + px;
+                *reinterpret_cast<uint4*>(a.zp + pp * a.C + c0) = pack8<DT>(mx);
+            }
+        }
+    }
+}
+
+// ---- backward ------------------------------------------------------------------------------------
+struct BwdArgs {
+    const unsigned short* y;
+    const unsigned short* dza;
+    const unsigned short* dzp;
+    const float *scale, *shift, *mean, *invstd, *c1, *c2;
+    float* partials;
+    unsigned short* dy;
+    int sa, ca, act, bn, N, H, W, C;
+    int tile_units;   // work units (pixels or 2x2 windows) per tile
+};
+
+// gradient w.r.t. z at one pixel for 8 channels: concat/skip part + max-pool routed part.
+// v[] are the pre-activation values (y*scale+shift) of THIS pixel; for the pool part the caller supplies
+// `win` = whether this pixel is the first arg-max of its window, per channel.
+template <int DT, bool POOL, bool APPLY>
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
+    __shared__ float red[2][256 * 8 / 8][8];   // [stat][thread][8 channels] -- reduced below
+    const int nch = a.C >> 3;
+    const int PH = POOL ? (a.H + 1) / 2 : a.H, PW = POOL ? (a.W + 1) / 2 : a.W;
+    const int64_t units = (int64_t)a.N * PH * PW;
+    // thread -> (chunk, unit-lane): chunk fastest so a wave reads contiguous channels
+    const int lanes_per_unit = nch < 256 ? nch : 256;      // threads covering the channel chunks of one unit
+    const int unit_lanes = 256 / lanes_per_unit;           // units processed concurrently per block
+    const int chl = threadIdx.x % lanes_per_unit, ul = threadIdx.x / lanes_per_unit;
+    const int64_t u0 = (int64_t)blockIdx.x * a.tile_units;
+    int64_t u1 = u0 + a.tile_units < units ? u0 + a.tile_units : units;
+    if (ul >= unit_lanes) u1 = u0;   // leftover threads (256 % lanes_per_unit) only join the barriers
+
+    for (int ch = chl; ch < nch; ch += lanes_per_unit) {
+        const int c0 = ch * 8;
+        float sc[8], sh[8], mu[8], is[8], k1[8], k2[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            sc[i] = a.scale ? a.scale[c0 + i] : 1.f;
+            sh[i] = a.shift ? a.shift[c0 + i] : 0.f;
+            mu[i] = a.mean ? a.mean[c0 + i] : 0.f;
+            is[i] = a.invstd ? a.invstd[c0 + i] : 1.f;
+            k1[i] = (APPLY && a.c1) ? a.c1[c0 + i] : 0.f;
+            k2[i] = (APPLY && a.c2) ? a.c2[c0 + i] : 0.f;
+        }
+        float s1[8], s2[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+
+        for (int64_t u = u0 + ul; u < u1; u += unit_lanes) {
+            int64_t r = u;
+            const int px = (int)(r % PW); r /= PW;
+            const int py = (int)(r % PH);
+            const int n = (int)(r / PH);
+            if (!POOL) {
+                const int64_t pix = ((int64_t)n * a.H + py) * a.W + px;
+                float yv[8], g[8];
+                unpack8<DT>(*reinterpret_cast<const uint4*>(a.y + pix * a.C + c0), yv);
+                if (a.dza) unpack8<DT>(*reinterpret_cast<const uint4*>(a.dza + pix * a.sa + a.ca + c0), g);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) g[i] = 0.f;
+                }
+                float out[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float v = yv[i] * sc[i] + sh[i];
+                    const float gh = g[i] * act_grad(v, a.act);
+                    const float xh = (yv[i] - mu[i]) * is[i];
+                    if (APPLY) out[i] = a.bn ? sc[i] * (gh - k1[i] - xh * k2[i]) : gh;
+                    else { s1[i] += gh; s2[i] += gh * xh; }
+                }
+                if (APPLY) *reinterpret_cast<uint4*>(a.dy + pix * a.C + c0) = pack8<DT>(out);
+            } else {
+                // 2x2 window: recompute the stored (rounded) z of the 4 pixels, route dzp to the first max
+                float yv[4][8], zr[4][8];
+                bool ok[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int yy = 2 * py + (k >> 1), xx = 2 * px + (k & 1);
+                    ok[k] = yy < a.H && xx < a.W;
+                    if (ok[k]) {
+                        const int64_t pix = ((int64_t)n * a.H + yy) * a.W + xx;
+                        unpack8<DT>(*reinterpret_cast<const uint4*>(a.y + pix * a.C + c0), yv[k]);
+                        float zt[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) zt[i] = act_fwd(yv[k][i] * sc[i] + sh[i], a.act);
+                        const uint4 pk = pack8<DT>(zt);
+                        unpack8<DT>(pk, zr[k]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { yv[k][i] = 0.f; zr[k][i] = -INFINITY; }
+                    }
+                }
+                const bool pooled = (py < a.H / 2) && (px < a.W / 2);
+                float gp[8];
+                if (pooled && a.dzp) {
+                    const int64_t pp = ((int64_t)n * (a.H / 2) + py) * (a.W / 2) + px;
+                    unpack8<DT>(*reinterpret_cast<const uint4*>(a.dzp + pp * a.C + c0), gp);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) gp[i] = 0.f;
+                }
+                int amax[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    int best = 0; float bv = zr[0][i];
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) if (zr[k][i] > bv) { bv = zr[k][i]; best = k; }
+                    amax[i] = best;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (!ok[k]) continue;
+                    const int yy = 2 * py + (k >> 1), xx = 2 * px + (k & 1);
+                    const int64_t pix = ((int64_t)n * a.H + yy) * a.W + xx;
+                    float g[8];
+                    if (a.dza) unpack8<DT>(*reinterpret_cast<const uint4*>(a.dza + pix * a.sa + a.ca + c0), g);
+                    else {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) g[i] = 0.f;
+                    }
+                    float out[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float gz = g[i] + (amax[i] == k ? gp[i] : 0.f);
+                        const float v = yv[k][i] * sc[i] + sh[i];
+                        const float gh = gz * act_grad(v, a.act);
+                        const float xh = (yv[k][i] - mu[i]) * is[i];
+                        if (APPLY) out[i] = a.bn ? sc[i] * (gh - k1[i] - xh * k2[i]) : gh;
+                        else { s1[i] += gh; s2[i] += gh * xh; }
+                    }
+                    if (APPLY) *reinterpret_cast<uint4*>(a.dy + pix * a.C + c0) = pack8<DT>(out);
+                }
+            }
+        }
+        if (!APPLY) {
+            // reduce over the unit lanes of this block (fixed order -> deterministic)
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { red[0][threadIdx.x][i] = s1[i]; red[1][threadIdx.x][i] = s2[i]; }
+            __syncthreads();
+            if (ul == 0) {
+                float t1[8], t2[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { t1[i] = 0.f; t2[i] = 0.f; }
+                for (int k = 0; k < unit_lanes; ++k)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        t1[i] += red[0][k * lanes_per_unit + chl][i];
+                        t2[i] += red[1][k * lanes_per_unit + chl][i];
+                    }
+                float* dst = a.partials + (int64_t)blockIdx.x * 2 * a.C + c0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { dst[i] = t1[i]; dst[a.C + i] = t2[i]; }
+            }
+        }
+    }
+}
+
+// ---- strided column sums ---------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void colsum_stage1(const unsigned short* __restrict__ t, int ps, int coff,
+                                                     int64_t npix, int C, int64_t pix_per_block, float* ws,
+                                                     int H, int W, int y0, int x0, int h, int w) {
+    __shared__ float red[256][8];
+    const int nch = C >> 3;
+    const int lpu = nch < 256 ? nch : 256, ulanes = 256 / lpu;
+    const int chl = threadIdx.x % lpu, ul = threadIdx.x / lpu;
+    const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+    int64_t p1 = p0 + pix_per_block < npix ? p0 + pix_per_block : npix;
+    if (ul >= ulanes) p1 = p0;
+    for (int ch = chl; ch < nch; ch += lpu) {
+        float s[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[i] = 0.f;
+        for (int64_t p = p0 + ul; p < p1; p += ulanes) {
+            float v[8];
+            const int xx = (int)(p % w);
+            const int64_t r = p / w;
+            const int yy = (int)(r % h);
+            const int64_t n = r / h;
+            const int64_t pp = (n * H + y0 + yy) * W + x0 + xx;
+            unpack8<DT>(*reinterpret_cast<const uint4*>(t + pp * ps + coff + ch * 8), v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] += v[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = s[i];
+        __syncthreads();
+        if (ul == 0) {
+            float tt[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) tt[i] = 0.f;
+            for (int k = 0; k < ulanes; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) tt[i] += red[k * lpu + chl][i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ws[(int64_t)blockIdx.x * C + ch * 8 + i] = tt[i];
+        }
+    }
+}
+__global__ void colsum_stage2(const float* ws, int nblocks, int C, float gscale, float* out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int i = 0; i < nblocks; ++i) s += (double)ws[(int64_t)i * C + c];
+    out[c] = (float)(s * gscale);
+}
+
+int reduce_partials(const float* partials, int ntiles, int C, double** out, int* nslices, hipStream_t s) {
+    // stage-1 output lives right behind the partials: [ntiles][2][C] floats, then [64][2][C] doubles
+    int slices = ntiles < RED_SLICES ? ntiles : RED_SLICES;
+    const int tps = cdiv(ntiles, slices);
+    slices = cdiv(ntiles, tps);
+    size_t off = ((size_t)ntiles * 2 * C * sizeof(float) + 15) & ~(size_t)15;
+    double* o1 = (double*)((char*)partials + off);
+    reduce_partials_stage1<<<dim3(cdiv(C, 32), slices), 256, 0, s>>>(partials, ntiles, C, tps, o1);
+    *out = o1;
+    *nslices = slices;
+    return 0;
+}
+
+}  // namespace
+
+// Size (in floats) a partials buffer needs for `ntiles` tiles of C channels, including the stage-1 area.
+extern "C" int64_t gs_bn_partials_floats(int ntiles, int C) {
+    return (int64_t)ntiles * 2 * C + 4 + (int64_t)RED_SLICES * 2 * C * 2;
+}
+
+extern "C" int gs_bn_finalize(const float* partials, int ntiles, int C, double count, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                              float* scale, float* shift, float* mean, float* invstd, void* stream) {
+    GS_CHECK_ARG(partials && scale && shift && mean && invstd && ntiles > 0 && C > 0 && count > 0,
+                 "gs_bn_finalize: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    double* o1; int ns;
+    reduce_partials(partials, ntiles, C, &o1, &ns, s);
+    bn_finalize_kernel<<<cdiv(C, 128), 128, 0, s>>>(o1, ns, C, count, gamma, beta, running_mean, running_var,
+                                                    momentum, eps, scale, shift, mean, invstd);
+    GS_CHECK_LAUNCH("gs_bn_finalize");
+    return GS_OK;
+}
+
+extern "C" int gs_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
+                                 const float* running_var, float eps, float* scale, float* shift, float* mean,
+                                 float* invstd, void* stream) {
+    GS_CHECK_ARG(C > 0 && running_mean && running_var && scale && shift && mean && invstd, "gs_bn_eval_coeffs: bad args");
+    bn_eval_coeffs_kernel<<<cdiv(C, 128), 128, 0, (hipStream_t)stream>>>(C, gamma, beta, running_mean, running_var, eps,
+                                                                         scale, shift, mean, invstd);
+    GS_CHECK_LAUNCH("gs_bn_eval_coeffs");
+    return GS_OK;
+}
+
+extern "C" int gs_bn_act_apply(const void* y, const float* scale, const float* shift, int act, void* z,
+                               int z_pix_stride, int z_coff, void* zp, const uint8_t* keep_mask, float keep_scale,
+                               int N, int H, int W, int C, int dtype, void* stream) {
+    GS_CHECK_ARG(y && z && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "gs_bn_act_apply: bad arguments");
+    GS_CHECK_ARG(z_pix_stride >= z_coff + C && z_pix_stride % 8 == 0 && z_coff % 8 == 0, "gs_bn_act_apply: bad z stride");
+    GS_CHECK_ARG((scale == nullptr) == (shift == nullptr), "gs_bn_act_apply: scale/shift must both be given or NULL");
+    GS_CHECK_ARG(!(zp && keep_mask), "gs_bn_act_apply: pool + dropout not supported together");
+    ApplyArgs a{(const unsigned short*)y, scale, shift, (unsigned short*)z, (unsigned short*)zp, keep_mask, keep_scale,
+                act, N, H, W, C, z_pix_stride, z_coff};
+    const bool pool = zp != nullptr;
+    const int PH = pool ? (H + 1) / 2 : H, PW = pool ? (W + 1) / 2 : W;
+    const int64_t total = (int64_t)N * PH * PW * (C / 8);
+    int64_t blocks = cdiv64(total, 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GS_F16) {
+        if (pool) bn_act_apply_kernel<GS_F16, true><<<(int)blocks, 256, 0, s>>>(a);
+        else bn_act_apply_kernel<GS_F16, false><<<(int)blocks, 256, 0, s>>>(a);
+    } else if (dtype == GS_BF16) {
+        if (pool) bn_act_apply_kernel<GS_BF16, true><<<(int)blocks, 256, 0, s>>>(a);
+        else bn_act_apply_kernel<GS_BF16, false><<<(int)blocks, 256, 0, s>>>(a);
+    } else {
+        GS_CHECK_ARG(false, "gs_bn_act_apply: bad dtype");
+    }
+    GS_CHECK_LAUNCH("gs_bn_act_apply");
+    return GS_OK;
+}
+
+static int bwd_tile_units(int64_t units) {
+    int64_t tu = cdiv64(units, 1024);
+    if (tu < 64) tu = 64;
+    return (int)tu;
+}
+
+extern "C" int gs_bn_bwd_tiles(int N, int H, int W) {
+    // the same tile count is valid for the pooled (2x2 window) and the plain variant: use the larger (plain)
+    const int64_t units = (int64_t)N * H * W;
+    return (int)cdiv64(units, bwd_tile_units(units));
+}
+
+static int launch_bwd(const BwdArgs& a0, bool apply, int dtype, hipStream_t s, int* ntiles_out) {
+    BwdArgs a = a0;
+    const bool pool = a.dzp != nullptr;
+    const int PH = pool ? (a.H + 1) / 2 : a.H, PW = pool ? (a.W + 1) / 2 : a.W;
+    const int64_t units = (int64_t)a.N * PH * PW;
+    // tiles are defined on the PLAIN pixel count so gs_bn_bwd_tiles() bounds both variants
+    const int ntiles_max = gs_bn_bwd_tiles(a.N, a.H, a.W);
+    a.tile_units = (int)cdiv64(units, ntiles_max);
+    if (a.tile_units < 1) a.tile_units = 1;
+    const int ntiles = (int)cdiv64(units, a.tile_units);
+    if (ntiles_out) *ntiles_out = ntiles;
+#define LAUNCH(DT)                                                                                      \
+    do {                                                                                                \
+        if (pool) {                                                                                     \
+            if (apply) bn_act_bwd_kernel<DT, true, true><<<ntiles, 256, 0, s>>>(a);                     \
+            else bn_act_bwd_kernel<DT, true, false><<<ntiles, 256, 0, s>>>(a);                          \
+        } else {                                                                                        \
+            if (apply) bn_act_bwd_kernel<DT, false, true><<<ntiles, 256, 0, s>>>(a);                    \
+            else bn_act_bwd_kernel<DT, false, false><<<ntiles, 256, 0, s>>>(a);                         \
+        }                                                                                               \
+    } while (0)
+    if (dtype == GS_F16) LAUNCH(GS_F16);
+    else LAUNCH(GS_BF16);
+#undef LAUNCH
+    return 0;
+}
+
+// number of tiles the reduce kernel actually writes (<= gs_bn_bwd_tiles)
+extern "C" int gs_bn_bwd_tiles_used(int N, int H, int W, int pooled) {
+    const int PH = pooled ? (H + 1) / 2 : H, PW = pooled ? (W + 1) / 2 : W;
+    const int64_t units = (int64_t)N * PH * PW;
+    const int ntiles_max = gs_bn_bwd_tiles(N, H, W);
+    int64_t tu = cdiv64(units, ntiles_max);
+    if (tu < 1) tu = 1;
+    return (int)cdiv64(units, tu);
+}
+
+extern "C" int gs_bn_act_bwd_reduce(const void* y, const void* dz_a, int sa, int coff_a, const void* dzp,
+                                    const float* scale, const float* shift, const float* mean, const float* invstd,
+                                    int act, float* partials, int N, int H, int W, int C, int dtype, void* stream) {
+    GS_CHECK_ARG(y && partials && (dz_a || dzp) && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= 2048,
+                 "gs_bn_act_bwd_reduce: bad arguments");
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_bn_act_bwd_reduce: bad dtype");
+    GS_CHECK_ARG(!dz_a || (sa >= coff_a + C && sa % 8 == 0 && coff_a % 8 == 0), "gs_bn_act_bwd_reduce: bad dz stride");
+    BwdArgs a{};
+    a.y = (const unsigned short*)y; a.dza = (const unsigned short*)dz_a; a.dzp = (const unsigned short*)dzp;
+    a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.c1 = nullptr; a.c2 = nullptr;
+    a.partials = partials; a.dy = nullptr; a.sa = sa; a.ca = coff_a; a.act = act; a.bn = 1;
+    a.N = N; a.H = H; a.W = W; a.C = C;
+    launch_bwd(a, false, dtype, (hipStream_t)stream, nullptr);
+    GS_CHECK_LAUNCH("gs_bn_act_bwd_reduce");
+    return GS_OK;
+}
+
+extern "C" int gs_bn_bwd_coeffs(const float* partials, int ntiles, int C, double count, float gscale, float* dgamma,
+                                float* dbeta, float* c1, float* c2, void* stream) {
+    GS_CHECK_ARG(partials && c1 && c2 && ntiles > 0 && C > 0 && count > 0, "gs_bn_bwd_coeffs: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    double* o1; int ns;
+    reduce_partials(partials, ntiles, C, &o1, &ns, s);
+    bn_bwd_coeffs_kernel<<<cdiv(C, 128), 128, 0, s>>>(o1, ns, C, count, gscale, dgamma, dbeta, c1, c2);
+    GS_CHECK_LAUNCH("gs_bn_bwd_coeffs");
+    return GS_OK;
+}
+
+extern "C" int gs_bn_act_bwd_apply(const void* y, const void* dz_a, int sa, int coff_a, const void* dzp,
+                                   const float* scale, const float* shift, const float* mean, const float* invstd,
+                                   const float* c1, const float* c2, int act, int bn, void* dy, int N, int H, int W,
+                                   int C, int dtype, void* stream) {
+    GS_CHECK_ARG(y && dy && (dz_a || dzp) && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= 2048,
+                 "gs_bn_act_bwd_apply: bad arguments");
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_bn_act_bwd_apply: bad dtype");
+    GS_CHECK_ARG(!bn || (scale && shift && mean && invstd && c1 && c2), "gs_bn_act_bwd_apply: bn=1 needs all coefficients");
+    GS_CHECK_ARG(!dz_a || (sa >= coff_a + C && sa % 8 == 0 && coff_a % 8 == 0), "gs_bn_act_bwd_apply: bad dz stride");
+    BwdArgs a{};
+    a.y = (const unsigned short*)y; a.dza = (const unsigned short*)dz_a; a.dzp = (const unsigned short*)dzp;
+    a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.c1 = c1; a.c2 = c2;
+    a.partials = nullptr; a.dy = (unsigned short*)dy; a.sa = sa; a.ca = coff_a; a.act = act; a.bn = bn;
+    a.N = N; a.H = H; a.W = W; a.C = C;
+    launch_bwd(a, true, dtype, (hipStream_t)stream, nullptr);
+    GS_CHECK_LAUNCH("gs_bn_act_bwd_apply");
+    return GS_OK;
+}
+
+extern "C" int gs_colsum(const void* t, int pix_stride, int coff, int N, int H, int W, int y0, int x0, int h, int w,
+                         int C, float gscale, float* ws, float* out, int dtype, void* stream) {
+    GS_CHECK_ARG(t && ws && out && N > 0 && h > 0 && w > 0 && y0 >= 0 && x0 >= 0 && y0 + h <= H && x0 + w <= W,
+                 "gs_colsum: bad region");
+    GS_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 2048 && pix_stride % 8 == 0 && coff % 8 == 0, "gs_colsum: bad channels");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t npix = (int64_t)N * h * w;
+    int64_t ppb = cdiv64(npix, 1024);
+    if (ppb < 32) ppb = 32;
+    const int nb = (int)cdiv64(npix, ppb);
+    if (dtype == GS_F16)
+        colsum_stage1<GS_F16><<<nb, 256, 0, s>>>((const unsigned short*)t, pix_stride, coff, npix, C, ppb, ws, H, W, y0, x0, h, w);
+    else if (dtype == GS_BF16)
+        colsum_stage1<GS_BF16><<<nb, 256, 0, s>>>((const unsigned short*)t, pix_stride, coff, npix, C, ppb, ws, H, W, y0, x0, h, w);
+    else GS_CHECK_ARG(false, "gs_colsum: bad dtype");
+    colsum_stage2<<<cdiv(C, 128), 128, 0, s>>>(ws, nb, C, gscale, out);
+    GS_CHECK_LAUNCH("gs_colsum");
+    return GS_OK;
+}

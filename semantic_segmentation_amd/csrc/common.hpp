@@ -1,0 +1,145 @@
+// Shared device/host helpers for the gfx950 kernels.  gfx950 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "gsseg.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short i16x4;
+typedef __attribute__((ext_vector_type(8))) short i16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define LDS_AS __attribute__((address_space(3)))
+
+void gs_set_error(const char* fmt, ...);
+
+#define GS_CHECK_ARG(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            gs_set_error(__VA_ARGS__);     \
+            return GS_EINVAL;              \
+        }                                  \
+    } while (0)
+
+#define GS_CHECK_LAUNCH(name)                                                         \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            gs_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));       \
+            return GS_ELAUNCH;                                                        \
+        }                                                                             \
+    } while (0)
+
+// ---- 16-bit element traits --------------------------------------------------------------------
+template <int DT>
+struct Elem;
+
+template <>
+struct Elem<GS_F16> {
+    typedef _Float16 T;
+    typedef f16x8 V8;
+    typedef f16x4 V4;
+    static __device__ __forceinline__ float to_f(unsigned short u) {
+        return (float)__builtin_bit_cast(_Float16, u);
+    }
+    static __device__ __forceinline__ unsigned short from_f(float f) {
+        return __builtin_bit_cast(unsigned short, (_Float16)f);
+    }
+    static __device__ __forceinline__ f32x16 mfma32(V8 a, V8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+
+};
+
+template <>
+struct Elem<GS_BF16> {
+    typedef __bf16 T;
+    typedef bf16x8 V8;
+    typedef bf16x4 V4;
+    static __device__ __forceinline__ float to_f(unsigned short u) {
+        return __builtin_bit_cast(float, ((unsigned int)u) << 16);
+    }
+    static __device__ __forceinline__ unsigned short from_f(float f) {
+        return __builtin_bit_cast(unsigned short, (__bf16)f);   // v_cvt_pk_bf16_f32: RNE, NaN-safe
+    }
+    static __device__ __forceinline__ f32x16 mfma32(V8 a, V8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+
+};
+
+// gfx950 transposing LDS read (ds_read_b64_tr_b16): two reads give one 8-element K-minor MFMA fragment
+__device__ __forceinline__ i16x4 tr_read4(const LDS_AS unsigned short* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS i16x4*)p);
+}
+template <int DT>
+__device__ __forceinline__ typename Elem<DT>::V8 tr_read8(const LDS_AS unsigned short* lo, const LDS_AS unsigned short* hi) {
+    const i16x4 a = tr_read4(lo), b = tr_read4(hi);
+    const i16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(typename Elem<DT>::V8, v);
+}
+
+// unpack / pack 8 consecutive 16-bit elements held in a uint4
+template <int DT>
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+    const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = Elem<DT>::to_f((unsigned short)(w[i] & 0xffffu));
+        f[2 * i + 1] = Elem<DT>::to_f((unsigned short)(w[i] >> 16));
+    }
+}
+template <int DT>
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    unsigned int w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        w[i] = (unsigned int)Elem<DT>::from_f(f[2 * i]) | ((unsigned int)Elem<DT>::from_f(f[2 * i + 1]) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+    switch (act) {
+        case GS_ACT_RELU: return v > 0.f ? v : 0.f;
+        case GS_ACT_LEAKY02: return v > 0.f ? v : 0.2f * v;
+        case GS_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+// derivative of act w.r.t. its input, given the pre-activation value v
+__device__ __forceinline__ float act_grad(float v, int act) {
+    switch (act) {
+        case GS_ACT_RELU: return v > 0.f ? 1.f : 0.f;
+        case GS_ACT_LEAKY02: return v > 0.f ? 1.f : 0.2f;
+        case GS_ACT_TANH: { float t = tanhf(v); return 1.f - t * t; }
+        default: return 1.f;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum for blockDim.x == 256 (4 waves); result valid in every thread
+__device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 floats of LDS */) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

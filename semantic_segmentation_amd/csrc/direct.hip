@@ -1,0 +1,515 @@
+// Direct (VALU) convolutions for the 1..4-channel ends of the networks, where the implicit-GEMM K or N
+// dimension is too small for MFMA and the kernels are HBM-bound:
+//   small-Cin : U-Net inc.0 (1->64, 3x3; unet_parts.py:16), generator outermost down-conv (1->64, 4x4 s2;
+//               networks.py:582), PatchGAN first conv (2->64, 4x4 s2; networks.py:640).  Reads the fp32 NCHW
+//               image directly (no separate layout pass), writes 16-bit NHWC + BatchNorm partial sums.
+//   small-Cout: OutConv 1x1 (64->n_classes; unet_parts.py:74) and the PatchGAN last conv (512->1, 4x4;
+//               networks.py:661).  Reads 16-bit NHWC, writes fp32 NCHW logits.
+#include "common.hpp"
+
+namespace {
+
+constexpr int SC_TILE = 256;        // output pixels per block / BN tile (small-Cin fwd)
+constexpr int SC_MAX_W = 8192;      // floats of weights cached in LDS
+
+struct SCArgs {
+    const float* x; const float* w; const float* bias; unsigned short* y; float* bnp;
+    int N, Cin, IH, IW, Cout, OH, OW, k, stride, pad, act;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void smallcin_fwd_kernel(const SCArgs a) {
+    __shared__ float wl[SC_MAX_W];            // [tap][Cout]
+    __shared__ float red[2][256][8];
+    const int T = a.Cin * a.k * a.k;
+    for (int i = threadIdx.x; i < T * a.Cout; i += 256) {
+        const int co = i % a.Cout, tap = i / a.Cout;
+        wl[i] = a.w[(int64_t)co * T + tap];   // [co][ci][ky][kx] -> [tap][co], tap = (ci*k+ky)*k+kx
+    }
+    __syncthreads();
+    const int nch = a.Cout >> 3;
+    const int lanes = 256 / nch;
+    const int ch = threadIdx.x % nch, pl = threadIdx.x / nch;
+    const int64_t M = (int64_t)a.N * a.OH * a.OW;
+    const int64_t m0 = (int64_t)blockIdx.x * SC_TILE;
+    float bv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bv[i] = a.bias ? a.bias[ch * 8 + i] : 0.f;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+    if (pl < lanes) {
+        for (int p = pl; p < SC_TILE; p += lanes) {
+            const int64_t m = m0 + p;
+            if (m >= M) break;
+            const int ox = (int)(m % a.OW);
+            const int64_t r = m / a.OW;
+            const int oy = (int)(r % a.OH);
+            const int n = (int)(r / a.OH);
+            float acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+            int tap = 0;
+            for (int ci = 0; ci < a.Cin; ++ci)
+                for (int ky = 0; ky < a.k; ++ky)
+                    for (int kx = 0; kx < a.k; ++kx, ++tap) {
+                        const int iy = oy * a.stride - a.pad + ky, ix = ox * a.stride - a.pad + kx;
+                        float xv = 0.f;
+                        if ((unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW)
+                            xv = a.x[(((int64_t)n * a.Cin + ci) * a.IH + iy) * a.IW + ix];
+                        const float* wp = wl + tap * a.Cout + ch * 8;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc[i] += xv * wp[i];
+                    }
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                s1[i] += acc[i]; s2[i] += acc[i] * acc[i];
+                o[i] = act_fwd(acc[i] + bv[i], a.act);
+            }
+            *reinterpret_cast<uint4*>(a.y + m * a.Cout + ch * 8) = pack8<DT>(o);
+        }
+    }
+    if (a.bnp) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { red[0][threadIdx.x][i] = s1[i]; red[1][threadIdx.x][i] = s2[i]; }
+        __syncthreads();
+        if (pl == 0) {
+            float t1[8], t2[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { t1[i] = 0.f; t2[i] = 0.f; }
+            for (int q = 0; q < lanes; ++q)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { t1[i] += red[0][q * nch + ch][i]; t2[i] += red[1][q * nch + ch][i]; }
+            float* dst = a.bnp + (int64_t)blockIdx.x * 2 * a.Cout + ch * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { dst[i] = t1[i]; dst[a.Cout + i] = t2[i]; }
+        }
+    }
+}
+
+struct SCWArgs {
+    const float* x; const unsigned short* dy; float* dw;
+    int N, Cin, IH, IW, Cout, OH, OW, k, stride, pad;
+    float gscale; int64_t pix_per_block;
+};
+
+constexpr int TG = 16;   // taps accumulated per pass
+
+template <int DT>
+__global__ __launch_bounds__(256) void smallcin_wgrad_kernel(const SCWArgs a) {
+    __shared__ float red[256][8];
+    const int T = a.Cin * a.k * a.k, kk = a.k * a.k;
+    const int nch = a.Cout >> 3, lanes = 256 / nch;
+    const int ch = threadIdx.x % nch, pl = threadIdx.x / nch;
+    const int64_t M = (int64_t)a.N * a.OH * a.OW;
+    const int64_t m0 = (int64_t)blockIdx.x * a.pix_per_block;
+    const int64_t m1 = m0 + a.pix_per_block < M ? m0 + a.pix_per_block : M;
+    for (int t0 = 0; t0 < T; t0 += TG) {
+        float acc[TG][8];
+#pragma unroll
+        for (int j = 0; j < TG; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
+        if (pl < lanes) {
+            for (int64_t m = m0 + pl; m < m1; m += lanes) {
+                const int ox = (int)(m % a.OW);
+                const int64_t r = m / a.OW;
+                const int oy = (int)(r % a.OH);
+                const int n = (int)(r / a.OH);
+                float g[8];
+                unpack8<DT>(*reinterpret_cast<const uint4*>(a.dy + m * a.Cout + ch * 8), g);
+#pragma unroll
+                for (int j = 0; j < TG; ++j) {
+                    const int tap = t0 + j;
+                    if (tap < T) {
+                        const int ci = tap / kk, rr = tap - ci * kk, ky = rr / a.k, kx = rr - ky * a.k;
+                        const int iy = oy * a.stride - a.pad + ky, ix = ox * a.stride - a.pad + kx;
+                        float xv = 0.f;
+                        if ((unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW)
+                            xv = a.x[(((int64_t)n * a.Cin + ci) * a.IH + iy) * a.IW + ix];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc[j][i] += g[i] * xv;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TG; ++j) {
+            const int tap = t0 + j;
+            if (tap < T) {                           // uniform
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = acc[j][i];
+                __syncthreads();
+                if (pl == 0) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        float s = 0.f;
+                        for (int q = 0; q < lanes; ++q) s += red[q * nch + ch][i];
+                        atomicAdd(a.dw + (int64_t)(ch * 8 + i) * T + tap, s * a.gscale);
+                    }
+                }
+            }
+        }
+    }
+}
+
+struct SCDArgs {
+    const unsigned short* dy; const float* w; float* dx;
+    int N, Cin, IH, IW, Cout, OH, OW, k, stride, pad; float gscale;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void smallcin_dgrad_kernel(const SCDArgs a) {
+    __shared__ float wl[SC_MAX_W];     // [ci][kk][co]
+    const int kk = a.k * a.k, T = a.Cin * kk;
+    for (int i = threadIdx.x; i < T * a.Cout; i += 256) {
+        const int co = i % a.Cout, tap = i / a.Cout;   // tap = ci*kk + ky*k + kx
+        wl[i] = a.w[(int64_t)co * T + tap];
+    }
+    __syncthreads();
+    const int64_t total = (int64_t)a.N * a.IH * a.IW;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (int64_t)gridDim.x * 256) {
+        const int ix = (int)(p % a.IW);
+        const int64_t r = p / a.IW;
+        const int iy = (int)(r % a.IH);
+        const int n = (int)(r / a.IH);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int ky = 0; ky < a.k; ++ky) {
+            const int ty = iy + a.pad - ky;
+            if (ty < 0 || ty % a.stride) continue;
+            const int oy = ty / a.stride;
+            if (oy >= a.OH) continue;
+            for (int kx = 0; kx < a.k; ++kx) {
+                const int tx = ix + a.pad - kx;
+                if (tx < 0 || tx % a.stride) continue;
+                const int ox = tx / a.stride;
+                if (ox >= a.OW) continue;
+                const unsigned short* dp = a.dy + (((int64_t)n * a.OH + oy) * a.OW + ox) * a.Cout;
+                for (int c0 = 0; c0 < a.Cout; c0 += 8) {
+                    float g[8];
+                    unpack8<DT>(*reinterpret_cast<const uint4*>(dp + c0), g);
+                    for (int ci = 0; ci < a.Cin; ++ci) {
+                        const float* wp = wl + ((ci * kk) + ky * a.k + kx) * a.Cout + c0;
+                        float s = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) s += g[i] * wp[i];
+                        acc[ci] += s;
+                    }
+                }
+            }
+        }
+        for (int ci = 0; ci < a.Cin; ++ci)
+            a.dx[(((int64_t)n * a.Cin + ci) * a.IH + iy) * a.IW + ix] = acc[ci] * a.gscale;
+    }
+}
+
+// ---- small-Cout head ---------------------------------------------------------------------------------
+struct HArgs {
+    const unsigned short* x; const float* w; const float* bias; float* y;
+    const float* dy; unsigned short* dx; float* dw; float* db;
+    int N, IH, IW, Cin, Cout, OH, OW, k, stride, pad; float gscale; int64_t pix_per_block;
+};
+
+// wl layout [c][tap][Cin]
+__device__ __forceinline__ void load_head_weights(const HArgs& a, float* wl) {
+    const int kk = a.k * a.k;
+    for (int i = threadIdx.x; i < a.Cout * kk * a.Cin; i += 256) {
+        const int ci = i % a.Cin;
+        const int r = i / a.Cin;
+        const int tap = r % kk, c = r / kk;
+        wl[i] = a.w[((int64_t)c * a.Cin + ci) * kk + tap];
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void smallcout_fwd_kernel(const HArgs a) {
+    __shared__ float wl[SC_MAX_W];
+    load_head_weights(a, wl);
+    __syncthreads();
+    const int kk = a.k * a.k;
+    const int nch = a.Cin >> 3;
+    const int gl = nch < 64 ? nch : 64;           // lanes cooperating on one pixel (power of two)
+    const int groups = 256 / gl;
+    const int li = threadIdx.x % gl, grp = threadIdx.x / gl;
+    const int64_t M = (int64_t)a.N * a.OH * a.OW;
+    const int64_t nit = (M + groups - 1) / groups;
+    for (int64_t it = blockIdx.x; it < nit; it += gridDim.x) {
+        const int64_t m = it * groups + grp;
+        const bool valid = m < M;
+        const int64_t mm = valid ? m : 0;
+        const int ox = (int)(mm % a.OW);
+        const int64_t r = mm / a.OW;
+        const int oy = (int)(r % a.OH);
+        const int n = (int)(r / a.OH);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int ky = 0; ky < a.k; ++ky)
+            for (int kx = 0; kx < a.k; ++kx) {
+                const int iy = oy * a.stride - a.pad + ky, ix = ox * a.stride - a.pad + kx;
+                if (!valid || (unsigned)iy >= (unsigned)a.IH || (unsigned)ix >= (unsigned)a.IW) continue;
+                const unsigned short* xp = a.x + (((int64_t)n * a.IH + iy) * a.IW + ix) * a.Cin;
+                for (int ch = li; ch < nch; ch += gl) {
+                    float v[8];
+                    unpack8<DT>(*reinterpret_cast<const uint4*>(xp + ch * 8), v);
+                    for (int c = 0; c < a.Cout; ++c) {
+                        const float* wp = wl + (c * kk + ky * a.k + kx) * a.Cin + ch * 8;
+                        float s = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) s += v[i] * wp[i];
+                        acc[c] += s;
+                    }
+                }
+            }
+        for (int c = 0; c < a.Cout; ++c) {
+            float s = acc[c];
+            for (int o = gl >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (li == 0 && valid)
+                a.y[(((int64_t)n * a.Cout + c) * a.OH + oy) * a.OW + ox] = s + (a.bias ? a.bias[c] : 0.f);
+        }
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void smallcout_dgrad_kernel(const HArgs a) {
+    __shared__ float wl[SC_MAX_W];
+    load_head_weights(a, wl);
+    __syncthreads();
+    const int kk = a.k * a.k;
+    const int nch = a.Cin >> 3;
+    const int64_t total = (int64_t)a.N * a.IH * a.IW * nch;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(idx % nch);
+        int64_t p = idx / nch;
+        const int ix = (int)(p % a.IW); p /= a.IW;
+        const int iy = (int)(p % a.IH);
+        const int n = (int)(p / a.IH);
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        for (int ky = 0; ky < a.k; ++ky) {
+            const int ty = iy + a.pad - ky;
+            if (ty < 0 || ty % a.stride) continue;
+            const int oy = ty / a.stride;
+            if (oy >= a.OH) continue;
+            for (int kx = 0; kx < a.k; ++kx) {
+                const int tx = ix + a.pad - kx;
+                if (tx < 0 || tx % a.stride) continue;
+                const int ox = tx / a.stride;
+                if (ox >= a.OW) continue;
+                for (int c = 0; c < a.Cout; ++c) {
+                    const float g = a.dy[(((int64_t)n * a.Cout + c) * a.OH + oy) * a.OW + ox];
+                    const float* wp = wl + (c * kk + ky * a.k + kx) * a.Cin + ch * 8;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] += g * wp[i];
+                }
+            }
+        }
+        const int64_t pix = ((int64_t)n * a.IH + iy) * a.IW + ix;
+        *reinterpret_cast<uint4*>(a.dx + pix * a.Cin + ch * 8) = pack8<DT>(acc);
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void smallcout_wgrad_kernel(const HArgs a) {
+    __shared__ float red[256][8];
+    __shared__ float redb[4][4];
+    const int kk = a.k * a.k;
+    const int nch = a.Cin >> 3;
+    const int lpu = nch < 256 ? nch : 256, lanes = 256 / lpu;
+    const int chl = threadIdx.x % lpu, pl = threadIdx.x / lpu;
+    const int64_t M = (int64_t)a.N * a.OH * a.OW;
+    const int64_t m0 = (int64_t)blockIdx.x * a.pix_per_block;
+    const int64_t m1 = m0 + a.pix_per_block < M ? m0 + a.pix_per_block : M;
+    // bias gradient: plain block reduction over this block's pixels
+    if (a.db) {
+        for (int c = 0; c < a.Cout; ++c) {
+            float s = 0.f;
+            for (int64_t m = m0 + threadIdx.x; m < m1; m += 256) {
+                const int64_t hw = m % ((int64_t)a.OH * a.OW), n = m / ((int64_t)a.OH * a.OW);
+                s += a.dy[(n * a.Cout + c) * (int64_t)a.OH * a.OW + hw];
+            }
+            s = wave_sum(s);
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) redb[c][threadIdx.x >> 6] = s;
+            __syncthreads();
+            if (threadIdx.x == 0) atomicAdd(a.db + c, (redb[c][0] + redb[c][1] + redb[c][2] + redb[c][3]) * a.gscale);
+        }
+    }
+    for (int tap = 0; tap < kk; ++tap) {
+        const int ky = tap / a.k, kx = tap - ky * a.k;
+        for (int ch = chl; ch < nch; ch += lpu) {       // one trip for Cin <= 2048
+            float acc[4][8];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[c][i] = 0.f;
+            if (pl < lanes) {
+                for (int64_t m = m0 + pl; m < m1; m += lanes) {
+                    const int ox = (int)(m % a.OW);
+                    const int64_t r = m / a.OW;
+                    const int oy = (int)(r % a.OH);
+                    const int n = (int)(r / a.OH);
+                    const int iy = oy * a.stride - a.pad + ky, ix = ox * a.stride - a.pad + kx;
+                    if ((unsigned)iy >= (unsigned)a.IH || (unsigned)ix >= (unsigned)a.IW) continue;
+                    float v[8];
+                    unpack8<DT>(*reinterpret_cast<const uint4*>(a.x + (((int64_t)n * a.IH + iy) * a.IW + ix) * a.Cin + ch * 8), v);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (c < a.Cout) {
+                            const float g = a.dy[(((int64_t)n * a.Cout + c) * a.OH + oy) * a.OW + ox];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) acc[c][i] += g * v[i];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c < a.Cout) {                    // uniform
+                    __syncthreads();
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = acc[c][i];
+                    __syncthreads();
+                    if (pl == 0) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            float s = 0.f;
+                            for (int q = 0; q < lanes; ++q) s += red[q * lpu + chl][i];
+                            atomicAdd(a.dw + ((int64_t)c * a.Cin + ch * 8 + i) * kk + tap, s * a.gscale);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int gs_conv_smallcin_mtiles(int N, int OH, int OW) {
+    return (int)cdiv64((int64_t)N * OH * OW, SC_TILE);
+}
+
+static int check_smallcin(const char* who, int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int k, int stride,
+                          int pad, int dtype) {
+    GS_CHECK_ARG(N > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, "%s: bad dims", who);
+    GS_CHECK_ARG(Cin >= 1 && Cin <= 4, "%s: Cin=%d must be 1..4", who, Cin);
+    GS_CHECK_ARG(Cout % 8 == 0 && Cout >= 8 && 256 % (Cout / 8) == 0, "%s: Cout=%d must be 8*2^j", who, Cout);
+    GS_CHECK_ARG(k >= 1 && stride >= 1 && pad >= 0 && Cin * k * k * Cout <= SC_MAX_W, "%s: weights exceed %d floats", who, SC_MAX_W);
+    GS_CHECK_ARG(OH == (IH + 2 * pad - k) / stride + 1 && OW == (IW + 2 * pad - k) / stride + 1, "%s: output size mismatch", who);
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "%s: bad dtype", who);
+    return GS_OK;
+}
+
+extern "C" int gs_conv_smallcin_fwd(const float* x, const float* w, const float* bias, void* y, float* bn_partials,
+                                    int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int k, int stride,
+                                    int pad, int act, int dtype, void* stream) {
+    int rc = check_smallcin("gs_conv_smallcin_fwd", N, Cin, IH, IW, Cout, OH, OW, k, stride, pad, dtype);
+    if (rc) return rc;
+    GS_CHECK_ARG(x && w && y, "gs_conv_smallcin_fwd: null pointer");
+    GS_CHECK_ARG(!(bias && bn_partials), "gs_conv_smallcin_fwd: BatchNorm partials are taken before the bias; pass only one");
+    SCArgs a{x, w, bias, (unsigned short*)y, bn_partials, N, Cin, IH, IW, Cout, OH, OW, k, stride, pad, act};
+    const int nb = gs_conv_smallcin_mtiles(N, OH, OW);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GS_F16) smallcin_fwd_kernel<GS_F16><<<nb, 256, 0, s>>>(a);
+    else smallcin_fwd_kernel<GS_BF16><<<nb, 256, 0, s>>>(a);
+    GS_CHECK_LAUNCH("gs_conv_smallcin_fwd");
+    return GS_OK;
+}
+
+extern "C" int gs_conv_smallcin_wgrad(const float* x, const void* dy, float* dw, int N, int Cin, int IH, int IW,
+                                      int Cout, int OH, int OW, int k, int stride, int pad, float gscale, int dtype,
+                                      void* stream) {
+    int rc = check_smallcin("gs_conv_smallcin_wgrad", N, Cin, IH, IW, Cout, OH, OW, k, stride, pad, dtype);
+    if (rc) return rc;
+    GS_CHECK_ARG(x && dy && dw, "gs_conv_smallcin_wgrad: null pointer");
+    const int64_t M = (int64_t)N * OH * OW;
+    int64_t ppb = cdiv64(M, 1024);
+    if (ppb < 64) ppb = 64;
+    SCWArgs a{x, (const unsigned short*)dy, dw, N, Cin, IH, IW, Cout, OH, OW, k, stride, pad, gscale, ppb};
+    const int nb = (int)cdiv64(M, ppb);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GS_F16) smallcin_wgrad_kernel<GS_F16><<<nb, 256, 0, s>>>(a);
+    else smallcin_wgrad_kernel<GS_BF16><<<nb, 256, 0, s>>>(a);
+    GS_CHECK_LAUNCH("gs_conv_smallcin_wgrad");
+    return GS_OK;
+}
+
+extern "C" int gs_conv_smallcin_dgrad(const void* dy, const float* w, float* dx, int N, int Cin, int IH, int IW,
+                                      int Cout, int OH, int OW, int k, int stride, int pad, float gscale, int dtype,
+                                      void* stream) {
+    int rc = check_smallcin("gs_conv_smallcin_dgrad", N, Cin, IH, IW, Cout, OH, OW, k, stride, pad, dtype);
+    if (rc) return rc;
+    GS_CHECK_ARG(dy && w && dx, "gs_conv_smallcin_dgrad: null pointer");
+    SCDArgs a{(const unsigned short*)dy, w, dx, N, Cin, IH, IW, Cout, OH, OW, k, stride, pad, gscale};
+    int64_t nb = cdiv64((int64_t)N * IH * IW, 256);
+    if (nb > 4096) nb = 4096;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GS_F16) smallcin_dgrad_kernel<GS_F16><<<(int)nb, 256, 0, s>>>(a);
+    else smallcin_dgrad_kernel<GS_BF16><<<(int)nb, 256, 0, s>>>(a);
+    GS_CHECK_LAUNCH("gs_conv_smallcin_dgrad");
+    return GS_OK;
+}
+
+static int check_head(const char* who, int N, int IH, int IW, int Cin, int Cout, int OH, int OW, int k, int stride,
+                      int pad, int dtype) {
+    GS_CHECK_ARG(N > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, "%s: bad dims", who);
+    GS_CHECK_ARG(Cout >= 1 && Cout <= 4, "%s: Cout=%d must be 1..4", who, Cout);
+    const int nch = Cin / 8;
+    GS_CHECK_ARG(Cin % 8 == 0 && nch >= 1 && (nch & (nch - 1)) == 0 && nch <= 256, "%s: Cin=%d must be 8*2^j <= 2048", who, Cin);
+    GS_CHECK_ARG(k >= 1 && stride >= 1 && pad >= 0 && Cout * k * k * Cin <= SC_MAX_W, "%s: weights exceed %d floats", who, SC_MAX_W);
+    GS_CHECK_ARG(OH == (IH + 2 * pad - k) / stride + 1 && OW == (IW + 2 * pad - k) / stride + 1, "%s: output size mismatch", who);
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "%s: bad dtype", who);
+    return GS_OK;
+}
+
+extern "C" int gs_conv_smallcout_fwd(const void* x, const float* w, const float* bias, float* y, int N, int IH, int IW,
+                                     int Cin, int Cout, int OH, int OW, int k, int stride, int pad, int dtype,
+                                     void* stream) {
+    int rc = check_head("gs_conv_smallcout_fwd", N, IH, IW, Cin, Cout, OH, OW, k, stride, pad, dtype);
+    if (rc) return rc;
+    GS_CHECK_ARG(x && w && y, "gs_conv_smallcout_fwd: null pointer");
+    HArgs a{};
+    a.x = (const unsigned short*)x; a.w = w; a.bias = bias; a.y = y;
+    a.N = N; a.IH = IH; a.IW = IW; a.Cin = Cin; a.Cout = Cout; a.OH = OH; a.OW = OW; a.k = k; a.stride = stride; a.pad = pad;
+    const int nch = Cin / 8, gl = nch < 64 ? nch : 64, groups = 256 / gl;
+    int64_t nb = cdiv64((int64_t)N * OH * OW, groups);
+    if (nb > 8192) nb = 8192;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GS_F16) smallcout_fwd_kernel<GS_F16><<<(int)nb, 256, 0, s>>>(a);
+    else smallcout_fwd_kernel<GS_BF16><<<(int)nb, 256, 0, s>>>(a);
+    GS_CHECK_LAUNCH("gs_conv_smallcout_fwd");
+    return GS_OK;
+}
+
+extern "C" int gs_conv_smallcout_bwd(const void* x, const float* w, const float* dy, void* dx, float* dw, float* db,
+                                     int N, int IH, int IW, int Cin, int Cout, int OH, int OW, int k, int stride,
+                                     int pad, float gscale, int dtype, void* stream) {
+    int rc = check_head("gs_conv_smallcout_bwd", N, IH, IW, Cin, Cout, OH, OW, k, stride, pad, dtype);
+    if (rc) return rc;
+    GS_CHECK_ARG(w && dy, "gs_conv_smallcout_bwd: null pointer");
+    HArgs a{};
+    a.x = (const unsigned short*)x; a.w = w; a.dy = dy; a.dx = (unsigned short*)dx; a.dw = dw; a.db = db;
+    a.N = N; a.IH = IH; a.IW = IW; a.Cin = Cin; a.Cout = Cout; a.OH = OH; a.OW = OW; a.k = k; a.stride = stride; a.pad = pad;
+    a.gscale = gscale;
+    hipStream_t s = (hipStream_t)stream;
+    if (dx) {
+        int64_t nb = cdiv64((int64_t)N * IH * IW * (Cin / 8), 256);
+        if (nb > 8192) nb = 8192;
+        if (dtype == GS_F16) smallcout_dgrad_kernel<GS_F16><<<(int)nb, 256, 0, s>>>(a);
+        else smallcout_dgrad_kernel<GS_BF16><<<(int)nb, 256, 0, s>>>(a);
+    }
+    if (dw) {
+        GS_CHECK_ARG(x != nullptr, "gs_conv_smallcout_bwd: dw needs x");
+        const int64_t M = (int64_t)N * OH * OW;
+        int64_t ppb = cdiv64(M, 1024);
+        if (ppb < 64) ppb = 64;
+        a.pix_per_block = ppb;
+        const int nb = (int)cdiv64(M, ppb);
+        if (dtype == GS_F16) smallcout_wgrad_kernel<GS_F16><<<nb, 256, 0, s>>>(a);
+        else smallcout_wgrad_kernel<GS_BF16><<<nb, 256, 0, s>>>(a);
+    }
+    GS_CHECK_LAUNCH("gs_conv_smallcout_bwd");
+    return GS_OK;
+}

@@ -1,0 +1,473 @@
+// MFMA implicit-GEMM convolution engine for gfx950 (MI355X): forward / data-gradient
+// (gs_conv_igemm) and weight-gradient (gs_conv_wgrad) of any Conv2d / ConvTranspose2d that the
+// GsConvGeom tap-list form can express.
+//
+// Forward:  Y[m][co] = sum_{tap,ci} X[inpix(m,tap)][ci] * W[tap][co][ci]
+//   GEMM view M = N*OHg*OWg pixels, N = Cout, K = ntaps*Cin.  Block tile 128(M) x BN(64|128) x 64(K),
+//   4 waves (2x2), each wave 64 x BN/2 as 32x32x16 MFMA tiles, fp32 accumulate.  A (gathered NHWC rows,
+//   zero outside the image) and B (packed weights) are register-staged into padded LDS rows
+//   (144 B stride: conflict-free ds_read_b128 for the 32x32x16 operand), double buffered, one barrier per
+//   K-step.  Epilogue: bias / activation, 16-bit store, and per-M-tile BatchNorm partial sums.
+// Weight gradient: dW[tap][co][ci] += sum_m dY[m][co] * X[inpix(m,tap)][ci]
+//   GEMM view M = Cout, N = (tap, ci), K = pixels.  Both operands are pixel-major in memory but the
+//   MFMA wants K(=pixel)-minor fragments: tiles are staged as [pixel][channel] and read with the
+//   gfx950 transposing LDS read (ds_read_b64_tr_b16).  Split-K over pixels, fp32 atomics into dW.
+#include "common.hpp"
+
+namespace {
+
+struct IgemmArgs {
+    GsConvGeom g;
+    const unsigned short* x;
+    const unsigned short* w;
+    unsigned short* y;
+    const float* bias;
+    float* bnp;
+    int act;
+    int M;        // N*OHg*OWg
+    int kchunks;  // ceil(Cin/64)
+    int ntn;      // number of N tiles
+    int nblocks;
+};
+
+// bijective XCD-aware remap: blocks that share an XCD (bid % 8) get a contiguous range of logical ids
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+constexpr int FW_BM = 128, FW_BK = 64, FW_LDR = 72;   // LDS row = 64 + 8 pad elements (144 B)
+
+template <int DT, int BN>
+__global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
+    typedef typename Elem<DT>::V8 V8;
+    constexpr int NT = BN / 64;            // 32-wide N tiles per wave
+    constexpr int BROWS = BN / 32;         // B rows staged per thread
+    constexpr int A_EL = FW_BM * FW_LDR, B_EL = BN * FW_LDR;
+    constexpr int BUF_EL = A_EL + B_EL;
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BUF_EL];
+
+    const GsConvGeom& g = a.g;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const int lid = xcd_remap(blockIdx.x, a.nblocks);
+    const int ntile = lid % a.ntn, mtile = lid / a.ntn;
+    const int m0 = mtile * FW_BM, n0 = ntile * BN;
+
+    // ---- per-thread staging rows ----
+    const int chunk = t & 7, rbase = t >> 3;
+    int a_iy0[4], a_ix0[4], a_n[4];
+    const int ohw = g.OHg * g.OWg;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + rbase + 32 * j;
+        if (m < a.M) {
+            const int n = m / ohw, rem = m - n * ohw;
+            const int oy = rem / g.OWg, ox = rem - oy * g.OWg;
+            a_n[j] = n; a_iy0[j] = oy * g.isy; a_ix0[j] = ox * g.isx;
+        } else {
+            a_n[j] = -1; a_iy0[j] = 0; a_ix0[j] = 0;
+        }
+    }
+    uint4 ra[4], rb[BROWS];
+    const int nk = g.ntaps * a.kchunks;
+
+    auto load_tile = [&](int ks) {
+        const int tap = ks / a.kchunks, cc = ks - tap * a.kchunks;
+        const int ci = cc * FW_BK + chunk * 8;
+        const int dy = g.tap_dy[tap], dx = g.tap_dx[tap];
+        const bool cok = ci < g.Cin;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
+            const bool ok = cok && a_n[j] >= 0 && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                const int64_t pix = ((int64_t)a_n[j] * g.IH + iy) * g.IW + ix;
+                v = *reinterpret_cast<const uint4*>(a.x + pix * g.in_pix_stride + g.in_coff + ci);
+            }
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < BROWS; ++j) {
+            const int co = n0 + rbase + 32 * j;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (cok && co < g.Cout)
+                v = *reinterpret_cast<const uint4*>(a.w + ((int64_t)tap * g.Cout + co) * g.Cin + ci);
+            rb[j] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned short* A = smem + buf * BUF_EL;
+        unsigned short* B = A + A_EL;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<uint4*>(A + (rbase + 32 * j) * FW_LDR + chunk * 8) = ra[j];
+#pragma unroll
+        for (int j = 0; j < BROWS; ++j)
+            *reinterpret_cast<uint4*>(B + (rbase + 32 * j) * FW_LDR + chunk * 8) = rb[j];
+    };
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < nk) load_tile(ks + 1);
+        const unsigned short* A = smem + cur * BUF_EL + (wm * 64 + l31) * FW_LDR + h * 8;
+        const unsigned short* B = smem + cur * BUF_EL + A_EL + (wn * (BN / 2) + l31) * FW_LDR + h * 8;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            V8 af[2], bf[NT];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const V8*>(A + i * 32 * FW_LDR + kk * 16);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const V8*>(B + j * 32 * FW_LDR + kk * 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = Elem<DT>::mfma32(af[i], bf[j], acc[i][j]);
+        }
+        if (ks + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: row table (output pixel index per tile row), stores, BN partial sums ----
+    int* rowpix = reinterpret_cast<int*>(smem);                       // 128 ints
+    float* red = reinterpret_cast<float*>(smem) + 128;                // [2 wm][2 stat][BN] floats
+    if (t < FW_BM) {
+        const int m = m0 + t;
+        int p = -1;
+        if (m < a.M) {
+            const int n = m / ohw, rem = m - n * ohw;
+            const int oy = rem / g.OWg, ox = rem - oy * g.OWg;
+            p = (n * g.OH + oy * g.osy + g.ooy) * g.OW + ox * g.osx + g.oox;
+        }
+        rowpix[t] = p;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int co = n0 + wn * (BN / 2) + j * 32 + l31;
+        const bool cok = co < g.Cout;
+        const float bv = (a.bias != nullptr && cok) ? a.bias[co] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[i][j][r];
+                s1 += v;
+                s2 += v * v;
+                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int p = rowpix[row];
+                if (cok && p >= 0)
+                    a.y[(int64_t)p * g.out_pix_stride + g.out_coff + co] = Elem<DT>::from_f(act_fwd(v + bv, a.act));
+            }
+        }
+        if (a.bnp != nullptr) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (h == 0) {
+                const int c = wn * (BN / 2) + j * 32 + l31;
+                red[(wm * 2 + 0) * BN + c] = s1;
+                red[(wm * 2 + 1) * BN + c] = s2;
+            }
+        }
+    }
+    if (a.bnp != nullptr) {
+        __syncthreads();
+        if (t < BN && n0 + t < g.Cout) {
+            float* dst = a.bnp + (int64_t)mtile * 2 * g.Cout + n0 + t;
+            dst[0] = red[(0 * 2 + 0) * BN + t] + red[(1 * 2 + 0) * BN + t];
+            dst[g.Cout] = red[(0 * 2 + 1) * BN + t] + red[(1 * 2 + 1) * BN + t];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    GsConvGeom g;
+    const unsigned short* x;
+    const unsigned short* dy;
+    float* dw;
+    int M;         // logical pixels N*OHg*OWg
+    int kchunks;   // ceil(Cin/64)
+    int ncb;       // ntaps*kchunks column blocks
+    int n_cotiles, n_cbgroups, ksplit;
+    int kper;      // pixels per K split (multiple of 64)
+    int d_n, d_oy, d_ox;   // mixed-radix decomposition of 64 pixels
+};
+
+constexpr int WG_KP = 64;   // pixels per K step
+
+// WR = wave rows: 2 -> block tile 128 co x 2 column blocks; 1 -> 64 co x 4 column blocks
+template <int DT, int WR>
+__global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs a) {
+    typedef typename Elem<DT>::V8 V8;
+    constexpr int WC = 4 / WR;                 // column blocks per block (= wave columns)
+    constexpr int BCO = 64 * WR;
+    constexpr int DY_LDR = BCO + 32;           // 320 B / 192 B rows: conflict-free transposed reads
+    constexpr int X_LDR = 64 + 32;
+    constexpr int DY_EL = WG_KP * DY_LDR, X_EL = WG_KP * X_LDR;
+    constexpr int DY_CH = BCO / 8;             // 16-byte chunks per dY row
+    constexpr int DY_PER_T = WG_KP * DY_CH / 256;
+    constexpr int DY_ROWS_STEP = 256 / DY_CH;
+    __shared__ __attribute__((aligned(16))) unsigned short smem[DY_EL + WC * X_EL];
+
+    const GsConvGeom& g = a.g;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = (WR == 2) ? (wave >> 1) : 0;
+    const int wn = (WR == 2) ? (wave & 1) : wave;
+    int bid = blockIdx.x;
+    const int cot = bid % a.n_cotiles; bid /= a.n_cotiles;
+    const int cbg = bid % a.n_cbgroups; bid /= a.n_cbgroups;
+    const int ks_id = bid;
+    const int co0 = cot * BCO;
+    const int kbeg = ks_id * a.kper;
+    const int kend = min(a.M, kbeg + a.kper);
+    const int ohw = g.OHg * g.OWg;
+
+    // column blocks of this block
+    int cb_tap[WC], cb_ci0[WC];
+#pragma unroll
+    for (int c = 0; c < WC; ++c) {
+        const int cb = cbg * WC + c;
+        if (cb < a.ncb) { cb_tap[c] = cb / a.kchunks; cb_ci0[c] = (cb - cb_tap[c] * a.kchunks) * 64; }
+        else { cb_tap[c] = -1; cb_ci0[c] = 0; }
+    }
+
+    // ---- staging rows of this thread: dY rows and X rows, tracked as (n, oy, ox) and advanced by 64 ----
+    const int dy_chunk = t % DY_CH, dy_row0 = t / DY_CH;
+    const int x_chunk = t & 7, x_row0 = t >> 3;
+    int dn[DY_PER_T], doy[DY_PER_T], dox[DY_PER_T], dm[DY_PER_T];
+    int xn[2], xoy[2], xox[2], xm[2];
+    auto decode = [&](int m, int& n, int& oy, int& ox) {
+        n = m / ohw; const int rem = m - n * ohw; oy = rem / g.OWg; ox = rem - oy * g.OWg;
+    };
+#pragma unroll
+    for (int j = 0; j < DY_PER_T; ++j) { dm[j] = kbeg + dy_row0 + DY_ROWS_STEP * j; decode(dm[j], dn[j], doy[j], dox[j]); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { xm[j] = kbeg + x_row0 + 32 * j; decode(xm[j], xn[j], xoy[j], xox[j]); }
+    auto advance = [&](int& m, int& n, int& oy, int& ox) {
+        m += WG_KP;
+        ox += a.d_ox; if (ox >= g.OWg) { ox -= g.OWg; oy += 1; }
+        oy += a.d_oy; if (oy >= g.OHg) { oy -= g.OHg; n += 1; }
+        n += a.d_n;
+    };
+
+    uint4 rdy[DY_PER_T], rx[WC][2];
+    auto load_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < DY_PER_T; ++j) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            const int co = co0 + dy_chunk * 8;
+            if (dm[j] < kend && co < g.Cout) {
+                const int64_t pix = ((int64_t)dn[j] * g.OH + doy[j] * g.osy + g.ooy) * g.OW + dox[j] * g.osx + g.oox;
+                v = *reinterpret_cast<const uint4*>(a.dy + pix * g.out_pix_stride + g.out_coff + co);
+            }
+            rdy[j] = v;
+        }
+#pragma unroll
+        for (int c = 0; c < WC; ++c) {
+            const int tap = cb_tap[c];
+            const int ci = cb_ci0[c] + x_chunk * 8;
+            const int tdy = tap >= 0 ? g.tap_dy[tap] : 0, tdx = tap >= 0 ? g.tap_dx[tap] : 0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                const int iy = xoy[j] * g.isy + tdy, ix = xox[j] * g.isx + tdx;
+                if (tap >= 0 && xm[j] < kend && ci < g.Cin && (unsigned)iy < (unsigned)g.IH &&
+                    (unsigned)ix < (unsigned)g.IW) {
+                    const int64_t pix = ((int64_t)xn[j] * g.IH + iy) * g.IW + ix;
+                    v = *reinterpret_cast<const uint4*>(a.x + pix * g.in_pix_stride + g.in_coff + ci);
+                }
+                rx[c][j] = v;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < DY_PER_T; ++j) advance(dm[j], dn[j], doy[j], dox[j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) advance(xm[j], xn[j], xoy[j], xox[j]);
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < DY_PER_T; ++j)
+            *reinterpret_cast<uint4*>(smem + (dy_row0 + DY_ROWS_STEP * j) * DY_LDR + dy_chunk * 8) = rdy[j];
+#pragma unroll
+        for (int c = 0; c < WC; ++c)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                *reinterpret_cast<uint4*>(smem + DY_EL + c * X_EL + (x_row0 + 32 * j) * X_LDR + x_chunk * 8) = rx[c][j];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposed-read lane addressing (ds_read_b64_tr_b16): 16-lane group G = lane>>4 covers channels
+    // 16*(G&1)..+15 and k (pixel) rows 8*(G>>1) + 4*r + q;  lane 4q+p supplies row q, channels 4p..4p+3.
+    const int G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int krow = 8 * (G >> 1) + q;
+    const int chn = 16 * (G & 1) + 4 * p;
+    const LDS_AS unsigned short* lds = (const LDS_AS unsigned short*)smem;
+    const LDS_AS unsigned short* a_base = lds + krow * DY_LDR + wm * 64 + chn;
+    const LDS_AS unsigned short* b_base = lds + DY_EL + wn * X_EL + krow * X_LDR + chn;
+
+    const int nsteps = (kend - kbeg + WG_KP - 1) / WG_KP;
+    if (nsteps > 0) load_tile();
+    for (int s = 0; s < nsteps; ++s) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (s + 1 < nsteps) load_tile();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            V8 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                af[i] = tr_read8<DT>(a_base + (kk * 16) * DY_LDR + i * 32, a_base + (kk * 16 + 4) * DY_LDR + i * 32);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bf[j] = tr_read8<DT>(b_base + (kk * 16) * X_LDR + j * 32, b_base + (kk * 16 + 4) * X_LDR + j * 32);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = Elem<DT>::mfma32(af[i], bf[j], acc[i][j]);
+        }
+    }
+
+    // ---- epilogue: fp32 atomics into dW[tap][co][ci] ----
+    const int tap = cb_tap[wn];
+    if (tap < 0 || nsteps <= 0) return;
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ci = cb_ci0[wn] + j * 32 + l31;
+            if (ci >= g.Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (co < g.Cout) atomicAdd(a.dw + ((int64_t)tap * g.Cout + co) * g.Cin + ci, acc[i][j][r]);
+            }
+        }
+}
+
+int check_geom(const GsConvGeom* g, const char* who) {
+    GS_CHECK_ARG(g != nullptr, "%s: null geometry", who);
+    GS_CHECK_ARG(g->N > 0 && g->IH > 0 && g->IW > 0 && g->OHg > 0 && g->OWg > 0 && g->OH > 0 && g->OW > 0,
+                 "%s: non-positive dims", who);
+    GS_CHECK_ARG(g->Cin > 0 && g->Cin % 8 == 0, "%s: Cin=%d must be a positive multiple of 8", who, g->Cin);
+    GS_CHECK_ARG(g->Cout > 0, "%s: Cout=%d", who, g->Cout);
+    GS_CHECK_ARG(g->ntaps > 0 && g->ntaps <= GS_MAX_TAPS, "%s: ntaps=%d out of range", who, g->ntaps);
+    GS_CHECK_ARG(g->in_pix_stride >= g->in_coff + g->Cin && g->in_pix_stride % 8 == 0 && g->in_coff % 8 == 0,
+                 "%s: input stride/offset (%d,%d) must cover Cin=%d and be multiples of 8", who, g->in_pix_stride,
+                 g->in_coff, g->Cin);
+    GS_CHECK_ARG(g->out_pix_stride >= g->out_coff + g->Cout, "%s: output stride %d < coff %d + Cout %d", who,
+                 g->out_pix_stride, g->out_coff, g->Cout);
+    GS_CHECK_ARG(g->isy > 0 && g->isx > 0 && g->osy > 0 && g->osx > 0 && g->ooy >= 0 && g->oox >= 0,
+                 "%s: bad steps/offsets", who);
+    GS_CHECK_ARG((int64_t)(g->OHg - 1) * g->osy + g->ooy < g->OH && (int64_t)(g->OWg - 1) * g->osx + g->oox < g->OW,
+                 "%s: logical output grid exceeds the physical output tensor", who);
+    GS_CHECK_ARG((int64_t)g->N * g->OHg * g->OWg < (int64_t)2147483000 &&
+                     (int64_t)g->N * g->OH * g->OW < (int64_t)2147483000 &&
+                     (int64_t)g->N * g->IH * g->IW < (int64_t)2147483000,
+                 "%s: pixel count exceeds int32", who);
+    return GS_OK;
+}
+
+}  // namespace
+
+extern "C" int gs_conv_igemm_mtiles(const GsConvGeom* g) {
+    if (!g) return GS_EINVAL;
+    return (int)cdiv64((int64_t)g->N * g->OHg * g->OWg, FW_BM);
+}
+
+extern "C" int gs_conv_igemm(const GsConvGeom* g, const void* x, const void* w, void* y, const float* bias,
+                             float* bn_partials, int act, int dtype, void* stream) {
+    int rc = check_geom(g, "gs_conv_igemm");
+    if (rc) return rc;
+    GS_CHECK_ARG(x && w && y, "gs_conv_igemm: null pointer");
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_conv_igemm: bad dtype %d", dtype);
+    IgemmArgs a;
+    a.g = *g;
+    a.x = (const unsigned short*)x; a.w = (const unsigned short*)w; a.y = (unsigned short*)y;
+    a.bias = bias; a.bnp = bn_partials; a.act = act;
+    a.M = g->N * g->OHg * g->OWg;
+    a.kchunks = cdiv(g->Cin, FW_BK);
+    const int bn = (g->Cout <= 64) ? 64 : 128;
+    a.ntn = cdiv(g->Cout, bn);
+    const int mt = cdiv(a.M, FW_BM);
+    a.nblocks = mt * a.ntn;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(a.nblocks), block(256);
+    if (dtype == GS_F16) {
+        if (bn == 64) igemm_fwd_kernel<GS_F16, 64><<<grid, block, 0, s>>>(a);
+        else igemm_fwd_kernel<GS_F16, 128><<<grid, block, 0, s>>>(a);
+    } else {
+        if (bn == 64) igemm_fwd_kernel<GS_BF16, 64><<<grid, block, 0, s>>>(a);
+        else igemm_fwd_kernel<GS_BF16, 128><<<grid, block, 0, s>>>(a);
+    }
+    GS_CHECK_LAUNCH("gs_conv_igemm");
+    return GS_OK;
+}
+
+extern "C" int gs_conv_wgrad(const GsConvGeom* g, const void* x, const void* dy, float* dw, int dtype,
+                             void* stream) {
+    int rc = check_geom(g, "gs_conv_wgrad");
+    if (rc) return rc;
+    GS_CHECK_ARG(x && dy && dw, "gs_conv_wgrad: null pointer");
+    GS_CHECK_ARG(g->Cout % 8 == 0 && g->out_pix_stride % 8 == 0 && g->out_coff % 8 == 0,
+                 "gs_conv_wgrad: Cout/out stride/offset must be multiples of 8");
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_conv_wgrad: bad dtype %d", dtype);
+    WgradArgs a;
+    a.g = *g;
+    a.x = (const unsigned short*)x; a.dy = (const unsigned short*)dy; a.dw = dw;
+    a.M = g->N * g->OHg * g->OWg;
+    a.kchunks = cdiv(g->Cin, 64);
+    a.ncb = g->ntaps * a.kchunks;
+    const int wr = (g->Cout <= 64) ? 1 : 2;
+    const int wc = 4 / wr;
+    a.n_cotiles = cdiv(g->Cout, 64 * wr);
+    a.n_cbgroups = cdiv(a.ncb, wc);
+    const int base_blocks = a.n_cotiles * a.n_cbgroups;
+    const int ksteps = cdiv(a.M, WG_KP);
+    int ksplit = cdiv(1024, base_blocks);           // aim at >= ~1024 blocks (4 per CU)
+    if (ksplit > ksteps) ksplit = ksteps;
+    if (ksplit < 1) ksplit = 1;
+    a.kper = cdiv(ksteps, ksplit) * WG_KP;
+    a.ksplit = cdiv(a.M, a.kper);
+    const int ohw = g->OHg * g->OWg;
+    a.d_n = WG_KP / ohw;
+    const int rem = WG_KP - a.d_n * ohw;
+    a.d_oy = rem / g->OWg;
+    a.d_ox = rem - a.d_oy * g->OWg;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(base_blocks * a.ksplit), block(256);
+    if (dtype == GS_F16) {
+        if (wr == 1) igemm_wgrad_kernel<GS_F16, 1><<<grid, block, 0, s>>>(a);
+        else igemm_wgrad_kernel<GS_F16, 2><<<grid, block, 0, s>>>(a);
+    } else {
+        if (wr == 1) igemm_wgrad_kernel<GS_BF16, 1><<<grid, block, 0, s>>>(a);
+        else igemm_wgrad_kernel<GS_BF16, 2><<<grid, block, 0, s>>>(a);
+    }
+    GS_CHECK_LAUNCH("gs_conv_wgrad");
+    return GS_OK;
+}

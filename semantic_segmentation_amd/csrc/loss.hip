@@ -1,0 +1,291 @@
+// Loss heads: fused BCE/CE + global-batch Dice (one pass over the logits), generic dice_loss, and the
+// mean-reduced GAN / L1 / BCE losses.  All HBM-bound single-pass reductions: per-thread fp32 partials ->
+// wave shuffle -> block -> fixed [<=1024 blocks] slab -> one finalising block in double (deterministic).
+// Reference: running_files/train_end2end_jsrt.py:136-138,181-183; util/dice_score.py:5-28;
+//            models_pix2pix/networks.py:263-281.
+#include "common.hpp"
+
+namespace {
+
+constexpr int LOSS_MAX_BLOCKS = 1024;
+constexpr float DICE_EPS = 1e-6f;
+
+__device__ __forceinline__ float softplus_neg_abs(float x) { return log1pf(expf(-fabsf(x))); }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// writes NS block sums to ws[s*LOSS_MAX_BLOCKS + blockIdx.x]
+template <int NS>
+__device__ __forceinline__ void block_store_sums(float (&v)[NS], float* ws) {
+    __shared__ float red[NS][4];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) v[s] = wave_sum(v[s]);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) red[s][w] = v[s];
+    }
+    __syncthreads();
+    if (threadIdx.x < NS) ws[threadIdx.x * LOSS_MAX_BLOCKS + blockIdx.x] =
+        red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+
+// sum of ws[s][0..nb) in double, by one block of 256 threads; result broadcast
+__device__ __forceinline__ double final_sum(const float* ws, int s, int nb, double* red) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) v += (double)ws[s * LOSS_MAX_BLOCKS + i];
+    __syncthreads();
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    return red[0];
+}
+
+// ---- segmentation loss ---------------------------------------------------------------------------
+// sums: 0 = sum ce/bce, 1 = sum p*t, 2 = sum p, 3 = sum t
+__global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ m,
+                                                           int N, int C, int64_t HW, float* ws) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    const int64_t total = (int64_t)N * HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int t = m[i];
+        if (C == 1) {
+            const float v = x[i];
+            const float tf = (float)t;
+            s[0] += fmaxf(v, 0.f) - v * tf + softplus_neg_abs(v);
+            const float p = sigmoidf_(v);
+            s[1] += p * tf; s[2] += p; s[3] += tf;
+        } else {
+            const int64_t n = i / HW, hw = i - n * HW;
+            const float* xp = x + n * C * HW + hw;
+            float mx = -INFINITY;
+            for (int c = 0; c < C; ++c) mx = fmaxf(mx, xp[(int64_t)c * HW]);
+            float den = 0.f, xt = 0.f;
+            for (int c = 0; c < C; ++c) {
+                const float v = xp[(int64_t)c * HW];
+                den += expf(v - mx);
+                if (c == t) xt = v;
+            }
+            const float lse = mx + logf(den);
+            s[0] += lse - xt;
+            s[1] += expf(xt - lse);     // p_t = sum_c p_c * onehot_c
+            s[2] += 1.f;                // sum_c p_c
+            s[3] += 1.f;                // sum_c onehot_c
+        }
+    }
+    block_store_sums<4>(s, ws);
+}
+
+__global__ __launch_bounds__(256) void seg_loss_finalize_kernel(const float* ws, int nb, double npix, float* out) {
+    __shared__ double red[256];
+    const double ce = final_sum(ws, 0, nb, red);
+    const double spt = final_sum(ws, 1, nb, red);
+    const double sp = final_sum(ws, 2, nb, red);
+    const double st = final_sum(ws, 3, nb, red);
+    if (threadIdx.x == 0) {
+        // dice_score.py:12-17 in fp32 like the reference
+        const float inter = 2.f * (float)spt;
+        float sets = (float)sp + (float)st;
+        if (sets == 0.f) sets = inter;
+        const float dice = (inter + DICE_EPS) / (sets + DICE_EPS);
+        const float l_ce = (float)(ce / npix);
+        out[0] = l_ce + (1.f - dice);
+        out[1] = l_ce;
+        out[2] = 1.f - dice;
+        out[3] = inter;
+        out[4] = (float)sp;
+        out[5] = (float)st;
+    }
+}
+
+__global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ m,
+                                                           const float* __restrict__ out, const float* gout, float gscale,
+                                                           float* __restrict__ dx, int N, int C, int64_t HW) {
+    const int64_t total = (int64_t)N * HW;
+    const float g = (gout ? gout[0] : 1.f) * gscale;
+    const float inter = out[3], sp = out[4], st = out[5];
+    const float S = sp + st;
+    const bool degenerate = (S == 0.f);               // torch.where(sets_sum == 0, inter, sets_sum): dice == 1, grad 0
+    const float den = (S + DICE_EPS), inv2 = 1.f / (den * den);
+    const float inv_m = 1.f / (float)total;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int t = m[i];
+        if (C == 1) {
+            const float v = x[i], tf = (float)t;
+            const float p = sigmoidf_(v);
+            // d(1-dice)/dp = -(2 t (S+eps) - (I+eps)) / (S+eps)^2
+            const float gd = degenerate ? 0.f : -(2.f * tf * den - (inter + DICE_EPS)) * inv2;
+            dx[i] = g * ((p - tf) * inv_m + gd * p * (1.f - p));
+        } else {
+            const int64_t n = i / HW, hw = i - n * HW;
+            const float* xp = x + n * C * HW + hw;
+            float* dp = dx + n * C * HW + hw;
+            float mx = -INFINITY;
+            for (int c = 0; c < C; ++c) mx = fmaxf(mx, xp[(int64_t)c * HW]);
+            float dsum = 0.f;
+            for (int c = 0; c < C; ++c) dsum += expf(xp[(int64_t)c * HW] - mx);
+            const float rden = 1.f / dsum;
+            // g_c = d(1-dice)/dp_c ; softmax backward dx_c = p_c (g_c - sum_k p_k g_k)
+            const float g1 = degenerate ? 0.f : -(2.f * den - (inter + DICE_EPS)) * inv2;   // onehot = 1
+            const float g0 = degenerate ? 0.f : (inter + DICE_EPS) * inv2;                  // onehot = 0
+            float pt = 0.f;
+            for (int c = 0; c < C; ++c) if (c == t) pt = expf(xp[(int64_t)c * HW] - mx) * rden;
+            const float dot = pt * g1 + (1.f - pt) * g0;
+            for (int c = 0; c < C; ++c) {
+                const float p = expf(xp[(int64_t)c * HW] - mx) * rden;
+                const float oh = (c == t) ? 1.f : 0.f;
+                dp[(int64_t)c * HW] = g * ((p - oh) * inv_m + p * ((c == t ? g1 : g0) - dot));
+            }
+        }
+    }
+}
+
+// ---- generic dice_loss ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dice_fwd_kernel(const float* __restrict__ p, const float* __restrict__ t,
+                                                       int64_t n, float* ws) {
+    float s[3] = {0.f, 0.f, 0.f};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float a = p[i], b = t[i];
+        s[0] += a * b; s[1] += a; s[2] += b;
+    }
+    block_store_sums<3>(s, ws);
+}
+__global__ __launch_bounds__(256) void dice_finalize_kernel(const float* ws, int nb, float* out) {
+    __shared__ double red[256];
+    const double spt = final_sum(ws, 0, nb, red);
+    const double sp = final_sum(ws, 1, nb, red);
+    const double st = final_sum(ws, 2, nb, red);
+    if (threadIdx.x == 0) {
+        const float inter = 2.f * (float)spt;
+        float sets = (float)sp + (float)st;
+        if (sets == 0.f) sets = inter;
+        out[0] = 1.f - (inter + DICE_EPS) / (sets + DICE_EPS);
+        out[1] = inter; out[2] = (float)sp; out[3] = (float)st;
+    }
+}
+__global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__ t, const float* __restrict__ out,
+                                                       const float* gout, float* __restrict__ dp, int64_t n) {
+    const float g = gout ? gout[0] : 1.f;
+    const float inter = out[1], S = out[2] + out[3];
+    const bool degenerate = (S == 0.f);
+    const float den = S + DICE_EPS, inv2 = 1.f / (den * den);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        dp[i] = degenerate ? 0.f : -g * (2.f * t[i] * den - (inter + DICE_EPS)) * inv2;
+}
+
+// ---- mean-reduced elementwise losses -------------------------------------------------------------
+__device__ __forceinline__ float mean_loss_term(float x, float t, float cval, int mode) {
+    switch (mode) {
+        case 0: return fmaxf(x, 0.f) - x * cval + softplus_neg_abs(x);
+        case 1: return (x - cval) * (x - cval);
+        case 2: return x * cval;
+        case 3: return fabsf(x - t);
+        default: return fmaxf(x, 0.f) - x * t + softplus_neg_abs(x);
+    }
+}
+__device__ __forceinline__ float mean_loss_grad(float x, float t, float cval, int mode) {
+    switch (mode) {
+        case 0: return sigmoidf_(x) - cval;
+        case 1: return 2.f * (x - cval);
+        case 2: return cval;
+        case 3: return x > t ? 1.f : (x < t ? -1.f : 0.f);     // torch sign(): 0 at equality
+        default: return sigmoidf_(x) - t;
+    }
+}
+__global__ __launch_bounds__(256) void mean_loss_fwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                            float cval, int mode, int64_t n, float* ws) {
+    float s[1] = {0.f};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        s[0] += mean_loss_term(x[i], t ? t[i] : 0.f, cval, mode);
+    block_store_sums<1>(s, ws);
+}
+__global__ __launch_bounds__(256) void mean_loss_finalize_kernel(const float* ws, int nb, double n, float* out) {
+    __shared__ double red[256];
+    const double s = final_sum(ws, 0, nb, red);
+    if (threadIdx.x == 0) out[0] = (float)(s / n);
+}
+__global__ __launch_bounds__(256) void mean_loss_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                            float cval, int mode, int64_t n, const float* gout,
+                                                            float gscale, float* __restrict__ dx) {
+    const float g = (gout ? gout[0] : 1.f) * gscale / (float)n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        dx[i] = g * mean_loss_grad(x[i], t ? t[i] : 0.f, cval, mode);
+}
+
+inline int loss_blocks(int64_t n) {
+    int64_t b = cdiv64(n, 256 * 4);
+    if (b < 1) b = 1;
+    if (b > LOSS_MAX_BLOCKS) b = LOSS_MAX_BLOCKS;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int gs_seg_loss_fwd(const float* logits, const uint8_t* mask, int N, int C, int H, int W, float* ws,
+                               float* out, void* stream) {
+    GS_CHECK_ARG(logits && mask && ws && out && N > 0 && C > 0 && C <= 64 && H > 0 && W > 0, "gs_seg_loss_fwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t npix = (int64_t)N * H * W;
+    const int nb = loss_blocks(npix);
+    seg_loss_fwd_kernel<<<nb, 256, 0, s>>>(logits, mask, N, C, (int64_t)H * W, ws);
+    seg_loss_finalize_kernel<<<1, 256, 0, s>>>(ws, nb, (double)npix, out);
+    GS_CHECK_LAUNCH("gs_seg_loss_fwd");
+    return GS_OK;
+}
+
+extern "C" int gs_seg_loss_bwd(const float* logits, const uint8_t* mask, const float* out, const float* gout,
+                               float gscale, float* dlogits, int N, int C, int H, int W, void* stream) {
+    GS_CHECK_ARG(logits && mask && out && dlogits && N > 0 && C > 0 && H > 0 && W > 0, "gs_seg_loss_bwd: bad arguments");
+    const int64_t npix = (int64_t)N * H * W;
+    int64_t nb = cdiv64(npix, 256);
+    if (nb > 4096) nb = 4096;
+    seg_loss_bwd_kernel<<<(int)nb, 256, 0, (hipStream_t)stream>>>(logits, mask, out, gout, gscale, dlogits, N, C,
+                                                                 (int64_t)H * W);
+    GS_CHECK_LAUNCH("gs_seg_loss_bwd");
+    return GS_OK;
+}
+
+extern "C" int gs_dice_loss_fwd(const float* p, const float* t, int64_t n, float* ws, float* out, void* stream) {
+    GS_CHECK_ARG(p && t && ws && out && n > 0, "gs_dice_loss_fwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = loss_blocks(n);
+    dice_fwd_kernel<<<nb, 256, 0, s>>>(p, t, n, ws);
+    dice_finalize_kernel<<<1, 256, 0, s>>>(ws, nb, out);
+    GS_CHECK_LAUNCH("gs_dice_loss_fwd");
+    return GS_OK;
+}
+
+extern "C" int gs_dice_loss_bwd(const float* t, const float* out, const float* gout, float* dp, int64_t n,
+                                void* stream) {
+    GS_CHECK_ARG(t && out && dp && n > 0, "gs_dice_loss_bwd: bad arguments");
+    int64_t nb = cdiv64(n, 256);
+    if (nb > 4096) nb = 4096;
+    dice_bwd_kernel<<<(int)nb, 256, 0, (hipStream_t)stream>>>(t, out, gout, dp, n);
+    GS_CHECK_LAUNCH("gs_dice_loss_bwd");
+    return GS_OK;
+}
+
+extern "C" int gs_mean_loss_fwd(const float* x, const float* t, float cval, int mode, int64_t n, float* ws,
+                                float* out, void* stream) {
+    GS_CHECK_ARG(x && ws && out && n > 0 && mode >= 0 && mode <= 4, "gs_mean_loss_fwd: bad arguments");
+    GS_CHECK_ARG(mode < 3 || t, "gs_mean_loss_fwd: mode %d needs a target tensor", mode);
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = loss_blocks(n);
+    mean_loss_fwd_kernel<<<nb, 256, 0, s>>>(x, t, cval, mode, n, ws);
+    mean_loss_finalize_kernel<<<1, 256, 0, s>>>(ws, nb, (double)n, out);
+    GS_CHECK_LAUNCH("gs_mean_loss_fwd");
+    return GS_OK;
+}
+
+extern "C" int gs_mean_loss_bwd(const float* x, const float* t, float cval, int mode, int64_t n, const float* gout,
+                                float gscale, float* dx, void* stream) {
+    GS_CHECK_ARG(x && dx && n > 0 && mode >= 0 && mode <= 4, "gs_mean_loss_bwd: bad arguments");
+    GS_CHECK_ARG(mode < 3 || t, "gs_mean_loss_bwd: mode %d needs a target tensor", mode);
+    int64_t nb = cdiv64(n, 256);
+    if (nb > 4096) nb = 4096;
+    mean_loss_bwd_kernel<<<(int)nb, 256, 0, (hipStream_t)stream>>>(x, t, cval, mode, n, gout, gscale, dx);
+    GS_CHECK_LAUNCH("gs_mean_loss_bwd");
+    return GS_OK;
+}

@@ -1,0 +1,115 @@
+"""Loss heads on the HIP kernels (csrc/loss.hip), as autograd Functions.
+
+seg_loss            fused single-pass  BCEWithLogits + Dice (n_classes == 1)  or  CrossEntropy + multiclass
+                    Dice (n_classes > 1): the per-step loss of running_files/train_end2end_jsrt.py:181-183.
+dice_loss_op        util/dice_score.py:25-28 (one global sum over the batch).
+mean_loss           GANLoss (networks.py:263-281), L1Loss and BCEWithLogits (train_end2end_jsrt.py:136-138).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+def _ws(dev):
+    return torch.empty(ops.LOSS_WS, dtype=torch.float32, device=dev)
+
+
+class _SegLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, mask_u8):
+        logits = logits.contiguous().float()
+        out = torch.empty(8, dtype=torch.float32, device=logits.device)
+        ops.seg_loss_fwd(logits, mask_u8, _ws(logits.device), out)
+        ctx.save_for_backward(logits, mask_u8, out)
+        return out[0].clone(), out.detach()
+
+    @staticmethod
+    def backward(ctx, gout, _gparts):
+        logits, mask_u8, out = ctx.saved_tensors
+        d = torch.empty_like(logits)
+        ops.seg_loss_bwd(logits, mask_u8, out, gout.contiguous().float().reshape(1), 1.0, d)
+        return d, None
+
+
+def _mask_u8(mask: torch.Tensor, n: int, h: int, w: int) -> torch.Tensor:
+    if mask.dim() == 4:
+        if mask.shape[1] != 1:
+            raise ValueError("mask must be [N,1,H,W] or [N,H,W] class indices")
+        mask = mask[:, 0]
+    if tuple(mask.shape) != (n, h, w):
+        raise ValueError(f"mask shape {tuple(mask.shape)} does not match logits [{n},*,{h},{w}]")
+    return mask.to(torch.uint8).contiguous()
+
+
+def seg_loss(logits: torch.Tensor, mask: torch.Tensor, return_parts: bool = False):
+    """loss = criterion(logits, mask) + dice_loss(prob(logits), mask) in one pass over the logits.
+
+    logits fp32 [N,C,H,W]; mask integer class indices ([N,1,H,W] or [N,H,W]; {0,1} when C == 1).
+    parts = [loss, ce_or_bce, dice_loss, 2*sum(p t), sum p, sum t, -, -] (device tensor)."""
+    n, c, h, w = logits.shape
+    loss, parts = _SegLoss.apply(logits, _mask_u8(mask, n, h, w))
+    return (loss, parts) if return_parts else loss
+
+
+class _DiceLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, target):
+        inp = inp.contiguous().float()
+        target = target.contiguous().float()
+        out = torch.empty(4, dtype=torch.float32, device=inp.device)
+        ops.dice_loss_fwd(inp, target, _ws(inp.device), out)
+        ctx.save_for_backward(target, out)
+        ctx.shape = inp.shape
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        target, out = ctx.saved_tensors
+        d = torch.empty(ctx.shape, dtype=torch.float32, device=target.device)
+        ops.dice_loss_bwd(target, out, gout.contiguous().float().reshape(1), d)
+        return d, None
+
+
+def dice_loss_op(inp: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """1 - dice with ONE global sum over every element (dice_score.py:25-28, reduce_batch_first=True)."""
+    return _DiceLoss.apply(inp, target)
+
+
+class _MeanLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, t, cval, mode):
+        x = x.contiguous().float()
+        t = None if t is None else t.contiguous().float()
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+        ops.mean_loss_fwd(x, t, cval, mode, _ws(x.device), out)
+        ctx.save_for_backward(x, t)
+        ctx.cval, ctx.mode = cval, mode
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, t = ctx.saved_tensors
+        d = torch.empty_like(x)
+        ops.mean_loss_bwd(x, t, ctx.cval, ctx.mode, gout.contiguous().float().reshape(1), 1.0, d)
+        return d, None, None, None
+
+
+MODE_BCE_CONST, MODE_MSE_CONST, MODE_MEAN, MODE_L1, MODE_BCE = 0, 1, 2, 3, 4
+
+
+def mean_loss(x, t=None, cval=0.0, mode=MODE_BCE):
+    if t is not None and t.shape != x.shape:
+        raise ValueError("input / target shape mismatch")
+    return _MeanLoss.apply(x, t, float(cval), int(mode))
+
+
+def bce_with_logits(x, t):
+    """nn.BCEWithLogitsLoss() (mean)."""
+    return mean_loss(x, t, 0.0, MODE_BCE)
+
+
+def l1_loss(a, b):
+    """torch.nn.L1Loss() (mean); gradient flows to `a`."""
+    return mean_loss(a, b.detach(), 0.0, MODE_L1)

@@ -1,0 +1,287 @@
+"""Tensor-level wrappers over the C ABI (include/gsseg.h).  Shapes/dtypes are validated HERE, before
+any launch, so failures are synchronous Python exceptions.  torch supplies device memory and the
+current HIP stream only; all arithmetic happens in libgsseg_hip.so."""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, GS_BF16, GS_F16, GsConvGeom
+
+DTYPES = {"f16": (GS_F16, torch.float16), "bf16": (GS_BF16, torch.bfloat16)}
+
+
+def dt_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float16:
+        return GS_F16
+    if t.dtype == torch.bfloat16:
+        return GS_BF16
+    raise TypeError(f"expected a float16/bfloat16 tensor, got {t.dtype}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("semantic_segmentation_amd ops need tensors on the MI355X (cuda) device; "
+                           "there is no CPU path")
+
+
+def _f32(t: Optional[torch.Tensor], name: str):
+    if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+        raise TypeError(f"{name} must be a contiguous float32 tensor")
+
+
+# ---------------------------------------------------------------------------- geometry builders
+def make_geom(N, IH, IW, Cin, OHg, OWg, Cout, OH, OW, taps: Sequence[Tuple[int, int]], isy=1, isx=1,
+              osy=1, osx=1, ooy=0, oox=0, in_stride=None, in_coff=0, out_stride=None, out_coff=0) -> GsConvGeom:
+    g = GsConvGeom()
+    g.N, g.IH, g.IW, g.Cin = N, IH, IW, Cin
+    g.in_pix_stride = Cin if in_stride is None else in_stride
+    g.in_coff = in_coff
+    g.OHg, g.OWg, g.Cout, g.OH, g.OW = OHg, OWg, Cout, OH, OW
+    g.out_pix_stride = Cout if out_stride is None else out_stride
+    g.out_coff = out_coff
+    g.isy, g.isx, g.osy, g.osx, g.ooy, g.oox = isy, isx, osy, osx, ooy, oox
+    if not 0 < len(taps) <= _lib.GS_MAX_TAPS:
+        raise ValueError(f"{len(taps)} taps out of range")
+    g.ntaps = len(taps)
+    for i, (dy, dx) in enumerate(taps):
+        g.tap_dy[i], g.tap_dx[i] = dy, dx
+    return g
+
+
+def conv_out_size(i: int, k: int, s: int, p: int) -> int:
+    return (i + 2 * p - k) // s + 1
+
+
+def geom_conv(N, IH, IW, Cin, Cout, k, stride, pad, **kw) -> GsConvGeom:
+    """nn.Conv2d(k, stride, pad): taps in (ky,kx) row-major order, weights [k*k][Cout][Cin]."""
+    OH, OW = conv_out_size(IH, k, stride, pad), conv_out_size(IW, k, stride, pad)
+    taps = [(ky - pad, kx - pad) for ky in range(k) for kx in range(k)]
+    return make_geom(N, IH, IW, Cin, OH, OW, Cout, OH, OW, taps, isy=stride, isx=stride, **kw)
+
+
+def geom_conv_dgrad_s1(N, IH, IW, Cin, Cout, k, pad, **kw) -> GsConvGeom:
+    """Data gradient of a stride-1 Conv2d as a convolution over dy: dx[i] = sum_t dy[i + pad - k_t] Wd[t].
+    'Input' of this launch is dy [N,OH,OW,Cout]; 'output' is dx [N,IH,IW,Cin]; weights [k*k][Cin][Cout]."""
+    OH, OW = conv_out_size(IH, k, 1, pad), conv_out_size(IW, k, 1, pad)
+    taps = [(pad - ky, pad - kx) for ky in range(k) for kx in range(k)]
+    return make_geom(N, OH, OW, Cout, IH, IW, Cin, IH, IW, taps, **kw)
+
+
+# ---------------------------------------------------------------------------- MFMA engine
+def conv_igemm(g: GsConvGeom, x, w, y, bias=None, bn_partials=None, act=ACT_NONE):
+    _dev(x)
+    _f32(bias, "bias"); _f32(bn_partials, "bn_partials")
+    if not (x.dtype == w.dtype == y.dtype):
+        raise TypeError("conv_igemm: x, w, y must share one 16-bit dtype")
+    if bn_partials is not None:
+        need = _lib.load().gs_bn_partials_floats(conv_igemm_mtiles(g), g.Cout)
+        if bn_partials.numel() < need:
+            raise ValueError(f"bn_partials too small: {bn_partials.numel()} < {need}")
+    _lib.call("gs_conv_igemm", g, _p(x), _p(w), _p(y), _p(bias), _p(bn_partials), act, dt_code(x), _stream())
+
+
+def conv_igemm_mtiles(g: GsConvGeom) -> int:
+    return _lib.load().gs_conv_igemm_mtiles(g)
+
+
+def conv_wgrad(g: GsConvGeom, x, dy, dw):
+    _dev(x)
+    _f32(dw, "dw")
+    if x.dtype != dy.dtype:
+        raise TypeError("conv_wgrad: x and dy must share one 16-bit dtype")
+    if dw.numel() < g.ntaps * g.Cout * g.Cin:
+        raise ValueError("conv_wgrad: dw too small")
+    _lib.call("gs_conv_wgrad", g, _p(x), _p(dy), _p(dw), dt_code(x), _stream())
+
+
+def bn_partials_numel(ntiles: int, C: int) -> int:
+    return int(_lib.load().gs_bn_partials_floats(ntiles, C))
+
+
+# ---------------------------------------------------------------------------- direct convs
+def conv_smallcin_fwd(x, w, bias, y, bn_partials, k, stride, pad, act=ACT_NONE):
+    _dev(x)
+    _f32(x, "x"); _f32(w, "w"); _f32(bias, "bias"); _f32(bn_partials, "bn_partials")
+    N, Cin, IH, IW = x.shape
+    _, OH, OW, Cout = y.shape
+    _lib.call("gs_conv_smallcin_fwd", _p(x), _p(w), _p(bias), _p(y), _p(bn_partials), N, Cin, IH, IW, Cout, OH, OW,
+              k, stride, pad, act, dt_code(y), _stream())
+
+
+def conv_smallcin_mtiles(N, OH, OW) -> int:
+    return _lib.load().gs_conv_smallcin_mtiles(N, OH, OW)
+
+
+def conv_smallcin_wgrad(x, dy, dw, k, stride, pad, gscale):
+    _f32(x, "x"); _f32(dw, "dw")
+    N, Cin, IH, IW = x.shape
+    _, OH, OW, Cout = dy.shape
+    _lib.call("gs_conv_smallcin_wgrad", _p(x), _p(dy), _p(dw), N, Cin, IH, IW, Cout, OH, OW, k, stride, pad,
+              float(gscale), dt_code(dy), _stream())
+
+
+def conv_smallcin_dgrad(dy, w, dx, k, stride, pad, gscale):
+    _f32(w, "w"); _f32(dx, "dx")
+    N, Cin, IH, IW = dx.shape
+    _, OH, OW, Cout = dy.shape
+    _lib.call("gs_conv_smallcin_dgrad", _p(dy), _p(w), _p(dx), N, Cin, IH, IW, Cout, OH, OW, k, stride, pad,
+              float(gscale), dt_code(dy), _stream())
+
+
+def conv_smallcout_fwd(x, w, bias, y, k=1, stride=1, pad=0):
+    _dev(x)
+    _f32(w, "w"); _f32(bias, "bias"); _f32(y, "y")
+    N, IH, IW, Cin = x.shape
+    _, Cout, OH, OW = y.shape
+    _lib.call("gs_conv_smallcout_fwd", _p(x), _p(w), _p(bias), _p(y), N, IH, IW, Cin, Cout, OH, OW, k, stride, pad,
+              dt_code(x), _stream())
+
+
+def conv_smallcout_bwd(x, w, dy, dx, dw, db, k=1, stride=1, pad=0, gscale=1.0):
+    _f32(w, "w"); _f32(dy, "dy"); _f32(dw, "dw"); _f32(db, "db")
+    ref = x if x is not None else dx
+    N, IH, IW, Cin = ref.shape
+    _, Cout, OH, OW = dy.shape
+    _lib.call("gs_conv_smallcout_bwd", _p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), N, IH, IW, Cin, Cout, OH, OW,
+              k, stride, pad, float(gscale), dt_code(ref), _stream())
+
+
+# ---------------------------------------------------------------------------- BatchNorm / activation
+def bn_finalize(partials, ntiles, C, count, gamma, beta, running_mean, running_var, momentum, eps,
+                scale, shift, mean, invstd):
+    for n, t in (("gamma", gamma), ("beta", beta), ("running_mean", running_mean), ("running_var", running_var),
+                 ("scale", scale), ("shift", shift), ("mean", mean), ("invstd", invstd)):
+        _f32(t, n)
+    _lib.call("gs_bn_finalize", _p(partials), ntiles, C, float(count), _p(gamma), _p(beta), _p(running_mean),
+              _p(running_var), float(momentum), float(eps), _p(scale), _p(shift), _p(mean), _p(invstd), _stream())
+
+
+def bn_eval_coeffs(C, gamma, beta, running_mean, running_var, eps, scale, shift, mean, invstd):
+    _lib.call("gs_bn_eval_coeffs", C, _p(gamma), _p(beta), _p(running_mean), _p(running_var), float(eps),
+              _p(scale), _p(shift), _p(mean), _p(invstd), _stream())
+
+
+def bn_act_apply(y, scale, shift, act, z, z_stride, z_coff, zp=None, keep_mask=None, keep_scale=1.0):
+    N, H, W, C = y.shape
+    if not y.is_contiguous():
+        raise ValueError("bn_act_apply: y must be dense NHWC")
+    _lib.call("gs_bn_act_apply", _p(y), _p(scale), _p(shift), act, _p(z), z_stride, z_coff, _p(zp), _p(keep_mask),
+              float(keep_scale), N, H, W, C, dt_code(y), _stream())
+
+
+def bn_bwd_tiles(N, H, W) -> int:
+    return _lib.load().gs_bn_bwd_tiles(N, H, W)
+
+
+def bn_bwd_tiles_used(N, H, W, pooled: bool) -> int:
+    return _lib.load().gs_bn_bwd_tiles_used(N, H, W, int(pooled))
+
+
+def bn_act_bwd_reduce(y, dz_a, sa, ca, dzp, scale, shift, mean, invstd, act, partials):
+    N, H, W, C = y.shape
+    _lib.call("gs_bn_act_bwd_reduce", _p(y), _p(dz_a), sa, ca, _p(dzp), _p(scale), _p(shift), _p(mean), _p(invstd),
+              act, _p(partials), N, H, W, C, dt_code(y), _stream())
+
+
+def bn_bwd_coeffs(partials, ntiles, C, count, gscale, dgamma, dbeta, c1, c2):
+    _lib.call("gs_bn_bwd_coeffs", _p(partials), ntiles, C, float(count), float(gscale), _p(dgamma), _p(dbeta),
+              _p(c1), _p(c2), _stream())
+
+
+def bn_act_bwd_apply(y, dz_a, sa, ca, dzp, scale, shift, mean, invstd, c1, c2, act, bn, dy):
+    N, H, W, C = y.shape
+    _lib.call("gs_bn_act_bwd_apply", _p(y), _p(dz_a), sa, ca, _p(dzp), _p(scale), _p(shift), _p(mean), _p(invstd),
+              _p(c1), _p(c2), act, int(bn), _p(dy), N, H, W, C, dt_code(y), _stream())
+
+
+def colsum(t, pix_stride, coff, N, H, W, y0, x0, h, w, C, gscale, ws, out):
+    _f32(ws, "ws"); _f32(out, "out")
+    if ws.numel() < 1024 * C:
+        raise ValueError("colsum: workspace must hold 1024*C floats")
+    _lib.call("gs_colsum", _p(t), pix_stride, coff, N, H, W, y0, x0, h, w, C, float(gscale), _p(ws), _p(out),
+              dt_code(t), _stream())
+
+
+# ---------------------------------------------------------------------------- packing / layout
+def pack_weight(w, w_fwd, w_dgrad, transposed: bool):
+    _dev(w)
+    _f32(w, "weight")
+    if transposed:
+        Cin, Cout = w.shape[0], w.shape[1]
+    else:
+        Cout, Cin = w.shape[0], w.shape[1]
+    taps = w.shape[2] * w.shape[3]
+    ref = w_fwd if w_fwd is not None else w_dgrad
+    _lib.call("gs_pack_weight", _p(w), _p(w_fwd), _p(w_dgrad), Cout, Cin, taps, int(transposed), dt_code(ref), _stream())
+
+
+def unpack_wgrad(dw, grad, A, B, taps, transposed: bool, gscale):
+    _f32(dw, "dw"); _f32(grad, "grad")
+    _lib.call("gs_unpack_wgrad", _p(dw), _p(grad), A, B, taps, int(transposed), float(gscale), _stream())
+
+
+def nchw_to_nhwc(src, dst, dst_stride=None, dst_coff=0):
+    _f32(src, "src")
+    N, C, H, W = src.shape
+    _lib.call("gs_nchw_to_nhwc", _p(src), _p(dst), N, C, H, W, C if dst_stride is None else dst_stride, dst_coff,
+              dt_code(dst), _stream())
+
+
+def nhwc_to_nchw(src, dst, src_stride=None, src_coff=0, gscale=1.0):
+    _f32(dst, "dst")
+    N, C, H, W = dst.shape
+    _lib.call("gs_nhwc_to_nchw", _p(src), C if src_stride is None else src_stride, src_coff, _p(dst), N, C, H, W,
+              float(gscale), dt_code(src), _stream())
+
+
+# ---------------------------------------------------------------------------- losses
+LOSS_WS = 4 * 1024
+
+
+def seg_loss_fwd(logits, mask_u8, ws, out):
+    _dev(logits)
+    _f32(logits, "logits"); _f32(ws, "ws"); _f32(out, "out")
+    if mask_u8.dtype != torch.uint8 or not mask_u8.is_contiguous():
+        raise TypeError("mask must be contiguous uint8 [N,H,W]")
+    N, C, H, W = logits.shape
+    if mask_u8.numel() != N * H * W:
+        raise ValueError("mask / logits shape mismatch")
+    _lib.call("gs_seg_loss_fwd", _p(logits), _p(mask_u8), N, C, H, W, _p(ws), _p(out), _stream())
+
+
+def seg_loss_bwd(logits, mask_u8, out, gout, gscale, dlogits):
+    N, C, H, W = logits.shape
+    _f32(dlogits, "dlogits"); _f32(gout, "gout")
+    _lib.call("gs_seg_loss_bwd", _p(logits), _p(mask_u8), _p(out), _p(gout), float(gscale), _p(dlogits), N, C, H, W,
+              _stream())
+
+
+def dice_loss_fwd(p, t, ws, out):
+    _dev(p)
+    _f32(p, "input"); _f32(t, "target")
+    _lib.call("gs_dice_loss_fwd", _p(p), _p(t), p.numel(), _p(ws), _p(out), _stream())
+
+
+def dice_loss_bwd(t, out, gout, dp):
+    _lib.call("gs_dice_loss_bwd", _p(t), _p(out), _p(gout), _p(dp), t.numel(), _stream())
+
+
+def mean_loss_fwd(x, t, cval, mode, ws, out):
+    _dev(x)
+    _f32(x, "x"); _f32(t, "target")
+    _lib.call("gs_mean_loss_fwd", _p(x), _p(t), float(cval), mode, x.numel(), _p(ws), _p(out), _stream())
+
+
+def mean_loss_bwd(x, t, cval, mode, gout, gscale, dx):
+    _lib.call("gs_mean_loss_bwd", _p(x), _p(t), float(cval), mode, x.numel(), _p(gout), float(gscale), _p(dx), _stream())

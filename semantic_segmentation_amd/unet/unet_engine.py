@@ -1,0 +1,373 @@
+"""Whole-network execution plan of the U-Net on the HIP kernels (forward + backward).
+
+Reference call sites: unet/unet_model.py:26-37 (forward), unet/unet_parts.py (blocks).  One
+torch.autograd.Function spans the network so that the plan is free to keep activations in 16-bit NHWC,
+to write the encoder outputs straight into the skip half of the decoder's concat buffers (torch.cat
+becomes free), to fuse the 2x2 max-pool into the BatchNorm+ReLU pass, and to run gradients through the
+same buffers in reverse.  Parameters stay ordinary fp32 nn.Parameters in the reference layouts.
+
+Data layout in HBM (per level i = 0..4, C_i = 64*2^i, h_i = H >> i):
+  y   raw conv output            [N, h, w, C]   16-bit   (kept for BatchNorm/ReLU backward)
+  z   relu(bn(y))                [N, h, w, C]   16-bit   (conv input of the next layer; kept for wgrad)
+  cat concat buffer of level i   [N, h_i, w_i, 2*C_i]:  channels [0,C_i) = skip (encoder z),
+                                                        channels [C_i,2C_i) = ConvTranspose2d output
+Gradients use the same layouts; they are carried multiplied by a power-of-two loss scale S ~ N*H*W so
+that fp16 storage never underflows (gradients are O(1) after scaling thanks to BatchNorm); every
+parameter gradient is multiplied by 1/S on its way out (exact).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from .. import ops
+from .._lib import ACT_NONE, ACT_RELU
+
+_TORCH_DT = {"f16": torch.float16, "bf16": torch.bfloat16}
+
+
+class _ConvRec:
+    """Saved state of one conv -> BN -> ReLU stage."""
+    __slots__ = ("name", "wkey", "bnkey", "inp", "inp_is_image", "y", "coef", "geom", "cin", "cout", "h", "w",
+                 "wd", "train_stats")
+
+
+class _UpRec:
+    __slots__ = ("name", "zin", "cat", "geom_bwd", "wd", "cin", "cout", "h", "w", "H2", "W2", "pt", "pl")
+
+
+def _pack_key(p: torch.Tensor):
+    return (p.data_ptr(), p._version, p.dtype, tuple(p.shape))
+
+
+class UNetEngine:
+    """Executes UNet.forward / backward for a `UNet` module tree on the HIP kernels."""
+
+    def __init__(self, net, dtype: str = "f16"):
+        if dtype not in _TORCH_DT:
+            raise ValueError("dtype must be 'f16' or 'bf16'")
+        self.net = net
+        self.dtype = dtype
+        self.tdt = _TORCH_DT[dtype]
+        self._packs: Dict[str, tuple] = {}
+        self.grad_ready_hook: Optional[Callable[[str, torch.Tensor], None]] = None
+
+    # ------------------------------------------------------------------ parameters
+    def param_items(self):
+        """(name, Parameter) in registration order -- the order autograd sees them."""
+        return list(self.net.named_parameters())
+
+    def _packed(self, name: str, w: torch.Tensor, transposed: bool, need_dgrad: bool):
+        """16-bit K-major packs of a conv weight, cached until the Parameter is modified."""
+        key = _pack_key(w)
+        ent = self._packs.get(name)
+        if ent is not None and ent[0] == key and (ent[2] is not None or not need_dgrad):
+            return ent[1], ent[2]
+        if transposed:
+            cin, cout = w.shape[0], w.shape[1]
+        else:
+            cout, cin = w.shape[0], w.shape[1]
+        taps = w.shape[2] * w.shape[3]
+        wf = torch.empty((taps, cout, cin), dtype=self.tdt, device=w.device)
+        wd = torch.empty((taps, cin, cout), dtype=self.tdt, device=w.device) if need_dgrad else None
+        ops.pack_weight(w.detach(), wf, wd, transposed)
+        self._packs[name] = (key, wf, wd)
+        return wf, wd
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor, params: Dict[str, torch.Tensor], training: bool, need_grad: bool):
+        net = self.net
+        if not x.is_cuda:
+            raise RuntimeError("UNet (semantic_segmentation_amd) runs on the MI355X only: move the input and the "
+                               "module to cuda; there is no CPU / ATen fallback")
+        if net.bilinear:
+            raise NotImplementedError("bilinear=True up-sampling path is not implemented on the HIP engine yet")
+        if x.dim() != 4 or x.shape[1] != net.n_channels:
+            raise ValueError(f"expected input [N,{net.n_channels},H,W], got {tuple(x.shape)}")
+        N, _, H, W = x.shape
+        if H < 16 or W < 16:
+            raise ValueError("input must be at least 16x16 (four 2x2 poolings)")
+        if net.n_channels > 4 or net.n_classes > 4:
+            raise NotImplementedError("n_channels / n_classes above 4 are not supported by the direct end kernels")
+        dev, tdt = x.device, self.tdt
+        x = x.contiguous().float()
+        bufs = dict(net.named_buffers())
+        hs = [H >> i for i in range(5)]
+        ws_ = [W >> i for i in range(5)]
+        C = [64, 128, 256, 512, 1024]
+
+        def empty(*shape, dtype=tdt):
+            return torch.empty(shape, dtype=dtype, device=dev)
+
+        # shared workspaces
+        max_part = ops.bn_partials_numel(ops.conv_smallcin_mtiles(N, H, W), 64)
+        for i in range(5):
+            mt = (N * hs[i] * ws_[i] + 127) // 128
+            max_part = max(max_part, ops.bn_partials_numel(mt, C[i]))
+        partials = empty(max_part, dtype=torch.float32)
+
+        recs: List[_ConvRec] = []
+        ups: List[_UpRec] = []
+
+        def bn_coeffs(bnkey, ntiles, cout, count):
+            coef = empty(4, cout, dtype=torch.float32)       # scale, shift, mean, invstd
+            gamma, beta = params[bnkey + ".weight"], params[bnkey + ".bias"]
+            rm, rv = bufs.get(bnkey + ".running_mean"), bufs.get(bnkey + ".running_var")
+            batch_stats = training or rm is None
+            if batch_stats:
+                nbt = bufs.get(bnkey + ".num_batches_tracked")
+                bn_mod = net.get_submodule(bnkey)
+                mom = bn_mod.momentum
+                if training and nbt is not None:
+                    nbt.add_(1)
+                if mom is None:
+                    mom = 1.0 / float(nbt.item()) if nbt is not None else 0.0
+                upd = training and rm is not None
+                ops.bn_finalize(partials, ntiles, cout, count, gamma.detach(), beta.detach(),
+                                rm if upd else None, rv if upd else None, mom, net.get_submodule(bnkey).eps,
+                                coef[0], coef[1], coef[2], coef[3])
+            else:
+                ops.bn_eval_coeffs(cout, gamma.detach(), beta.detach(), rm, rv, net.get_submodule(bnkey).eps,
+                                   coef[0], coef[1], coef[2], coef[3])
+            return coef, batch_stats
+
+        def conv_bn_relu(prefix, idx, inp, cin, cout, h, w, z, z_stride, z_coff, zp, image=False):
+            """prefix.double_conv.{idx} conv + .{idx+1} BN + ReLU."""
+            wkey, bnkey = f"{prefix}.double_conv.{idx}.weight", f"{prefix}.double_conv.{idx + 1}"
+            wparam = params[wkey]
+            rm = bufs.get(bnkey + ".running_mean")
+            batch_stats = training or rm is None
+            y = empty(N, h, w, cout)
+            rec = _ConvRec()
+            rec.name, rec.wkey, rec.bnkey = f"{prefix}.{idx}", wkey, bnkey
+            rec.cin, rec.cout, rec.h, rec.w, rec.inp_is_image = cin, cout, h, w, image
+            if image:
+                ntiles = ops.conv_smallcin_mtiles(N, h, w)
+                ops.conv_smallcin_fwd(inp, wparam.detach().contiguous(), None, y, partials if batch_stats else None,
+                                      3, 1, 1)
+                rec.geom, rec.wd = None, None
+            else:
+                wf, wd = self._packed(wkey, wparam, False, need_grad)
+                g = ops.geom_conv(N, h, w, cin, cout, 3, 1, 1)
+                ntiles = ops.conv_igemm_mtiles(g)
+                ops.conv_igemm(g, inp, wf, y, None, partials if batch_stats else None)
+                rec.geom, rec.wd = g, wd
+            coef, rec.train_stats = bn_coeffs(bnkey, ntiles, cout, N * h * w)
+            ops.bn_act_apply(y, coef[0], coef[1], ACT_RELU, z, z_stride, z_coff, zp)
+            if need_grad:
+                rec.inp, rec.y, rec.coef = inp, y, coef
+                recs.append(rec)
+            return rec
+
+        # ---- encoder ----
+        cats = [None] * 4
+        for i in range(4):
+            zero_needed = (hs[i] - 2 * hs[i + 1]) or (ws_[i] - 2 * ws_[i + 1])
+            alloc = torch.zeros if zero_needed else torch.empty
+            cats[i] = alloc((N, hs[i], ws_[i], 2 * C[i]), dtype=tdt, device=dev)
+        inp = x
+        cin = net.n_channels
+        pooled = None
+        for i in range(5):
+            prefix = "inc" if i == 0 else f"down{i}.maxpool_conv.1"
+            h, w = hs[i], ws_[i]
+            zmid = empty(N, h, w, C[i])
+            conv_bn_relu(prefix, 0, inp, cin, C[i], h, w, zmid, C[i], 0, None, image=(i == 0))
+            if i < 4:
+                pooled = empty(N, hs[i + 1], ws_[i + 1], C[i])
+                conv_bn_relu(prefix, 3, zmid, C[i], C[i], h, w, cats[i], 2 * C[i], 0, pooled)
+                inp, cin = pooled, C[i]
+            else:
+                x5 = empty(N, h, w, C[i])
+                conv_bn_relu(prefix, 3, zmid, C[i], C[i], h, w, x5, C[i], 0, None)
+                inp = x5
+
+        # ---- decoder ----
+        for j in range(1, 5):
+            lvl = 4 - j                      # output level of up_j
+            prefix = f"up{j}"
+            cin_t, cout_t = C[lvl + 1], C[lvl]
+            h, w = hs[lvl + 1], ws_[lvl + 1]
+            H2, W2 = hs[lvl], ws_[lvl]
+            pt, pl = (H2 - 2 * h) // 2, (W2 - 2 * w) // 2
+            wkey = prefix + ".up.weight"
+            wf, wd = self._packed(wkey, params[wkey], True, need_grad)
+            bias = params[prefix + ".up.bias"].detach()
+            cat = cats[lvl]
+            for py in range(2):
+                for px in range(2):
+                    g = ops.make_geom(N, h, w, cin_t, h, w, cout_t, H2, W2, [(0, 0)], osy=2, osx=2,
+                                      ooy=py + pt, oox=px + pl, out_stride=2 * cout_t, out_coff=cout_t)
+                    ops.conv_igemm(g, inp, wf[py * 2 + px], cat, bias, None)
+            if need_grad:
+                u = _UpRec()
+                u.name, u.zin, u.cat, u.wd = prefix, inp, cat, wd
+                u.cin, u.cout, u.h, u.w, u.H2, u.W2, u.pt, u.pl = cin_t, cout_t, h, w, H2, W2, pt, pl
+                taps = [(py + pt, px + pl) for py in range(2) for px in range(2)]
+                # the ConvTranspose2d seen from its output side: a stride-2, 4-tap conv dU -> x
+                u.geom_bwd = ops.make_geom(N, H2, W2, cout_t, h, w, cin_t, h, w, taps, isy=2, isx=2,
+                                           in_stride=2 * cout_t, in_coff=cout_t)
+                ups.append(u)
+            zmid = empty(N, H2, W2, cout_t)
+            conv_bn_relu(prefix + ".conv", 0, cat, 2 * cout_t, cout_t, H2, W2, zmid, cout_t, 0, None)
+            zout = empty(N, H2, W2, cout_t)
+            conv_bn_relu(prefix + ".conv", 3, zmid, cout_t, cout_t, H2, W2, zout, cout_t, 0, None)
+            inp = zout
+
+        logits = empty(N, net.n_classes, H, W, dtype=torch.float32)
+        ops.conv_smallcout_fwd(inp, params["outc.conv.weight"].detach().contiguous(),
+                               params["outc.conv.bias"].detach(), logits)
+        ctx = None
+        if need_grad:
+            ctx = dict(recs=recs, ups=ups, x=x, z_last=inp, N=N, H=H, W=W, hs=hs, ws=ws_, C=C, training=training)
+        return logits, ctx
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, ctx, params: Dict[str, torch.Tensor], dlogits: torch.Tensor, need_dx: bool):
+        net, tdt = self.net, self.tdt
+        N, H, W, hs, ws_, C = ctx["N"], ctx["H"], ctx["W"], ctx["hs"], ctx["ws"], ctx["C"]
+        dev = dlogits.device
+        recs: Dict[str, _ConvRec] = {r.name: r for r in ctx["recs"]}
+        ups: Dict[str, _UpRec] = {u.name: u for u in ctx["ups"]}
+        S = float(2 ** round(math.log2(N * H * W)))
+        inv_s = 1.0 / S
+        grads: Dict[str, torch.Tensor] = {}
+
+        def empty(*shape, dtype=tdt):
+            return torch.empty(shape, dtype=dtype, device=dev)
+
+        def emit(name, g):
+            grads[name] = g
+            if self.grad_ready_hook is not None:
+                self.grad_ready_hook(name, g)
+
+        # workspaces
+        max_w = max(p.numel() for k, p in params.items() if k.endswith("weight") and p.dim() == 4)
+        dw_ws = empty(max_w, dtype=torch.float32)
+        npart = 0
+        for i in range(5):
+            npart = max(npart, ops.bn_partials_numel(ops.bn_bwd_tiles(N, hs[i], ws_[i]), C[i]))
+        partials = empty(npart, dtype=torch.float32)
+        col_ws = empty(1024 * 1024, dtype=torch.float32)
+
+        # ---- head ----
+        z_last = ctx["z_last"]
+        dl = (dlogits.contiguous().float() * S)
+        wout = params["outc.conv.weight"]
+        dwo = torch.zeros_like(wout, memory_format=torch.contiguous_format)
+        dbo = torch.zeros_like(params["outc.conv.bias"])
+        dz = empty(N, H, W, 64)
+        ops.conv_smallcout_bwd(z_last, wout.detach().contiguous(), dl, dz, dwo, dbo, gscale=inv_s)
+        emit("outc.conv.weight", dwo)
+        emit("outc.conv.bias", dbo)
+
+        def conv_stage_bwd(rec: _ConvRec, dz_a, sa, ca, dzp, need_dinp: bool):
+            """Backward of conv -> BN -> ReLU.  Returns d(input) (dense NHWC) or None."""
+            h, w, cin, cout = rec.h, rec.w, rec.cin, rec.cout
+            coef = rec.coef
+            pooled = dzp is not None
+            ntiles = ops.bn_bwd_tiles_used(N, h, w, pooled)
+            ops.bn_act_bwd_reduce(rec.y, dz_a, sa, ca, dzp, coef[0], coef[1], coef[2], coef[3], ACT_RELU, partials)
+            dgamma = empty(cout, dtype=torch.float32)
+            dbeta = empty(cout, dtype=torch.float32)
+            c12 = empty(2, cout, dtype=torch.float32)
+            ops.bn_bwd_coeffs(partials, ntiles, cout, N * h * w, inv_s, dgamma, dbeta, c12[0], c12[1])
+            if not rec.train_stats:
+                c12.zero_()          # eval-mode BN: statistics are constants
+            dy = empty(N, h, w, cout)
+            ops.bn_act_bwd_apply(rec.y, dz_a, sa, ca, dzp, coef[0], coef[1], coef[2], coef[3], c12[0], c12[1],
+                                 ACT_RELU, True, dy)
+            wparam = params[rec.wkey]
+            dinp = None
+            if rec.inp_is_image:
+                dw = torch.zeros_like(wparam, memory_format=torch.contiguous_format)
+                ops.conv_smallcin_wgrad(rec.inp, dy, dw, 3, 1, 1, inv_s)
+                if need_dinp:
+                    dinp = torch.empty_like(rec.inp)
+                    ops.conv_smallcin_dgrad(dy, wparam.detach().contiguous(), dinp, 3, 1, 1, inv_s)
+            else:
+                dwp = dw_ws[: wparam.numel()]
+                dwp.zero_()
+                ops.conv_wgrad(rec.geom, rec.inp, dy, dwp)
+                dw = torch.empty_like(wparam, memory_format=torch.contiguous_format)
+                ops.unpack_wgrad(dwp, dw, cout, cin, 9, False, inv_s)
+                if need_dinp:
+                    dinp = empty(N, h, w, cin)
+                    gd = ops.geom_conv_dgrad_s1(N, h, w, cin, cout, 3, 1)
+                    ops.conv_igemm(gd, dy, rec.wd, dinp)
+            emit(rec.wkey, dw)
+            emit(rec.bnkey + ".weight", dgamma)
+            emit(rec.bnkey + ".bias", dbeta)
+            return dinp
+
+        # ---- decoder, reversed ----
+        dcats = [None] * 4
+        for j in range(4, 0, -1):
+            lvl = 4 - j
+            prefix = f"up{j}"
+            cout_t = C[lvl]
+            dmid = conv_stage_bwd(recs[prefix + ".conv.3"], dz, cout_t, 0, None, True)
+            dcat = conv_stage_bwd(recs[prefix + ".conv.0"], dmid, cout_t, 0, None, True)
+            dcats[lvl] = dcat
+            u = ups[prefix]
+            wkey = prefix + ".up.weight"
+            wparam = params[wkey]
+            db = empty(cout_t, dtype=torch.float32)
+            ops.colsum(dcat, 2 * cout_t, cout_t, N, u.H2, u.W2, u.pt, u.pl, 2 * u.h, 2 * u.w, cout_t, inv_s, col_ws, db)
+            dwp = dw_ws[: wparam.numel()]
+            dwp.zero_()
+            ops.conv_wgrad(u.geom_bwd, dcat, u.zin, dwp)
+            dw = torch.empty_like(wparam, memory_format=torch.contiguous_format)
+            ops.unpack_wgrad(dwp, dw, u.cin, u.cout, 4, False, inv_s)
+            dz = empty(N, u.h, u.w, u.cin)
+            ops.conv_igemm(u.geom_bwd, dcat, u.wd, dz)
+            emit(wkey, dw)
+            emit(prefix + ".up.bias", db)
+
+        # ---- encoder, reversed ----
+        dx = None
+        dpool = None
+        for i in range(4, -1, -1):
+            prefix = "inc" if i == 0 else f"down{i}.maxpool_conv.1"
+            if i == 4:
+                dmid = conv_stage_bwd(recs[prefix + ".3"], dz, C[i], 0, None, True)
+            else:
+                dmid = conv_stage_bwd(recs[prefix + ".3"], dcats[i], 2 * C[i], 0, dpool, True)
+            r0 = recs[prefix + ".0"]
+            dinp = conv_stage_bwd(r0, dmid, C[i], 0, None, (i > 0) or need_dx)
+            if i > 0:
+                dpool = dinp
+            else:
+                dx = dinp
+        return grads, dx
+
+
+class _UNetFunction(torch.autograd.Function):
+    """autograd bridge: (x, *params) -> logits."""
+
+    @staticmethod
+    def forward(ctx, engine: UNetEngine, names, training: bool, x, *plist):
+        params = dict(zip(names, plist))
+        need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in plist))
+        logits, ectx = engine.forward(x, params, training, need_grad)
+        ctx.engine, ctx.names, ctx.ectx, ctx.plist = engine, names, ectx, plist
+        ctx.x_needs_grad = x.requires_grad
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        if ctx.ectx is None:
+            raise RuntimeError("UNet forward ran without gradient tracking")
+        params = dict(zip(ctx.names, ctx.plist))
+        grads, dx = ctx.engine.backward(ctx.ectx, params, dlogits, ctx.x_needs_grad)
+        out = [grads.get(n) if p.requires_grad else None for n, p in zip(ctx.names, ctx.plist)]
+        return (None, None, None, dx if ctx.x_needs_grad else None, *out)
+
+
+def run_unet(engine: UNetEngine, x: torch.Tensor) -> torch.Tensor:
+    items = engine.param_items()
+    names = tuple(n for n, _ in items)
+    plist = tuple(p for _, p in items)
+    return _UNetFunction.apply(engine, names, engine.net.training, x, *plist)

@@ -1,0 +1,395 @@
+"""Per-kernel parity tests: every C-ABI entry point against a plain fp32 torch (CPU) statement of the
+same op, on the same 16-bit-rounded inputs.  GPU only (`-m gpu`)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTS = [("f16", torch.float16), ("bf16", torch.bfloat16)]
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / max(b.norm().item(), 1e-30))
+
+
+def rnd(g, *shape, dt=None, scale=1.0):
+    t = torch.randn(*shape, generator=g) * scale
+    return t.to(dt).float() if dt is not None else t
+
+
+def nhwc(t16_src: torch.Tensor, dt) -> torch.Tensor:
+    """fp32 NCHW (already representable) -> device NHWC tensor of dtype dt"""
+    return t16_src.permute(0, 2, 3, 1).contiguous().to(dt).to(dev())
+
+
+def from_nhwc(t: torch.Tensor) -> torch.Tensor:
+    return t.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def tol(dt):
+    return 3e-3 if dt == torch.float16 else 1.5e-2
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtn,dt", DTS)
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 13, 9, 64, 64), (1, 16, 16, 128, 192), (3, 7, 20, 72, 40),
+                                            (1, 32, 32, 256, 128)])
+def test_conv3x3_fwd_bn_partials(dtn, dt, N, H, W, Cin, Cout):
+    from semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = rnd(g, N, Cin, H, W, dt=dt)
+    w = rnd(g, Cout, Cin, 3, 3, dt=dt, scale=0.05)
+    ref = F.conv2d(x, w, None, padding=1)
+    xd = nhwc(x, dt)
+    wf = torch.empty(9, Cout, Cin, dtype=dt, device=dev())
+    wd = torch.empty(9, Cin, Cout, dtype=dt, device=dev())
+    ops.pack_weight(w.to(dev()), wf, wd, False)
+    # pack layout check
+    assert torch.equal(wf.float().cpu(), w.permute(2, 3, 0, 1).reshape(9, Cout, Cin))
+    assert torch.equal(wd.float().cpu(), w.permute(2, 3, 1, 0).reshape(9, Cin, Cout))
+    geom = ops.geom_conv(N, H, W, Cin, Cout, 3, 1, 1)
+    mt = ops.conv_igemm_mtiles(geom)
+    part = torch.zeros(ops.bn_partials_numel(mt, Cout), dtype=torch.float32, device=dev())
+    y = torch.full((N, H, W, Cout), float("nan"), dtype=dt, device=dev())
+    ops.conv_igemm(geom, xd, wf, y, None, part)
+    torch.cuda.synchronize()
+    got = from_nhwc(y)
+    assert torch.isfinite(got).all()
+    assert rel_err(got, ref) < tol(dt), rel_err(got, ref)
+    p = part[: mt * 2 * Cout].view(mt, 2, Cout).double().sum(0).cpu()
+    s1, s2 = ref.double().sum((0, 2, 3)), (ref.double() ** 2).sum((0, 2, 3))
+    assert (p[0] - s1).abs().max() < 1e-3 * max(1.0, s1.abs().max().item())
+    assert (p[1] - s2).abs().max() < 1e-3 * s2.abs().max().item()
+
+
+@pytest.mark.parametrize("dtn,dt", DTS)
+def test_conv_strided_io_bias_act(dtn, dt):
+    """channel-sliced input/output (concat buffers), bias and LeakyReLU epilogue, stride-2 4x4 conv"""
+    from semantic_segmentation_amd import ops
+    from semantic_segmentation_amd._lib import ACT_LEAKY02
+    g = torch.Generator().manual_seed(2)
+    N, H, W, Cin, Cout = 2, 12, 10, 64, 96
+    x = rnd(g, N, Cin, H, W, dt=dt)
+    w = rnd(g, Cout, Cin, 4, 4, dt=dt, scale=0.05)
+    b = rnd(g, Cout)
+    ref = F.leaky_relu(F.conv2d(x, w, b, stride=2, padding=1), 0.2)
+    big = torch.zeros(N, H, W, Cin + 16, dtype=dt, device=dev())
+    big[..., 8:8 + Cin] = nhwc(x, dt)
+    wf = torch.empty(16, Cout, Cin, dtype=dt, device=dev())
+    ops.pack_weight(w.to(dev()), wf, None, False)
+    OH, OW = ref.shape[2], ref.shape[3]
+    out = torch.zeros(N, OH, OW, Cout + 32, dtype=dt, device=dev())
+    geom = ops.geom_conv(N, H, W, Cin, Cout, 4, 2, 1, in_stride=Cin + 16, in_coff=8, out_stride=Cout + 32, out_coff=32)
+    ops.conv_igemm(geom, big, wf, out, b.to(dev()), None, ACT_LEAKY02)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(out[..., 32:]), ref) < tol(dt)
+    assert float(out[..., :32].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtn,dt", DTS)
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 13, 9, 64, 64), (1, 16, 16, 128, 192), (2, 8, 8, 256, 64),
+                                            (3, 9, 5, 72, 40)])
+def test_conv3x3_dgrad_wgrad(dtn, dt, N, H, W, Cin, Cout):
+    from semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = rnd(g, N, Cin, H, W, dt=dt).requires_grad_(True)
+    w = rnd(g, Cout, Cin, 3, 3, dt=dt, scale=0.05).requires_grad_(True)
+    dy = rnd(g, N, Cout, H, W, dt=dt)
+    F.conv2d(x, w, None, padding=1).backward(dy)
+    wf = torch.empty(9, Cout, Cin, dtype=dt, device=dev())
+    wd = torch.empty(9, Cin, Cout, dtype=dt, device=dev())
+    ops.pack_weight(w.detach().to(dev()), wf, wd, False)
+    dyd = nhwc(dy, dt)
+    dx = torch.empty(N, H, W, Cin, dtype=dt, device=dev())
+    ops.conv_igemm(ops.geom_conv_dgrad_s1(N, H, W, Cin, Cout, 3, 1), dyd, wd, dx)
+    assert rel_err(from_nhwc(dx), x.grad) < tol(dt)
+    dwp = torch.zeros(9, Cout, Cin, dtype=torch.float32, device=dev())
+    ops.conv_wgrad(ops.geom_conv(N, H, W, Cin, Cout, 3, 1, 1), nhwc(x.detach(), dt), dyd, dwp)
+    dw = torch.empty(Cout, Cin, 3, 3, dtype=torch.float32, device=dev())
+    ops.unpack_wgrad(dwp, dw, Cout, Cin, 9, False, 0.5)
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu() * 2, w.grad) < 2e-3, rel_err(dw.cpu() * 2, w.grad)
+
+
+@pytest.mark.parametrize("dtn,dt", DTS)
+def test_wgrad_large_k_split(dtn, dt):
+    """many pixels, 64 channels: exercises split-K + atomics and the 1x4 wave arrangement"""
+    from semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(4)
+    N, H, W, Cin, Cout = 2, 96, 80, 64, 64
+    x = rnd(g, N, Cin, H, W, dt=dt).requires_grad_(False)
+    w = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    dy = rnd(g, N, Cout, H, W, dt=dt, scale=0.1)
+    F.conv2d(x, w, None, padding=1).backward(dy)
+    dwp = torch.zeros(9, Cout, Cin, dtype=torch.float32, device=dev())
+    ops.conv_wgrad(ops.geom_conv(N, H, W, Cin, Cout, 3, 1, 1), nhwc(x, dt), nhwc(dy, dt), dwp)
+    torch.cuda.synchronize()
+    got = dwp.cpu().view(3, 3, Cout, Cin).permute(2, 3, 0, 1)
+    assert rel_err(got, w.grad) < 2e-3, rel_err(got, w.grad)
+
+
+@pytest.mark.parametrize("dtn,dt", DTS)
+@pytest.mark.parametrize("pad", [(0, 0), (1, 1)])
+def test_conv_transpose2x2_fwd_bwd(dtn, dt, pad):
+    """ConvTranspose2d(k2,s2)+bias written into the second half of a concat buffer (unet_parts.py:53-67)"""
+    from semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(5)
+    N, h, w_, Cin, Cout = 2, 5, 6, 128, 64
+    H2, W2 = 2 * h + pad[0], 2 * w_ + pad[1]
+    pt, pl = pad[0] // 2, pad[1] // 2
+    x = rnd(g, N, Cin, h, w_, dt=dt).requires_grad_(True)
+    wt = rnd(g, Cin, Cout, 2, 2, dt=dt, scale=0.05).requires_grad_(True)
+    b = rnd(g, Cout).requires_grad_(True)
+    up = F.conv_transpose2d(x, wt, b, stride=2)
+    up_p = F.pad(up, [pl, pad[1] - pl, pt, pad[0] - pt])
+    dcat = rnd(g, N, 2 * Cout, H2, W2, dt=dt)
+    up_p.backward(dcat[:, Cout:])
+    wf = torch.empty(4, Cout, Cin, dtype=dt, device=dev())
+    wd = torch.empty(4, Cin, Cout, dtype=dt, device=dev())
+    ops.pack_weight(wt.detach().to(dev()), wf, wd, True)
+    cat = torch.zeros(N, H2, W2, 2 * Cout, dtype=dt, device=dev())
+    xd = nhwc(x.detach(), dt)
+    for py in range(2):
+        for px in range(2):
+            geom = ops.make_geom(N, h, w_, Cin, h, w_, Cout, H2, W2, [(0, 0)], osy=2, osx=2, ooy=py + pt, oox=px + pl,
+                                 out_stride=2 * Cout, out_coff=Cout)
+            ops.conv_igemm(geom, xd, wf[py * 2 + px], cat, b.detach().to(dev()), None)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(cat[..., Cout:]), up_p.detach()) < tol(dt)
+    assert float(cat[..., :Cout].abs().max()) == 0.0
+    # backward
+    taps = [(py + pt, px + pl) for py in range(2) for px in range(2)]
+    gb = ops.make_geom(N, H2, W2, Cout, h, w_, Cin, h, w_, taps, isy=2, isx=2, in_stride=2 * Cout, in_coff=Cout)
+    dcd = nhwc(dcat, dt)
+    dx = torch.empty(N, h, w_, Cin, dtype=dt, device=dev())
+    ops.conv_igemm(gb, dcd, wd, dx)
+    assert rel_err(from_nhwc(dx), x.grad) < tol(dt)
+    dwp = torch.zeros(4, Cin, Cout, dtype=torch.float32, device=dev())
+    ops.conv_wgrad(gb, dcd, xd, dwp)
+    dw = torch.empty(Cin, Cout, 2, 2, dtype=torch.float32, device=dev())
+    ops.unpack_wgrad(dwp, dw, Cin, Cout, 4, False, 1.0)
+    assert rel_err(dw.cpu(), wt.grad) < 2e-3
+    ws = torch.empty(1024 * Cout, dtype=torch.float32, device=dev())
+    db = torch.empty(Cout, dtype=torch.float32, device=dev())
+    ops.colsum(dcd, 2 * Cout, Cout, N, H2, W2, pt, pl, 2 * h, 2 * w_, Cout, 1.0, ws, db)
+    assert rel_err(db.cpu(), b.grad) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtn,dt", DTS)
+@pytest.mark.parametrize("N,H,W,C,pool", [(2, 8, 6, 64, True), (2, 9, 7, 64, True), (3, 5, 5, 128, False),
+                                          (1, 4, 4, 1024, True), (2, 6, 6, 24, False)])
+def test_bn_relu_pool_fwd_bwd(dtn, dt, N, H, W, C, pool):
+    from semantic_segmentation_amd import ops
+    from semantic_segmentation_amd._lib import ACT_RELU
+    g = torch.Generator().manual_seed(6)
+    y = rnd(g, N, C, H, W, dt=dt).requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    z = F.relu(F.batch_norm(y, rm, rv, gamma, beta, True, 0.1, 1e-5))
+    zr = z.detach().to(dt).float()
+    # fake conv-epilogue partials: per-tile sums over 2 tiles
+    yd = nhwc(y.detach(), dt)
+    flat = y.detach().permute(0, 2, 3, 1).reshape(-1, C).double()
+    half = flat.shape[0] // 2
+    ntiles = 2
+    part = torch.zeros(ops.bn_partials_numel(ntiles, C), dtype=torch.float32, device=dev())
+    pv = torch.stack([torch.stack([flat[:half].sum(0), (flat[:half] ** 2).sum(0)]),
+                      torch.stack([flat[half:].sum(0), (flat[half:] ** 2).sum(0)])]).float()
+    part[: ntiles * 2 * C] = pv.reshape(-1).to(dev())
+    coef = torch.empty(4, C, dtype=torch.float32, device=dev())
+    rmd, rvd = torch.zeros(C, device=dev()), torch.ones(C, device=dev())
+    ops.bn_finalize(part, ntiles, C, N * H * W, gamma.detach().to(dev()), beta.detach().to(dev()), rmd, rvd, 0.1, 1e-5,
+                    coef[0], coef[1], coef[2], coef[3])
+    assert torch.allclose(rmd.cpu(), rm, atol=1e-5) and torch.allclose(rvd.cpu(), rv, rtol=1e-4, atol=1e-5)
+    zbuf = torch.zeros(N, H, W, 2 * C, dtype=dt, device=dev())
+    zp = torch.empty(N, H // 2, W // 2, C, dtype=dt, device=dev()) if pool else None
+    ops.bn_act_apply(yd, coef[0], coef[1], ACT_RELU, zbuf, 2 * C, C, zp)
+    torch.cuda.synchronize()
+    got = from_nhwc(zbuf[..., C:])
+    assert (got - z.detach()).abs().max() < (4e-3 if dt == torch.float16 else 3e-2)
+    assert float(zbuf[..., :C].abs().max()) == 0.0
+    if pool:
+        assert torch.equal(from_nhwc(zp), F.max_pool2d(got, 2))
+    # backward: dz from a concat-half (strided) + pooled gradient
+    dza = rnd(g, N, C, H, W, dt=dt)
+    loss = (z * dza).sum()
+    dzp_t = None
+    if pool:
+        dzp_t = rnd(g, N, C, H // 2, W // 2, dt=dt)
+        # pool the ROUNDED z like the kernel does (ties/arg-max follow the stored values)
+        zq = z + (zr - z).detach()
+        loss = loss + (F.max_pool2d(zq, 2) * dzp_t).sum()
+    loss.backward()
+    dbuf = torch.zeros(N, H, W, 2 * C, dtype=dt, device=dev())
+    dbuf[..., C:] = nhwc(dza, dt)
+    dzp = nhwc(dzp_t, dt) if pool else None
+    nt = ops.bn_bwd_tiles_used(N, H, W, pool)
+    assert nt <= ops.bn_bwd_tiles(N, H, W)
+    part2 = torch.zeros(ops.bn_partials_numel(ops.bn_bwd_tiles(N, H, W), C), dtype=torch.float32, device=dev())
+    ops.bn_act_bwd_reduce(yd, dbuf, 2 * C, C, dzp, coef[0], coef[1], coef[2], coef[3], ACT_RELU, part2)
+    dgamma = torch.empty(C, device=dev()); dbeta = torch.empty(C, device=dev())
+    c12 = torch.empty(2, C, device=dev())
+    ops.bn_bwd_coeffs(part2, nt, C, N * H * W, 0.25, dgamma, dbeta, c12[0], c12[1])
+    dy = torch.empty(N, H, W, C, dtype=dt, device=dev())
+    ops.bn_act_bwd_apply(yd, dbuf, 2 * C, C, dzp, coef[0], coef[1], coef[2], coef[3], c12[0], c12[1], ACT_RELU, True, dy)
+    torch.cuda.synchronize()
+    assert rel_err(dgamma.cpu() * 4, gamma.grad) < 5e-3, rel_err(dgamma.cpu() * 4, gamma.grad)
+    assert rel_err(dbeta.cpu() * 4, beta.grad) < 5e-3
+    assert rel_err(from_nhwc(dy), y.grad) < (5e-3 if dt == torch.float16 else 2e-2), rel_err(from_nhwc(dy), y.grad)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtn,dt", DTS)
+@pytest.mark.parametrize("Cin,k,s,p,bias", [(1, 3, 1, 1, False), (2, 4, 2, 1, True), (1, 4, 2, 1, False), (3, 3, 1, 1, False)])
+def test_smallcin(dtn, dt, Cin, k, s, p, bias):
+    from semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(7)
+    N, H, W, Cout = 2, 18, 22, 64
+    x = torch.randn(N, Cin, H, W, generator=g).requires_grad_(True)
+    w = (0.2 * torch.randn(Cout, Cin, k, k, generator=g)).requires_grad_(True)
+    b = torch.randn(Cout, generator=g) if bias else None
+    ref = F.conv2d(x, w, b, stride=s, padding=p)
+    OH, OW = ref.shape[2], ref.shape[3]
+    y = torch.empty(N, OH, OW, Cout, dtype=dt, device=dev())
+    mt = ops.conv_smallcin_mtiles(N, OH, OW)
+    part = None if bias else torch.zeros(ops.bn_partials_numel(mt, Cout), dtype=torch.float32, device=dev())
+    ops.conv_smallcin_fwd(x.detach().to(dev()), w.detach().to(dev()), None if b is None else b.to(dev()), y, part, k, s, p)
+    torch.cuda.synchronize()
+    assert (from_nhwc(y) - ref.detach()).abs().max() < (5e-3 if dt == torch.float16 else 4e-2)
+    if part is not None:
+        pp = part[: mt * 2 * Cout].view(mt, 2, Cout).double().sum(0).cpu()
+        assert (pp[0] - ref.detach().double().sum((0, 2, 3))).abs().max() < 1e-2
+        assert rel_err(pp[1], (ref.detach().double() ** 2).sum((0, 2, 3))) < 1e-4
+    dy = rnd(g, N, Cout, OH, OW, dt=dt)
+    ref.backward(dy)
+    dyd = nhwc(dy, dt)
+    dw = torch.zeros(Cout, Cin, k, k, dtype=torch.float32, device=dev())
+    ops.conv_smallcin_wgrad(x.detach().to(dev()), dyd, dw, k, s, p, 0.5)
+    dx = torch.empty(N, Cin, H, W, dtype=torch.float32, device=dev())
+    ops.conv_smallcin_dgrad(dyd, w.detach().to(dev()), dx, k, s, p, 0.5)
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu() * 2, w.grad) < 1e-4
+    assert rel_err(dx.cpu() * 2, x.grad) < 1e-4
+
+
+@pytest.mark.parametrize("dtn,dt", DTS)
+@pytest.mark.parametrize("Cin,Cout,k,p", [(64, 2, 1, 0), (64, 1, 1, 0), (512, 1, 4, 1)])
+def test_smallcout(dtn, dt, Cin, Cout, k, p):
+    from semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(8)
+    N, H, W = 2, 11, 9
+    x = rnd(g, N, Cin, H, W, dt=dt).requires_grad_(True)
+    w = (0.1 * torch.randn(Cout, Cin, k, k, generator=g)).requires_grad_(True)
+    b = torch.randn(Cout, generator=g).requires_grad_(True)
+    ref = F.conv2d(x, w, b, padding=p)
+    OH, OW = ref.shape[2], ref.shape[3]
+    y = torch.empty(N, Cout, OH, OW, dtype=torch.float32, device=dev())
+    xd = nhwc(x.detach(), dt)
+    ops.conv_smallcout_fwd(xd, w.detach().to(dev()), b.detach().to(dev()), y, k, 1, p)
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu(), ref.detach()) < 1e-5
+    dy = torch.randn(N, Cout, OH, OW, generator=g)
+    ref.backward(dy)
+    dx = torch.empty(N, H, W, Cin, dtype=dt, device=dev())
+    dw = torch.zeros_like(w.detach()).to(dev()); db = torch.zeros(Cout, device=dev())
+    ops.conv_smallcout_bwd(xd, w.detach().to(dev()), dy.to(dev()), dx, dw, db, k, 1, p, 0.5)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(dx), x.grad) < tol(dt)
+    assert rel_err(dw.cpu() * 2, w.grad) < 1e-4
+    assert rel_err(db.cpu() * 2, b.grad) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C", [1, 2, 3])
+@pytest.mark.parametrize("mode", ["rand", "zeros", "ones"])
+def test_seg_loss_matches_oracle(C, mode):
+    from oracle import oracle
+    from semantic_segmentation_amd.losses import seg_loss
+    g = torch.Generator().manual_seed(9)
+    N, H, W = 3, 37, 29
+    logits = (2 * torch.randn(N, C, H, W, generator=g)).requires_grad_(True)
+    hi = max(C, 2)
+    mask = torch.randint(0, hi, (N, 1, H, W), generator=g)
+    if mode == "zeros":
+        mask.zero_()
+    elif mode == "ones":
+        mask.fill_(1 if C <= 2 else C - 1)
+    ref = oracle.seg_loss(logits, mask)
+    ref.backward()
+    lg = logits.detach().to(dev()).requires_grad_(True)
+    loss, parts = seg_loss(lg, mask.to(dev()), return_parts=True)
+    (loss * 3.0).backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - ref.item()) < 2e-6 * max(1, abs(ref.item())), (loss.item(), ref.item())
+    assert rel_err(lg.grad.cpu() / 3.0, logits.grad) < 1e-4
+
+
+def test_dice_api_matches_golden(golden_dir):
+    import os
+    from semantic_segmentation_amd.util.dice_score import dice_coeff, dice_loss, multiclass_dice_coeff
+    z = np.load(os.path.join(golden_dir, "dice_cases.npz"))
+    p, t = torch.from_numpy(z["p"]).to(dev()), torch.from_numpy(z["t"]).to(dev())
+    assert abs(dice_coeff(p, t, False).item() - float(z["coeff_rbf_false"])) < 1e-6
+    assert abs(dice_coeff(p, t, True).item() - float(z["coeff_rbf_true"])) < 1e-6
+    assert abs(dice_loss(p, t).item() - float(z["loss"])) < 1e-6
+    zz = torch.zeros_like(p)
+    assert dice_loss(zz, zz).item() == 0.0
+    assert abs(dice_loss(p, zz).item() - float(z["zero_target_loss"])) < 1e-6
+    assert abs(dice_coeff(p[0], t[0]).item() - float(z["coeff_2d"])) < 1e-6
+    pm, tm = torch.from_numpy(z["pm"]).to(dev()), torch.from_numpy(z["tm"]).to(dev())
+    assert abs(multiclass_dice_coeff(pm, tm, False).item() - float(z["mc_rbf_false"])) < 1e-6
+    assert abs(dice_loss(pm, tm, multiclass=True).item() - float(z["mc_loss"])) < 1e-6
+    pg = p.clone().requires_grad_(True)
+    dice_loss(pg, t).backward()
+    np.testing.assert_allclose(pg.grad.cpu().numpy(), z["loss_grad_p"], rtol=1e-4, atol=1e-9)
+
+
+def test_mean_losses_match_golden(golden_dir):
+    import os
+    from semantic_segmentation_amd import losses
+    z = np.load(os.path.join(golden_dir, "ops_micro.npz"))
+    pred = torch.from_numpy(z["gan/pred"]).to(dev())
+    for mode, code in (("vanilla", losses.MODE_BCE_CONST), ("lsgan", losses.MODE_MSE_CONST)):
+        assert abs(losses.mean_loss(pred, None, 1.0, code).item() - float(z[f"gan/{mode}/real"])) < 1e-6
+        assert abs(losses.mean_loss(pred, None, 0.0, code).item() - float(z[f"gan/{mode}/fake"])) < 1e-6
+    assert abs(losses.mean_loss(pred, None, -1.0, losses.MODE_MEAN).item() - float(z["gan/wgangp/real"])) < 1e-6
+    assert abs(losses.mean_loss(pred, None, 1.0, losses.MODE_MEAN).item() - float(z["gan/wgangp/fake"])) < 1e-6
+    a, b = torch.from_numpy(z["l1/a"]).to(dev()), torch.from_numpy(z["l1/b"]).to(dev())
+    assert abs(losses.l1_loss(a, b).item() - float(z["l1/y"])) < 1e-6
+    x, t = torch.from_numpy(z["bce/x"]).to(dev()), torch.from_numpy(z["bce/t"]).to(dev())
+    assert abs(losses.bce_with_logits(x, t).item() - float(z["bce/y"])) < 1e-6
+    # gradients vs torch autograd on CPU
+    xc = torch.from_numpy(z["bce/x"]).requires_grad_(True)
+    F.binary_cross_entropy_with_logits(xc, torch.from_numpy(z["bce/t"])).backward()
+    xg = x.clone().requires_grad_(True)
+    losses.bce_with_logits(xg, t).backward()
+    assert rel_err(xg.grad.cpu(), xc.grad) < 1e-5
+    ac = torch.from_numpy(z["l1/a"]).requires_grad_(True)
+    F.l1_loss(ac, torch.from_numpy(z["l1/b"])).backward()
+    ag = a.clone().requires_grad_(True)
+    losses.l1_loss(ag, b).backward()
+    assert rel_err(ag.grad.cpu(), ac.grad) < 1e-6
+
+
+def test_layout_roundtrip():
+    from semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(2, 5, 7, 6, generator=g).half().float()
+    d = torch.zeros(2, 7, 6, 8, dtype=torch.float16, device=dev())
+    ops.nchw_to_nhwc(x.to(dev()), d, 8, 3)
+    back = torch.empty(2, 5, 7, 6, dtype=torch.float32, device=dev())
+    ops.nhwc_to_nchw(d, back, 8, 3, 2.0)
+    torch.cuda.synchronize()
+    assert torch.equal(back.cpu(), x * 2)
+    assert float(d[..., :3].abs().max()) == 0.0

@@ -1,0 +1,87 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/gsseg.h declares,
+the Python surface keeps the reference's names / state-dict keys, host-side geometry is right, and the
+product package never imports the oracle."""
+import ast
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from semantic_segmentation_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from semantic_segmentation_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "gsseg.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in gsseg.h but not exported"
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    assert lib.gs_abi_version() == _lib.ABI_VERSION
+
+
+def test_argument_validation_is_synchronous(lib):
+    from semantic_segmentation_amd import _lib
+    g = _lib.GsConvGeom()
+    assert lib.gs_conv_igemm(g, None, None, None, None, None, 0, 0, None) != 0
+    assert b"gs_conv_igemm" in lib.gs_last_error()
+    assert lib.gs_bn_finalize(None, 0, 0, 0.0, None, None, None, None, 0.1, 1e-5, None, None, None, None, None) != 0
+    assert lib.gs_bn_partials_floats(10, 64) >= 10 * 2 * 64
+
+
+def test_unet_api_surface_and_state_dict_keys():
+    from oracle import oracle
+    from semantic_segmentation_amd.unet import UNet
+    for n_classes in (1, 2):
+        net = UNet(1, n_classes)
+        assert (net.n_channels, net.n_classes, net.bilinear) == (1, n_classes, False)
+        assert [n for n, _ in net.named_children()] == ["inc", "down1", "down2", "down3", "down4", "up1", "up2",
+                                                        "up3", "up4", "outc"]
+        sd = oracle.unet_state_dict(1, n_classes, seed=0)
+        assert list(net.state_dict().keys()) == list(sd.keys())
+        assert len(sd) == 118
+        for k, v in net.state_dict().items():
+            assert tuple(v.shape) == tuple(sd[k].shape), k
+        assert sum(p.numel() for p in net.parameters()) == (31036481 if n_classes == 1 else 31036546)
+        net.load_state_dict(sd, strict=True)
+    with pytest.raises(RuntimeError):
+        UNet(1, 1)(torch.zeros(1, 1, 32, 32))       # CPU tensor: no fallback
+
+
+def test_geometry_builders():
+    from semantic_segmentation_amd import ops
+    g = ops.geom_conv(2, 17, 9, 64, 128, 3, 1, 1)
+    assert (g.OHg, g.OWg, g.OH, g.OW, g.ntaps) == (17, 9, 17, 9, 9)
+    assert (g.tap_dy[0], g.tap_dx[0], g.tap_dy[8], g.tap_dx[8]) == (-1, -1, 1, 1)
+    g = ops.geom_conv(1, 256, 256, 64, 128, 4, 2, 1)
+    assert (g.OH, g.OW, g.isy, g.ntaps) == (128, 128, 2, 16)
+    d = ops.geom_conv_dgrad_s1(2, 17, 9, 64, 128, 3, 1)
+    assert (d.Cin, d.Cout, d.tap_dy[0], d.tap_dy[8]) == (128, 64, 1, -1)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "semantic_segmentation_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            tree = ast.parse(open(os.path.join(dp, f)).read())
+            for node in ast.walk(tree):
+                mods = []
+                if isinstance(node, ast.Import):
+                    mods = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom) and node.module:
+                    mods = [node.module]
+                for m in mods:
+                    assert not m.split(".")[0] == "oracle", f"{f} imports {m}"
