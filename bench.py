@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the U-Net 256x256 forward+backward (seg loss included, optimiser
+step and data loading excluded) on N MI355X, one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): unet.UNet(n_channels=1, n_classes=2), 256x256, batch 32 PER GPU
+(weak scaling), synthetic images/masks resident in HBM, random-init weights, loss = CrossEntropy +
+multiclass Dice (the n_classes=2 form of train_end2end_jsrt.py:181-183).  Data parallel: RCCL all-reduce
+(average) of the 31 M gradients, bucketed and overlapped with backward.
+
+One JSON line on rank 0.  `roofline` is for the dominant MFMA kernel, measured live with HIP events on the
+launch stream inside the timed region: achieved = algorithmic FLOPs (2*M*N*K of the convolutions it ran)
+/ its summed launch time.  `cpu_baseline` is the CPU oracle (a port, oracle/oracle.py) timed on the host
+cores of this box on a bounded sample (batch 4), N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GF_PER_IMG_FWDBWD = {1: 288.48, 2: 288.50}     # conv/convT 2*MACs, 256x256
+MFMA_PEAK_TFLOPS = 2500.0                      # dense bf16/fp16, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--classes", type=int, default=2)
+    ap.add_argument("--dtype", default=os.environ.get("GSSEG_DTYPE", "f16"), choices=["f16", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def host_cores() -> int:
+    """CPU share of this process: cgroup quota if set, else affinity; a 1-GPU box gives 16 cores."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return int(os.environ.get("GSSEG_CPU_THREADS", min(n, 16)))
+
+
+def cpu_baseline(args):
+    """The oracle (CPU port of the reference path) timed on this box's host cores: fp32, fwd+loss+bwd."""
+    from oracle import oracle
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    sd = oracle.unet_state_dict(1, args.classes, seed=0)
+    x, mask = oracle.synthetic_batch(args.cpu_batch, args.size, seed=1234)
+    oracle.unet_step(sd, x, mask, train=True)                       # warm-up (oneDNN primitive creation)
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_steps):
+        oracle.unet_step(sd, x, mask, train=True)
+    dt = (time.perf_counter() - t0) / args.cpu_steps
+    ips = args.cpu_batch / dt
+    return {"value": round(ips, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle.unet_step fp32, UNet(1,{args.classes}) {args.size}x{args.size} batch {args.cpu_batch}, "
+                      f"{args.cpu_steps} timed steps after 1 warm-up, torch {torch.__version__} CPU",
+            "gflops": round(ips * GF_PER_IMG_FWDBWD.get(args.classes, 288.5) * (args.size / 256.0) ** 2, 1)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from oracle import oracle          # synthetic data generator only (inputs), never the measured path
+    from semantic_segmentation_amd import ops
+    from semantic_segmentation_amd.losses import seg_loss
+    from semantic_segmentation_amd.parallel import GradReducer, broadcast_module_state
+    from semantic_segmentation_amd.unet import UNet
+
+    torch.manual_seed(1234)
+    net = UNet(1, args.classes, compute_dtype=args.dtype).to(dev)
+    net.train()
+    broadcast_module_state(net)
+    reducer = None
+    if world > 1:
+        reducer = GradReducer(net.named_parameters()).attach(net.engine)
+    x, mask = oracle.synthetic_batch(args.batch, args.size, seed=1234 + rank)
+    x, mask = x.to(dev), mask.to(dev)
+
+    def step():
+        for p in net.parameters():
+            p.grad = None
+        loss = seg_loss(net(x), mask)
+        loss.backward()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    timer = ops.KernelTimer()
+    ops.TIMER = timer
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.TIMER = None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ksum = timer.summary()
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms = elapsed / args.steps * 1e3
+    value = world * args.batch * args.steps / elapsed
+    gf = GF_PER_IMG_FWDBWD.get(args.classes, 288.5) * (args.size / 256.0) ** 2
+    kern = {}
+    for kind, d in ksum.items():
+        tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+        kern[kind] = {"launches_per_step": d["launches"] / args.steps, "ms_per_step": round(d["ms"] / args.steps, 4),
+                      "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2), "tflops": round(tf, 1),
+                      "tflop_per_step": round(d["flops"] / args.steps / 1e12, 4)}
+    dom = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
+    roof = None
+    if dom:
+        roof = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "avg_launch_us": kern[dom]["avg_launch_us"],
+                "flop_per_launch": round(kern[dom]["tflop_per_step"] * 1e12 / kern[dom]["launches_per_step"], 0)}
+    out = {
+        "metric": "images/sec (fwd+bwd) U-Net 256x256 bs=32 per GPU", "value": round(value, 2), "unit": "images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"unet.UNet(1,{args.classes}) {args.size}x{args.size} fwd+bwd, CE+Dice loss, "
+                               f"batch {args.batch}/GPU (BASELINE configs[1])",
+                   "global_batch": world * args.batch, "parallelism": f"dp{world}", "loss": float(loss.item())},
+        "whole_step_tflops": round(value * gf / 1e3, 1),
+        "whole_step_frac_of_mfma_peak": round(value * gf / 1e3 / (MFMA_PEAK_TFLOPS * world), 4),
+        "roofline": roof, "kernels": kern,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

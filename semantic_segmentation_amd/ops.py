@@ -78,6 +78,44 @@ def geom_conv_dgrad_s1(N, IH, IW, Cin, Cout, k, pad, **kw) -> GsConvGeom:
     return make_geom(N, OH, OW, Cout, IH, IW, Cin, IH, IW, taps, **kw)
 
 
+# ---------------------------------------------------------------------------- per-launch timing
+class KernelTimer:
+    """Brackets selected launches with HIP events on the launch stream (torch's current stream, which is
+    the stream handed to the C ABI) and accumulates algorithmic work per kernel class.  Used by bench.py
+    for the roofline figures; off by default (TIMER is None)."""
+
+    def __init__(self):
+        self.records = []          # (kind, flops, bytes, ev0, ev1)
+
+    def start(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def stop(self, kind, ev0, flops=0.0, nbytes=0.0):
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        self.records.append((kind, float(flops), float(nbytes), ev0, ev1))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, fl, nb, e0, e1 in self.records:
+            d = out.setdefault(kind, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += nb
+        return out
+
+
+TIMER: Optional[KernelTimer] = None
+
+
+def _geom_flops(g: GsConvGeom) -> float:
+    return 2.0 * g.N * g.OHg * g.OWg * g.Cout * g.ntaps * g.Cin
+
+
 # ---------------------------------------------------------------------------- MFMA engine
 def conv_igemm(g: GsConvGeom, x, w, y, bias=None, bn_partials=None, act=ACT_NONE):
     _dev(x)
@@ -88,7 +126,10 @@ def conv_igemm(g: GsConvGeom, x, w, y, bias=None, bn_partials=None, act=ACT_NONE
         need = _lib.load().gs_bn_partials_floats(conv_igemm_mtiles(g), g.Cout)
         if bn_partials.numel() < need:
             raise ValueError(f"bn_partials too small: {bn_partials.numel()} < {need}")
+    ev = TIMER.start() if TIMER is not None else None
     _lib.call("gs_conv_igemm", g, _p(x), _p(w), _p(y), _p(bias), _p(bn_partials), act, dt_code(x), _stream())
+    if ev is not None:
+        TIMER.stop("igemm_fwd", ev, _geom_flops(g))
 
 
 def conv_igemm_mtiles(g: GsConvGeom) -> int:
@@ -102,7 +143,10 @@ def conv_wgrad(g: GsConvGeom, x, dy, dw):
         raise TypeError("conv_wgrad: x and dy must share one 16-bit dtype")
     if dw.numel() < g.ntaps * g.Cout * g.Cin:
         raise ValueError("conv_wgrad: dw too small")
+    ev = TIMER.start() if TIMER is not None else None
     _lib.call("gs_conv_wgrad", g, _p(x), _p(dy), _p(dw), dt_code(x), _stream())
+    if ev is not None:
+        TIMER.stop("igemm_wgrad", ev, _geom_flops(g))
 
 
 def bn_partials_numel(ntiles: int, C: int) -> int:

@@ -1,0 +1,108 @@
+"""Data parallelism for the hot path: one process per GPU, identical replicas, ONE exchange per step --
+a sum/avg all-reduce of the parameter gradients over RCCL (torch.distributed backend "nccl" on ROCm),
+bucketed in backward order and launched while the rest of backward still runs.
+
+The reference has no collective on this path (only single-process nn.DataParallel,
+unreachable from its scripts), so this is new.  Semantics follow DDP: per-rank BatchNorm statistics and
+per-rank Dice; rank 0's buffers are broadcast at start.
+
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): a 124 MB fp32 gradient set is ~0.2 ms as a direct
+reduce-scatter+all-gather but ~1.4 ms through a single-link ring, so buckets are few and large (default
+32 MB) and always overlapped with the remaining backward kernels."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    """Owns flat fp32 gradient buckets; plugs into UNetEngine via grad_alloc / grad_ready_hook / after_backward.
+
+    Parameters are laid out in REVERSE registration order (= the order backward finishes them), cut into
+    buckets of ~bucket_bytes.  When the last gradient of a bucket is announced its all-reduce is issued
+    asynchronously; `finish()` makes the current stream wait for all of them."""
+
+    def __init__(self, named_params, bucket_bytes: int = 32 << 20, group=None, average: bool = True):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        items = [(n, p) for n, p in named_params if p.requires_grad][::-1]
+        if not items:
+            raise ValueError("no trainable parameters")
+        dev = items[0][1].device
+        total = sum(p.numel() for _, p in items)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.views: Dict[str, torch.Tensor] = {}
+        self.bucket_of: Dict[str, int] = {}
+        self.buckets: List[dict] = []
+        off, start, names = 0, 0, []
+        for n, p in items:
+            self.views[n] = self.flat[off:off + p.numel()].view(p.shape)
+            names.append(n)
+            off += p.numel()
+            if (off - start) * 4 >= bucket_bytes:
+                self._close(start, off, names)
+                start, names = off, []
+        if names:
+            self._close(start, off, names)
+        self.op = dist.ReduceOp.AVG if (average and dist.is_initialized() and dist.get_backend(group) == "nccl") \
+            else dist.ReduceOp.SUM
+        self.average = average
+        self._works: list = []
+        self._pending: List[int] = []
+
+    def _close(self, a, b, names):
+        idx = len(self.buckets)
+        self.buckets.append({"range": (a, b), "names": list(names)})
+        for n in names:
+            self.bucket_of[n] = idx
+
+    # -- engine hooks --------------------------------------------------------------------------------
+    def begin(self):
+        self._works = []
+        self._pending = [len(b["names"]) for b in self.buckets]
+
+    def alloc(self, name: str, like: torch.Tensor) -> torch.Tensor:
+        return self.views[name]
+
+    def ready(self, name: str, grad: torch.Tensor):
+        if not self._pending:
+            self.begin()
+        b = self.bucket_of[name]
+        if grad.data_ptr() != self.views[name].data_ptr():
+            self.views[name].copy_(grad)
+        self._pending[b] -= 1
+        if self._pending[b] == 0 and self.world > 1:
+            a, e = self.buckets[b]["range"]
+            self._works.append(dist.all_reduce(self.flat[a:e], op=self.op, group=self.group, async_op=True))
+
+    def finish(self):
+        for w in self._works:
+            w.wait()
+        if self.world > 1 and self.average and self.op == dist.ReduceOp.SUM:
+            self.flat.mul_(1.0 / self.world)
+        self._works = []
+        self._pending = []
+
+    def attach(self, engine):
+        engine.grad_alloc = self.alloc
+        engine.grad_ready_hook = self.ready
+        engine.after_backward = self.finish
+        return self
+
+
+def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None):
+    """Replicas start identical: parameters and buffers of rank `src` (DDP broadcast_buffers semantics)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)
+
+
+def shard_batch(n_global: int, rank: int, world: int):
+    """Contiguous shard [lo, hi) of a global batch (rank r owns samples r*B/world ...)."""
+    per = n_global // world
+    if per * world != n_global:
+        raise ValueError("global batch must be divisible by the world size")
+    return rank * per, (rank + 1) * per

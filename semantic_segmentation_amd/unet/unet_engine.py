@@ -52,7 +52,12 @@ class UNetEngine:
         self.dtype = dtype
         self.tdt = _TORCH_DT[dtype]
         self._packs: Dict[str, tuple] = {}
+        # data-parallel hooks (parallel.GradReducer): grads are allocated inside the reducer's flat buckets,
+        # announced as soon as they are final (so the RCCL all-reduce overlaps the rest of backward), and
+        # `after_backward` makes the compute stream wait for the collectives.
         self.grad_ready_hook: Optional[Callable[[str, torch.Tensor], None]] = None
+        self.grad_alloc: Optional[Callable[[str, torch.Tensor], torch.Tensor]] = None
+        self.after_backward: Optional[Callable[[], None]] = None
 
     # ------------------------------------------------------------------ parameters
     def param_items(self):
@@ -243,6 +248,14 @@ class UNetEngine:
             if self.grad_ready_hook is not None:
                 self.grad_ready_hook(name, g)
 
+        def galloc(name, like, zero=False):
+            if self.grad_alloc is not None:
+                g = self.grad_alloc(name, like)
+                if zero:
+                    g.zero_()
+                return g
+            return (torch.zeros_like if zero else torch.empty_like)(like, memory_format=torch.contiguous_format)
+
         # workspaces
         max_w = max(p.numel() for k, p in params.items() if k.endswith("weight") and p.dim() == 4)
         dw_ws = empty(max_w, dtype=torch.float32)
@@ -256,8 +269,8 @@ class UNetEngine:
         z_last = ctx["z_last"]
         dl = (dlogits.contiguous().float() * S)
         wout = params["outc.conv.weight"]
-        dwo = torch.zeros_like(wout, memory_format=torch.contiguous_format)
-        dbo = torch.zeros_like(params["outc.conv.bias"])
+        dwo = galloc("outc.conv.weight", wout, zero=True)
+        dbo = galloc("outc.conv.bias", params["outc.conv.bias"], zero=True)
         dz = empty(N, H, W, 64)
         ops.conv_smallcout_bwd(z_last, wout.detach().contiguous(), dl, dz, dwo, dbo, gscale=inv_s)
         emit("outc.conv.weight", dwo)
@@ -270,8 +283,8 @@ class UNetEngine:
             pooled = dzp is not None
             ntiles = ops.bn_bwd_tiles_used(N, h, w, pooled)
             ops.bn_act_bwd_reduce(rec.y, dz_a, sa, ca, dzp, coef[0], coef[1], coef[2], coef[3], ACT_RELU, partials)
-            dgamma = empty(cout, dtype=torch.float32)
-            dbeta = empty(cout, dtype=torch.float32)
+            dgamma = galloc(rec.bnkey + ".weight", params[rec.bnkey + ".weight"])
+            dbeta = galloc(rec.bnkey + ".bias", params[rec.bnkey + ".bias"])
             c12 = empty(2, cout, dtype=torch.float32)
             ops.bn_bwd_coeffs(partials, ntiles, cout, N * h * w, inv_s, dgamma, dbeta, c12[0], c12[1])
             if not rec.train_stats:
@@ -282,7 +295,7 @@ class UNetEngine:
             wparam = params[rec.wkey]
             dinp = None
             if rec.inp_is_image:
-                dw = torch.zeros_like(wparam, memory_format=torch.contiguous_format)
+                dw = galloc(rec.wkey, wparam, zero=True)
                 ops.conv_smallcin_wgrad(rec.inp, dy, dw, 3, 1, 1, inv_s)
                 if need_dinp:
                     dinp = torch.empty_like(rec.inp)
@@ -291,7 +304,7 @@ class UNetEngine:
                 dwp = dw_ws[: wparam.numel()]
                 dwp.zero_()
                 ops.conv_wgrad(rec.geom, rec.inp, dy, dwp)
-                dw = torch.empty_like(wparam, memory_format=torch.contiguous_format)
+                dw = galloc(rec.wkey, wparam)
                 ops.unpack_wgrad(dwp, dw, cout, cin, 9, False, inv_s)
                 if need_dinp:
                     dinp = empty(N, h, w, cin)
@@ -314,12 +327,12 @@ class UNetEngine:
             u = ups[prefix]
             wkey = prefix + ".up.weight"
             wparam = params[wkey]
-            db = empty(cout_t, dtype=torch.float32)
+            db = galloc(prefix + ".up.bias", params[prefix + ".up.bias"])
             ops.colsum(dcat, 2 * cout_t, cout_t, N, u.H2, u.W2, u.pt, u.pl, 2 * u.h, 2 * u.w, cout_t, inv_s, col_ws, db)
             dwp = dw_ws[: wparam.numel()]
             dwp.zero_()
             ops.conv_wgrad(u.geom_bwd, dcat, u.zin, dwp)
-            dw = torch.empty_like(wparam, memory_format=torch.contiguous_format)
+            dw = galloc(wkey, wparam)
             ops.unpack_wgrad(dwp, dw, u.cin, u.cout, 4, False, inv_s)
             dz = empty(N, u.h, u.w, u.cin)
             ops.conv_igemm(u.geom_bwd, dcat, u.wd, dz)
@@ -341,6 +354,8 @@ class UNetEngine:
                 dpool = dinp
             else:
                 dx = dinp
+        if self.after_backward is not None:
+            self.after_backward()
         return grads, dx
 
 
@@ -348,9 +363,8 @@ class _UNetFunction(torch.autograd.Function):
     """autograd bridge: (x, *params) -> logits."""
 
     @staticmethod
-    def forward(ctx, engine: UNetEngine, names, training: bool, x, *plist):
+    def forward(ctx, engine: UNetEngine, names, training: bool, need_grad: bool, x, *plist):
         params = dict(zip(names, plist))
-        need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in plist))
         logits, ectx = engine.forward(x, params, training, need_grad)
         ctx.engine, ctx.names, ctx.ectx, ctx.plist = engine, names, ectx, plist
         ctx.x_needs_grad = x.requires_grad
@@ -362,12 +376,18 @@ class _UNetFunction(torch.autograd.Function):
             raise RuntimeError("UNet forward ran without gradient tracking")
         params = dict(zip(ctx.names, ctx.plist))
         grads, dx = ctx.engine.backward(ctx.ectx, params, dlogits, ctx.x_needs_grad)
-        out = [grads.get(n) if p.requires_grad else None for n, p in zip(ctx.names, ctx.plist)]
-        return (None, None, None, dx if ctx.x_needs_grad else None, *out)
+        # gradients living in a GradReducer bucket are handed to autograd as copies: a stolen bucket view
+        # would be overwritten (not accumulated) by the next backward
+        alias = ctx.engine.grad_alloc is not None
+        out = [(grads[n].clone() if alias else grads[n]) if (p.requires_grad and n in grads) else None
+               for n, p in zip(ctx.names, ctx.plist)]
+        return (None, None, None, None, dx if ctx.x_needs_grad else None, *out)
 
 
 def run_unet(engine: UNetEngine, x: torch.Tensor) -> torch.Tensor:
     items = engine.param_items()
     names = tuple(n for n, _ in items)
     plist = tuple(p for _, p in items)
-    return _UNetFunction.apply(engine, names, engine.net.training, x, *plist)
+    # grad mode is always off inside Function.forward: decide here whether to keep activations
+    need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in plist))
+    return _UNetFunction.apply(engine, names, engine.net.training, need_grad, x, *plist)
