@@ -114,6 +114,7 @@ def main():
     def step():
         for p in net.parameters():
             p.grad = None
+        net.engine.invalidate_packs()      # weights change every step in training: re-pack inside the timed region
         loss = seg_loss(net(x), mask)
         loss.backward()
         return loss

@@ -63,6 +63,15 @@ int gs_conv_igemm_mtiles(const GsConvGeom* g);
 int gs_conv_igemm(const GsConvGeom* g, const void* x, const void* w, void* y, const float* bias,
                   float* bn_partials, int act, int dtype, void* stream);
 
+/* ---- 3x3 / stride 1 / pad 1 convolution with LDS halo reuse (the U-Net DoubleConv hot loop,
+ * unet_parts.py:16,19) and its data gradient (pass flipped taps and the [9][Cin][Cout] pack).
+ * Same operands as gs_conv_igemm; tap t reads input pixel (y + tap_dy[t], x + tap_dx[t]), offsets in [-1,1];
+ * bn_partials is [gs_conv3x3_mtiles][2][Cout] (one tile per spatial patch). */
+int gs_conv3x3_mtiles(int N, int H, int W, int Cout);
+int gs_conv3x3(const void* x, const void* w, void* y, const float* bias, float* bn_partials, int N, int H, int W,
+               int Cin, int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff,
+               const int32_t* tap_dy, const int32_t* tap_dx, int act, int dtype, void* stream);
+
 /* ---- MFMA weight gradient -------------------------------------------------------------------
  * dw[t][co][ci] (fp32, ACCUMULATED with atomics: caller zeroes) += sum over logical pixels of
  * dy[pix][co] * x[inpix(pix,t)][ci].  `g` describes the forward conv: dy lives on the OUTPUT side

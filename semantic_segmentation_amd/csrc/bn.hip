@@ -363,12 +363,22 @@ __global__ __launch_bounds__(256) void colsum_stage1(const unsigned short* __res
         }
     }
 }
-__global__ void colsum_stage2(const float* ws, int nblocks, int C, float gscale, float* out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// block 256 = 8 row-lanes x 32 channels; fixed summation order -> deterministic
+__global__ __launch_bounds__(256) void colsum_stage2(const float* ws, int nblocks, int C, float gscale, float* out) {
+    __shared__ double red[8][32];
+    const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     double s = 0.0;
-    for (int i = 0; i < nblocks; ++i) s += (double)ws[(int64_t)i * C + c];
-    out[c] = (float)(s * gscale);
+    if (c < C)
+        for (int i = tl; i < nblocks; i += 8) s += (double)ws[(int64_t)i * C + c];
+    red[tl][cl] = s;
+    __syncthreads();
+    if (tl == 0 && c < C) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[i][cl];
+        out[c] = (float)(t * gscale);
+    }
 }
 
 int reduce_partials(const float* partials, int ntiles, int C, double** out, int* nslices, hipStream_t s) {
@@ -554,7 +564,7 @@ extern "C" int gs_colsum(const void* t, int pix_stride, int coff, int N, int H, 
     else if (dtype == GS_BF16)
         colsum_stage1<GS_BF16><<<nb, 256, 0, s>>>((const unsigned short*)t, pix_stride, coff, npix, C, ppb, ws, H, W, y0, x0, h, w);
     else GS_CHECK_ARG(false, "gs_colsum: bad dtype");
-    colsum_stage2<<<cdiv(C, 128), 128, 0, s>>>(ws, nb, C, gscale, out);
+    colsum_stage2<<<cdiv(C, 32), 256, 0, s>>>(ws, nb, C, gscale, out);
     GS_CHECK_LAUNCH("gs_colsum");
     return GS_OK;
 }

@@ -1,0 +1,616 @@
+// 3x3 / stride-1 / pad-1 convolution (and its data gradient) as an MFMA implicit GEMM with HALO REUSE.
+//
+// The generic engine (igemm.hip) gathers the A operand once per tap, i.e. every input pixel travels
+// L2 -> LDS nine times; at the 256x256 / 64-channel end of the U-Net that makes the kernel L2-bandwidth
+// bound.  Here a block owns a spatial patch TH x TW of one image: the (TH+2) x (TW+2) x 64-channel input
+// halo is staged in LDS ONCE per channel chunk and all nine taps read it at shifted row offsets, so the
+// activation traffic drops ~7x and only the (L2-resident) weight tile is re-staged per tap.
+//
+//   block  : 256 threads = 4 waves; each wave owns 64 pixels x 64 couts (2x2 tiles of mfma_f32_32x32x16)
+//   BN=128 : waves 2(M) x 2(N), patch 128 pixels (4x32 or 8x16)
+//   BN=64  : waves 4(M) x 1(N), patch 256 pixels (8x32 or 16x16)   -- the Cout = 64 layers
+//   LDS    : halo [(TH+2)(TW+2)][72] + 2 x weights [BN][72]   (144-B padded rows: conflict-free b128 reads)
+//   K loop : for each 64-channel chunk { halo resident; 9 taps x { weights double-buffered, 16 MFMAs/wave } }
+//            the next chunk's halo is fetched into registers while the 9 taps run (issue early, write late).
+//   epilogue as igemm.hip: bias/act, 16-bit NHWC store (strided), per-patch BatchNorm partial sums.
+#include <stdlib.h>
+#include <type_traits>
+
+#include "common.hpp"
+
+namespace {
+
+struct C3Args {
+    const unsigned short* x;
+    const unsigned short* w;      // [9][Cout][Cin]
+    unsigned short* y;
+    const float* bias;
+    float* bnp;                   // [npatches][2][Cout]
+    int act;
+    int N, H, W, Cin, in_stride, in_coff, Cout, out_stride, out_coff;
+    int tiles_x, tiles_y, ntn, nblocks;
+    int tap_dy[9], tap_dx[9];
+};
+
+__device__ __forceinline__ int xcd_remap3(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+constexpr int C3_LDR = 72;
+
+template <int DT, int BN, int TW>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const C3Args a) {
+    typedef typename Elem<DT>::V8 V8;
+    constexpr int WM = (BN == 128) ? 2 : 4;       // waves along M
+    constexpr int BM = WM * 64;                   // pixels per patch
+    constexpr int TH = BM / TW;
+    constexpr int HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;
+    constexpr int HALO_EL = HP * C3_LDR, B_EL = BN * C3_LDR;
+    constexpr int HCH = (HP * 8 + 255) / 256;     // 16-byte halo chunks per thread
+    constexpr int BROWS = BN / 32;
+    constexpr int TWS = (TW == 32) ? 5 : 4;
+    __shared__ __attribute__((aligned(16))) unsigned short smem[HALO_EL + 2 * B_EL];
+    unsigned short* halo = smem;
+    unsigned short* Bs = smem + HALO_EL;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = (BN == 128) ? (wave >> 1) : wave;
+    const int wn = (BN == 128) ? (wave & 1) : 0;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int lid = xcd_remap3(blockIdx.x, a.nblocks);
+    const int ntile = lid % a.ntn;
+    int patch = lid / a.ntn;
+    const int tx = patch % a.tiles_x; patch /= a.tiles_x;
+    const int ty = patch % a.tiles_y;
+    const int n = patch / a.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW, n0 = ntile * BN;
+    const int mtile = lid / a.ntn;
+
+    // ---- staging assignments ----
+    int h_off[HCH];           // element offset into the image of the halo pixel (or -1), channel part added later
+    int h_lds[HCH];           // LDS element offset
+#pragma unroll
+    for (int j = 0; j < HCH; ++j) {
+        const int id = t + 256 * j;
+        const int hp = id >> 3, c = id & 7;
+        h_lds[j] = -1; h_off[j] = -1;
+        if (hp < HP) {
+            const int hy = hp / HWD, hx = hp - hy * HWD;
+            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+            h_lds[j] = hp * C3_LDR + c * 8;
+            if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) h_off[j] = (n * a.H + gy) * a.W + gx;
+        }
+    }
+    const int chunk = t & 7, rbase = t >> 3;
+    uint4 rh[HCH], rb[BROWS];
+    const int nchunks = (a.Cin + 63) >> 6;
+
+    auto load_halo = [&](int cc) {
+        const int ci = cc * 64 + (t & 7) * 8;
+#pragma unroll
+        for (int j = 0; j < HCH; ++j) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (h_off[j] >= 0 && ci < a.Cin)
+                v = *reinterpret_cast<const uint4*>(a.x + (int64_t)h_off[j] * a.in_stride + a.in_coff + ci);
+            rh[j] = v;
+        }
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int j = 0; j < HCH; ++j)
+            if (h_lds[j] >= 0) *reinterpret_cast<uint4*>(halo + h_lds[j]) = rh[j];
+    };
+    auto load_b = [&](int cc, int tap) {
+        const int ci = cc * 64 + chunk * 8;
+#pragma unroll
+        for (int j = 0; j < BROWS; ++j) {
+            const int co = n0 + rbase + 32 * j;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ci < a.Cin && co < a.Cout)
+                v = *reinterpret_cast<const uint4*>(a.w + ((int64_t)tap * a.Cout + co) * a.Cin + ci);
+            rb[j] = v;
+        }
+    };
+    auto store_b = [&](int buf) {
+        unsigned short* B = Bs + buf * B_EL;
+#pragma unroll
+        for (int j = 0; j < BROWS; ++j)
+            *reinterpret_cast<uint4*>(B + (rbase + 32 * j) * C3_LDR + chunk * 8) = rb[j];
+    };
+
+    // A fragment base offsets (centre tap) of the wave's two 32-pixel M tiles
+    int a_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int p = (wm * 2 + i) * 32 + l31;
+        const int py = p >> TWS, px = p & (TW - 1);
+        a_off[i] = ((py + 1) * HWD + px + 1) * C3_LDR + h * 8;
+    }
+    const int b_off = (wn * 64 + l31) * C3_LDR + h * 8;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_halo(0);
+    load_b(0, 0);
+    store_halo();
+    store_b(0);
+    __syncthreads();
+    int ks = 0;
+    const int dbg = a.act >> 8;
+    for (int cc = 0; cc < ((dbg & 2) ? 0 : nchunks); ++cc) {
+        const bool more = cc + 1 < nchunks;
+        if (more) load_halo(cc + 1);
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap, ++ks) {
+            const bool last = (tap == 8) && !more;
+            if (!last) {
+                if (tap < 8) load_b(cc, tap + 1);
+                else load_b(cc + 1, 0);
+            }
+            const int toff = (a.tap_dy[tap] * HWD + a.tap_dx[tap]) * C3_LDR;
+            const unsigned short* B = Bs + (ks & 1) * B_EL + b_off;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                V8 af[2], bf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const V8*>(halo + a_off[i] + toff + kk * 16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const V8*>(B + j * 32 * C3_LDR + kk * 16);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = Elem<DT>::mfma32(af[i], bf[j], acc[i][j]);
+            }
+            if (!last) store_b((ks + 1) & 1);
+            if (tap == 8 && more) {
+                __syncthreads();          // every wave is done with this chunk's halo
+                store_halo();
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue ----
+    int* rowpix = reinterpret_cast<int*>(smem);                 // BM ints
+    float* red = reinterpret_cast<float*>(smem) + BM;           // [WM][2][BN] floats
+    if (t < BM) {
+        const int py = t >> TWS, px = t & (TW - 1);
+        const int gy = y0 + py, gx = x0 + px;
+        rowpix[t] = (gy < a.H && gx < a.W) ? (n * a.H + gy) * a.W + gx : -1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int cl = wn * 64 + j * 32 + l31;
+        const int co = n0 + cl;
+        const bool cok = co < a.Cout;
+        const float bv = (a.bias != nullptr && cok) ? a.bias[co] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int p = rowpix[row];
+                const float v = p >= 0 ? acc[i][j][r] : 0.f;     // pixels outside the image carry no statistics
+                s1 += v;
+                s2 += v * v;
+                if (cok && p >= 0 && !(dbg & 1))
+                    a.y[(int64_t)p * a.out_stride + a.out_coff + co] = Elem<DT>::from_f(act_fwd(v + bv, a.act & 0xff));
+            }
+        }
+        if (a.bnp != nullptr) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (h == 0) {
+                red[(wm * 2 + 0) * BN + cl] = s1;
+                red[(wm * 2 + 1) * BN + cl] = s2;
+            }
+        }
+    }
+    if (a.bnp != nullptr) {
+        __syncthreads();
+        if (t < BN && n0 + t < a.Cout) {
+            float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < WM; ++m) { v1 += red[(m * 2 + 0) * BN + t]; v2 += red[(m * 2 + 1) * BN + t]; }
+            float* dst = a.bnp + (int64_t)mtile * 2 * a.Cout + n0 + t;
+            dst[0] = v1;
+            dst[a.Cout] = v2;
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// v2: PERSISTENT blocks.  A block walks work items (patch, N-tile) it, it+grid, ... ; the halo of the next
+// (item, chunk) is fetched into registers while the current nine taps run, so HBM reads, MFMA work and the
+// output stores of consecutive patches overlap inside one block.  Epilogue: the wave transposes its 64x64
+// tile through a small LDS staging area (packed pairs via DPP + v_perm, ds_write_b32 / ds_read_b128) and
+// writes whole 128-byte channel rows with 16-byte stores instead of 64 two-byte stores per lane.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int dpp_xor1(unsigned int v) {
+    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false);
+}
+
+template <int DT, int BN, int TW>
+__global__ __launch_bounds__(256, 2) void conv3x3_persist_kernel(const C3Args a) {
+    typedef typename Elem<DT>::V8 V8;
+    constexpr int WM = (BN == 128) ? 2 : 4;
+    constexpr int BM = WM * 64;
+    constexpr int TH = BM / TW;
+    constexpr int HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;
+    constexpr int HALO_EL = HP * C3_LDR, B_EL = BN * C3_LDR;
+    constexpr int HCH = (HP * 8 + 255) / 256;
+    constexpr int BROWS = BN / 32;
+    constexpr int TWS = (TW == 32) ? 5 : 4;
+    constexpr int STG_EL = 32 * C3_LDR;            // per-wave staging: 32 rows x (64+8) elements
+    constexpr unsigned OOB = 0xFFFFFFFFu;          // buffer loads beyond num_records return 0
+    static_assert(4 * STG_EL + WM * 2 * BN * 2 <= HALO_EL, "epilogue staging must fit in the halo region");
+    __shared__ __attribute__((aligned(16))) unsigned short smem[HALO_EL + 2 * B_EL];
+    unsigned short* halo = smem;
+    unsigned short* Bs = smem + HALO_EL;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = (BN == 128) ? (wave >> 1) : wave;
+    const int wn = (BN == 128) ? (wave & 1) : 0;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nitems = a.nblocks;
+    const int dbg = a.act >> 8;
+    const int act = a.act & 0xff;
+    const int chunk = t & 7, rbase = t >> 3;
+    const int nchunks = (a.Cin + 63) >> 6;
+    const unsigned img_bytes = (unsigned)a.H * a.W * a.in_stride * 2u;   // host guarantees < 4 GiB
+
+    struct Item { int n, y0, x0, n0, mtile; };
+    auto decode = [&](int it) __attribute__((always_inline)) {
+        Item r;
+        const int ntile = it % a.ntn;
+        int patch = it / a.ntn;
+        r.mtile = patch;
+        const int tx = patch % a.tiles_x; patch /= a.tiles_x;
+        const int ty = patch % a.tiles_y;
+        r.n = patch / a.tiles_y;
+        r.y0 = ty * TH; r.x0 = tx * TW; r.n0 = ntile * BN;
+        return r;
+    };
+    auto x_rsrc = [&](int n) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)n * a.H * a.W * a.in_stride), 0, img_bytes, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t w_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)(9u * a.Cout * a.Cin * 2u), 0x00020000);
+
+    // ---- halo staging: byte offsets inside the image (OOB when the halo pixel is outside) ----
+    unsigned h_off[HCH];
+    const int h_lds0 = (t >> 3) * C3_LDR + chunk * 8;     // chunk j lives 32 halo pixels further
+    auto setup_halo = [&](const Item& itn) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < HCH; ++j) {
+            const int hp = (t + 256 * j) >> 3;
+            const int hy = hp / HWD, hx = hp - hy * HWD;
+            const int gy = itn.y0 + hy - 1, gx = itn.x0 + hx - 1;
+            const bool ok = hp < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            h_off[j] = ok ? (unsigned)(((gy * a.W + gx) * a.in_stride + a.in_coff + chunk * 8) * 2) : OOB;
+        }
+    };
+    uint4 rh[HCH];
+    auto load_halo = [&](const __amdgpu_buffer_rsrc_t& rs, int cc) __attribute__((always_inline)) {
+        const bool cok = cc * 64 + chunk * 8 < a.Cin;
+#pragma unroll
+        for (int j = 0; j < HCH; ++j) {
+            const unsigned off = (cok && h_off[j] != OOB) ? h_off[j] + (unsigned)cc * 128u : OOB;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+            rh[j] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+    };
+    auto store_halo = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < HCH; ++j)
+            if ((t >> 3) + 32 * j < HP) *reinterpret_cast<uint4*>(halo + h_lds0 + j * 32 * C3_LDR) = rh[j];
+    };
+
+    // ---- weight tiles: cursor runs two K-steps ahead of the compute cursor ----
+    uint4 rb3[1][BROWS];
+    int bl_it = blockIdx.x, bl_cc = 0, bl_tap = 0, bl_n0 = 0;
+    bool bl_valid = true;
+    auto bl_advance = [&]() __attribute__((always_inline)) {
+        if (++bl_tap == 9) {
+            bl_tap = 0;
+            if (++bl_cc == nchunks) {
+                bl_cc = 0;
+                bl_it += gridDim.x;
+                bl_valid = bl_it < nitems;
+                bl_n0 = bl_valid ? (bl_it % a.ntn) * BN : 0;
+            }
+        }
+    };
+    auto load_b2 = [&](uint4 (&dst)[BROWS]) {
+        const int ci = bl_cc * 64 + chunk * 8;
+#pragma unroll
+        for (int j = 0; j < BROWS; ++j) {
+            const int co = bl_n0 + rbase + 32 * j;
+            const bool ok = bl_valid && ci < a.Cin && co < a.Cout;
+            const unsigned off = ok ? (unsigned)((((bl_tap * a.Cout) + co) * a.Cin + ci) * 2) : OOB;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, off, 0, 0);
+            dst[j] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+        bl_advance();
+    };
+    auto store_b2 = [&](const uint4 (&src)[BROWS], int buf) {
+        unsigned short* B = Bs + buf * B_EL;
+#pragma unroll
+        for (int j = 0; j < BROWS; ++j)
+            *reinterpret_cast<uint4*>(B + (rbase + 32 * j) * C3_LDR + chunk * 8) = src[j];
+    };
+
+    int a_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int p = (wm * 2 + i) * 32 + l31;
+        a_off[i] = (((p >> TWS) + 1) * HWD + (p & (TW - 1)) + 1) * C3_LDR + h * 8;
+    }
+    const int b_off = (wn * 64 + l31) * C3_LDR + h * 8;
+
+    f32x16 acc[2][2];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    auto mma_tap = [&](int tap, int buf) __attribute__((always_inline)) {
+        const int toff = (a.tap_dy[tap] * HWD + a.tap_dx[tap]) * C3_LDR;
+        const unsigned short* B = Bs + buf * B_EL + b_off;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            V8 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const V8*>(halo + a_off[i] + toff + kk * 16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const V8*>(B + j * 32 * C3_LDR + kk * 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = Elem<DT>::mfma32(af[i], bf[j], acc[i][j]);
+        }
+    };
+
+    // ---- epilogue of one finished item (called between two block barriers) ----
+    unsigned short* stg = halo + wave * STG_EL;
+    float* red = reinterpret_cast<float*>(halo + 4 * STG_EL);          // [WM][2][BN]
+    const bool odd = lane & 1;
+    const unsigned int psel = odd ? 0x03020706u : 0x05040100u;
+    const float neg_slope = act == GS_ACT_RELU ? 0.f : (act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
+    auto epilogue = [&](const Item& itc) __attribute__((always_inline)) {
+        float bv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int co = itc.n0 + wn * 64 + j * 32 + l31;
+            bv[j] = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
+        }
+        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+        const bool want_stats = a.bnp != nullptr;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int prow0 = (wm * 2 + i) * 32;       // first patch pixel of this M tile
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int r0 = 2 * m;
+                const int rowa = (r0 & 3) + 8 * (r0 >> 2) + 4 * h;      // row of reg r0; reg r0+1 is rowa+1
+                // BatchNorm statistics weight of the two rows: 1 inside the image, 0 outside (edge patches);
+                // arithmetic instead of compares so no lane masks are kept live
+                float w0 = 1.f, w1 = 1.f;
+                if (want_stats) {
+                    const int p0 = prow0 + rowa;
+                    const int gy0 = itc.y0 + (p0 >> TWS), gx0 = itc.x0 + (p0 & (TW - 1));
+                    const int gy1 = itc.y0 + ((p0 + 1) >> TWS), gx1 = itc.x0 + ((p0 + 1) & (TW - 1));
+                    w0 = (float)((unsigned)((gy0 - a.H) & (gx0 - a.W)) >> 31);
+                    w1 = (float)((unsigned)((gy1 - a.H) & (gx1 - a.W)) >> 31);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v0 = acc[i][j][r0], v1 = acc[i][j][r0 + 1];
+                    if (want_stats) {
+                        const float u0 = v0 * w0, u1 = v1 * w1;
+                        s1[j] += u0 + u1;
+                        s2[j] += u0 * u0 + u1 * u1;
+                    }
+                    v0 += bv[j];
+                    v1 += bv[j];
+                    v0 = v0 > 0.f ? v0 : v0 * neg_slope;      // NONE: slope 1, RELU: 0, LEAKY: 0.2 (branch free)
+                    v1 = v1 > 0.f ? v1 : v1 * neg_slope;
+                    const unsigned int own = (unsigned int)Elem<DT>::from_f(v0) | ((unsigned int)Elem<DT>::from_f(v1) << 16);
+                    const unsigned int oth = dpp_xor1(own);
+                    const unsigned int pk = __builtin_amdgcn_perm(oth, own, psel);
+                    const int row = rowa + (odd ? 1 : 0);
+                    *reinterpret_cast<unsigned int*>(stg + row * C3_LDR + j * 32 + (l31 & ~1)) = pk;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rrow = q * 8 + (lane >> 3), ch = lane & 7;
+                const uint4 v = *reinterpret_cast<const uint4*>(stg + rrow * C3_LDR + ch * 8);
+                const int p = prow0 + rrow;
+                const int gy = itc.y0 + (p >> TWS), gx = itc.x0 + (p & (TW - 1));
+                const int co = itc.n0 + wn * 64 + ch * 8;
+                // host guarantees Cout % 8 == 0 and 16-byte aligned output rows: whole 16-byte stores only
+                if (gy < a.H && gx < a.W && co < a.Cout && !(dbg & 1))
+                    *reinterpret_cast<uint4*>(a.y + (int64_t)((itc.n * a.H + gy) * a.W + gx) * a.out_stride +
+                                              a.out_coff + co) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (a.bnp != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                s1[j] += __shfl_xor(s1[j], 32, 64);
+                s2[j] += __shfl_xor(s2[j], 32, 64);
+                if (h == 0) {
+                    const int cl = wn * 64 + j * 32 + l31;
+                    red[(wm * 2 + 0) * BN + cl] = s1[j];
+                    red[(wm * 2 + 1) * BN + cl] = s2[j];
+                }
+            }
+        }
+    };
+    auto finish_stats = [&](const Item& itc) __attribute__((always_inline)) {       // after a block barrier
+        if (a.bnp != nullptr && t < BN && itc.n0 + t < a.Cout) {
+            float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < WM; ++m) { v1 += red[(m * 2 + 0) * BN + t]; v2 += red[(m * 2 + 1) * BN + t]; }
+            float* dst = a.bnp + (int64_t)itc.mtile * 2 * a.Cout + itc.n0 + t;
+            dst[0] = v1;
+            dst[a.Cout] = v2;
+        }
+    };
+
+    int it = blockIdx.x;
+    if (it >= nitems) return;
+    Item cur = decode(it);
+    bl_n0 = cur.n0;
+
+    // Weights are prefetched ONE K-step ahead (registers -> the other LDS buffer), the halo one chunk ahead.
+    // (A two-step-ahead variant with rotating register sets kept counted vmcnt waits in the loop but did not
+    // pay: the two co-resident blocks run their load/LDS/barrier and MFMA phases in lockstep -- see DESIGN.md.)
+    setup_halo(cur);
+    load_halo(x_rsrc(cur.n), 0);
+    load_b2(rb3[0]);                 // K-step 0
+    zero_acc();
+    store_halo();
+    store_b2(rb3[0], 0);
+    __syncthreads();
+    int ks = 0;
+    for (;;) {
+        const int nit = it + gridDim.x;
+        const bool more_items = nit < nitems;
+        Item nxt = cur;
+        if (more_items) nxt = decode(nit);
+        for (int cc = 0; cc < nchunks; ++cc) {
+            const bool more_cc = cc + 1 < nchunks;
+            const bool have_next = more_cc || more_items;
+            if (have_next) {                                      // next halo: one chunk ahead
+                if (!more_cc) setup_halo(nxt);
+                load_halo(x_rsrc(more_cc ? cur.n : nxt.n), more_cc ? cc + 1 : 0);
+            }
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap, ++ks) {
+                load_b2(rb3[0]);                                  // weights of K-step ks+1 (zeros past the end)
+                if (!(dbg & 2)) mma_tap(tap, ks & 1);
+                store_b2(rb3[0], (ks + 1) & 1);
+                if (tap < 8) __syncthreads();
+            }
+            if (!more_cc) {
+                __syncthreads();               // all waves finished reading the halo
+                epilogue(cur);
+                zero_acc();
+                __syncthreads();
+                finish_stats(cur);
+            } else {
+                __syncthreads();
+            }
+            if (have_next) store_halo();
+            __syncthreads();
+        }
+        if (!more_items) break;
+        it = nit;
+        cur = nxt;
+    }
+}
+
+struct C3Plan { int bn, tw, th, tiles_x, tiles_y; };
+
+C3Plan c3_plan(int H, int W, int Cout) {
+    C3Plan p;
+    p.bn = (Cout <= 64) ? 64 : 128;
+    p.tw = (W >= 24) ? 32 : 16;
+    const int bm = (p.bn == 128) ? 128 : 256;
+    p.th = bm / p.tw;
+    p.tiles_x = cdiv(W, p.tw);
+    p.tiles_y = cdiv(H, p.th);
+    return p;
+}
+
+}  // namespace
+
+extern "C" int gs_conv3x3_mtiles(int N, int H, int W, int Cout) {
+    const C3Plan p = c3_plan(H, W, Cout);
+    return N * p.tiles_x * p.tiles_y;
+}
+
+extern "C" int gs_conv3x3(const void* x, const void* w, void* y, const float* bias, float* bn_partials, int N, int H,
+                          int W, int Cin, int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff,
+                          const int32_t* tap_dy, const int32_t* tap_dx, int act, int dtype, void* stream) {
+    GS_CHECK_ARG(x && w && y && tap_dy && tap_dx, "gs_conv3x3: null pointer");
+    GS_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0 && Cout > 0, "gs_conv3x3: bad dims");
+    GS_CHECK_ARG(in_pix_stride >= in_coff + Cin && in_pix_stride % 8 == 0 && in_coff % 8 == 0, "gs_conv3x3: bad input stride");
+    GS_CHECK_ARG(out_pix_stride >= out_coff + Cout, "gs_conv3x3: bad output stride");
+    GS_CHECK_ARG((int64_t)N * H * W < 2147483000LL, "gs_conv3x3: pixel count exceeds int32");
+    GS_CHECK_ARG((int64_t)H * W * in_pix_stride * 2 < 4294967000LL && (int64_t)9 * Cout * Cin * 2 < 4294967000LL,
+                 "gs_conv3x3: one image / the weight pack must stay below 4 GiB (32-bit buffer offsets)");
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_conv3x3: bad dtype");
+    C3Args a;
+    a.x = (const unsigned short*)x; a.w = (const unsigned short*)w; a.y = (unsigned short*)y;
+    a.bias = bias; a.bnp = bn_partials; a.act = act;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.in_stride = in_pix_stride; a.in_coff = in_coff;
+    a.Cout = Cout; a.out_stride = out_pix_stride; a.out_coff = out_coff;
+    for (int i = 0; i < 9; ++i) {
+        GS_CHECK_ARG(tap_dy[i] >= -1 && tap_dy[i] <= 1 && tap_dx[i] >= -1 && tap_dx[i] <= 1, "gs_conv3x3: tap offsets must be in [-1,1]");
+        a.tap_dy[i] = tap_dy[i]; a.tap_dx[i] = tap_dx[i];
+    }
+    const C3Plan p = c3_plan(H, W, Cout);
+    a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y;
+    a.ntn = cdiv(Cout, p.bn);
+    a.nblocks = N * p.tiles_x * p.tiles_y * a.ntn;
+    hipStream_t s = (hipStream_t)stream;
+    GS_CHECK_ARG((act & 0xff) == GS_ACT_NONE || (act & 0xff) == GS_ACT_RELU || (act & 0xff) == GS_ACT_LEAKY02,
+                 "gs_conv3x3: activation %d not supported (use gs_conv_igemm)", act & 0xff);
+    static const bool force_v1 = getenv("GSSEG_C3_V1") != nullptr;
+    // the persistent kernel stores whole 16-byte channel groups; odd shapes go to the one-patch-per-block kernel
+    const bool use_v1 = force_v1 || (Cout % 8) != 0 || (out_pix_stride % 8) != 0 || (out_coff % 8) != 0;
+    static const int persist_blocks = getenv("GSSEG_C3_GRID") ? atoi(getenv("GSSEG_C3_GRID")) : 512;
+    dim3 grid(a.nblocks), block(256);
+    if (!use_v1) {
+        dim3 pgrid(a.nblocks < persist_blocks ? a.nblocks : persist_blocks);
+#define C3P_LAUNCH(DT)                                                                        \
+    do {                                                                                      \
+        if (p.bn == 128) {                                                                    \
+            if (p.tw == 32) conv3x3_persist_kernel<DT, 128, 32><<<pgrid, block, 0, s>>>(a);   \
+            else conv3x3_persist_kernel<DT, 128, 16><<<pgrid, block, 0, s>>>(a);              \
+        } else {                                                                              \
+            if (p.tw == 32) conv3x3_persist_kernel<DT, 64, 32><<<pgrid, block, 0, s>>>(a);    \
+            else conv3x3_persist_kernel<DT, 64, 16><<<pgrid, block, 0, s>>>(a);               \
+        }                                                                                     \
+    } while (0)
+        if (dtype == GS_F16) C3P_LAUNCH(GS_F16);
+        else C3P_LAUNCH(GS_BF16);
+#undef C3P_LAUNCH
+        GS_CHECK_LAUNCH("gs_conv3x3");
+        return GS_OK;
+    }
+#define C3_LAUNCH(DT)                                                                    \
+    do {                                                                                 \
+        if (p.bn == 128) {                                                               \
+            if (p.tw == 32) conv3x3_halo_kernel<DT, 128, 32><<<grid, block, 0, s>>>(a);  \
+            else conv3x3_halo_kernel<DT, 128, 16><<<grid, block, 0, s>>>(a);             \
+        } else {                                                                         \
+            if (p.tw == 32) conv3x3_halo_kernel<DT, 64, 32><<<grid, block, 0, s>>>(a);   \
+            else conv3x3_halo_kernel<DT, 64, 16><<<grid, block, 0, s>>>(a);              \
+        }                                                                                \
+    } while (0)
+    if (dtype == GS_F16) C3_LAUNCH(GS_F16);
+    else C3_LAUNCH(GS_BF16);
+#undef C3_LAUNCH
+    GS_CHECK_LAUNCH("gs_conv3x3");
+    return GS_OK;
+}

@@ -3,6 +3,8 @@ any launch, so failures are synchronous Python exceptions.  torch supplies devic
 current HIP stream only; all arithmetic happens in libgsseg_hip.so."""
 from __future__ import annotations
 
+import ctypes
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -130,6 +132,36 @@ def conv_igemm(g: GsConvGeom, x, w, y, bias=None, bn_partials=None, act=ACT_NONE
     _lib.call("gs_conv_igemm", g, _p(x), _p(w), _p(y), _p(bias), _p(bn_partials), act, dt_code(x), _stream())
     if ev is not None:
         TIMER.stop("igemm_fwd", ev, _geom_flops(g))
+
+
+# taps of a 3x3/pad-1 conv in weight order, and the flipped list that turns the same kernel into its dgrad
+TAPS3_FWD = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
+TAPS3_DGRAD = [(1 - ky, 1 - kx) for ky in range(3) for kx in range(3)]
+USE_HALO_CONV = os.environ.get("GSSEG_CONV3X3", "halo") != "generic"
+
+
+def conv3x3_mtiles(N, H, W, Cout) -> int:
+    return _lib.load().gs_conv3x3_mtiles(N, H, W, Cout)
+
+
+def conv3x3(x, w, y, N, H, W, Cin, Cout, taps=TAPS3_FWD, bias=None, bn_partials=None, act=ACT_NONE,
+            in_stride=None, in_coff=0, out_stride=None, out_coff=0):
+    """3x3/s1/p1 convolution (or its data gradient with TAPS3_DGRAD + the dgrad weight pack) on the
+    halo-reuse MFMA kernel.  x/y NHWC 16-bit (strided), w [9][Cout][Cin]."""
+    _dev(x)
+    _f32(bias, "bias"); _f32(bn_partials, "bn_partials")
+    if not (x.dtype == w.dtype == y.dtype):
+        raise TypeError("conv3x3: x, w, y must share one 16-bit dtype")
+    if bn_partials is not None and bn_partials.numel() < bn_partials_numel(conv3x3_mtiles(N, H, W, Cout), Cout):
+        raise ValueError("conv3x3: bn_partials too small")
+    dy = (ctypes.c_int32 * 9)(*[t[0] for t in taps])
+    dx = (ctypes.c_int32 * 9)(*[t[1] for t in taps])
+    ev = TIMER.start() if TIMER is not None else None
+    _lib.call("gs_conv3x3", _p(x), _p(w), _p(y), _p(bias), _p(bn_partials), N, H, W, Cin,
+              Cin if in_stride is None else in_stride, in_coff, Cout, Cout if out_stride is None else out_stride,
+              out_coff, dy, dx, act, dt_code(x), _stream())
+    if ev is not None:
+        TIMER.stop("conv3x3_halo", ev, 2.0 * N * H * W * Cout * 9 * Cin)
 
 
 def conv_igemm_mtiles(g: GsConvGeom) -> int:

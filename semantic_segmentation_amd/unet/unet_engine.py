@@ -64,6 +64,10 @@ class UNetEngine:
         """(name, Parameter) in registration order -- the order autograd sees them."""
         return list(self.net.named_parameters())
 
+    def invalidate_packs(self):
+        """Drop the cached 16-bit weight packs (they are otherwise reused until a Parameter changes)."""
+        self._packs.clear()
+
     def _packed(self, name: str, w: torch.Tensor, transposed: bool, need_dgrad: bool):
         """16-bit K-major packs of a conv weight, cached until the Parameter is modified."""
         key = _pack_key(w)
@@ -106,12 +110,7 @@ class UNetEngine:
         def empty(*shape, dtype=tdt):
             return torch.empty(shape, dtype=dtype, device=dev)
 
-        # shared workspaces
-        max_part = ops.bn_partials_numel(ops.conv_smallcin_mtiles(N, H, W), 64)
-        for i in range(5):
-            mt = (N * hs[i] * ws_[i] + 127) // 128
-            max_part = max(max_part, ops.bn_partials_numel(mt, C[i]))
-        partials = empty(max_part, dtype=torch.float32)
+        partials = None      # BatchNorm partial-sum workspace, (re)allocated per conv from torch's cache
 
         recs: List[_ConvRec] = []
         ups: List[_UpRec] = []
@@ -148,16 +147,24 @@ class UNetEngine:
             rec = _ConvRec()
             rec.name, rec.wkey, rec.bnkey = f"{prefix}.{idx}", wkey, bnkey
             rec.cin, rec.cout, rec.h, rec.w, rec.inp_is_image = cin, cout, h, w, image
+            nonlocal partials
+            g = None if image else ops.geom_conv(N, h, w, cin, cout, 3, 1, 1)
             if image:
                 ntiles = ops.conv_smallcin_mtiles(N, h, w)
-                ops.conv_smallcin_fwd(inp, wparam.detach().contiguous(), None, y, partials if batch_stats else None,
-                                      3, 1, 1)
+            elif ops.USE_HALO_CONV:
+                ntiles = ops.conv3x3_mtiles(N, h, w, cout)
+            else:
+                ntiles = ops.conv_igemm_mtiles(g)
+            partials = empty(ops.bn_partials_numel(ntiles, cout), dtype=torch.float32) if batch_stats else None
+            if image:
+                ops.conv_smallcin_fwd(inp, wparam.detach().contiguous(), None, y, partials, 3, 1, 1)
                 rec.geom, rec.wd = None, None
             else:
                 wf, wd = self._packed(wkey, wparam, False, need_grad)
-                g = ops.geom_conv(N, h, w, cin, cout, 3, 1, 1)
-                ntiles = ops.conv_igemm_mtiles(g)
-                ops.conv_igemm(g, inp, wf, y, None, partials if batch_stats else None)
+                if ops.USE_HALO_CONV:
+                    ops.conv3x3(inp, wf, y, N, h, w, cin, cout, ops.TAPS3_FWD, None, partials)
+                else:
+                    ops.conv_igemm(g, inp, wf, y, None, partials)
                 rec.geom, rec.wd = g, wd
             coef, rec.train_stats = bn_coeffs(bnkey, ntiles, cout, N * h * w)
             ops.bn_act_apply(y, coef[0], coef[1], ACT_RELU, z, z_stride, z_coff, zp)
@@ -308,8 +315,10 @@ class UNetEngine:
                 ops.unpack_wgrad(dwp, dw, cout, cin, 9, False, inv_s)
                 if need_dinp:
                     dinp = empty(N, h, w, cin)
-                    gd = ops.geom_conv_dgrad_s1(N, h, w, cin, cout, 3, 1)
-                    ops.conv_igemm(gd, dy, rec.wd, dinp)
+                    if ops.USE_HALO_CONV:
+                        ops.conv3x3(dy, rec.wd, dinp, N, h, w, cout, cin, ops.TAPS3_DGRAD)
+                    else:
+                        ops.conv_igemm(ops.geom_conv_dgrad_s1(N, h, w, cin, cout, 3, 1), dy, rec.wd, dinp)
             emit(rec.wkey, dw)
             emit(rec.bnkey + ".weight", dgamma)
             emit(rec.bnkey + ".bias", dbeta)

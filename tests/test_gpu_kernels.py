@@ -393,3 +393,35 @@ def test_layout_roundtrip():
     torch.cuda.synchronize()
     assert torch.equal(back.cpu(), x * 2)
     assert float(d[..., :3].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtn,dt", DTS)
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 13, 9, 64, 64), (1, 16, 16, 128, 192), (2, 37, 41, 64, 64),
+                                            (1, 40, 33, 128, 128), (3, 7, 20, 72, 40), (1, 32, 64, 192, 64)])
+def test_conv3x3_halo_fwd_dgrad(dtn, dt, N, H, W, Cin, Cout):
+    """halo-reuse 3x3 kernel: forward with BN partials into a strided output, and the data gradient"""
+    from semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(12)
+    x = rnd(g, N, Cin, H, W, dt=dt).requires_grad_(True)
+    w = rnd(g, Cout, Cin, 3, 3, dt=dt, scale=0.05).requires_grad_(True)
+    ref = F.conv2d(x, w, None, padding=1)
+    dy = rnd(g, N, Cout, H, W, dt=dt)
+    ref.backward(dy)
+    wf = torch.empty(9, Cout, Cin, dtype=dt, device=dev())
+    wd = torch.empty(9, Cin, Cout, dtype=dt, device=dev())
+    ops.pack_weight(w.detach().to(dev()), wf, wd, False)
+    mt = ops.conv3x3_mtiles(N, H, W, Cout)
+    part = torch.zeros(ops.bn_partials_numel(mt, Cout), dtype=torch.float32, device=dev())
+    y = torch.zeros(N, H, W, Cout + 8, dtype=dt, device=dev())
+    ops.conv3x3(nhwc(x.detach(), dt), wf, y, N, H, W, Cin, Cout, ops.TAPS3_FWD, None, part, out_stride=Cout + 8, out_coff=8)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(y[..., 8:]), ref.detach()) < tol(dt)
+    assert float(y[..., :8].abs().max()) == 0.0
+    p = part[: mt * 2 * Cout].view(mt, 2, Cout).double().sum(0).cpu()
+    s1, s2 = ref.detach().double().sum((0, 2, 3)), (ref.detach().double() ** 2).sum((0, 2, 3))
+    assert (p[0] - s1).abs().max() < 1e-3 * max(1.0, s1.abs().max().item())
+    assert (p[1] - s2).abs().max() < 1e-3 * s2.abs().max().item()
+    dx = torch.empty(N, H, W, Cin, dtype=dt, device=dev())
+    ops.conv3x3(nhwc(dy, dt), wd, dx, N, H, W, Cout, Cin, ops.TAPS3_DGRAD)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(dx), x.grad) < tol(dt)
