@@ -1,0 +1,81 @@
+"""Data-parallel logic on CPU: gloo, world size 2 (the N>1 path of bench.py / parallel.py without a GPU)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from semantic_segmentation_amd.parallel import GradReducer, broadcast_module_state, shard_batch
+        torch.manual_seed(100 + rank)                      # replicas start DIFFERENT ...
+        net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 3))
+        broadcast_module_state(net)                        # ... and end identical to rank 0
+        flat = torch.cat([p.detach().flatten() for p in net.parameters()] + [b.flatten().float() for b in net.buffers()])
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        assert all(torch.equal(gathered[0], g) for g in gathered)
+
+        # the engine protocol: grads are allocated in the reducer's buckets, announced in backward order,
+        # all-reduced bucket by bucket, and averaged
+        red = GradReducer(net.named_parameters(), bucket_bytes=64)       # tiny buckets -> several collectives
+        assert len(red.buckets) >= 2
+        names = [n for n, _ in net.named_parameters()][::-1]
+        params = dict(net.named_parameters())
+        red.begin()
+        local = {}
+        for n in names:
+            g = red.alloc(n, params[n])
+            g.copy_(torch.full_like(params[n], float(rank + 1)) * (1 + names.index(n)))
+            local[n] = g.clone()
+            red.ready(n, g)
+        red.finish()
+        for n in names:
+            want = (1 + names.index(n)) * (sum(range(1, world + 1)) / world)
+            assert torch.allclose(red.views[n], torch.full_like(params[n], want)), n
+        # a gradient produced outside the bucket is copied in
+        red.begin()
+        for n in names:
+            red.ready(n, torch.ones_like(params[n]) * (rank + 1))
+        red.finish()
+        assert torch.allclose(red.flat, torch.full_like(red.flat, (world + 1) / 2))
+        lo, hi = shard_batch(8, rank, world)
+        assert (lo, hi) == (rank * 4, rank * 4 + 4)
+        q.put((rank, "ok"))
+    except Exception as e:      # noqa: BLE001
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_reducer_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_shard_batch_rejects_uneven():
+    from semantic_segmentation_amd.parallel import shard_batch
+    with pytest.raises(ValueError):
+        shard_batch(10, 0, 4)

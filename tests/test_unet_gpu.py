@@ -191,3 +191,23 @@ def test_unet_gradient_is_descent_direction(n_classes):
     _dump()
     assert 0.8 < ratios[0] < 1.15, ratios
     assert 0.6 < ratios[1] < 1.15, ratios
+
+
+@pytest.mark.parametrize("name", ["unet_c1_64", "unet_c2_64"])
+def test_evaluate_matches_reference(golden_dir, name):
+    """unet/evaluate.py:10-43 semantics through the compat import path the reference scripts use."""
+    import semantic_segmentation_amd.compat as compat
+    compat.install()
+    from unet import UNet                     # noqa: F401  (resolves to this package)
+    from unet.evaluate import evaluate
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    n_classes, seed = int(z["n_classes"]), int(z["seed"])
+    net, _ = build_net(n_classes, seed)
+    net.train()
+    x = torch.from_numpy(z["x"])
+    mask = torch.from_numpy(z["mask"].astype(np.int64))
+    net(x.cuda())                              # one train-mode step updates the running statistics like the fixture
+    loader = [{"image": x, "mask": mask}]      # same keys as util/JSRT_loader.py:96-101
+    score = evaluate(net, loader, torch.device("cuda:0"), amp=True)
+    assert net.training                        # evaluate() restores train mode (evaluate.py:42)
+    assert abs(float(score) - float(z["eval_dice"])) < 1e-3
