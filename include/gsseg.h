@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 1
+#define GS_ABI_VERSION 3
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -47,6 +47,8 @@ typedef struct GsConvGeom {
     int32_t isy, isx, osy, osx, ooy, oox;
     int32_t ntaps;
     int32_t tap_dy[GS_MAX_TAPS], tap_dx[GS_MAX_TAPS];
+    int32_t tap_w[GS_MAX_TAPS];   /* weight slot of tap t: weights of tap t start at w + tap_w[t]*Cout*Cin (lets a
+                                     sub-pixel class use a subset of a full [kh*kw][Cout][Cin] pack) */
 } GsConvGeom;
 
 const char* gs_last_error(void);
@@ -124,19 +126,23 @@ int gs_bn_act_apply(const void* y, const float* scale, const float* shift, int a
                     int z_coff, void* zp, const uint8_t* keep_mask, float keep_scale, int N, int H, int W, int C,
                     int dtype, void* stream);
 
-/* backward of  z = act(bn(y)) [-> maxpool]:  dz = dz_a[pix*sa + coff_a + c] (may be NULL) + the
- * max-pool gradient routed from dzp [N,H/2,W/2,C] (may be NULL; first-max tie rule as ATen).
+/* backward of  z = act(bn(y)) [-> maxpool]:  dz = dz_a[pix*sa + coff_a + c] (may be NULL; optionally times a
+ * dropout keep-mask, networks.py:606-607) + the max-pool gradient routed from dzp [N,H/2,W/2,C] (may be NULL;
+ * first-max tie rule as ATen).  dz_b (dense, may be NULL) is a second consumer of the same pre-activation with
+ * its own activation act_b: gh = dz*act'(v) + dz_b*act_b'(v)  (the generator's leaky-skip / relu-concat pair).
  * reduce: partial sums of dzh and dzh*xhat -> [gs_bn_bwd_tiles][2][C];
  * coeffs: from partials -> dgamma, dbeta (fp32, OVERWRITE, multiplied by gscale) and c1,c2 = sums/count;
  * apply:  dy = scale*(dzh - c1 - xhat*c2)   (bn==0: dy = dzh, act gradient only). */
 int gs_bn_bwd_tiles(int N, int H, int W);                       /* upper bound, sizes the partials buffer */
 int gs_bn_bwd_tiles_used(int N, int H, int W, int pooled);      /* tiles actually written -> gs_bn_bwd_coeffs */
 int gs_bn_act_bwd_reduce(const void* y, const void* dz_a, int sa, int coff_a, const void* dzp,
+                         const void* dz_b, int act_b, const uint8_t* keep_mask, float keep_scale,
                          const float* scale, const float* shift, const float* mean, const float* invstd, int act,
                          float* partials, int N, int H, int W, int C, int dtype, void* stream);
 int gs_bn_bwd_coeffs(const float* partials, int ntiles, int C, double count, float gscale, float* dgamma,
                      float* dbeta, float* c1, float* c2, void* stream);
 int gs_bn_act_bwd_apply(const void* y, const void* dz_a, int sa, int coff_a, const void* dzp,
+                        const void* dz_b, int act_b, const uint8_t* keep_mask, float keep_scale,
                         const float* scale, const float* shift, const float* mean, const float* invstd,
                         const float* c1, const float* c2, int act, int bn, void* dy, int N, int H, int W, int C,
                         int dtype, void* stream);
@@ -156,6 +162,22 @@ int gs_colsum(const void* t, int pix_stride, int coff, int N, int H, int W, int 
 int gs_pack_weight(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int taps, int transposed,
                    int dtype, void* stream);
 int gs_unpack_wgrad(const float* dw, float* grad, int A, int B, int taps, int transposed, float gscale, void* stream);
+
+/* ---- Pix2Pix mixed transposed convolution (networks.py:486-511, operations.py:14-39) ------------------
+ * The softmax-weighted sum of ConvTranspose2d k4p1 / k6p2 / k8p3 (stride 2) equals ONE k8/s2/p3 transposed
+ * conv with Wm = s2*W8 + s1*pad1(W6) + s0*pad2(W4).  merge_pack builds, from the three fp32 parameters
+ * [Cin][Cout][k][k] and the device vector softmax3 = softmax(arch[layer]), any of:
+ *   pack_fwd   16-bit [4 classes][16 taps][Cout][Cin]  (class c = py*2+px, tap t = a*4+b, ky = 2a+1-py, kx = 2b+1-px;
+ *              input offset of the tap: dy = 1-a+py, dx = 1-b+px)
+ *   pack_dgrad 16-bit [64][Cin][Cout]                  (dX = stride-2, pad-3 conv of dY with taps (ky-3, kx-3))
+ *   merged_f32 fp32 [Cin][Cout][8][8]
+ * split_wgrad: dwm fp32 [4][16][Cout][Cin] -> dw4/dw6/dw8 (OVERWRITE, times gscale*softmax3[j]) and
+ *   dots3[j] += gscale * <dwm restricted to kernel j's window, Wj>  (= dLoss/d softmax3[j]; caller zeroes). */
+int gs_upconv_merge_pack(const float* w4, const float* w6, const float* w8, const float* softmax3, void* pack_fwd,
+                         void* pack_dgrad, float* merged_f32, int Cin, int Cout, int dtype, void* stream);
+int gs_upconv_split_wgrad(const float* dwm, const float* w4, const float* w6, const float* w8, const float* softmax3,
+                          float gscale, float* dw4, float* dw6, float* dw8, float* dots3, int Cin, int Cout,
+                          void* stream);
 
 /* layout helpers: fp32 NCHW <-> 16-bit NHWC */
 int gs_nchw_to_nhwc(const float* src, void* dst, int N, int C, int H, int W, int dst_pix_stride, int dst_coff,

@@ -169,6 +169,10 @@ struct BwdArgs {
     const unsigned short* y;
     const unsigned short* dza;
     const unsigned short* dzp;
+    const unsigned short* dzb;      // second dense gradient source with its own activation (act_b)
+    const uint8_t* keep;            // dropout keep-mask applied to dza (dense [N,H,W,C])
+    float keep_scale;
+    int act_b;
     const float *scale, *shift, *mean, *invstd, *c1, *c2;
     float* partials;
     unsigned short* dy;
@@ -223,11 +227,23 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) g[i] = 0.f;
                 }
+                if (a.keep) {
+                    const uint2 k = *reinterpret_cast<const uint2*>(a.keep + pix * a.C + c0);
+                    const unsigned int kw[2] = {k.x, k.y};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) g[i] *= ((kw[i >> 2] >> (8 * (i & 3))) & 0xffu) ? a.keep_scale : 0.f;
+                }
+                float gb[8];
+                if (a.dzb) unpack8<DT>(*reinterpret_cast<const uint4*>(a.dzb + pix * a.C + c0), gb);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) gb[i] = 0.f;
+                }
                 float out[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const float v = yv[i] * sc[i] + sh[i];
-                    const float gh = g[i] * act_grad(v, a.act);
+                    const float gh = g[i] * act_grad(v, a.act) + (a.dzb ? gb[i] * act_grad(v, a.act_b) : 0.f);
                     const float xh = (yv[i] - mu[i]) * is[i];
                     if (APPLY) out[i] = a.bn ? sc[i] * (gh - k1[i] - xh * k2[i]) : gh;
                     else { s1[i] += gh; s2[i] += gh * xh; }
@@ -503,15 +519,18 @@ extern "C" int gs_bn_bwd_tiles_used(int N, int H, int W, int pooled) {
 }
 
 extern "C" int gs_bn_act_bwd_reduce(const void* y, const void* dz_a, int sa, int coff_a, const void* dzp,
+                                    const void* dz_b, int act_b, const uint8_t* keep_mask, float keep_scale,
                                     const float* scale, const float* shift, const float* mean, const float* invstd,
                                     int act, float* partials, int N, int H, int W, int C, int dtype, void* stream) {
-    GS_CHECK_ARG(y && partials && (dz_a || dzp) && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= 2048,
+    GS_CHECK_ARG(!(dzp && (dz_b || keep_mask)), "gs_bn_act_bwd_reduce: pooled gradient cannot be combined with dz_b / keep_mask");
+    GS_CHECK_ARG(y && partials && (dz_a || dzp || dz_b) && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= 2048,
                  "gs_bn_act_bwd_reduce: bad arguments");
     GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_bn_act_bwd_reduce: bad dtype");
     GS_CHECK_ARG(!dz_a || (sa >= coff_a + C && sa % 8 == 0 && coff_a % 8 == 0), "gs_bn_act_bwd_reduce: bad dz stride");
     BwdArgs a{};
     a.y = (const unsigned short*)y; a.dza = (const unsigned short*)dz_a; a.dzp = (const unsigned short*)dzp;
     a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.c1 = nullptr; a.c2 = nullptr;
+    a.dzb = (const unsigned short*)dz_b; a.act_b = act_b; a.keep = keep_mask; a.keep_scale = keep_scale;
     a.partials = partials; a.dy = nullptr; a.sa = sa; a.ca = coff_a; a.act = act; a.bn = 1;
     a.N = N; a.H = H; a.W = W; a.C = C;
     launch_bwd(a, false, dtype, (hipStream_t)stream, nullptr);
@@ -531,10 +550,12 @@ extern "C" int gs_bn_bwd_coeffs(const float* partials, int ntiles, int C, double
 }
 
 extern "C" int gs_bn_act_bwd_apply(const void* y, const void* dz_a, int sa, int coff_a, const void* dzp,
+                                   const void* dz_b, int act_b, const uint8_t* keep_mask, float keep_scale,
                                    const float* scale, const float* shift, const float* mean, const float* invstd,
                                    const float* c1, const float* c2, int act, int bn, void* dy, int N, int H, int W,
                                    int C, int dtype, void* stream) {
-    GS_CHECK_ARG(y && dy && (dz_a || dzp) && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= 2048,
+    GS_CHECK_ARG(!(dzp && (dz_b || keep_mask)), "gs_bn_act_bwd_apply: pooled gradient cannot be combined with dz_b / keep_mask");
+    GS_CHECK_ARG(y && dy && (dz_a || dzp || dz_b) && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= 2048,
                  "gs_bn_act_bwd_apply: bad arguments");
     GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_bn_act_bwd_apply: bad dtype");
     GS_CHECK_ARG(!bn || (scale && shift && mean && invstd && c1 && c2), "gs_bn_act_bwd_apply: bn=1 needs all coefficients");
@@ -542,6 +563,7 @@ extern "C" int gs_bn_act_bwd_apply(const void* y, const void* dz_a, int sa, int 
     BwdArgs a{};
     a.y = (const unsigned short*)y; a.dza = (const unsigned short*)dz_a; a.dzp = (const unsigned short*)dzp;
     a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.c1 = c1; a.c2 = c2;
+    a.dzb = (const unsigned short*)dz_b; a.act_b = act_b; a.keep = keep_mask; a.keep_scale = keep_scale;
     a.partials = nullptr; a.dy = (unsigned short*)dy; a.sa = sa; a.ca = coff_a; a.act = act; a.bn = bn;
     a.N = N; a.H = H; a.W = W; a.C = C;
     launch_bwd(a, true, dtype, (hipStream_t)stream, nullptr);

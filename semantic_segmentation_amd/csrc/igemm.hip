@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
             const int co = n0 + rbase + 32 * j;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (cok && co < g.Cout)
-                v = *reinterpret_cast<const uint4*>(a.w + ((int64_t)tap * g.Cout + co) * g.Cin + ci);
+                v = *reinterpret_cast<const uint4*>(a.w + ((int64_t)g.tap_w[tap] * g.Cout + co) * g.Cin + ci);
             rb[j] = v;
         }
     };
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (co < g.Cout) atomicAdd(a.dw + ((int64_t)tap * g.Cout + co) * g.Cin + ci, acc[i][j][r]);
+                if (co < g.Cout) atomicAdd(a.dw + ((int64_t)g.tap_w[tap] * g.Cout + co) * g.Cin + ci, acc[i][j][r]);
             }
         }
 }

@@ -1,0 +1,126 @@
+// Pix2Pix generator up-path: the DARTS-style mixed transposed convolution
+//   y = sum_j softmax(arch)[j] * ConvTranspose2d_j(x),  (k,s,p) = (4,2,1), (6,2,2), (8,2,3)
+// (models_pix2pix/networks.py:486-511, architecture_pix2pix/operations.py:14-39) is linear and centre
+// aligned (k - 2p = 2 for all three), hence EXACTLY one ConvTranspose2d(k=8,s=2,p=3) with the merged kernel
+//   Wm = w2*W8 + w1*pad1(W6) + w0*pad2(W4)            (116 taps -> 64 taps, -45 % FLOPs)
+// This file merges the three fp32 parameter tensors straight into the 16-bit K-major packs the MFMA
+// engine consumes (one pass over the 1.09 GB of generator weights, HBM-bound), and splits the merged
+// weight gradient back into dW4/dW6/dW8 plus the three architecture-weight dot products.
+//
+// Sub-pixel decomposition of the stride-2 transposed conv: output pixel (2i+py, 2j+px) only sees taps
+// ky == py+1 (mod 2), kx == px+1 (mod 2): 4 classes x 16 taps, input offset dy = (py+3-ky)/2.
+//   fwd pack   P[c][t][Cout][Cin],  c = py*2+px, t = a*4+b, ky = 2a + (1-py), kx = 2b + (1-px)
+//   dgrad pack D[ky*8+kx][Cin][Cout]   (dX = stride-2 conv of dY with the un-flipped kernel)
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ float merged_tap(const float* w4, const float* w6, const float* w8, int ky, int kx,
+                                            float s0, float s1, float s2) {
+    float v = s2 * w8[ky * 8 + kx];
+    if (ky >= 1 && ky <= 6 && kx >= 1 && kx <= 6) v += s1 * w6[(ky - 1) * 6 + kx - 1];
+    if (ky >= 2 && ky <= 5 && kx >= 2 && kx <= 5) v += s0 * w4[(ky - 2) * 4 + kx - 2];
+    return v;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void upconv_merge_pack_kernel(const float* __restrict__ W4, const float* __restrict__ W6,
+                                                                const float* __restrict__ W8, const float* __restrict__ sm,
+                                                                unsigned short* pf, unsigned short* pd, float* wm32,
+                                                                int Cin, int Cout) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)Cin * Cout) return;
+    const int ci = (int)(idx % Cin), co = (int)(idx / Cin);
+    const float s0 = sm[0], s1 = sm[1], s2 = sm[2];
+    const int64_t pair = (int64_t)ci * Cout + co;
+    const float* w4 = W4 + pair * 16;
+    const float* w6 = W6 + pair * 36;
+    const float* w8 = W8 + pair * 64;
+    const int64_t plane = (int64_t)Cout * Cin;
+    for (int ky = 0; ky < 8; ++ky)
+        for (int kx = 0; kx < 8; ++kx) {
+            const float v = merged_tap(w4, w6, w8, ky, kx, s0, s1, s2);
+            const unsigned short h = Elem<DT>::from_f(v);
+            if (pf) {
+                const int py = 1 - (ky & 1), px = 1 - (kx & 1);
+                const int c = py * 2 + px, t = (ky >> 1) * 4 + (kx >> 1);
+                pf[((int64_t)(c * 16 + t)) * plane + (int64_t)co * Cin + ci] = h;
+            }
+            if (pd) pd[((int64_t)(ky * 8 + kx)) * plane + (int64_t)ci * Cout + co] = h;
+            if (wm32) wm32[pair * 64 + ky * 8 + kx] = v;
+        }
+}
+
+// dWm [4][16][Cout][Cin] fp32 (class major, from gs_conv_wgrad per class) -> dW4/dW6/dW8 (reference layouts,
+// OVERWRITE, scaled by gscale*softmax weight) and dots[j] += gscale * <dWm window_j, W_j>.
+__global__ __launch_bounds__(256) void upconv_split_wgrad_kernel(const float* __restrict__ dWm, const float* __restrict__ W4,
+                                                                 const float* __restrict__ W6, const float* __restrict__ W8,
+                                                                 const float* __restrict__ sm, float gscale, float* dW4,
+                                                                 float* dW6, float* dW8, float* dots, int Cin, int Cout) {
+    __shared__ float red[3][4];
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    if (idx < (int64_t)Cin * Cout) {
+        const int ci = (int)(idx % Cin), co = (int)(idx / Cin);
+        const float s0 = sm[0] * gscale, s1 = sm[1] * gscale, s2 = sm[2] * gscale;
+        const int64_t pair = (int64_t)ci * Cout + co;
+        const int64_t plane = (int64_t)Cout * Cin;
+        for (int ky = 0; ky < 8; ++ky)
+            for (int kx = 0; kx < 8; ++kx) {
+                const int py = 1 - (ky & 1), px = 1 - (kx & 1);
+                const int c = py * 2 + px, t = (ky >> 1) * 4 + (kx >> 1);
+                const float g = dWm[((int64_t)(c * 16 + t)) * plane + (int64_t)co * Cin + ci];
+                dW8[pair * 64 + ky * 8 + kx] = s2 * g;
+                d2 += g * W8[pair * 64 + ky * 8 + kx];
+                if (ky >= 1 && ky <= 6 && kx >= 1 && kx <= 6) {
+                    const int o = (ky - 1) * 6 + kx - 1;
+                    dW6[pair * 36 + o] = s1 * g;
+                    d1 += g * W6[pair * 36 + o];
+                }
+                if (ky >= 2 && ky <= 5 && kx >= 2 && kx <= 5) {
+                    const int o = (ky - 2) * 4 + kx - 2;
+                    dW4[pair * 16 + o] = s0 * g;
+                    d0 += g * W4[pair * 16 + o];
+                }
+            }
+    }
+    d0 = wave_sum(d0); d1 = wave_sum(d1); d2 = wave_sum(d2);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = d0; red[1][w] = d1; red[2][w] = d2; }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        atomicAdd(dots + threadIdx.x, (red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]) * gscale);
+}
+
+}  // namespace
+
+extern "C" int gs_upconv_merge_pack(const float* w4, const float* w6, const float* w8, const float* softmax3,
+                                    void* pack_fwd, void* pack_dgrad, float* merged_f32, int Cin, int Cout, int dtype,
+                                    void* stream) {
+    GS_CHECK_ARG(w4 && w6 && w8 && softmax3 && (pack_fwd || pack_dgrad || merged_f32) && Cin > 0 && Cout > 0,
+                 "gs_upconv_merge_pack: bad arguments");
+    const int64_t n = (int64_t)Cin * Cout;
+    const int nb = (int)cdiv64(n, 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GS_F16)
+        upconv_merge_pack_kernel<GS_F16><<<nb, 256, 0, s>>>(w4, w6, w8, softmax3, (unsigned short*)pack_fwd,
+                                                             (unsigned short*)pack_dgrad, merged_f32, Cin, Cout);
+    else if (dtype == GS_BF16)
+        upconv_merge_pack_kernel<GS_BF16><<<nb, 256, 0, s>>>(w4, w6, w8, softmax3, (unsigned short*)pack_fwd,
+                                                              (unsigned short*)pack_dgrad, merged_f32, Cin, Cout);
+    else GS_CHECK_ARG(false, "gs_upconv_merge_pack: bad dtype");
+    GS_CHECK_LAUNCH("gs_upconv_merge_pack");
+    return GS_OK;
+}
+
+extern "C" int gs_upconv_split_wgrad(const float* dwm, const float* w4, const float* w6, const float* w8,
+                                     const float* softmax3, float gscale, float* dw4, float* dw6, float* dw8,
+                                     float* dots3, int Cin, int Cout, void* stream) {
+    GS_CHECK_ARG(dwm && w4 && w6 && w8 && softmax3 && dw4 && dw6 && dw8 && dots3 && Cin > 0 && Cout > 0,
+                 "gs_upconv_split_wgrad: bad arguments");
+    const int nb = (int)cdiv64((int64_t)Cin * Cout, 256);
+    upconv_split_wgrad_kernel<<<nb, 256, 0, (hipStream_t)stream>>>(dwm, w4, w6, w8, softmax3, gscale, dw4, dw6, dw8, dots3,
+                                                                   Cin, Cout);
+    GS_CHECK_LAUNCH("gs_upconv_split_wgrad");
+    return GS_OK;
+}

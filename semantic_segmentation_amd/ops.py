@@ -44,7 +44,8 @@ def _f32(t: Optional[torch.Tensor], name: str):
 
 # ---------------------------------------------------------------------------- geometry builders
 def make_geom(N, IH, IW, Cin, OHg, OWg, Cout, OH, OW, taps: Sequence[Tuple[int, int]], isy=1, isx=1,
-              osy=1, osx=1, ooy=0, oox=0, in_stride=None, in_coff=0, out_stride=None, out_coff=0) -> GsConvGeom:
+              osy=1, osx=1, ooy=0, oox=0, in_stride=None, in_coff=0, out_stride=None, out_coff=0,
+              tap_w: Optional[Sequence[int]] = None) -> GsConvGeom:
     g = GsConvGeom()
     g.N, g.IH, g.IW, g.Cin = N, IH, IW, Cin
     g.in_pix_stride = Cin if in_stride is None else in_stride
@@ -58,6 +59,7 @@ def make_geom(N, IH, IW, Cin, OHg, OWg, Cout, OH, OW, taps: Sequence[Tuple[int, 
     g.ntaps = len(taps)
     for i, (dy, dx) in enumerate(taps):
         g.tap_dy[i], g.tap_dx[i] = dy, dx
+        g.tap_w[i] = i if tap_w is None else tap_w[i]
     return g
 
 
@@ -116,6 +118,31 @@ TIMER: Optional[KernelTimer] = None
 
 def _geom_flops(g: GsConvGeom) -> float:
     return 2.0 * g.N * g.OHg * g.OWg * g.Cout * g.ntaps * g.Cin
+
+
+def geom_convT_class(N, IH, IW, Cin, Cout, k, pad, py, px, OH=None, OW=None, **kw) -> GsConvGeom:
+    """Sub-pixel class (py,px) of ConvTranspose2d(k, stride 2, pad): output pixels (2i+py, 2j+px) <- input
+    (i+dy, j+dx) for the taps with ky == py+pad (mod 2); weight slots index a [k*k][Cout][Cin] pack."""
+    kys = [ky for ky in range(k) if (py + pad - ky) % 2 == 0]
+    kxs = [kx for kx in range(k) if (px + pad - kx) % 2 == 0]
+    taps = [((py + pad - ky) // 2, (px + pad - kx) // 2) for ky in kys for kx in kxs]
+    slots = [ky * k + kx for ky in kys for kx in kxs]
+    OHf = (IH - 1) * 2 - 2 * pad + k if OH is None else OH
+    OWf = (IW - 1) * 2 - 2 * pad + k if OW is None else OW
+    ohg, owg = (OHf - py + 1) // 2, (OWf - px + 1) // 2
+    return make_geom(N, IH, IW, Cin, ohg, owg, Cout, OHf, OWf, taps, osy=2, osx=2, ooy=py, oox=px, tap_w=slots, **kw)
+
+
+def geom_conv_s2_dgrad_class(N, IH, IW, Cin, Cout, k, pad, py, px, **kw) -> GsConvGeom:
+    """Data gradient of Conv2d(k, stride 2, pad) for input pixels (2i+py, 2j+px): reads dy [N,OH,OW,Cout] at
+    (i + (py+pad-ky)/2, ...) for ky == py+pad (mod 2); weight slots index the [k*k][Cin][Cout] dgrad pack."""
+    OH, OW = conv_out_size(IH, k, 2, pad), conv_out_size(IW, k, 2, pad)
+    kys = [ky for ky in range(k) if (py + pad - ky) % 2 == 0]
+    kxs = [kx for kx in range(k) if (px + pad - kx) % 2 == 0]
+    taps = [((py + pad - ky) // 2, (px + pad - kx) // 2) for ky in kys for kx in kxs]
+    slots = [ky * k + kx for ky in kys for kx in kxs]
+    ihg, iwg = (IH - py + 1) // 2, (IW - px + 1) // 2
+    return make_geom(N, OH, OW, Cout, ihg, iwg, Cin, IH, IW, taps, osy=2, osx=2, ooy=py, oox=px, tap_w=slots, **kw)
 
 
 # ---------------------------------------------------------------------------- MFMA engine
@@ -264,10 +291,12 @@ def bn_bwd_tiles_used(N, H, W, pooled: bool) -> int:
     return _lib.load().gs_bn_bwd_tiles_used(N, H, W, int(pooled))
 
 
-def bn_act_bwd_reduce(y, dz_a, sa, ca, dzp, scale, shift, mean, invstd, act, partials):
+def bn_act_bwd_reduce(y, dz_a, sa, ca, dzp, scale, shift, mean, invstd, act, partials, dz_b=None, act_b=ACT_NONE,
+                      keep_mask=None, keep_scale=1.0):
     N, H, W, C = y.shape
-    _lib.call("gs_bn_act_bwd_reduce", _p(y), _p(dz_a), sa, ca, _p(dzp), _p(scale), _p(shift), _p(mean), _p(invstd),
-              act, _p(partials), N, H, W, C, dt_code(y), _stream())
+    _lib.call("gs_bn_act_bwd_reduce", _p(y), _p(dz_a), sa, ca, _p(dzp), _p(dz_b), act_b, _p(keep_mask),
+              float(keep_scale), _p(scale), _p(shift), _p(mean), _p(invstd), act, _p(partials), N, H, W, C,
+              dt_code(y), _stream())
 
 
 def bn_bwd_coeffs(partials, ntiles, C, count, gscale, dgamma, dbeta, c1, c2):
@@ -275,10 +304,12 @@ def bn_bwd_coeffs(partials, ntiles, C, count, gscale, dgamma, dbeta, c1, c2):
               _p(c1), _p(c2), _stream())
 
 
-def bn_act_bwd_apply(y, dz_a, sa, ca, dzp, scale, shift, mean, invstd, c1, c2, act, bn, dy):
+def bn_act_bwd_apply(y, dz_a, sa, ca, dzp, scale, shift, mean, invstd, c1, c2, act, bn, dy, dz_b=None,
+                     act_b=ACT_NONE, keep_mask=None, keep_scale=1.0):
     N, H, W, C = y.shape
-    _lib.call("gs_bn_act_bwd_apply", _p(y), _p(dz_a), sa, ca, _p(dzp), _p(scale), _p(shift), _p(mean), _p(invstd),
-              _p(c1), _p(c2), act, int(bn), _p(dy), N, H, W, C, dt_code(y), _stream())
+    _lib.call("gs_bn_act_bwd_apply", _p(y), _p(dz_a), sa, ca, _p(dzp), _p(dz_b), act_b, _p(keep_mask),
+              float(keep_scale), _p(scale), _p(shift), _p(mean), _p(invstd), _p(c1), _p(c2), act, int(bn), _p(dy),
+              N, H, W, C, dt_code(y), _stream())
 
 
 def colsum(t, pix_stride, coff, N, H, W, y0, x0, h, w, C, gscale, ws, out):
@@ -319,6 +350,26 @@ def nhwc_to_nchw(src, dst, src_stride=None, src_coff=0, gscale=1.0):
     N, C, H, W = dst.shape
     _lib.call("gs_nhwc_to_nchw", _p(src), C if src_stride is None else src_stride, src_coff, _p(dst), N, C, H, W,
               float(gscale), dt_code(src), _stream())
+
+
+# ---------------------------------------------------------------------------- Pix2Pix mixed up-conv
+def upconv_merge_pack(w4, w6, w8, softmax3, pack_fwd=None, pack_dgrad=None, merged_f32=None):
+    _dev(w8)
+    for n, t in (("w4", w4), ("w6", w6), ("w8", w8), ("softmax3", softmax3), ("merged", merged_f32)):
+        _f32(t, n)
+    Cin, Cout = w8.shape[0], w8.shape[1]
+    ref = pack_fwd if pack_fwd is not None else pack_dgrad
+    code = dt_code(ref) if ref is not None else GS_F16
+    _lib.call("gs_upconv_merge_pack", _p(w4), _p(w6), _p(w8), _p(softmax3), _p(pack_fwd), _p(pack_dgrad),
+              _p(merged_f32), Cin, Cout, code, _stream())
+
+
+def upconv_split_wgrad(dwm, w4, w6, w8, softmax3, gscale, dw4, dw6, dw8, dots3):
+    for n, t in (("dwm", dwm), ("dw4", dw4), ("dw6", dw6), ("dw8", dw8), ("dots3", dots3)):
+        _f32(t, n)
+    Cin, Cout = w8.shape[0], w8.shape[1]
+    _lib.call("gs_upconv_split_wgrad", _p(dwm), _p(w4), _p(w6), _p(w8), _p(softmax3), float(gscale), _p(dw4), _p(dw6),
+              _p(dw8), _p(dots3), Cin, Cout, _stream())
 
 
 # ---------------------------------------------------------------------------- losses

@@ -85,3 +85,23 @@ def test_product_never_imports_oracle():
                     mods = [node.module]
                 for m in mods:
                     assert not m.split(".")[0] == "oracle", f"{f} imports {m}"
+
+
+def test_pix2pix_api_surface_and_state_dict_keys():
+    from golden_util import seeded_discriminator_state_dict, seeded_generator_state_dict
+    from semantic_segmentation_amd.models_pix2pix import networks
+    norm = networks.get_norm_layer("batch")
+    G = networks.define_G(1, 1, 64, "unet_256", "batch", True)
+    D = networks.define_D(2, 64, "basic", 3, "batch")
+    sdG, sdD = seeded_generator_state_dict(1), seeded_discriminator_state_dict(2)
+    # golden_util's key SETS were validated against the reference with load_state_dict(strict=True)
+    assert sorted(G.state_dict().keys()) == sorted(sdG.keys()) and len(sdG) == 100
+    assert sorted(D.state_dict().keys()) == sorted(sdD.keys()) and len(sdD) == 22
+    for k, v in G.state_dict().items():
+        assert tuple(v.shape) == tuple(sdG[k].shape), k
+    assert sum(p.numel() for p in G.parameters()) == 272327811
+    assert sum(p.numel() for p in D.parameters()) == 2764609
+    assert len(networks.arch_parameters()) == 2 and tuple(networks.upconv_arch.shape) == (8, 3)
+    assert networks.GANLoss("vanilla").gan_mode == "vanilla"
+    with pytest.raises(RuntimeError):
+        D(torch.zeros(1, 2, 64, 64))                  # CPU tensor: no fallback
