@@ -74,6 +74,11 @@ int gs_conv3x3(const void* x, const void* w, void* y, const float* bias, float* 
                int Cin, int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff,
                const int32_t* tap_dy, const int32_t* tap_dx, int act, int dtype, void* stream);
 
+/* weight gradient of the same 3x3/s1/p1 convolution with halo reuse: dw fp32 [9][Cout][Cin] (ACCUMULATED with
+ * atomics; caller zeroes) += sum_p dy[p][co] * x[p + tap][ci];  x / dy NHWC 16-bit with pixel stride / offset. */
+int gs_conv3x3_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int in_pix_stride,
+                     int in_coff, int Cout, int out_pix_stride, int out_coff, int dtype, void* stream);
+
 /* ---- MFMA weight gradient -------------------------------------------------------------------
  * dw[t][co][ci] (fp32, ACCUMULATED with atomics: caller zeroes) += sum over logical pixels of
  * dy[pix][co] * x[inpix(pix,t)][ci].  `g` describes the forward conv: dy lives on the OUTPUT side

@@ -37,6 +37,7 @@ PROTOTYPES = {
     "gs_conv_igemm": (c_int, [POINTER(GsConvGeom), _P, _P, _P, _F, _F, c_int, c_int, c_void_p]),
     "gs_conv3x3_mtiles": (c_int, [c_int, c_int, c_int, c_int]),
     "gs_conv3x3": (c_int, [_P, _P, _P, _F, _F] + [c_int] * 9 + [POINTER(c_int32), POINTER(c_int32), c_int, c_int, c_void_p]),
+    "gs_conv3x3_wgrad": (c_int, [_P, _P, _F] + [c_int] * 10 + [c_void_p]),
     "gs_conv_wgrad": (c_int, [POINTER(GsConvGeom), _P, _P, _F, c_int, c_void_p]),
     "gs_conv_smallcin_mtiles": (c_int, [c_int, c_int, c_int]),
     "gs_conv_smallcin_fwd": (c_int, [_F, _F, _F, _P, _F] + [c_int] * 12 + [c_void_p]),

@@ -425,7 +425,7 @@ extern "C" int gs_conv_smallcin_wgrad(const float* x, const void* dy, float* dw,
     if (rc) return rc;
     GS_CHECK_ARG(x && dy && dw, "gs_conv_smallcin_wgrad: null pointer");
     const int64_t M = (int64_t)N * OH * OW;
-    int64_t ppb = cdiv64(M, 8192);
+    int64_t ppb = cdiv64(M, 1024);      // few blocks: every block ends in atomics on the same Cout*taps addresses
     if (ppb < 64) ppb = 64;
     SCWArgs a{x, (const unsigned short*)dy, dw, N, Cin, IH, IW, Cout, OH, OW, k, stride, pad, gscale, ppb};
     const int nb = (int)cdiv64(M, ppb);
@@ -503,7 +503,7 @@ extern "C" int gs_conv_smallcout_bwd(const void* x, const float* w, const float*
     if (dw) {
         GS_CHECK_ARG(x != nullptr, "gs_conv_smallcout_bwd: dw needs x");
         const int64_t M = (int64_t)N * OH * OW;
-        int64_t ppb = cdiv64(M, 8192);
+        int64_t ppb = cdiv64(M, 1024);
         if (ppb < 64) ppb = 64;
         a.pix_per_block = ppb;
         const int nb = (int)cdiv64(M, ppb);

@@ -1,0 +1,184 @@
+// Weight gradient of the 3x3 / stride-1 / pad-1 convolution with LDS HALO REUSE.
+//
+//   dW[tap][co][ci] += sum_pixels dY[p][co] * X[p + tap][ci]
+//
+// The generic wgrad (igemm.hip) stages X once per tap (and dY once per group of taps): at the 256x256 /
+// 64-channel end of the U-Net it fetches 2.8 GB per launch for 0.54 GB of algorithmic traffic (rocprofv3 PMC,
+// profiles/r01_v2_pmc_traffic.json).  Here a block owns ONE (64 co x 64 ci) channel-block pair and a range of
+// spatial patches (split-K over patches): per patch the dY tile [128 px][64 co] and the X halo
+// [(TH+2)(TW+2) px][64 ci] are staged in LDS once and ALL NINE taps are accumulated from them
+// (9 taps x 4 MFMA 32x32 tiles = 36 accumulator tiles per block, 9 per wave: waves split co-half x ci-half).
+// Both MFMA operands are K(=pixel)-minor, read with the transposing LDS read ds_read_b64_tr_b16 from
+// [pixel][channel] images (192-B rows: conflict free).  The next patch is prefetched into registers while the
+// current one is multiplied.  One fp32 atomic pass per block at the end.
+#include <stdlib.h>
+
+#include "common.hpp"
+
+namespace {
+
+struct W3Args {
+    const unsigned short* x;
+    const unsigned short* dy;
+    float* dw;                  // [9][Cout][Cin]
+    int N, H, W, Cin, in_stride, in_coff, Cout, out_stride, out_coff;
+    int tiles_x, tiles_y, npatches, ncob, ncib, ksplit, pps;   // pps = patches per split
+};
+
+constexpr int W3_LDR = 96;      // 64 channels + 32 pad elements = 192-byte rows
+constexpr int W3_BM = 128;      // pixels per patch
+
+template <int DT, int TW>
+__global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const W3Args a) {
+    typedef typename Elem<DT>::V8 V8;
+    constexpr int TH = W3_BM / TW;
+    constexpr int HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;
+    constexpr int DY_EL = W3_BM * W3_LDR, H_EL = HP * W3_LDR;
+    constexpr int HCH = (HP * 8 + 255) / 256;
+    constexpr int TWS = (TW == 32) ? 5 : 4;
+    constexpr unsigned OOB = 0xFFFFFFFFu;
+    __shared__ __attribute__((aligned(16))) unsigned short smem[DY_EL + H_EL];
+    unsigned short* dyt = smem;
+    unsigned short* halo = smem + DY_EL;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int bid = blockIdx.x;
+    const int cob = bid % a.ncob; bid /= a.ncob;
+    const int cib = bid % a.ncib; bid /= a.ncib;
+    const int ks = bid;
+    const int co0 = cob * 64, ci0 = cib * 64;
+    const int p_begin = ks * a.pps;
+    const int p_end = min(a.npatches, p_begin + a.pps);
+    if (p_begin >= p_end) return;
+
+    const unsigned x_img_bytes = (unsigned)a.H * a.W * a.in_stride * 2u;
+    const unsigned dy_img_bytes = (unsigned)a.H * a.W * a.out_stride * 2u;
+    const int chunk = t & 7, row0 = t >> 3;
+    const bool ci_ok = ci0 + chunk * 8 < a.Cin, co_ok = co0 + chunk * 8 < a.Cout;
+
+    uint4 rd[4], rh[HCH];
+    auto load_patch = [&](int patch) __attribute__((always_inline)) {
+        const int tx = patch % a.tiles_x;
+        const int r = patch / a.tiles_x;
+        const int ty = r % a.tiles_y, n = r / a.tiles_y;
+        const int y0 = ty * TH, x0 = tx * TW;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.x + (int64_t)n * a.H * a.W * a.in_stride), 0, x_img_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.dy + (int64_t)n * a.H * a.W * a.out_stride), 0, dy_img_bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = row0 + 32 * j;
+            const int gy = y0 + (p >> TWS), gx = x0 + (p & (TW - 1));
+            const bool ok = co_ok && gy < a.H && gx < a.W;
+            const unsigned off = ok ? (unsigned)(((gy * a.W + gx) * a.out_stride + a.out_coff + co0 + chunk * 8) * 2) : OOB;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0);
+            rd[j] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+#pragma unroll
+        for (int j = 0; j < HCH; ++j) {
+            const int hp = row0 + 32 * j;
+            const int hy = hp / HWD, hx = hp - hy * HWD;
+            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+            const bool ok = ci_ok && hp < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            const unsigned off = ok ? (unsigned)(((gy * a.W + gx) * a.in_stride + a.in_coff + ci0 + chunk * 8) * 2) : OOB;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+            rh[j] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+    };
+    auto store_patch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<uint4*>(dyt + (row0 + 32 * j) * W3_LDR + chunk * 8) = rd[j];
+#pragma unroll
+        for (int j = 0; j < HCH; ++j)
+            if (row0 + 32 * j < HP) *reinterpret_cast<uint4*>(halo + (row0 + 32 * j) * W3_LDR + chunk * 8) = rh[j];
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // transposed-read lane addressing: 16-lane group G covers channels 16*(G&1).. and k rows 8*(G>>1)+4r+q
+    const int G = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int krow = 8 * (G >> 1) + q;
+    const int chn = 16 * (G & 1) + 4 * pp;
+    const LDS_AS unsigned short* lds = (const LDS_AS unsigned short*)smem;
+    const LDS_AS unsigned short* a_base = lds + krow * W3_LDR + wm * 32 + chn;
+    const LDS_AS unsigned short* b_base = lds + DY_EL + krow * W3_LDR + wn * 32 + chn;
+
+    load_patch(p_begin);
+    for (int patch = p_begin; patch < p_end; ++patch) {
+        __syncthreads();                 // previous patch fully consumed
+        store_patch();
+        __syncthreads();
+        if (patch + 1 < p_end) load_patch(patch + 1);
+#pragma unroll 2
+        for (int k16 = 0; k16 < W3_BM / 16; ++k16) {
+            const int pb = k16 * 16;
+            const int py = pb >> TWS, px0 = pb & (TW - 1);
+            const V8 af = tr_read8<DT>(a_base + pb * W3_LDR, a_base + (pb + 4) * W3_LDR);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int hrow = (py + tap / 3) * HWD + px0 + tap % 3;      // (py+1+dy)*HWD + px0+1+dx
+                const V8 bf = tr_read8<DT>(b_base + hrow * W3_LDR, b_base + (hrow + 4) * W3_LDR);
+                acc[tap] = Elem<DT>::mfma32(af, bf, acc[tap]);
+            }
+        }
+    }
+
+    const int l31 = lane & 31, h = lane >> 5;
+    const int ci = ci0 + wn * 32 + l31;
+    if (ci < a.Cin) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (co < a.Cout) atomicAdd(a.dw + ((int64_t)tap * a.Cout + co) * a.Cin + ci, acc[tap][r]);
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int gs_conv3x3_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin,
+                                int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff, int dtype,
+                                void* stream) {
+    GS_CHECK_ARG(x && dy && dw, "gs_conv3x3_wgrad: null pointer");
+    GS_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 8 == 0, "gs_conv3x3_wgrad: bad dims");
+    GS_CHECK_ARG(in_pix_stride >= in_coff + Cin && in_pix_stride % 8 == 0 && in_coff % 8 == 0, "gs_conv3x3_wgrad: bad x stride");
+    GS_CHECK_ARG(out_pix_stride >= out_coff + Cout && out_pix_stride % 8 == 0 && out_coff % 8 == 0, "gs_conv3x3_wgrad: bad dy stride");
+    GS_CHECK_ARG((int64_t)H * W * in_pix_stride * 2 < 4294967000LL && (int64_t)H * W * out_pix_stride * 2 < 4294967000LL,
+                 "gs_conv3x3_wgrad: one image must stay below 4 GiB (32-bit buffer offsets)");
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_conv3x3_wgrad: bad dtype");
+    W3Args a;
+    a.x = (const unsigned short*)x; a.dy = (const unsigned short*)dy; a.dw = dw;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.in_stride = in_pix_stride; a.in_coff = in_coff;
+    a.Cout = Cout; a.out_stride = out_pix_stride; a.out_coff = out_coff;
+    const int tw = (W >= 24) ? 32 : 16, th = W3_BM / tw;
+    a.tiles_x = cdiv(W, tw); a.tiles_y = cdiv(H, th);
+    a.npatches = N * a.tiles_x * a.tiles_y;
+    a.ncob = cdiv(Cout, 64); a.ncib = cdiv(Cin, 64);
+    const int pairs = a.ncob * a.ncib;
+    static const int target = getenv("GSSEG_W3_GRID") ? atoi(getenv("GSSEG_W3_GRID")) : 512;
+    int ksplit = cdiv(target, pairs);
+    if (ksplit > a.npatches) ksplit = a.npatches;
+    if (ksplit < 1) ksplit = 1;
+    a.pps = cdiv(a.npatches, ksplit);
+    a.ksplit = cdiv(a.npatches, a.pps);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(pairs * a.ksplit), block(256);
+    if (dtype == GS_F16) {
+        if (tw == 32) wgrad3x3_kernel<GS_F16, 32><<<grid, block, 0, s>>>(a);
+        else wgrad3x3_kernel<GS_F16, 16><<<grid, block, 0, s>>>(a);
+    } else {
+        if (tw == 32) wgrad3x3_kernel<GS_BF16, 32><<<grid, block, 0, s>>>(a);
+        else wgrad3x3_kernel<GS_BF16, 16><<<grid, block, 0, s>>>(a);
+    }
+    GS_CHECK_LAUNCH("gs_conv3x3_wgrad");
+    return GS_OK;
+}

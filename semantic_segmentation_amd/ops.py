@@ -191,6 +191,21 @@ def conv3x3(x, w, y, N, H, W, Cin, Cout, taps=TAPS3_FWD, bias=None, bn_partials=
         TIMER.stop("conv3x3_halo", ev, 2.0 * N * H * W * Cout * 9 * Cin)
 
 
+def conv3x3_wgrad(x, dy, dw, N, H, W, Cin, Cout, in_stride=None, in_coff=0, out_stride=None, out_coff=0):
+    """dw[9][Cout][Cin] (fp32, caller zeroes) += weight gradient of the 3x3/s1/p1 conv, halo-reuse MFMA kernel."""
+    _dev(x)
+    _f32(dw, "dw")
+    if x.dtype != dy.dtype:
+        raise TypeError("conv3x3_wgrad: x and dy must share one 16-bit dtype")
+    if dw.numel() < 9 * Cout * Cin:
+        raise ValueError("conv3x3_wgrad: dw too small")
+    ev = TIMER.start() if TIMER is not None else None
+    _lib.call("gs_conv3x3_wgrad", _p(x), _p(dy), _p(dw), N, H, W, Cin, Cin if in_stride is None else in_stride,
+              in_coff, Cout, Cout if out_stride is None else out_stride, out_coff, dt_code(x), _stream())
+    if ev is not None:
+        TIMER.stop("wgrad3x3_halo", ev, 2.0 * N * H * W * Cout * 9 * Cin)
+
+
 def conv_igemm_mtiles(g: GsConvGeom) -> int:
     return _lib.load().gs_conv_igemm_mtiles(g)
 

@@ -310,7 +310,10 @@ class UNetEngine:
             else:
                 dwp = dw_ws[: wparam.numel()]
                 dwp.zero_()
-                ops.conv_wgrad(rec.geom, rec.inp, dy, dwp)
+                if ops.USE_HALO_CONV and cin % 8 == 0 and cout % 8 == 0:
+                    ops.conv3x3_wgrad(rec.inp, dy, dwp, N, h, w, cin, cout)
+                else:
+                    ops.conv_wgrad(rec.geom, rec.inp, dy, dwp)
                 dw = galloc(rec.wkey, wparam)
                 ops.unpack_wgrad(dwp, dw, cout, cin, 9, False, inv_s)
                 if need_dinp:

@@ -40,8 +40,8 @@ def main():
     dt = torch.float16 if a.dtype == "f16" else torch.bfloat16
     dev = torch.device("cuda:0")
     N = a.batch
-    print(f"{'layer':8s} {'GF':>8s} | {'halo fwd':>9s} {'gen fwd':>9s} {'halo dgr':>9s} {'gen dgr':>9s} {'wgrad':>9s}  (TFLOP/s)")
-    tot = {"halo": 0.0, "gen": 0.0, "wgrad": 0.0}
+    print(f"{'layer':8s} {'GF':>8s} | {'halo fwd':>9s} {'gen fwd':>9s} {'halo dgr':>9s} {'gen dgr':>9s} {'gen wgr':>9s} {'halo wgr':>9s}  (TFLOP/s)")
+    tot = {"halo": 0.0, "gen": 0.0, "wgrad": 0.0, "hw": 0.0}
     for name, H, Cin, Cout in LAYERS:
         if a.only and a.only not in name:
             continue
@@ -62,10 +62,12 @@ def main():
         t_hd = timeit(lambda: ops.conv3x3(dy, wd, dx, N, H, H, Cout, Cin, ops.TAPS3_DGRAD))
         t_gd = timeit(lambda: ops.conv_igemm(gd, dy, wd, dx))
         t_w = timeit(lambda: ops.conv_wgrad(g, x, dy, dw))
-        tot["halo"] += t_hf + t_hd; tot["gen"] += t_gf + t_gd; tot["wgrad"] += t_w
+        t_hw = timeit(lambda: ops.conv3x3_wgrad(x, dy, dw, N, H, H, Cin, Cout))
+        tot["halo"] += t_hf + t_hd; tot["gen"] += t_gf + t_gd; tot["wgrad"] += t_w; tot["hw"] += t_hw
         print(f"{name:8s} {fl / 1e9:8.1f} | {fl / t_hf / 1e12:9.1f} {fl / t_gf / 1e12:9.1f} {fl / t_hd / 1e12:9.1f} "
-              f"{fl / t_gd / 1e12:9.1f} {fl / t_w / 1e12:9.1f}")
-    print("sum ms: halo fwd+dgrad %.3f  generic fwd+dgrad %.3f  wgrad %.3f" % (tot["halo"] * 1e3, tot["gen"] * 1e3, tot["wgrad"] * 1e3))
+              f"{fl / t_gd / 1e12:9.1f} {fl / t_w / 1e12:9.1f} {fl / t_hw / 1e12:9.1f}")
+    print("sum ms: halo fwd+dgrad %.3f  generic fwd+dgrad %.3f  generic wgrad %.3f  halo wgrad %.3f"
+          % (tot["halo"] * 1e3, tot["gen"] * 1e3, tot["wgrad"] * 1e3, tot["hw"] * 1e3))
 
 
 if __name__ == "__main__":
