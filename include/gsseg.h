@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 3
+#define GS_ABI_VERSION 4
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -90,14 +90,16 @@ int gs_conv_wgrad(const GsConvGeom* g, const void* x, const void* dy, float* dw,
  * gs_conv_smallcin_fwd: x fp32 NCHW [N,Cin,IH,IW] (the image / mask as the loader hands it,
  *   unet_model.py:27, networks.py:582 outermost, :640) -> y NHWC dtype [N,OH,OW,Cout] (+bias,
  *   +act, +bn_partials as above; bn tile = 256 output pixels).  w fp32 [Cout][Cin][k][k] (reference layout).
- * gs_conv_smallcin_wgrad: dw fp32 [Cout][Cin][k][k] += sum dy*x (atomics; caller zeroes). `gscale` multiplies.
+ * gs_conv_smallcin_wgrad: dw fp32 [Cout][Cin][k][k] += gscale * sum dy*x (caller zeroes); deterministic two-stage
+ *   reduction through the caller's workspace ws (gs_conv_direct_wgrad_ws_floats floats).
  * gs_conv_smallcin_dgrad: dx fp32 NCHW [N,Cin,IH,IW] = conv_transpose(dy, w)*gscale (overwrites). */
 int gs_conv_smallcin_mtiles(int N, int OH, int OW);
 int gs_conv_smallcin_fwd(const float* x, const float* w, const float* bias, void* y, float* bn_partials,
                          int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int k, int stride, int pad,
                          int act, int dtype, void* stream);
-int gs_conv_smallcin_wgrad(const float* x, const void* dy, float* dw, int N, int Cin, int IH, int IW, int Cout,
-                           int OH, int OW, int k, int stride, int pad, float gscale, int dtype, void* stream);
+int64_t gs_conv_direct_wgrad_ws_floats(int N, int OH, int OW, int Cin, int Cout, int k);   /* workspace of the two below */
+int gs_conv_smallcin_wgrad(const float* x, const void* dy, float* dw, float* ws, int N, int Cin, int IH, int IW,
+                           int Cout, int OH, int OW, int k, int stride, int pad, float gscale, int dtype, void* stream);
 int gs_conv_smallcin_dgrad(const void* dy, const float* w, float* dx, int N, int Cin, int IH, int IW, int Cout,
                            int OH, int OW, int k, int stride, int pad, float gscale, int dtype, void* stream);
 
@@ -106,7 +108,7 @@ int gs_conv_smallcin_dgrad(const void* dy, const float* w, float* dx, int N, int
  * bwd: dlogits fp32 NCHW (already multiplied by the loss scale) -> dx NHWC dtype; dw/db fp32 accumulate*gscale. */
 int gs_conv_smallcout_fwd(const void* x, const float* w, const float* bias, float* y, int N, int IH, int IW, int Cin,
                           int Cout, int OH, int OW, int k, int stride, int pad, int dtype, void* stream);
-int gs_conv_smallcout_bwd(const void* x, const float* w, const float* dy, void* dx, float* dw, float* db,
+int gs_conv_smallcout_bwd(const void* x, const float* w, const float* dy, void* dx, float* dw, float* db, float* ws,
                           int N, int IH, int IW, int Cin, int Cout, int OH, int OW, int k, int stride, int pad,
                           float gscale, int dtype, void* stream);
 

@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 GS_F16, GS_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH = 0, 1, 2, 3
 GS_MAX_TAPS = 64
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class GsConvGeom(ctypes.Structure):
@@ -41,10 +41,11 @@ PROTOTYPES = {
     "gs_conv_wgrad": (c_int, [POINTER(GsConvGeom), _P, _P, _F, c_int, c_void_p]),
     "gs_conv_smallcin_mtiles": (c_int, [c_int, c_int, c_int]),
     "gs_conv_smallcin_fwd": (c_int, [_F, _F, _F, _P, _F] + [c_int] * 12 + [c_void_p]),
-    "gs_conv_smallcin_wgrad": (c_int, [_F, _P, _F] + [c_int] * 10 + [c_float, c_int, c_void_p]),
+    "gs_conv_direct_wgrad_ws_floats": (c_int64, [c_int] * 6),
+    "gs_conv_smallcin_wgrad": (c_int, [_F, _P, _F, _F] + [c_int] * 10 + [c_float, c_int, c_void_p]),
     "gs_conv_smallcin_dgrad": (c_int, [_P, _F, _F] + [c_int] * 10 + [c_float, c_int, c_void_p]),
     "gs_conv_smallcout_fwd": (c_int, [_P, _F, _F, _F] + [c_int] * 11 + [c_void_p]),
-    "gs_conv_smallcout_bwd": (c_int, [_P, _F, _F, _P, _F, _F] + [c_int] * 10 + [c_float, c_int, c_void_p]),
+    "gs_conv_smallcout_bwd": (c_int, [_P, _F, _F, _P, _F, _F, _F] + [c_int] * 10 + [c_float, c_int, c_void_p]),
     "gs_bn_partials_floats": (c_int64, [c_int, c_int]),
     "gs_bn_finalize": (c_int, [_F, c_int, c_int, c_double, _F, _F, _F, _F, c_float, c_float, _F, _F, _F, _F, c_void_p]),
     "gs_bn_eval_coeffs": (c_int, [c_int, _F, _F, _F, _F, c_float, _F, _F, _F, _F, c_void_p]),

@@ -37,14 +37,31 @@ __global__ __launch_bounds__(256) void reduce_partials_stage1(const float* __res
     }
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ s, int nslices, int C, double count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* running_mean, float* running_var, float momentum, float eps,
-                                   float* scale, float* shift, float* mean_out, float* invstd_out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int i = 0; i < nslices; ++i) { s1 += s[((int64_t)i * 2 + 0) * C + c]; s2 += s[((int64_t)i * 2 + 1) * C + c]; }
+// sum of the stage-1 slices for 32 channels per block: 8 slice-lanes per channel through LDS (fixed order)
+__device__ __forceinline__ void sum_slices_32x8(const double* __restrict__ s, int nslices, int C, double& s1, double& s2) {
+    __shared__ double red[2][8][32];
+    const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int i = tl; i < nslices; i += 8) { a += s[((int64_t)i * 2 + 0) * C + c]; b += s[((int64_t)i * 2 + 1) * C + c]; }
+    red[0][tl][cl] = a;
+    red[1][tl][cl] = b;
+    __syncthreads();
+    s1 = 0.0; s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s1 += red[0][i][cl]; s2 += red[1][i][cl]; }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ s, int nslices, int C, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* running_mean, float* running_var, float momentum,
+                                                          float eps, float* scale, float* shift, float* mean_out,
+                                                          float* invstd_out) {
+    double s1, s2;
+    sum_slices_32x8(s, nslices, C, s1, s2);
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    if (c >= C || threadIdx.x >= 32) return;
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -74,12 +91,12 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* be
     invstd[c] = is;
 }
 
-__global__ void bn_bwd_coeffs_kernel(const double* __restrict__ s, int nslices, int C, double count, float gscale,
-                                     float* dgamma, float* dbeta, float* c1, float* c2) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int i = 0; i < nslices; ++i) { s1 += s[((int64_t)i * 2 + 0) * C + c]; s2 += s[((int64_t)i * 2 + 1) * C + c]; }
+__global__ __launch_bounds__(256) void bn_bwd_coeffs_kernel(const double* __restrict__ s, int nslices, int C, double count,
+                                                            float gscale, float* dgamma, float* dbeta, float* c1, float* c2) {
+    double s1, s2;
+    sum_slices_32x8(s, nslices, C, s1, s2);
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    if (c >= C || threadIdx.x >= 32) return;
     if (dbeta) dbeta[c] = (float)(s1 * gscale);
     if (dgamma) dgamma[c] = (float)(s2 * gscale);
     c1[c] = (float)(s1 / count);
@@ -425,7 +442,7 @@ extern "C" int gs_bn_finalize(const float* partials, int ntiles, int C, double c
     hipStream_t s = (hipStream_t)stream;
     double* o1; int ns;
     reduce_partials(partials, ntiles, C, &o1, &ns, s);
-    bn_finalize_kernel<<<cdiv(C, 128), 128, 0, s>>>(o1, ns, C, count, gamma, beta, running_mean, running_var,
+    bn_finalize_kernel<<<cdiv(C, 32), 256, 0, s>>>(o1, ns, C, count, gamma, beta, running_mean, running_var,
                                                     momentum, eps, scale, shift, mean, invstd);
     GS_CHECK_LAUNCH("gs_bn_finalize");
     return GS_OK;
@@ -544,7 +561,7 @@ extern "C" int gs_bn_bwd_coeffs(const float* partials, int ntiles, int C, double
     hipStream_t s = (hipStream_t)stream;
     double* o1; int ns;
     reduce_partials(partials, ntiles, C, &o1, &ns, s);
-    bn_bwd_coeffs_kernel<<<cdiv(C, 128), 128, 0, s>>>(o1, ns, C, count, gscale, dgamma, dbeta, c1, c2);
+    bn_bwd_coeffs_kernel<<<cdiv(C, 32), 256, 0, s>>>(o1, ns, C, count, gscale, dgamma, dbeta, c1, c2);
     GS_CHECK_LAUNCH("gs_bn_bwd_coeffs");
     return GS_OK;
 }

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void smallcin_fwd_kernel(const SCArgs a) {
 }
 
 struct SCWArgs {
-    const float* x; const unsigned short* dy; float* dw;
+    const float* x; const unsigned short* dy; float* dw;   // dw: partial slab [nblocks][Cout*T] (stage 1)
     int N, Cin, IH, IW, Cout, OH, OW, k, stride, pad;
     float gscale; int64_t pix_per_block;
 };
@@ -107,10 +107,15 @@ __global__ __launch_bounds__(256) void smallcin_wgrad_kernel(const SCWArgs a) {
     const int64_t m1 = m0 + a.pix_per_block < M ? m0 + a.pix_per_block : M;
     for (int t0 = 0; t0 < T; t0 += TG) {
         float acc[TG][8];
+        int tdy[TG], tdx[TG], tco[TG];       // tap decode hoisted out of the pixel loop (integer divisions)
 #pragma unroll
-        for (int j = 0; j < TG; ++j)
+        for (int j = 0; j < TG; ++j) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
+            const int tap = t0 + j;
+            const int ci = tap / kk, rr = tap - ci * kk, ky = rr / a.k, kx = rr - ky * a.k;
+            tdy[j] = ky - a.pad; tdx[j] = kx - a.pad; tco[j] = ci * a.IH * a.IW;
+        }
         if (pl < lanes) {
             for (int64_t m = m0 + pl; m < m1; m += lanes) {
                 const int ox = (int)(m % a.OW);
@@ -123,11 +128,10 @@ __global__ __launch_bounds__(256) void smallcin_wgrad_kernel(const SCWArgs a) {
                 for (int j = 0; j < TG; ++j) {
                     const int tap = t0 + j;
                     if (tap < T) {
-                        const int ci = tap / kk, rr = tap - ci * kk, ky = rr / a.k, kx = rr - ky * a.k;
-                        const int iy = oy * a.stride - a.pad + ky, ix = ox * a.stride - a.pad + kx;
+                        const int iy = oy * a.stride + tdy[j], ix = ox * a.stride + tdx[j];
                         float xv = 0.f;
                         if ((unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW)
-                            xv = a.x[(((int64_t)n * a.Cin + ci) * a.IH + iy) * a.IW + ix];
+                            xv = a.x[(int64_t)n * a.Cin * a.IH * a.IW + tco[j] + iy * a.IW + ix];
 #pragma unroll
                         for (int i = 0; i < 8; ++i) acc[j][i] += g[i] * xv;
                     }
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256) void smallcin_wgrad_kernel(const SCWArgs a) {
                     for (int i = 0; i < 8; ++i) {
                         float s = 0.f;
                         for (int q = 0; q < lanes; ++q) s += red[q * nch + ch][i];
-                        atomicAdd(a.dw + (int64_t)(ch * 8 + i) * T + tap, s * a.gscale);
+                        a.dw[(int64_t)blockIdx.x * a.Cout * T + (int64_t)(ch * 8 + i) * T + tap] = s;
                     }
                 }
             }
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(256) void smallcout_wgrad_kernel(const HArgs a) {
             __syncthreads();
             if ((threadIdx.x & 63) == 0) redb[c][threadIdx.x >> 6] = s;
             __syncthreads();
-            if (threadIdx.x == 0) atomicAdd(a.db + c, (redb[c][0] + redb[c][1] + redb[c][2] + redb[c][3]) * a.gscale);
+            if (threadIdx.x == 0) a.db[(int64_t)blockIdx.x * 4 + c] = redb[c][0] + redb[c][1] + redb[c][2] + redb[c][3];
         }
     }
     for (int tap = 0; tap < kk; ++tap) {
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(256) void smallcout_wgrad_kernel(const HArgs a) {
                         for (int i = 0; i < 8; ++i) {
                             float s = 0.f;
                             for (int q = 0; q < lanes; ++q) s += red[q * lpu + chl][i];
-                            atomicAdd(a.dw + ((int64_t)c * a.Cin + ch * 8 + i) * kk + tap, s * a.gscale);
+                            a.dw[(int64_t)blockIdx.x * a.Cout * a.Cin * kk + ((int64_t)c * a.Cin + ch * 8 + i) * kk + tap] = s;
                         }
                     }
                 }
@@ -385,7 +389,34 @@ __global__ __launch_bounds__(256) void smallcout_wgrad_kernel(const HArgs a) {
     }
 }
 
+// stage 2 of the direct weight gradients: out[j] += gscale * sum_b slab[b*stride + j]  (fixed order)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int nb, int64_t stride, int n,
+                                                          float gscale, float* out) {
+    __shared__ double red[8][32];
+    const int jl = threadIdx.x & 31, bl = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + jl;
+    double s = 0.0;
+    if (j < n)
+        for (int b = bl; b < nb; b += 8) s += (double)slab[(int64_t)b * stride + j];
+    red[bl][jl] = s;
+    __syncthreads();
+    if (bl == 0 && j < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[i][jl];
+        out[j] += (float)(t * gscale);
+    }
+}
+
 }  // namespace
+
+extern "C" int64_t gs_conv_direct_wgrad_ws_floats(int N, int OH, int OW, int Cin, int Cout, int k) {
+    const int64_t M = (int64_t)N * OH * OW;
+    int64_t ppb = cdiv64(M, 2048);
+    if (ppb < 64) ppb = 64;
+    const int64_t nb = cdiv64(M, ppb);
+    return nb * ((int64_t)Cout * Cin * k * k + 4);
+}
 
 extern "C" int gs_conv_smallcin_mtiles(int N, int OH, int OW) {
     return (int)cdiv64((int64_t)N * OH * OW, SC_TILE);
@@ -418,20 +449,22 @@ extern "C" int gs_conv_smallcin_fwd(const float* x, const float* w, const float*
     return GS_OK;
 }
 
-extern "C" int gs_conv_smallcin_wgrad(const float* x, const void* dy, float* dw, int N, int Cin, int IH, int IW,
-                                      int Cout, int OH, int OW, int k, int stride, int pad, float gscale, int dtype,
-                                      void* stream) {
+extern "C" int gs_conv_smallcin_wgrad(const float* x, const void* dy, float* dw, float* ws, int N, int Cin, int IH,
+                                      int IW, int Cout, int OH, int OW, int k, int stride, int pad, float gscale,
+                                      int dtype, void* stream) {
     int rc = check_smallcin("gs_conv_smallcin_wgrad", N, Cin, IH, IW, Cout, OH, OW, k, stride, pad, dtype);
     if (rc) return rc;
-    GS_CHECK_ARG(x && dy && dw, "gs_conv_smallcin_wgrad: null pointer");
+    GS_CHECK_ARG(x && dy && dw && ws, "gs_conv_smallcin_wgrad: null pointer");
     const int64_t M = (int64_t)N * OH * OW;
-    int64_t ppb = cdiv64(M, 1024);      // few blocks: every block ends in atomics on the same Cout*taps addresses
+    int64_t ppb = cdiv64(M, 2048);      // many blocks, each writes its partial slab; a second kernel sums them in order
     if (ppb < 64) ppb = 64;
-    SCWArgs a{x, (const unsigned short*)dy, dw, N, Cin, IH, IW, Cout, OH, OW, k, stride, pad, gscale, ppb};
+    SCWArgs a{x, (const unsigned short*)dy, ws, N, Cin, IH, IW, Cout, OH, OW, k, stride, pad, gscale, ppb};
     const int nb = (int)cdiv64(M, ppb);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == GS_F16) smallcin_wgrad_kernel<GS_F16><<<nb, 256, 0, s>>>(a);
     else smallcin_wgrad_kernel<GS_BF16><<<nb, 256, 0, s>>>(a);
+    const int n = Cout * Cin * k * k;
+    slab_reduce_kernel<<<cdiv(n, 32), 256, 0, s>>>(ws, nb, n, n, gscale, dw);
     GS_CHECK_LAUNCH("gs_conv_smallcin_wgrad");
     return GS_OK;
 }
@@ -484,8 +517,8 @@ extern "C" int gs_conv_smallcout_fwd(const void* x, const float* w, const float*
 }
 
 extern "C" int gs_conv_smallcout_bwd(const void* x, const float* w, const float* dy, void* dx, float* dw, float* db,
-                                     int N, int IH, int IW, int Cin, int Cout, int OH, int OW, int k, int stride,
-                                     int pad, float gscale, int dtype, void* stream) {
+                                     float* ws, int N, int IH, int IW, int Cin, int Cout, int OH, int OW, int k,
+                                     int stride, int pad, float gscale, int dtype, void* stream) {
     int rc = check_head("gs_conv_smallcout_bwd", N, IH, IW, Cin, Cout, OH, OW, k, stride, pad, dtype);
     if (rc) return rc;
     GS_CHECK_ARG(w && dy, "gs_conv_smallcout_bwd: null pointer");
@@ -501,14 +534,20 @@ extern "C" int gs_conv_smallcout_bwd(const void* x, const float* w, const float*
         else smallcout_dgrad_kernel<GS_BF16><<<(int)nb, 256, 0, s>>>(a);
     }
     if (dw) {
-        GS_CHECK_ARG(x != nullptr, "gs_conv_smallcout_bwd: dw needs x");
+        GS_CHECK_ARG(x != nullptr && ws != nullptr, "gs_conv_smallcout_bwd: dw needs x and a workspace");
         const int64_t M = (int64_t)N * OH * OW;
-        int64_t ppb = cdiv64(M, 1024);
+        int64_t ppb = cdiv64(M, 2048);
         if (ppb < 64) ppb = 64;
         a.pix_per_block = ppb;
         const int nb = (int)cdiv64(M, ppb);
-        if (dtype == GS_F16) smallcout_wgrad_kernel<GS_F16><<<nb, 256, 0, s>>>(a);
-        else smallcout_wgrad_kernel<GS_BF16><<<nb, 256, 0, s>>>(a);
+        const int n = Cout * Cin * k * k;
+        HArgs b = a;
+        b.dw = ws;                                   // partial slabs [nb][n], then bias partials [nb][4]
+        b.db = db ? ws + (int64_t)nb * n : nullptr;
+        if (dtype == GS_F16) smallcout_wgrad_kernel<GS_F16><<<nb, 256, 0, s>>>(b);
+        else smallcout_wgrad_kernel<GS_BF16><<<nb, 256, 0, s>>>(b);
+        slab_reduce_kernel<<<cdiv(n, 32), 256, 0, s>>>(ws, nb, n, n, gscale, dw);
+        if (db) slab_reduce_kernel<<<1, 256, 0, s>>>(ws + (int64_t)nb * n, nb, 4, Cout, gscale, db);
     }
     GS_CHECK_LAUNCH("gs_conv_smallcout_bwd");
     return GS_OK;

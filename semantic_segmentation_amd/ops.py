@@ -241,11 +241,17 @@ def conv_smallcin_mtiles(N, OH, OW) -> int:
     return _lib.load().gs_conv_smallcin_mtiles(N, OH, OW)
 
 
+def _direct_wgrad_ws(N, OH, OW, Cin, Cout, k, dev):
+    n = int(_lib.load().gs_conv_direct_wgrad_ws_floats(N, OH, OW, Cin, Cout, k))
+    return torch.empty(n, dtype=torch.float32, device=dev)
+
+
 def conv_smallcin_wgrad(x, dy, dw, k, stride, pad, gscale):
     _f32(x, "x"); _f32(dw, "dw")
     N, Cin, IH, IW = x.shape
     _, OH, OW, Cout = dy.shape
-    _lib.call("gs_conv_smallcin_wgrad", _p(x), _p(dy), _p(dw), N, Cin, IH, IW, Cout, OH, OW, k, stride, pad,
+    ws = _direct_wgrad_ws(N, OH, OW, Cin, Cout, k, x.device)
+    _lib.call("gs_conv_smallcin_wgrad", _p(x), _p(dy), _p(dw), _p(ws), N, Cin, IH, IW, Cout, OH, OW, k, stride, pad,
               float(gscale), dt_code(dy), _stream())
 
 
@@ -271,8 +277,9 @@ def conv_smallcout_bwd(x, w, dy, dx, dw, db, k=1, stride=1, pad=0, gscale=1.0):
     ref = x if x is not None else dx
     N, IH, IW, Cin = ref.shape
     _, Cout, OH, OW = dy.shape
-    _lib.call("gs_conv_smallcout_bwd", _p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), N, IH, IW, Cin, Cout, OH, OW,
-              k, stride, pad, float(gscale), dt_code(ref), _stream())
+    ws = _direct_wgrad_ws(N, OH, OW, Cin, Cout, k, ref.device) if dw is not None else None
+    _lib.call("gs_conv_smallcout_bwd", _p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), _p(ws), N, IH, IW, Cin, Cout,
+              OH, OW, k, stride, pad, float(gscale), dt_code(ref), _stream())
 
 
 # ---------------------------------------------------------------------------- BatchNorm / activation
