@@ -1,0 +1,73 @@
+"""The per-iteration step losses (train_end2end_jsrt.py:141-236) through this package vs the oracle's
+restatement of the same steps.  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import seeded_discriminator_state_dict, seeded_generator_state_dict
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_equalize_gamma_matches_definition():
+    from semantic_segmentation_amd.steps import equalize_gamma_u8
+    g = torch.Generator().manual_seed(1)
+    img = (torch.rand(3, 1, 32, 40, generator=g) ** 2 * 200).to(torch.uint8)
+    img[2] = 7                                                     # constant image: step == 0 -> identity
+    out = equalize_gamma_u8(img.cuda(), 0.5).cpu()
+    for n in range(3):
+        v = img[n].flatten().numpy().astype(np.int64)
+        hist = np.bincount(v, minlength=256)
+        nz = hist[hist > 0]
+        step = (hist.sum() - nz[-1]) // 255
+        if step == 0:
+            eq = v
+        else:
+            lut = np.clip((np.cumsum(hist) - hist + step // 2) // step, 0, 255)
+            eq = lut[v]
+        want = np.clip(255.0 * (eq / 255.0) ** 0.5, 0, 255).astype(np.uint8)
+        assert np.array_equal(out[n].flatten().numpy(), want)
+
+
+def test_gan_and_unet_steps_vs_oracle():
+    from semantic_segmentation_amd import steps
+    from semantic_segmentation_amd.models_pix2pix import networks
+    from semantic_segmentation_amd.unet import UNet
+    N = 4
+    sdG, sdD = seeded_generator_state_dict(41), seeded_discriminator_state_dict(42)
+    sdU = oracle.unet_state_dict(1, 1, seed=43)
+    norm = networks.get_norm_layer("batch")
+    G = networks.UnetGenerator(1, 1, 8, 64, norm_layer=norm, use_dropout=False)      # dropout-free for parity
+    D = networks.NLayerDiscriminator(2, 64, 3, norm)
+    G.load_state_dict(sdG, strict=True); D.load_state_dict(sdD, strict=True)
+    U = UNet(1, 1); U.load_state_dict(sdU, strict=True)
+    G, D, U = G.cuda().train(), D.cuda().train(), U.cuda().train()
+    g = torch.Generator().manual_seed(5)
+    arch = 0.3 * torch.randn(8, 3, generator=g)
+    networks.upconv_arch = arch.cuda()
+    x, mask = oracle.synthetic_batch(N, 256, seed=11)
+    real_image = torch.rand(N, 1, 256, 256, generator=g)
+    maskf = mask.float()
+    crit = networks.GANLoss("vanilla").cuda()
+    lG = steps.generator_step_loss(G, D, crit, maskf.cuda(), real_image.cuda(), 100.0)
+    G.load_state_dict(sdG, strict=True); D.load_state_dict(sdD, strict=True)        # reset BN buffers
+    lD = steps.discriminator_step_loss(G, D, crit, maskf.cuda(), real_image.cuda())
+    with torch.no_grad():
+        rG = oracle.generator_step_loss(sdG, sdD, arch, maskf, real_image, 100.0)
+        rD = oracle.discriminator_step_loss(sdG, sdD, arch, maskf, real_image)
+    assert abs(lG.item() - rG.item()) < 2e-3 * abs(rG.item()), (lG.item(), rG.item())
+    assert abs(lD.item() - rD.item()) < 5e-3, (lD.item(), rD.item())
+    # Unet step: compare against the same composition evaluated with the oracle's networks
+    G.load_state_dict(sdG, strict=True)
+    lU = steps.unet_step_loss(U, G, x.cuda(), mask.cuda(), 1.0)
+    with torch.no_grad():
+        fm = (maskf > 0.1).float()
+        fake = oracle.unet_generator_forward(sdG, arch, fm, train=True)
+        fake = steps.fake_image_postprocess(fake)
+        l1 = oracle.seg_loss(oracle.unet_forward(sdU, x, True), mask)
+        l2 = oracle.seg_loss(oracle.unet_forward(sdU, fake, True), fm.long())
+    assert abs(lU.item() - (l1 + l2).item()) < 5e-3, (lU.item(), (l1 + l2).item())
+    lU.backward()
+    assert all(p.grad is not None for p in U.parameters())
+    assert all(p.grad is None for p in G.parameters())            # G is cut by the detach (:197)
