@@ -528,11 +528,273 @@ __global__ __launch_bounds__(256, 2) void conv3x3_persist_kernel(const C3Args a)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// v3 "big K-step": one 4-wave block per CU (full register file, 132 KB LDS).  Per (patch of 256 pixels,
+// 64-channel chunk) the halo AND the weights of all nine taps (9 x 64 co x 64 ci) are staged ONCE; each wave
+// then issues 9 x 4 x 4 = 144 MFMAs with no barrier in between, so LDS reads and MFMAs pipeline freely inside
+// the wave while the NEXT (patch, chunk) is prefetched into registers (29 x 16 B per lane).  N tile = 64 couts.
+// Modelled on wgrad3x3_kernel, which reaches ~1 PFLOP/s with 72 MFMAs per barrier pair.
+// ---------------------------------------------------------------------------------------------------
+template <int DT, int TW>
+__global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
+    typedef typename Elem<DT>::V8 V8;
+    constexpr int BN = 64, BM = 256;
+    constexpr int TH = BM / TW;
+    constexpr int HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;
+    constexpr int HALO_EL = HP * C3_LDR, W_EL = 9 * BN * C3_LDR;
+    constexpr int HCH = (HP * 8 + 255) / 256;
+    constexpr int WCH = 9 * BN * 8 / 256;           // 18 weight chunks per lane
+    constexpr int TWS = (TW == 32) ? 5 : 4;
+    constexpr int STG_EL = 32 * C3_LDR;
+    constexpr unsigned OOB = 0xFFFFFFFFu;
+    __shared__ __attribute__((aligned(16))) unsigned short smem[HALO_EL + W_EL];
+    unsigned short* halo = smem;
+    unsigned short* Ws = smem + HALO_EL;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nitems = a.nblocks;
+    const int dbg = a.act >> 8;
+    const int act = a.act & 0xff;
+    const int chunk = t & 7, rbase = t >> 3;
+    const int nchunks = (a.Cin + 63) >> 6;
+    const unsigned img_bytes = (unsigned)a.H * a.W * a.in_stride * 2u;
+
+    struct Item { int n, y0, x0, n0, mtile; };
+    auto decode = [&](int it) __attribute__((always_inline)) {
+        Item r;
+        const int ntile = it % a.ntn;
+        int patch = it / a.ntn;
+        r.mtile = patch;
+        const int tx = patch % a.tiles_x; patch /= a.tiles_x;
+        const int ty = patch % a.tiles_y;
+        r.n = patch / a.tiles_y;
+        r.y0 = ty * TH; r.x0 = tx * TW; r.n0 = ntile * BN;
+        return r;
+    };
+    const __amdgpu_buffer_rsrc_t w_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)(9u * a.Cout * a.Cin * 2u), 0x00020000);
+
+    // Staging addresses are strength reduced: per ITEM each lane keeps the byte offsets of its two weight rows
+    // and of its halo pixels (voffset; 0x80000000 = out of range -> the buffer load returns zeros), the per-tap
+    // and per-chunk parts are wave-uniform and ride in the scalar soffset operand: no vector ALU per load.
+    constexpr unsigned VOOB = 0x80000000u;
+    uint4 rh[HCH], rw[WCH];
+    unsigned wv[2], hv[HCH];
+    const unsigned tap_stride = (unsigned)a.Cout * a.Cin * 2u;
+    auto setup_item = [&](const Item& itn) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int co = itn.n0 + rbase + 32 * j;
+            wv[j] = co < a.Cout ? (unsigned)((co * a.Cin + chunk * 8) * 2) : VOOB;
+        }
+#pragma unroll
+        for (int j = 0; j < HCH; ++j) {
+            const int hp = rbase + 32 * j;
+            const int hy = hp / HWD, hx = hp - hy * HWD;
+            const int gy = itn.y0 + hy - 1, gx = itn.x0 + hx - 1;
+            const bool ok = hp < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            hv[j] = ok ? (unsigned)(((gy * a.W + gx) * a.in_stride + a.in_coff + chunk * 8) * 2) : VOOB;
+        }
+    };
+    auto load_stage = [&](const Item& itn, int cc) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.x + (int64_t)itn.n * a.H * a.W * a.in_stride), 0, img_bytes, 0x00020000);
+        const unsigned sc = (unsigned)cc * 128u;                  // 64 channels x 2 bytes per chunk
+#pragma unroll
+        for (int j = 0; j < WCH; ++j) {                           // row = rbase + 32 j = (j>>1)*64 + (rbase + 32 (j&1))
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wv[j & 1], sc + (unsigned)(j >> 1) * tap_stride, 0);
+            rw[j] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+#pragma unroll
+        for (int j = 0; j < HCH; ++j) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, hv[j], sc, 0);
+            rh[j] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+    };
+    auto store_stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < WCH; ++j)
+            *reinterpret_cast<uint4*>(Ws + (rbase + 32 * j) * C3_LDR + chunk * 8) = rw[j];
+#pragma unroll
+        for (int j = 0; j < HCH; ++j)
+            if (rbase + 32 * j < HP) *reinterpret_cast<uint4*>(halo + (rbase + 32 * j) * C3_LDR + chunk * 8) = rh[j];
+    };
+
+    int a_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int p = (wm * 2 + i) * 32 + l31;
+        a_off[i] = (((p >> TWS) + 1) * HWD + (p & (TW - 1)) + 1) * C3_LDR + h * 8;
+    }
+    const int b_off = l31 * C3_LDR + h * 8;
+
+    f32x16 acc[2][2];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+
+    // ---- epilogue (same scheme as conv3x3_persist_kernel, N tile = 64) ----
+    unsigned short* stg = Ws + wave * STG_EL;                     // staging overlays the (consumed) weights
+    float* red = reinterpret_cast<float*>(Ws + 4 * STG_EL);       // [4 waves][2][64]
+    const bool odd = lane & 1;
+    const unsigned int psel = odd ? 0x03020706u : 0x05040100u;
+    const float neg_slope = act == GS_ACT_RELU ? 0.f : (act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
+    auto epilogue = [&](const Item& itc) __attribute__((always_inline)) {
+        float bv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int co = itc.n0 + j * 32 + l31;
+            bv[j] = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
+        }
+        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+        const bool want_stats = a.bnp != nullptr;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int prow0 = (wm * 2 + i) * 32;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int r0 = 2 * m;
+                const int rowa = (r0 & 3) + 8 * (r0 >> 2) + 4 * h;
+                float w0 = 1.f, w1 = 1.f;
+                if (want_stats) {
+                    const int p0 = prow0 + rowa;
+                    const int gy0 = itc.y0 + (p0 >> TWS), gx0 = itc.x0 + (p0 & (TW - 1));
+                    const int gy1 = itc.y0 + ((p0 + 1) >> TWS), gx1 = itc.x0 + ((p0 + 1) & (TW - 1));
+                    w0 = (float)((unsigned)((gy0 - a.H) & (gx0 - a.W)) >> 31);
+                    w1 = (float)((unsigned)((gy1 - a.H) & (gx1 - a.W)) >> 31);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v0 = acc[i][j][r0], v1 = acc[i][j][r0 + 1];
+                    if (want_stats) {
+                        const float u0 = v0 * w0, u1 = v1 * w1;
+                        s1[j] += u0 + u1;
+                        s2[j] += u0 * u0 + u1 * u1;
+                    }
+                    v0 += bv[j];
+                    v1 += bv[j];
+                    v0 = v0 > 0.f ? v0 : v0 * neg_slope;
+                    v1 = v1 > 0.f ? v1 : v1 * neg_slope;
+                    const unsigned int own = (unsigned int)Elem<DT>::from_f(v0) | ((unsigned int)Elem<DT>::from_f(v1) << 16);
+                    const unsigned int oth = dpp_xor1(own);
+                    const unsigned int pk = __builtin_amdgcn_perm(oth, own, psel);
+                    const int row = rowa + (odd ? 1 : 0);
+                    *reinterpret_cast<unsigned int*>(stg + row * C3_LDR + j * 32 + (l31 & ~1)) = pk;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rrow = q * 8 + (lane >> 3), ch = lane & 7;
+                const uint4 v = *reinterpret_cast<const uint4*>(stg + rrow * C3_LDR + ch * 8);
+                const int p = prow0 + rrow;
+                const int gy = itc.y0 + (p >> TWS), gx = itc.x0 + (p & (TW - 1));
+                const int co = itc.n0 + ch * 8;
+                if (gy < a.H && gx < a.W && co < a.Cout && !(dbg & 1))
+                    *reinterpret_cast<uint4*>(a.y + (int64_t)((itc.n * a.H + gy) * a.W + gx) * a.out_stride +
+                                              a.out_coff + co) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (want_stats) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                s1[j] += __shfl_xor(s1[j], 32, 64);
+                s2[j] += __shfl_xor(s2[j], 32, 64);
+                if (h == 0) {
+                    red[(wm * 2 + 0) * BN + j * 32 + l31] = s1[j];
+                    red[(wm * 2 + 1) * BN + j * 32 + l31] = s2[j];
+                }
+            }
+        }
+    };
+    auto finish_stats = [&](const Item& itc) __attribute__((always_inline)) {
+        if (a.bnp != nullptr && t < BN && itc.n0 + t < a.Cout) {
+            float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { v1 += red[(m * 2 + 0) * BN + t]; v2 += red[(m * 2 + 1) * BN + t]; }
+            float* dst = a.bnp + (int64_t)itc.mtile * 2 * a.Cout + itc.n0 + t;
+            dst[0] = v1;
+            dst[a.Cout] = v2;
+        }
+    };
+
+    int it = blockIdx.x;
+    if (it >= nitems) return;
+    Item cur = decode(it);
+    setup_item(cur);
+    load_stage(cur, 0);
+    zero_acc();
+    for (;;) {
+        const int nit = it + gridDim.x;
+        const bool more_items = nit < nitems;
+        Item nxt = cur;
+        if (more_items) nxt = decode(nit);
+        for (int cc = 0; cc < nchunks; ++cc) {
+            const bool more_cc = cc + 1 < nchunks;
+            __syncthreads();                       // previous stage fully consumed (and epilogue staging done)
+            store_stage();
+            __syncthreads();
+            if (more_cc) load_stage(cur, cc + 1);
+            else if (more_items) { setup_item(nxt); load_stage(nxt, 0); }
+            if (!(dbg & 2)) {
+                // 36 steps (tap, kk) of 4 MFMAs; the four fragment reads of step s+1 are issued BEFORE the MFMAs
+                // of step s (hipcc otherwise schedules them just-in-time behind lgkmcnt(0) and the LDS latency
+                // is exposed three times per four MFMAs -- fatal with one wave per SIMD)
+                V8 af[2][2], bf[2][2];
+                auto frag_load = [&](int step, V8 (&fa)[2], V8 (&fb)[2]) __attribute__((always_inline)) {
+                    const int tap = step >> 2, kk = step & 3;
+                    const int toff = (a.tap_dy[tap] * HWD + a.tap_dx[tap]) * C3_LDR;
+                    const unsigned short* B = Ws + tap * BN * C3_LDR + b_off;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const V8*>(halo + a_off[i] + toff + kk * 16);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const V8*>(B + j * 32 * C3_LDR + kk * 16);
+                };
+                frag_load(0, af[0], bf[0]);
+#pragma unroll
+                for (int step = 0; step < 36; ++step) {
+                    const int cur = step & 1;
+                    if (step + 1 < 36) frag_load(step + 1, af[cur ^ 1], bf[cur ^ 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[i][j] = Elem<DT>::mfma32(af[cur][i], bf[cur][j], acc[i][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (!more_cc) {
+                __syncthreads();                   // every wave is done reading the weights: staging may overlay them
+                epilogue(cur);
+                zero_acc();
+                __syncthreads();
+                finish_stats(cur);
+            }
+        }
+        if (!more_items) break;
+        it = nit;
+        cur = nxt;
+    }
+}
+
 struct C3Plan { int bn, tw, th, tiles_x, tiles_y; };
+
+int c3_variant_get();
 
 C3Plan c3_plan(int H, int W, int Cout) {
     C3Plan p;
-    p.bn = (Cout <= 64) ? 64 : 128;
+    // variant 2 (big K-step kernel) tiles every layer as 256-pixel patches x 64 couts; its fallbacks keep the same
+    // tiling so gs_conv3x3_mtiles() never depends on which kernel finally runs
+    p.bn = (Cout <= 64 || (c3_variant_get() == 2 && Cout % 8 == 0)) ? 64 : 128;
     p.tw = (W >= 24) ? 32 : 16;
     const int bm = (p.bn == 128) ? 128 : 256;
     p.th = bm / p.tw;
@@ -542,6 +804,19 @@ C3Plan c3_plan(int H, int W, int Cout) {
 }
 
 }  // namespace
+
+static int c3_variant() {          // 0 = v1 one patch per block, 1 = persistent (v2), 2 = big K-step (v3)
+    static const int v = getenv("GSSEG_C3") ? atoi(getenv("GSSEG_C3")) : 2;
+    return v;
+}
+namespace { int c3_variant_get() { return c3_variant(); } }
+
+static bool c3_use_big(int Cout, int out_pix_stride, int out_coff) {
+    return c3_variant() == 2 && (Cout % 8) == 0 && (out_pix_stride % 8) == 0 && (out_coff % 8) == 0;
+}
+static bool c3_big_ok(int H, int W, int Cin, int in_pix_stride, int Cout) {
+    return (Cin % 64) == 0 && (int64_t)H * W * in_pix_stride * 2 < 2147483000LL && (int64_t)9 * Cout * Cin * 2 < 2147483000LL;
+}
 
 extern "C" int gs_conv3x3_mtiles(int N, int H, int W, int Cout) {
     const C3Plan p = c3_plan(H, W, Cout);
@@ -575,7 +850,25 @@ extern "C" int gs_conv3x3(const void* x, const void* w, void* y, const float* bi
     hipStream_t s = (hipStream_t)stream;
     GS_CHECK_ARG((act & 0xff) == GS_ACT_NONE || (act & 0xff) == GS_ACT_RELU || (act & 0xff) == GS_ACT_LEAKY02,
                  "gs_conv3x3: activation %d not supported (use gs_conv_igemm)", act & 0xff);
-    static const bool force_v1 = getenv("GSSEG_C3_V1") != nullptr;
+    if (c3_use_big(Cout, out_pix_stride, out_coff) && c3_big_ok(H, W, Cin, in_pix_stride, Cout)) {
+        const int tw = (W >= 24) ? 32 : 16, th = 256 / tw;
+        a.tiles_x = cdiv(W, tw); a.tiles_y = cdiv(H, th);
+        a.ntn = cdiv(Cout, 64);
+        a.nblocks = N * a.tiles_x * a.tiles_y * a.ntn;
+        static const int big_blocks = getenv("GSSEG_C3_GRID") ? atoi(getenv("GSSEG_C3_GRID")) : 256;
+        dim3 bgrid(a.nblocks < big_blocks ? a.nblocks : big_blocks);
+        hipStream_t bs = (hipStream_t)stream;
+        if (dtype == GS_F16) {
+            if (tw == 32) conv3x3_big_kernel<GS_F16, 32><<<bgrid, 256, 0, bs>>>(a);
+            else conv3x3_big_kernel<GS_F16, 16><<<bgrid, 256, 0, bs>>>(a);
+        } else {
+            if (tw == 32) conv3x3_big_kernel<GS_BF16, 32><<<bgrid, 256, 0, bs>>>(a);
+            else conv3x3_big_kernel<GS_BF16, 16><<<bgrid, 256, 0, bs>>>(a);
+        }
+        GS_CHECK_LAUNCH("gs_conv3x3");
+        return GS_OK;
+    }
+    static const bool force_v1 = c3_variant() == 0;
     // the persistent kernel stores whole 16-byte channel groups; odd shapes go to the one-patch-per-block kernel
     const bool use_v1 = force_v1 || (Cout % 8) != 0 || (out_pix_stride % 8) != 0 || (out_coff % 8) != 0;
     static const int persist_blocks = getenv("GSSEG_C3_GRID") ? atoi(getenv("GSSEG_C3_GRID")) : 512;
