@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 4
+#define GS_ABI_VERSION 5
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -49,6 +49,11 @@ typedef struct GsConvGeom {
     int32_t tap_dy[GS_MAX_TAPS], tap_dx[GS_MAX_TAPS];
     int32_t tap_w[GS_MAX_TAPS];   /* weight slot of tap t: weights of tap t start at w + tap_w[t]*Cout*Cin (lets a
                                      sub-pixel class use a subset of a full [kh*kw][Cout][Cin] pack) */
+    /* depth (Conv3d / ConvTranspose3d, GenSeg-3D/UNet3D/unet3d.py): a volume is a stack of images.  Logical image
+     * index n' = nb*Dg + d; tap t reads input image nb*Din + d*isz + tap_dz[t] (zero outside [0,Din)) and the
+     * output image is nb*Dout + d*osz + ooz.  2-D: Dg = Din = Dout = 1, isz = osz = 1, ooz = 0, tap_dz = 0. */
+    int32_t Dg, Din, Dout, isz, osz, ooz;
+    int32_t tap_dz[GS_MAX_TAPS];
 } GsConvGeom;
 
 const char* gs_last_error(void);
@@ -153,6 +158,15 @@ int gs_bn_act_bwd_apply(const void* y, const void* dz_a, int sa, int coff_a, con
                         const float* scale, const float* shift, const float* mean, const float* invstd,
                         const float* c1, const float* c2, int act, int bn, void* dy, int N, int H, int W, int C,
                         int dtype, void* stream);
+
+/* MaxPool3d(2, stride 2) on NDHWC 16-bit volumes (GenSeg-3D/UNet3D/unet3d.py:37,44).  fwd: z [NB,D,H,W,*] (strided) ->
+ * zp [NB,D/2,H/2,W/2,C].  bwd: dz (dense, OVERWRITE) = dres[pix*stride + coff + c] (skip gradient, may be NULL)
+ * + dzp routed to the first maximum of each window (ATen scan order). */
+int gs_maxpool3d_fwd(const void* z, int z_pix_stride, int z_coff, void* zp, int NB, int D, int H, int W, int C,
+                     int dtype, void* stream);
+int gs_maxpool3d_bwd(const void* z, int z_pix_stride, int z_coff, const void* dzp, const void* dres,
+                     int res_pix_stride, int res_coff, void* dz, int NB, int D, int H, int W, int C, int dtype,
+                     void* stream);
 
 /* per-channel column sums over the sub-rectangle [y0,y0+h) x [x0,x0+w) of a (strided) NHWC tensor
  * [N,H,W,*]: out[c] (OVERWRITE) = gscale * sum t[pix*s + coff + c]  (bias gradient of ConvTranspose2d,

@@ -18,14 +18,15 @@ CSRC = os.path.join(_HERE, "csrc")
 GS_F16, GS_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH = 0, 1, 2, 3
 GS_MAX_TAPS = 64
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class GsConvGeom(ctypes.Structure):
     _fields_ = [(n, c_int32) for n in (
         "N", "IH", "IW", "Cin", "in_pix_stride", "in_coff", "OHg", "OWg", "Cout", "OH", "OW",
         "out_pix_stride", "out_coff", "isy", "isx", "osy", "osx", "ooy", "oox", "ntaps")] + [
-        ("tap_dy", c_int32 * GS_MAX_TAPS), ("tap_dx", c_int32 * GS_MAX_TAPS), ("tap_w", c_int32 * GS_MAX_TAPS)]
+        ("tap_dy", c_int32 * GS_MAX_TAPS), ("tap_dx", c_int32 * GS_MAX_TAPS), ("tap_w", c_int32 * GS_MAX_TAPS)] + [
+        (n, c_int32) for n in ("Dg", "Din", "Dout", "isz", "osz", "ooz")] + [("tap_dz", c_int32 * GS_MAX_TAPS)]
 
 
 # name -> (restype, argtypes): exactly the declarations of include/gsseg.h
@@ -58,6 +59,8 @@ PROTOTYPES = {
     "gs_bn_act_bwd_apply": (c_int, [_P, _P, c_int, c_int, _P, _P, c_int, _P, c_float, _F, _F, _F, _F, _F, _F, c_int,
                                     c_int, _P]
                             + [c_int] * 5 + [c_void_p]),
+    "gs_maxpool3d_fwd": (c_int, [_P, c_int, c_int, _P] + [c_int] * 6 + [c_void_p]),
+    "gs_maxpool3d_bwd": (c_int, [_P, c_int, c_int, _P, _P, c_int, c_int, _P] + [c_int] * 6 + [c_void_p]),
     "gs_colsum": (c_int, [_P, c_int, c_int] + [c_int] * 8 + [c_float, _F, _F, c_int, c_void_p]),
     "gs_pack_weight": (c_int, [_F, _P, _P, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "gs_unpack_wgrad": (c_int, [_F, _F, c_int, c_int, c_int, c_int, c_float, c_void_p]),

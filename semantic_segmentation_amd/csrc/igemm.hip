@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
 
     // ---- per-thread staging rows ----
     const int chunk = t & 7, rbase = t >> 3;
-    int a_iy0[4], a_ix0[4], a_n[4];
+    int a_iy0[4], a_ix0[4], a_n[4], a_d0[4];      // a_n: input image index before the depth tap; a_d0: depth part
     const int ohw = g.OHg * g.OWg;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -65,9 +65,10 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
         if (m < a.M) {
             const int n = m / ohw, rem = m - n * ohw;
             const int oy = rem / g.OWg, ox = rem - oy * g.OWg;
-            a_n[j] = n; a_iy0[j] = oy * g.isy; a_ix0[j] = ox * g.isx;
+            const int nb = n / g.Dg, d = n - nb * g.Dg;
+            a_d0[j] = d * g.isz; a_n[j] = nb * g.Din + d * g.isz; a_iy0[j] = oy * g.isy; a_ix0[j] = ox * g.isx;
         } else {
-            a_n[j] = -1; a_iy0[j] = 0; a_ix0[j] = 0;
+            a_n[j] = -1; a_d0[j] = 0; a_iy0[j] = 0; a_ix0[j] = 0;
         }
     }
     uint4 ra[4], rb[BROWS];
@@ -76,15 +77,16 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
     auto load_tile = [&](int ks) {
         const int tap = ks / a.kchunks, cc = ks - tap * a.kchunks;
         const int ci = cc * FW_BK + chunk * 8;
-        const int dy = g.tap_dy[tap], dx = g.tap_dx[tap];
+        const int dy = g.tap_dy[tap], dx = g.tap_dx[tap], dz = g.tap_dz[tap];
         const bool cok = ci < g.Cin;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
-            const bool ok = cok && a_n[j] >= 0 && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
+            const bool ok = cok && a_n[j] >= 0 && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW &&
+                            (unsigned)(a_d0[j] + dz) < (unsigned)g.Din;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (ok) {
-                const int64_t pix = ((int64_t)a_n[j] * g.IH + iy) * g.IW + ix;
+                const int64_t pix = ((int64_t)(a_n[j] + dz) * g.IH + iy) * g.IW + ix;
                 v = *reinterpret_cast<const uint4*>(a.x + pix * g.in_pix_stride + g.in_coff + ci);
             }
             ra[j] = v;
@@ -150,7 +152,8 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
         if (m < a.M) {
             const int n = m / ohw, rem = m - n * ohw;
             const int oy = rem / g.OWg, ox = rem - oy * g.OWg;
-            p = (n * g.OH + oy * g.osy + g.ooy) * g.OW + ox * g.osx + g.oox;
+            const int nb = n / g.Dg, d = n - nb * g.Dg;
+            p = ((nb * g.Dout + d * g.osz + g.ooz) * g.OH + oy * g.osy + g.ooy) * g.OW + ox * g.osx + g.oox;
         }
         rowpix[t] = p;
     }
@@ -274,7 +277,9 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs a) {
             uint4 v = make_uint4(0, 0, 0, 0);
             const int co = co0 + dy_chunk * 8;
             if (dm[j] < kend && co < g.Cout) {
-                const int64_t pix = ((int64_t)dn[j] * g.OH + doy[j] * g.osy + g.ooy) * g.OW + dox[j] * g.osx + g.oox;
+                const int nb = dn[j] / g.Dg, d = dn[j] - nb * g.Dg;
+                const int64_t pix = ((int64_t)(nb * g.Dout + d * g.osz + g.ooz) * g.OH + doy[j] * g.osy + g.ooy) * g.OW +
+                                    dox[j] * g.osx + g.oox;
                 v = *reinterpret_cast<const uint4*>(a.dy + pix * g.out_pix_stride + g.out_coff + co);
             }
             rdy[j] = v;
@@ -284,13 +289,16 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs a) {
             const int tap = cb_tap[c];
             const int ci = cb_ci0[c] + x_chunk * 8;
             const int tdy = tap >= 0 ? g.tap_dy[tap] : 0, tdx = tap >= 0 ? g.tap_dx[tap] : 0;
+            const int tdz = tap >= 0 ? g.tap_dz[tap] : 0;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 uint4 v = make_uint4(0, 0, 0, 0);
                 const int iy = xoy[j] * g.isy + tdy, ix = xox[j] * g.isx + tdx;
+                const int nb = xn[j] / g.Dg, d = xn[j] - nb * g.Dg;
+                const int iz = d * g.isz + tdz;
                 if (tap >= 0 && xm[j] < kend && ci < g.Cin && (unsigned)iy < (unsigned)g.IH &&
-                    (unsigned)ix < (unsigned)g.IW) {
-                    const int64_t pix = ((int64_t)xn[j] * g.IH + iy) * g.IW + ix;
+                    (unsigned)ix < (unsigned)g.IW && (unsigned)iz < (unsigned)g.Din) {
+                    const int64_t pix = ((int64_t)(nb * g.Din + iz) * g.IH + iy) * g.IW + ix;
                     v = *reinterpret_cast<const uint4*>(a.x + pix * g.in_pix_stride + g.in_coff + ci);
                 }
                 rx[c][j] = v;
@@ -374,6 +382,10 @@ int check_geom(const GsConvGeom* g, const char* who) {
     GS_CHECK_ARG(g != nullptr, "%s: null geometry", who);
     GS_CHECK_ARG(g->N > 0 && g->IH > 0 && g->IW > 0 && g->OHg > 0 && g->OWg > 0 && g->OH > 0 && g->OW > 0,
                  "%s: non-positive dims", who);
+    GS_CHECK_ARG(g->Dg > 0 && g->Din > 0 && g->Dout > 0 && g->isz > 0 && g->osz > 0 && g->ooz >= 0 &&
+                     (int64_t)(g->Dg - 1) * g->osz + g->ooz < g->Dout,
+                 "%s: bad depth geometry (Dg=%d Din=%d Dout=%d isz=%d osz=%d ooz=%d); 2-D launches use 1,1,1,1,1,0", who,
+                 g->Dg, g->Din, g->Dout, g->isz, g->osz, g->ooz);
     GS_CHECK_ARG(g->Cin > 0 && g->Cin % 8 == 0, "%s: Cin=%d must be a positive multiple of 8", who, g->Cin);
     GS_CHECK_ARG(g->Cout > 0, "%s: Cout=%d", who, g->Cout);
     GS_CHECK_ARG(g->ntaps > 0 && g->ntaps <= GS_MAX_TAPS, "%s: ntaps=%d out of range", who, g->ntaps);
@@ -386,9 +398,9 @@ int check_geom(const GsConvGeom* g, const char* who) {
                  "%s: bad steps/offsets", who);
     GS_CHECK_ARG((int64_t)(g->OHg - 1) * g->osy + g->ooy < g->OH && (int64_t)(g->OWg - 1) * g->osx + g->oox < g->OW,
                  "%s: logical output grid exceeds the physical output tensor", who);
-    GS_CHECK_ARG((int64_t)g->N * g->OHg * g->OWg < (int64_t)2147483000 &&
-                     (int64_t)g->N * g->OH * g->OW < (int64_t)2147483000 &&
-                     (int64_t)g->N * g->IH * g->IW < (int64_t)2147483000,
+    GS_CHECK_ARG((int64_t)g->N * g->Dg * g->OHg * g->OWg < (int64_t)2147483000 &&
+                     (int64_t)g->N * g->Dout * g->OH * g->OW < (int64_t)2147483000 &&
+                     (int64_t)g->N * g->Din * g->IH * g->IW < (int64_t)2147483000,
                  "%s: pixel count exceeds int32", who);
     return GS_OK;
 }
@@ -397,7 +409,7 @@ int check_geom(const GsConvGeom* g, const char* who) {
 
 extern "C" int gs_conv_igemm_mtiles(const GsConvGeom* g) {
     if (!g) return GS_EINVAL;
-    return (int)cdiv64((int64_t)g->N * g->OHg * g->OWg, FW_BM);
+    return (int)cdiv64((int64_t)g->N * (g->Dg > 0 ? g->Dg : 1) * g->OHg * g->OWg, FW_BM);
 }
 
 extern "C" int gs_conv_igemm(const GsConvGeom* g, const void* x, const void* w, void* y, const float* bias,
@@ -410,7 +422,7 @@ extern "C" int gs_conv_igemm(const GsConvGeom* g, const void* x, const void* w, 
     a.g = *g;
     a.x = (const unsigned short*)x; a.w = (const unsigned short*)w; a.y = (unsigned short*)y;
     a.bias = bias; a.bnp = bn_partials; a.act = act;
-    a.M = g->N * g->OHg * g->OWg;
+    a.M = g->N * g->Dg * g->OHg * g->OWg;
     a.kchunks = cdiv(g->Cin, FW_BK);
     const int bn = (g->Cout <= 64) ? 64 : 128;
     a.ntn = cdiv(g->Cout, bn);
@@ -440,7 +452,7 @@ extern "C" int gs_conv_wgrad(const GsConvGeom* g, const void* x, const void* dy,
     WgradArgs a;
     a.g = *g;
     a.x = (const unsigned short*)x; a.dy = (const unsigned short*)dy; a.dw = dw;
-    a.M = g->N * g->OHg * g->OWg;
+    a.M = g->N * g->Dg * g->OHg * g->OWg;
     a.kchunks = cdiv(g->Cin, 64);
     a.ncb = g->ntaps * a.kchunks;
     const int wr = (g->Cout <= 64) ? 1 : 2;

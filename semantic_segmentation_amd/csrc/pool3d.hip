@@ -1,0 +1,130 @@
+// MaxPool3d(kernel 2, stride 2) forward and backward on NDHWC 16-bit volumes
+// (GenSeg-3D/UNet3D/unet3d.py:37,44: nn.MaxPool3d((2,2,2), stride=2)).  HBM-bound, 16-byte accesses.
+// Backward follows ATen: the whole window gradient goes to the FIRST maximum in (d,h,w) scan order; the skip
+// ("residual") gradient of the un-pooled tensor is added in the same pass.
+#include "common.hpp"
+
+namespace {
+
+struct P3Args {
+    const unsigned short* z; unsigned short* zp;
+    const unsigned short* dzp; const unsigned short* dres; unsigned short* dz;
+    int rs, rc, zs, zc;
+    int NB, D, H, W, C;
+};
+
+template <int DT, bool BWD>
+__global__ __launch_bounds__(256) void maxpool3d_kernel(const P3Args a) {
+    const int nch = a.C >> 3;
+    const int PD = (a.D + 1) / 2, PH = (a.H + 1) / 2, PW = (a.W + 1) / 2;     // ceil grid: covers the leftovers
+    const int64_t total = (int64_t)a.NB * PD * PH * PW * nch;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(idx % nch);
+        int64_t r = idx / nch;
+        const int px = (int)(r % PW); r /= PW;
+        const int py = (int)(r % PH); r /= PH;
+        const int pd = (int)(r % PD);
+        const int nb = (int)(r / PD);
+        const int c0 = ch * 8;
+        const bool pooled = pd < a.D / 2 && py < a.H / 2 && px < a.W / 2;
+        float v[8][8];
+        bool ok[8];
+        int64_t pix[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int dd = 2 * pd + (k >> 2), yy = 2 * py + ((k >> 1) & 1), xx = 2 * px + (k & 1);
+            ok[k] = dd < a.D && yy < a.H && xx < a.W;
+            pix[k] = (((int64_t)nb * a.D + dd) * a.H + yy) * a.W + xx;
+            if (ok[k]) unpack8<DT>(*reinterpret_cast<const uint4*>(a.z + pix[k] * a.zs + a.zc + c0), v[k]);
+            else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[k][i] = -INFINITY;
+            }
+        }
+        if (!BWD) {
+            if (pooled) {
+                float m[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    m[i] = v[0][i];
+#pragma unroll
+                    for (int k = 1; k < 8; ++k) m[i] = fmaxf(m[i], v[k][i]);
+                }
+                const int64_t pp = (((int64_t)nb * (a.D / 2) + pd) * (a.H / 2) + py) * (a.W / 2) + px;
+                *reinterpret_cast<uint4*>(a.zp + pp * a.C + c0) = pack8<DT>(m);
+            }
+        } else {
+            float gp[8];
+            if (pooled) {
+                const int64_t pp = (((int64_t)nb * (a.D / 2) + pd) * (a.H / 2) + py) * (a.W / 2) + px;
+                unpack8<DT>(*reinterpret_cast<const uint4*>(a.dzp + pp * a.C + c0), gp);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) gp[i] = 0.f;
+            }
+            int amax[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int best = 0; float bv = v[0][i];
+#pragma unroll
+                for (int k = 1; k < 8; ++k) if (v[k][i] > bv) { bv = v[k][i]; best = k; }
+                amax[i] = best;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (!ok[k]) continue;
+                float g[8];
+                if (a.dres) unpack8<DT>(*reinterpret_cast<const uint4*>(a.dres + pix[k] * a.rs + a.rc + c0), g);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) g[i] = 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) g[i] += (amax[i] == k) ? gp[i] : 0.f;
+                *reinterpret_cast<uint4*>(a.dz + pix[k] * a.C + c0) = pack8<DT>(g);
+            }
+        }
+    }
+}
+
+int launch(const P3Args& a, bool bwd, int dtype, hipStream_t s) {
+    const int64_t total = (int64_t)a.NB * ((a.D + 1) / 2) * ((a.H + 1) / 2) * ((a.W + 1) / 2) * (a.C / 8);
+    int64_t nb = cdiv64(total, 256);
+    if (nb > 8192) nb = 8192;
+    if (dtype == GS_F16) {
+        if (bwd) maxpool3d_kernel<GS_F16, true><<<(int)nb, 256, 0, s>>>(a);
+        else maxpool3d_kernel<GS_F16, false><<<(int)nb, 256, 0, s>>>(a);
+    } else {
+        if (bwd) maxpool3d_kernel<GS_BF16, true><<<(int)nb, 256, 0, s>>>(a);
+        else maxpool3d_kernel<GS_BF16, false><<<(int)nb, 256, 0, s>>>(a);
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int gs_maxpool3d_fwd(const void* z, int z_pix_stride, int z_coff, void* zp, int NB, int D, int H, int W, int C,
+                                int dtype, void* stream) {
+    GS_CHECK_ARG(z && zp && NB > 0 && D > 1 && H > 1 && W > 1 && C > 0 && C % 8 == 0, "gs_maxpool3d_fwd: bad arguments");
+    GS_CHECK_ARG(z_pix_stride >= z_coff + C && z_pix_stride % 8 == 0 && z_coff % 8 == 0, "gs_maxpool3d_fwd: bad z stride");
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_maxpool3d_fwd: bad dtype");
+    P3Args a{(const unsigned short*)z, (unsigned short*)zp, nullptr, nullptr, nullptr, 0, 0, z_pix_stride, z_coff, NB, D, H, W, C};
+    launch(a, false, dtype, (hipStream_t)stream);
+    GS_CHECK_LAUNCH("gs_maxpool3d_fwd");
+    return GS_OK;
+}
+
+extern "C" int gs_maxpool3d_bwd(const void* z, int z_pix_stride, int z_coff, const void* dzp, const void* dres,
+                                int res_pix_stride, int res_coff, void* dz, int NB, int D, int H, int W, int C, int dtype,
+                                void* stream) {
+    GS_CHECK_ARG(z_pix_stride >= z_coff + C && z_pix_stride % 8 == 0 && z_coff % 8 == 0, "gs_maxpool3d_bwd: bad z stride");
+    GS_CHECK_ARG(z && dzp && dz && NB > 0 && D > 1 && H > 1 && W > 1 && C > 0 && C % 8 == 0, "gs_maxpool3d_bwd: bad arguments");
+    GS_CHECK_ARG(!dres || (res_pix_stride >= res_coff + C && res_pix_stride % 8 == 0 && res_coff % 8 == 0),
+                 "gs_maxpool3d_bwd: bad residual stride");
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_maxpool3d_bwd: bad dtype");
+    P3Args a{(const unsigned short*)z, nullptr, (const unsigned short*)dzp, (const unsigned short*)dres,
+             (unsigned short*)dz, res_pix_stride, res_coff, z_pix_stride, z_coff, NB, D, H, W, C};
+    launch(a, true, dtype, (hipStream_t)stream);
+    GS_CHECK_LAUNCH("gs_maxpool3d_bwd");
+    return GS_OK;
+}

@@ -45,7 +45,8 @@ def _f32(t: Optional[torch.Tensor], name: str):
 # ---------------------------------------------------------------------------- geometry builders
 def make_geom(N, IH, IW, Cin, OHg, OWg, Cout, OH, OW, taps: Sequence[Tuple[int, int]], isy=1, isx=1,
               osy=1, osx=1, ooy=0, oox=0, in_stride=None, in_coff=0, out_stride=None, out_coff=0,
-              tap_w: Optional[Sequence[int]] = None) -> GsConvGeom:
+              tap_w: Optional[Sequence[int]] = None, Dg=1, Din=1, Dout=1, isz=1, osz=1, ooz=0,
+              tap_dz: Optional[Sequence[int]] = None) -> GsConvGeom:
     g = GsConvGeom()
     g.N, g.IH, g.IW, g.Cin = N, IH, IW, Cin
     g.in_pix_stride = Cin if in_stride is None else in_stride
@@ -60,6 +61,8 @@ def make_geom(N, IH, IW, Cin, OHg, OWg, Cout, OH, OW, taps: Sequence[Tuple[int, 
     for i, (dy, dx) in enumerate(taps):
         g.tap_dy[i], g.tap_dx[i] = dy, dx
         g.tap_w[i] = i if tap_w is None else tap_w[i]
+        g.tap_dz[i] = 0 if tap_dz is None else tap_dz[i]
+    g.Dg, g.Din, g.Dout, g.isz, g.osz, g.ooz = Dg, Din, Dout, isz, osz, ooz
     return g
 
 
@@ -117,7 +120,7 @@ TIMER: Optional[KernelTimer] = None
 
 
 def _geom_flops(g: GsConvGeom) -> float:
-    return 2.0 * g.N * g.OHg * g.OWg * g.Cout * g.ntaps * g.Cin
+    return 2.0 * g.N * g.Dg * g.OHg * g.OWg * g.Cout * g.ntaps * g.Cin
 
 
 def geom_convT_class(N, IH, IW, Cin, Cout, k, pad, py, px, OH=None, OW=None, **kw) -> GsConvGeom:
@@ -332,6 +335,17 @@ def bn_act_bwd_apply(y, dz_a, sa, ca, dzp, scale, shift, mean, invstd, c1, c2, a
     _lib.call("gs_bn_act_bwd_apply", _p(y), _p(dz_a), sa, ca, _p(dzp), _p(dz_b), act_b, _p(keep_mask),
               float(keep_scale), _p(scale), _p(shift), _p(mean), _p(invstd), _p(c1), _p(c2), act, int(bn), _p(dy),
               N, H, W, C, dt_code(y), _stream())
+
+
+def maxpool3d_fwd(z, zp, NB, D, H, W, C, z_stride=None, z_coff=0):
+    _dev(z)
+    _lib.call("gs_maxpool3d_fwd", _p(z), C if z_stride is None else z_stride, z_coff, _p(zp), NB, D, H, W, C,
+              dt_code(z), _stream())
+
+
+def maxpool3d_bwd(z, dzp, dres, dz, NB, D, H, W, C, z_stride=None, z_coff=0, res_stride=0, res_coff=0):
+    _lib.call("gs_maxpool3d_bwd", _p(z), C if z_stride is None else z_stride, z_coff, _p(dzp), _p(dres), res_stride,
+              res_coff, _p(dz), NB, D, H, W, C, dt_code(z), _stream())
 
 
 def colsum(t, pix_stride, coff, N, H, W, y0, x0, h, w, C, gscale, ws, out):

@@ -1,0 +1,73 @@
+"""3-D U-Net of GenSeg-3D (reference: GenSeg-3D/UNet3D/unet3d.py:14-126) on the MI355X HIP engine.
+
+Same class / attribute names and state-dict keys as the reference (`a_block1.conv1.weight`, `s_block3.upconv1.bias`,
+`s_block1.conv3.weight`, ...).  Reference quirks kept: channel doubling INSIDE the block (conv1: in -> out/2,
+conv2: out/2 -> out, :28-31), convolutions WITH bias in front of BatchNorm3d, `torch.cat((up, residual), 1)` -- up
+first, opposite of the 2-D U-Net (:80), and ONE shared `self.bn` applied after both decoder convolutions (:70,81-82)
+whose running statistics are therefore updated twice per forward.  The leaf modules only hold parameters; `forward`
+runs the whole network on the HIP kernels (unet3d_engine.py).  No ATen / CPU fallback."""
+import os
+
+from torch import nn
+
+from .unet3d_engine import UNet3DEngine, run_unet3d
+
+
+class Conv3DBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, bottleneck=False) -> None:
+        super(Conv3DBlock, self).__init__()
+        self.conv1 = nn.Conv3d(in_channels=in_channels, out_channels=out_channels // 2, kernel_size=(3, 3, 3), padding=1)
+        self.bn1 = nn.BatchNorm3d(num_features=out_channels // 2)
+        self.conv2 = nn.Conv3d(in_channels=out_channels // 2, out_channels=out_channels, kernel_size=(3, 3, 3), padding=1)
+        self.bn2 = nn.BatchNorm3d(num_features=out_channels)
+        self.relu = nn.ReLU()
+        self.bottleneck = bottleneck
+        if not bottleneck:
+            self.pooling = nn.MaxPool3d(kernel_size=(2, 2, 2), stride=2)
+
+    def forward(self, input):
+        raise RuntimeError("Conv3DBlock is executed as part of UNet3D.forward on the HIP engine")
+
+
+class UpConv3DBlock(nn.Module):
+    def __init__(self, in_channels, res_channels=0, last_layer=False, num_classes=None) -> None:
+        super(UpConv3DBlock, self).__init__()
+        assert (last_layer == False and num_classes == None) or (last_layer == True and num_classes != None), \
+            'Invalid arguments'
+        self.upconv1 = nn.ConvTranspose3d(in_channels=in_channels, out_channels=in_channels, kernel_size=(2, 2, 2), stride=2)
+        self.relu = nn.ReLU()
+        self.bn = nn.BatchNorm3d(num_features=in_channels // 2)
+        self.conv1 = nn.Conv3d(in_channels=in_channels + res_channels, out_channels=in_channels // 2,
+                               kernel_size=(3, 3, 3), padding=(1, 1, 1))
+        self.conv2 = nn.Conv3d(in_channels=in_channels // 2, out_channels=in_channels // 2, kernel_size=(3, 3, 3),
+                               padding=(1, 1, 1))
+        self.last_layer = last_layer
+        if last_layer:
+            self.conv3 = nn.Conv3d(in_channels=in_channels // 2, out_channels=num_classes, kernel_size=(1, 1, 1))
+
+    def forward(self, input, residual=None):
+        raise RuntimeError("UpConv3DBlock is executed as part of UNet3D.forward on the HIP engine")
+
+
+class UNet3D(nn.Module):
+    def __init__(self, in_channels, num_classes, level_channels=[64, 128, 256], bottleneck_channel=512,
+                 compute_dtype=None) -> None:
+        super(UNet3D, self).__init__()
+        l1, l2, l3 = level_channels[0], level_channels[1], level_channels[2]
+        self.a_block1 = Conv3DBlock(in_channels=in_channels, out_channels=l1)
+        self.a_block2 = Conv3DBlock(in_channels=l1, out_channels=l2)
+        self.a_block3 = Conv3DBlock(in_channels=l2, out_channels=l3)
+        self.bottleNeck = Conv3DBlock(in_channels=l3, out_channels=bottleneck_channel, bottleneck=True)
+        self.s_block3 = UpConv3DBlock(in_channels=bottleneck_channel, res_channels=l3)
+        self.s_block2 = UpConv3DBlock(in_channels=l3, res_channels=l2)
+        self.s_block1 = UpConv3DBlock(in_channels=l2, res_channels=l1, num_classes=num_classes, last_layer=True)
+        self.in_channels, self.num_classes = in_channels, num_classes
+        dt = compute_dtype or os.environ.get("GSSEG_DTYPE", "f16")
+        object.__setattr__(self, "_engine", UNet3DEngine(self, dt))
+
+    @property
+    def engine(self):
+        return self._engine
+
+    def forward(self, input):
+        return run_unet3d(self._engine, input)

@@ -1,0 +1,321 @@
+"""Whole-network plan of the GenSeg-3D UNet3D (GenSeg-3D/UNet3D/unet3d.py:14-126) on the HIP kernels.
+
+A volume is a stack of NHWC images: every tensor is [NB*D, H, W, C] 16-bit, so the 2-D BatchNorm / activation /
+column-sum kernels apply unchanged (statistics over NB*D*H*W).  Conv3d 3x3x3 is the generic MFMA implicit GEMM
+with 27 taps whose depth component moves the image index (GsConvGeom.tap_dz / Dg / Din); ConvTranspose3d k2 s2 is
+eight one-tap sub-voxel classes written into the concat buffer (up channels FIRST, :80).  The 1-channel first
+convolution runs on the direct kernel over a depth-unfolded view of the fp32 volume ([NB*D, 3, H, W]).
+Bias in front of train-mode BatchNorm cancels in the output; it is folded into the running mean (train) or into
+the shift (eval), and its gradient is the column sum of the conv-output gradient."""
+from __future__ import annotations
+
+import math
+from typing import Dict, List
+
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+from .._lib import ACT_RELU
+
+_TORCH_DT = {"f16": torch.float16, "bf16": torch.bfloat16}
+K3 = [(kd, ky, kx) for kd in range(3) for ky in range(3) for kx in range(3)]
+
+
+def geom_conv3d(NB, D, H, W, Cin, Cout, dgrad=False, **kw):
+    if not dgrad:
+        taps = [(ky - 1, kx - 1) for (_, ky, kx) in K3]
+        dz = [kd - 1 for (kd, _, _) in K3]
+        return ops.make_geom(NB, H, W, Cin, H, W, Cout, H, W, taps, tap_dz=dz, Dg=D, Din=D, Dout=D, **kw)
+    taps = [(1 - ky, 1 - kx) for (_, ky, kx) in K3]
+    dz = [1 - kd for (kd, _, _) in K3]
+    return ops.make_geom(NB, H, W, Cout, H, W, Cin, H, W, taps, tap_dz=dz, Dg=D, Din=D, Dout=D, **kw)
+
+
+class _Stage:
+    __slots__ = ("conv", "bn", "inp", "in_stride", "in_coff", "y", "coef", "stats", "geom", "wd", "cin", "cout",
+                 "D", "H", "W", "first", "x3")
+
+
+class UNet3DEngine:
+    def __init__(self, net, dtype="f16"):
+        if dtype not in _TORCH_DT:
+            raise ValueError("dtype must be 'f16' or 'bf16'")
+        self.net, self.dtype, self.tdt = net, dtype, _TORCH_DT[dtype]
+
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, x, training, need_grad):
+        net, tdt = self.net, self.tdt
+        if not x.is_cuda:
+            raise RuntimeError("UNet3D (semantic_segmentation_amd) runs on the MI355X only (no CPU / ATen fallback)")
+        if x.dim() != 5 or x.shape[1] != net.in_channels:
+            raise ValueError(f"expected input [N,{net.in_channels},D,H,W], got {tuple(x.shape)}")
+        if net.in_channels != 1:
+            raise NotImplementedError("UNet3D on the HIP engine supports in_channels == 1 (BASELINE config 5)")
+        NB, _, D0, H0, W0 = x.shape
+        if D0 % 8 or H0 % 8 or W0 % 8:
+            raise ValueError("volume dims must be multiples of 8 (three 2x2x2 poolings, no padding in the reference)")
+        dev = x.device
+        x = x.contiguous().float()
+
+        def empty(*shape, dtype=tdt):
+            return torch.empty(shape, dtype=dtype, device=dev)
+
+        stages: List[_Stage] = []
+
+        def bn_coeffs(bn, bias, part, ntiles, C, count):
+            coef = empty(4, C, dtype=torch.float32)
+            batch = training or bn.running_mean is None
+            if batch:
+                if training and bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked.add_(1)
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked.item())
+                upd = training and bn.running_mean is not None
+                ops.bn_finalize(part, ntiles, C, count, bn.weight.detach(), bn.bias.detach(),
+                                bn.running_mean if upd else None, bn.running_var if upd else None, mom, bn.eps,
+                                coef[0], coef[1], coef[2], coef[3])
+                if upd and bias is not None:       # statistics were taken before the bias: mean(y + b) = mean(y) + b
+                    bn.running_mean.add_(bias.detach(), alpha=mom)
+            else:
+                rm = bn.running_mean if bias is None else (bn.running_mean - bias.detach())
+                ops.bn_eval_coeffs(C, bn.weight.detach(), bn.bias.detach(), rm.contiguous(), bn.running_var, bn.eps,
+                                   coef[0], coef[1], coef[2], coef[3])
+            return coef, batch
+
+        def conv_bn_relu(conv, bn, inp, in_stride, in_coff, cin, D, H, W, z, z_stride, z_coff, first=False):
+            cout = conv.out_channels
+            st = _Stage()
+            st.conv, st.bn, st.cin, st.cout, st.D, st.H, st.W, st.first = conv, bn, cin, cout, D, H, W, first
+            st.inp, st.in_stride, st.in_coff = inp, in_stride, in_coff
+            y = empty(NB * D, H, W, cout)
+            batch = training or bn.running_mean is None
+            if first:
+                # depth-unfolded view of the volume: X3[nb*D + d][kd] = x[nb][0][d + kd - 1] (zero outside)
+                xp = F.pad(inp[:, 0], (0, 0, 0, 0, 1, 1))
+                x3 = xp.unfold(1, 3, 1).permute(0, 1, 4, 2, 3).reshape(NB * D, 3, H, W).contiguous()
+                st.x3 = x3
+                nt = ops.conv_smallcin_mtiles(NB * D, H, W)
+                part = empty(ops.bn_partials_numel(nt, cout), dtype=torch.float32) if batch else None
+                ops.conv_smallcin_fwd(x3, conv.weight.detach().reshape(cout, 3, 3, 3).contiguous(), None, y, part, 3, 1, 1)
+                st.geom = st.wd = None
+            else:
+                w4 = conv.weight.detach().reshape(cout, cin, 27, 1)
+                wf = empty(27, cout, cin)
+                wd = empty(27, cin, cout) if need_grad else None
+                ops.pack_weight(w4, wf, wd, False)
+                g = geom_conv3d(NB, D, H, W, cin, cout, in_stride=in_stride, in_coff=in_coff)
+                nt = ops.conv_igemm_mtiles(g)
+                part = empty(ops.bn_partials_numel(nt, cout), dtype=torch.float32) if batch else None
+                ops.conv_igemm(g, inp, wf, y, None, part)
+                st.geom, st.wd = g, wd
+            st.coef, st.stats = bn_coeffs(bn, conv.bias, part, nt, cout, NB * D * H * W)
+            ops.bn_act_apply(y, st.coef[0], st.coef[1], ACT_RELU, z, z_stride, z_coff)
+            st.y = y
+            if need_grad:
+                stages.append(st)
+            return st
+
+        a_blocks = [net.a_block1, net.a_block2, net.a_block3]
+        s_blocks = {3: net.s_block3, 2: net.s_block2, 1: net.s_block1}
+        dims = [(D0 >> k, H0 >> k, W0 >> k) for k in range(4)]
+        cats, cup = {}, {}
+        for k in (1, 2, 3):
+            sb = s_blocks[k]
+            cup[k] = sb.upconv1.out_channels
+            cres = a_blocks[k - 1].conv2.out_channels
+            D, H, W = dims[k - 1]
+            cats[k] = empty(NB * D, H, W, cup[k] + cres)
+
+        # ---- analysis path ----
+        enc = []
+        inp, in_stride, cin = x, None, net.in_channels
+        for k, blk in enumerate(a_blocks, 1):
+            D, H, W = dims[k - 1]
+            cmid, cout = blk.conv1.out_channels, blk.conv2.out_channels
+            z1 = empty(NB * D, H, W, cmid)
+            s1 = conv_bn_relu(blk.conv1, blk.bn1, inp, cin if k > 1 else None, 0, cin, D, H, W, z1, cmid, 0, first=(k == 1))
+            ctot = cats[k].shape[3]
+            s2 = conv_bn_relu(blk.conv2, blk.bn2, z1, cmid, 0, cmid, D, H, W, cats[k], ctot, cup[k])
+            pooled = empty(NB * (D // 2), H // 2, W // 2, cout)
+            ops.maxpool3d_fwd(cats[k], pooled, NB, D, H, W, cout, ctot, cup[k])
+            enc.append((s1, s2, pooled))
+            inp, cin = pooled, cout
+        D, H, W = dims[3]
+        bb = net.bottleNeck
+        zb1 = empty(NB * D, H, W, bb.conv1.out_channels)
+        sb1 = conv_bn_relu(bb.conv1, bb.bn1, inp, cin, 0, cin, D, H, W, zb1, bb.conv1.out_channels, 0)
+        zb = empty(NB * D, H, W, bb.conv2.out_channels)
+        sb2 = conv_bn_relu(bb.conv2, bb.bn2, zb1, bb.conv1.out_channels, 0, bb.conv1.out_channels, D, H, W, zb,
+                           bb.conv2.out_channels, 0)
+
+        # ---- synthesis path ----
+        ups = {}
+        cur, ccur = zb, bb.conv2.out_channels
+        for k in (3, 2, 1):
+            sb = s_blocks[k]
+            d, h, w = dims[k]
+            D, H, W = dims[k - 1]
+            cu, ctot = cup[k], cats[k].shape[3]
+            wt = sb.upconv1.weight.detach().reshape(ccur, cu, 8, 1)
+            wf = empty(8, cu, ccur)
+            wd = empty(8, ccur, cu) if need_grad else None
+            ops.pack_weight(wt, wf, wd, True)
+            bias = sb.upconv1.bias.detach()
+            for cls in range(8):
+                pz, py, px = cls >> 2, (cls >> 1) & 1, cls & 1
+                g = ops.make_geom(NB, h, w, ccur, h, w, cu, H, W, [(0, 0)], osy=2, osx=2, ooy=py, oox=px,
+                                  out_stride=ctot, out_coff=0, Dg=d, Din=d, Dout=D, osz=2, ooz=pz)
+                ops.conv_igemm(g, cur, wf[cls], cats[k], bias, None)
+            if need_grad:
+                taps = [((c >> 1) & 1, c & 1) for c in range(8)]
+                gb = ops.make_geom(NB, H, W, cu, h, w, ccur, h, w, taps, isy=2, isx=2, in_stride=ctot, in_coff=0,
+                                   tap_dz=[c >> 2 for c in range(8)], Dg=d, Din=D, Dout=d, isz=2)
+                ups[k] = dict(zin=cur, wd=wd, geom=gb, cin=ccur, cup=cu, ctot=ctot, dims=(d, h, w, D, H, W))
+            cmid = sb.conv1.out_channels
+            z1 = empty(NB * D, H, W, cmid)
+            conv_bn_relu(sb.conv1, sb.bn, cats[k], ctot, 0, ctot, D, H, W, z1, cmid, 0)
+            z2 = empty(NB * D, H, W, cmid)
+            conv_bn_relu(sb.conv2, sb.bn, z1, cmid, 0, cmid, D, H, W, z2, cmid, 0)
+            cur, ccur = z2, cmid
+        head = net.s_block1.conv3
+        ncls = head.out_channels
+        if ncls > 4:
+            raise NotImplementedError("num_classes above 4 is not supported by the direct head kernel")
+        l2d = empty(NB * D0, ncls, H0, W0, dtype=torch.float32)
+        ops.conv_smallcout_fwd(cur, head.weight.detach().reshape(ncls, ccur, 1, 1).contiguous(), head.bias.detach(), l2d)
+        logits = l2d.view(NB, D0, ncls, H0, W0).permute(0, 2, 1, 3, 4).contiguous()
+        ctx = None
+        if need_grad:
+            ctx = dict(stages=stages, enc=enc, bott=(sb1, sb2), ups=ups, cats=cats, cup=cup, dims=dims, NB=NB,
+                       z_last=cur, c_last=ccur, ncls=ncls)
+        return logits, ctx
+
+    # ------------------------------------------------------------------------------------------------
+    def backward(self, ctx, dlogits):
+        net, tdt = self.net, self.tdt
+        NB, dims, cats, cup, ups = ctx["NB"], ctx["dims"], ctx["cats"], ctx["cup"], ctx["ups"]
+        dev = dlogits.device
+        D0, H0, W0 = dims[0]
+        S = float(2 ** round(math.log2(NB * D0 * H0 * W0)))
+        inv_s = 1.0 / S
+        names = {id(p): n for n, p in net.named_parameters()}
+        grads: Dict[str, torch.Tensor] = {}
+
+        def empty(*shape, dtype=tdt):
+            return torch.empty(shape, dtype=dtype, device=dev)
+
+        def emit(p, g):
+            n = names[id(p)]
+            grads[n] = g if n not in grads else grads[n] + g       # the decoder's shared bn is used twice
+
+        col_ws = empty(1024 * 1024, dtype=torch.float32)
+
+        def stage_bwd(st: _Stage, dz, dz_stride, dz_coff, need_dinp):
+            D, H, W, cin, cout = st.D, st.H, st.W, st.cin, st.cout
+            n2 = NB * D
+            nt = ops.bn_bwd_tiles_used(n2, H, W, False)
+            part = empty(ops.bn_partials_numel(ops.bn_bwd_tiles(n2, H, W), cout), dtype=torch.float32)
+            c = st.coef
+            ops.bn_act_bwd_reduce(st.y, dz, dz_stride, dz_coff, None, c[0], c[1], c[2], c[3], ACT_RELU, part)
+            dgamma, dbeta = empty(cout, dtype=torch.float32), empty(cout, dtype=torch.float32)
+            c12 = empty(2, cout, dtype=torch.float32)
+            ops.bn_bwd_coeffs(part, nt, cout, n2 * H * W, inv_s, dgamma, dbeta, c12[0], c12[1])
+            if not st.stats:
+                c12.zero_()
+            dy = empty(n2, H, W, cout)
+            ops.bn_act_bwd_apply(st.y, dz, dz_stride, dz_coff, None, c[0], c[1], c[2], c[3], c12[0], c12[1], ACT_RELU,
+                                 True, dy)
+            emit(st.bn.weight, dgamma)
+            emit(st.bn.bias, dbeta)
+            if st.conv.bias is not None:
+                db = empty(cout, dtype=torch.float32)
+                ops.colsum(dy, cout, 0, n2, H, W, 0, 0, H, W, cout, inv_s, col_ws, db)
+                emit(st.conv.bias, db)
+            wparam = st.conv.weight
+            dinp = None
+            if st.first:
+                dw = torch.zeros((cout, 3, 3, 3), dtype=torch.float32, device=dev)
+                ops.conv_smallcin_wgrad(st.x3, dy, dw, 3, 1, 1, inv_s)
+                emit(wparam, dw.view(wparam.shape))
+            else:
+                dwp = torch.zeros((27, cout, cin), dtype=torch.float32, device=dev)
+                ops.conv_wgrad(st.geom, st.inp, dy, dwp)
+                dw = torch.empty((cout, cin, 27), dtype=torch.float32, device=dev)
+                ops.unpack_wgrad(dwp, dw, cout, cin, 27, False, inv_s)
+                emit(wparam, dw.view(wparam.shape))
+                if need_dinp:
+                    dinp = empty(n2, H, W, cin)
+                    ops.conv_igemm(geom_conv3d(NB, D, H, W, cin, cout, dgrad=True), dy, st.wd, dinp)
+            return dinp
+
+        stages = {id(s): s for s in ctx["stages"]}
+        by_conv = {id(s.conv): s for s in ctx["stages"]}
+        head = net.s_block1.conv3
+        ncls = ctx["ncls"]
+        dl = (dlogits.contiguous().float() * S).permute(0, 2, 1, 3, 4).contiguous().view(NB * D0, ncls, H0, W0)
+        dwo = torch.zeros((ncls, ctx["c_last"], 1, 1), dtype=torch.float32, device=dev)
+        dbo = torch.zeros(ncls, dtype=torch.float32, device=dev)
+        dz = empty(NB * D0, H0, W0, ctx["c_last"])
+        ops.conv_smallcout_bwd(ctx["z_last"], head.weight.detach().reshape(ncls, ctx["c_last"], 1, 1).contiguous(), dl,
+                               dz, dwo, dbo, gscale=inv_s)
+        emit(head.weight, dwo.view(head.weight.shape))
+        emit(head.bias, dbo)
+
+        s_blocks = {3: net.s_block3, 2: net.s_block2, 1: net.s_block1}
+        dres = {}
+        for k in (1, 2, 3):
+            sb = s_blocks[k]
+            st2, st1 = by_conv[id(sb.conv2)], by_conv[id(sb.conv1)]
+            dmid = stage_bwd(st2, dz, st2.cout, 0, True)
+            dcat = stage_bwd(st1, dmid, st1.cout, 0, True)                 # [NB*D, H, W, cup + cres]
+            u = ups[k]
+            d, h, w, D, H, W = u["dims"]
+            cu, ctot, ccur = u["cup"], u["ctot"], u["cin"]
+            dres[k] = dcat
+            db = empty(cu, dtype=torch.float32)
+            ops.colsum(dcat, ctot, 0, NB * D, H, W, 0, 0, H, W, cu, inv_s, col_ws, db)
+            emit(sb.upconv1.bias, db)
+            dwp = torch.zeros((8, ccur, cu), dtype=torch.float32, device=dev)
+            ops.conv_wgrad(u["geom"], dcat, u["zin"], dwp)
+            dw = torch.empty((ccur, cu, 8), dtype=torch.float32, device=dev)
+            ops.unpack_wgrad(dwp, dw, ccur, cu, 8, False, inv_s)
+            emit(sb.upconv1.weight, dw.view(sb.upconv1.weight.shape))
+            dz = empty(NB * d, h, w, ccur)
+            ops.conv_igemm(u["geom"], dcat, u["wd"], dz)
+        # bottleneck
+        sb1, sb2 = ctx["bott"]
+        dmid = stage_bwd(sb2, dz, sb2.cout, 0, True)
+        dpool = stage_bwd(sb1, dmid, sb1.cout, 0, True)
+        # analysis path, deepest first
+        for k in (3, 2, 1):
+            s1, s2, _ = ctx["enc"][k - 1]
+            D, H, W = dims[k - 1]
+            ctot = cats[k].shape[3]
+            dz2 = empty(NB * D, H, W, s2.cout)
+            ops.maxpool3d_bwd(cats[k], dpool, dres[k], dz2, NB, D, H, W, s2.cout, ctot, cup[k], ctot, cup[k])
+            dmid = stage_bwd(s2, dz2, s2.cout, 0, True)
+            dpool = stage_bwd(s1, dmid, s1.cout, 0, k > 1)
+        return grads
+
+
+class _UNet3DFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, engine, training, need_grad, x, *plist):
+        logits, ectx = engine.forward(x, training, need_grad)
+        ctx.engine, ctx.ectx, ctx.plist = engine, ectx, plist
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        if ctx.ectx is None:
+            raise RuntimeError("UNet3D forward ran without gradient tracking")
+        grads = ctx.engine.backward(ctx.ectx, dlogits)
+        names = [n for n, _ in ctx.engine.net.named_parameters()]
+        out = [grads.get(n) if p.requires_grad else None for n, p in zip(names, ctx.plist)]
+        return (None, None, None, None, *out)
+
+
+def run_unet3d(engine, x):
+    plist = tuple(p for p in engine.net.parameters())
+    need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in plist)
+    return _UNet3DFunction.apply(engine, engine.net.training, need_grad, x, *plist)

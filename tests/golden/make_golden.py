@@ -256,6 +256,40 @@ def make_pix2pix(size=256, batch=2):
     print("pix2pix", size, "loss_G", loss_G.item(), "loss_D", loss_D.item())
 
 
+def make_unet3d(name, n_classes, batch, size, seed):
+    """GenSeg-3D/UNet3D/unet3d.py imported with a stub `torchsummary` (its only use is the __main__ block, :8,134)."""
+    import importlib.util, types
+    sys.modules.setdefault("torchsummary", types.SimpleNamespace(summary=lambda *a, **k: None))
+    spec = importlib.util.spec_from_file_location("ref_unet3d", os.path.join(REF, "GenSeg-3D", "UNet3D", "unet3d.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    sd = oracle.unet3d_state_dict(1, n_classes, seed=seed)
+    net = mod.UNet3D(in_channels=1, num_classes=n_classes)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    g = torch.Generator().manual_seed(100 + seed)
+    x = torch.randn(batch, 1, size, size, size, generator=g)
+    mask = (torch.rand(batch, size, size, size, generator=g) > 0.6).long()
+    logits = net(x)
+    n, c, d, h, w = logits.shape
+    loss = oracle.seg_loss(logits.reshape(n, c, d * h, w), mask.reshape(n, d * h, w))
+    loss.backward()
+    out = {"n_classes": n_classes, "seed": seed, "x": x.numpy(), "mask": mask.numpy().astype(np.uint8),
+           "logits": logits.detach().numpy(), "loss": loss.item()}
+    for k, p_ in net.named_parameters():
+        out["gsum/" + k] = grad_summary(p_.grad)
+    for k, b in net.named_buffers():
+        out["buf/" + k] = b.detach().numpy().copy()
+    for k, v in sd.items():
+        if v.is_floating_point():
+            out["wsum/" + k] = tensor_checksum(v)
+    net.eval()
+    with torch.no_grad():
+        out["logits_eval"] = net(x).numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "loss", loss.item(), "logits", tuple(logits.shape))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -272,3 +306,6 @@ if __name__ == "__main__":
         make_ops_micro()
     if a.only in ("", "pix2pix"):
         make_pix2pix(256, 2)
+    if a.only in ("", "unet3d"):
+        make_unet3d("unet3d_c2_16", 2, 2, 16, seed=51)
+        make_unet3d("unet3d_c1_16", 1, 2, 16, seed=52)

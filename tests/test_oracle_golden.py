@@ -146,3 +146,31 @@ def test_pix2pix_matches_reference(golden_dir):
         assert abs(got[1] - ref[1]) / scale < 1e-2, k
     loss_D = oracle.discriminator_step_loss(sdG, sdD, arch, mask, real_image)
     assert abs(loss_D.item() - float(z["loss_D"])) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["unet3d_c2_16", "unet3d_c1_16"])
+def test_unet3d_step_matches_reference(golden_dir, name):
+    z = load(golden_dir, name)
+    n_classes, seed = int(z["n_classes"]), int(z["seed"])
+    sd = oracle.unet3d_state_dict(1, n_classes, seed=seed)
+    for k, v in sd.items():
+        if v.is_floating_point():
+            np.testing.assert_allclose(tensor_checksum(v), z["wsum/" + k], rtol=1e-12, atol=0)
+    x = torch.from_numpy(z["x"])
+    mask = torch.from_numpy(z["mask"].astype(np.int64))
+    logits, loss, grads, updates = oracle.unet3d_step(sd, x, mask, train=True)
+    assert np.abs(logits.numpy() - z["logits"]).max() < 5e-5
+    assert abs(loss.item() - float(z["loss"])) < 2e-6
+    for k, g in grads.items():
+        ref = z["gsum/" + k]
+        got = grad_summary(g)
+        scale = max(ref[1], 1e-12)
+        assert abs(got[1] - ref[1]) / scale < 5e-3, k
+    for k, v in updates.items():               # includes the shared decoder bn updated TWICE per forward
+        if "num_batches" in k:
+            assert int(v) == int(z["buf/" + k])
+        else:
+            np.testing.assert_allclose(v.numpy(), z["buf/" + k], rtol=5e-4, atol=5e-6)
+    sd2 = dict(sd); sd2.update(updates)
+    le = oracle.unet3d_forward(sd2, x, train=False)
+    assert np.abs(le.numpy() - z["logits_eval"]).max() < 1e-3 * max(1.0, np.abs(z["logits_eval"]).max())

@@ -1,0 +1,122 @@
+"""UNet3D (GenSeg-3D/UNet3D/unet3d.py) on the HIP engine vs the golden vectors from the reference and the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import grad_summary
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+REPORT = {}
+
+
+def _dump():
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_unet3d.json"), "w") as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+def vol_loss(logits, mask):
+    from semantic_segmentation_amd.losses import seg_loss
+    n, c, d, h, w = logits.shape
+    return seg_loss(logits.reshape(n, c, d * h, w), mask.reshape(n, d * h, w))
+
+
+@pytest.mark.parametrize("name", ["unet3d_c2_16", "unet3d_c1_16"])
+def test_unet3d_step_vs_golden(golden_dir, name):
+    from semantic_segmentation_amd.unet3d import UNet3D
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    n_classes, seed = int(z["n_classes"]), int(z["seed"])
+    sd = oracle.unet3d_state_dict(1, n_classes, seed=seed)
+    net = UNet3D(1, n_classes)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    x = torch.from_numpy(z["x"]).cuda()
+    mask = torch.from_numpy(z["mask"].astype(np.int64)).cuda()
+    logits = net(x)
+    loss = vol_loss(logits, mask)
+    loss.backward()
+    torch.cuda.synchronize()
+    d = np.abs(logits.detach().cpu().numpy() - z["logits"])
+    errs = {}
+    for k, p in net.named_parameters():
+        ref = z["gsum/" + k]
+        got = grad_summary(p.grad.cpu())
+        errs[k] = abs(got[1] - ref[1]) / max(ref[1], 1e-12)
+    bworst = 0.0
+    for k, b in net.named_buffers():
+        ref = z["buf/" + k]
+        if "num_batches" in k:
+            assert int(b) == int(ref), k            # the shared decoder bn counts 2 per forward
+        else:
+            bworst = max(bworst, float(np.abs(b.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-6)))
+    rep = {"logit_max_abs": float(d.max()), "logit_mean_abs": float(d.mean()), "loss": float(loss.item()),
+           "loss_ref": float(z["loss"]), "grad_norm_rel_err_median": float(np.median(list(errs.values()))),
+           "grad_norm_rel_err_worst": float(max(errs.values())), "worst_key": max(errs, key=errs.get),
+           "bn_buffer_rel_err_worst": bworst}
+    REPORT[name] = rep
+    _dump()
+    assert abs(rep["loss"] - rep["loss_ref"]) < 1e-3, rep
+    assert rep["logit_mean_abs"] < 2e-3 and rep["logit_max_abs"] < 2e-2, rep
+    assert rep["grad_norm_rel_err_median"] < 0.05, rep
+    assert bworst < 1e-2, rep
+    net.eval()
+    with torch.no_grad():
+        le = net(x)
+    de = np.abs(le.cpu().numpy() - z["logits_eval"])
+    REPORT[name]["eval_logit_max_abs"] = float(de.max())
+    _dump()
+    assert de.max() < 2e-2 * max(1.0, np.abs(z["logits_eval"]).max())
+
+
+def test_unet3d_descent_direction():
+    from semantic_segmentation_amd.unet3d import UNet3D
+    sd = oracle.unet3d_state_dict(1, 2, seed=61)
+    net = UNet3D(1, 2)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 1, 16, 32, 32, generator=g).cuda()
+    mask = (torch.rand(2, 16, 32, 32, generator=g) > 0.5).long().cuda()
+    l0 = vol_loss(net(x), mask)
+    l0.backward()
+    g2 = sum(float((p.grad.double() ** 2).sum()) for p in net.parameters())
+    target = 3e-3
+    eps = target / g2
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(p.grad, alpha=-eps)
+        l1 = vol_loss(net(x), mask)
+    ratio = (l0.item() - l1.item()) / target
+    REPORT["descent_ratio"] = ratio
+    _dump()
+    assert 0.7 < ratio < 1.2, ratio
+
+
+def test_maxpool3d_kernels():
+    from semantic_segmentation_amd import ops
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(2)
+    NB, D, H, W, C = 2, 6, 5, 8, 16
+    z = torch.randn(NB, C, D, H, W, generator=g).half().float().requires_grad_(True)
+    zp = F.max_pool3d(z, 2)
+    dzp = torch.randn(zp.shape, generator=g).half().float()
+    dres = torch.randn(z.shape, generator=g).half().float()
+    (zp * dzp).sum().backward()
+    want = z.grad + dres
+    zd = torch.zeros(NB * D, H, W, C + 8, dtype=torch.float16, device="cuda")
+    zd[..., 8:] = z.detach().permute(0, 2, 3, 4, 1).reshape(NB * D, H, W, C).half().cuda()
+    out = torch.empty(NB * (D // 2), H // 2, W // 2, C, dtype=torch.float16, device="cuda")
+    ops.maxpool3d_fwd(zd, out, NB, D, H, W, C, C + 8, 8)
+    got = out.float().cpu().view(NB, D // 2, H // 2, W // 2, C).permute(0, 4, 1, 2, 3)
+    assert torch.equal(got, zp.detach())
+    dz = torch.empty(NB * D, H, W, C, dtype=torch.float16, device="cuda")
+    dr = dres.permute(0, 2, 3, 4, 1).reshape(NB * D, H, W, C).half().cuda().contiguous()
+    dp = dzp.permute(0, 2, 3, 4, 1).reshape(NB * (D // 2), H // 2, W // 2, C).half().cuda().contiguous()
+    ops.maxpool3d_bwd(zd, dp, dr, dz, NB, D, H, W, C, C + 8, 8, C, 0)
+    gotd = dz.float().cpu().view(NB, D, H, W, C).permute(0, 4, 1, 2, 3)
+    assert (gotd - want).abs().max() < 2e-2

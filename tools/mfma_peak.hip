@@ -53,6 +53,42 @@ __global__ __launch_bounds__(64 * WAVES) void k_lds(const h8* in, float* out, in
     out[blockIdx.x * blockDim.x + threadIdx.x] = t;
 }
 
+typedef __attribute__((ext_vector_type(4))) float f4v;
+// 16x16x32: a 64x64 wave tile = 4x4 tiles; per K=32 step 4 A + 4 B fragments (16 B each) feed 16 MFMAs
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_lds16(const h8* in, float* out, int iters) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds[128 * 72 * 2];
+    for (int i = threadIdx.x; i < 128 * 72 * 2 / 8; i += blockDim.x) ((h8*)lds)[i] = in[i % 1024];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, l15 = lane & 15, q = lane >> 4, w = threadIdx.x >> 6;
+    const unsigned short* A = lds + (w % 2) * 64 * 72 + l15 * 72 + q * 8;
+    const unsigned short* B = lds + 128 * 72 + (w / 2 % 2) * 64 * 72 + l15 * 72 + q * 8;
+    f4v c[4][4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) c[i][j] = f4v{0, 0, 0, 0};
+    h8 a[4], b[4];
+    for (int i = 0; i < 4; ++i) { a[i] = *(const h8*)(A + i * 16 * 72); b[i] = *(const h8*)(B + i * 16 * 72); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int nk = ((kk + 1) & 1) * 32;
+            h8 na[4], nb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { na[i] = *(const h8*)(A + i * 16 * 72 + nk); nb[i] = *(const h8*)(B + i * 16 * 72 + nk); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], c[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = na[i]; b[i] = nb[i]; }
+        }
+    }
+    float t = 0;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) t += c[i][j][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = t;
+}
+
 template <typename F> double run(F f, int blocks, int threads, const h8* in, float* out, int iters, int mfma_per_iter) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(f, dim3(blocks), dim3(threads), 0, 0, in, out, iters / 10);
@@ -75,5 +111,8 @@ int main() {
     printf("reg  8 waves/CU (2/SIMD): %.0f TFLOP/s\n", run(k_reg<4>, 512, 256, in, out, 20000, 4));
     printf("lds  4 waves/CU (1/SIMD): %.0f TFLOP/s\n", run(k_lds<4>, 256, 256, in, out, 5000, 16));
     printf("lds  8 waves/CU (2/SIMD): %.0f TFLOP/s\n", run(k_lds<4>, 512, 256, in, out, 5000, 16));
+    // 16x16x32: 32 MFMAs of 16384 FLOP per iteration = 16 "32x32x16-equivalents"
+    printf("lds16x16x32 4 waves/CU: %.0f TFLOP/s\n", run(k_lds16<4>, 256, 256, in, out, 5000, 16));
+    printf("lds16x16x32 8 waves/CU: %.0f TFLOP/s\n", run(k_lds16<4>, 512, 256, in, out, 5000, 16));
     return 0;
 }
