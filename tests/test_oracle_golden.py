@@ -164,8 +164,10 @@ def test_unet3d_step_matches_reference(golden_dir, name):
     for k, g in grads.items():
         ref = z["gsum/" + k]
         got = grad_summary(g)
-        scale = max(ref[1], 1e-12)
-        assert abs(got[1] - ref[1]) / scale < 5e-3, k
+        if ref[1] < 1e-6:            # conv bias in front of train-mode BatchNorm: the true gradient is exactly 0
+            assert got[1] < 1e-6, k
+            continue
+        assert abs(got[1] - ref[1]) / ref[1] < 5e-3, k
     for k, v in updates.items():               # includes the shared decoder bn updated TWICE per forward
         if "num_batches" in k:
             assert int(v) == int(z["buf/" + k])
