@@ -12,7 +12,7 @@ import subprocess
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsseg_hip.so")
+LIB_PATH = os.environ.get("GSSEG_LIB", os.path.join(_HERE, "libgsseg_hip.so"))
 CSRC = os.path.join(_HERE, "csrc")
 
 GS_F16, GS_BF16 = 0, 1

@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_persist_kernel(const C3Args a)
 // the wave while the NEXT (patch, chunk) is prefetched into registers (29 x 16 B per lane).  N tile = 64 couts.
 // Modelled on wgrad3x3_kernel, which reaches ~1 PFLOP/s with 72 MFMAs per barrier pair.
 // ---------------------------------------------------------------------------------------------------
-template <int DT, int TW>
+template <int DT, int TW, bool WRES>
 __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
     typedef typename Elem<DT>::V8 V8;
     constexpr int BN = 64, BM = 256;
@@ -547,7 +547,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
     constexpr int WCH = 9 * BN * 8 / 256;           // 18 weight chunks per lane
     constexpr int TWS = (TW == 32) ? 5 : 4;
     constexpr int STG_EL = 32 * C3_LDR;
-    constexpr unsigned OOB = 0xFFFFFFFFu;
     __shared__ __attribute__((aligned(16))) unsigned short smem[HALO_EL + W_EL];
     unsigned short* halo = smem;
     unsigned short* Ws = smem + HALO_EL;
@@ -599,14 +598,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
             hv[j] = ok ? (unsigned)(((gy * a.W + gx) * a.in_stride + a.in_coff + chunk * 8) * 2) : VOOB;
         }
     };
-    auto load_stage = [&](const Item& itn, int cc) __attribute__((always_inline)) {
+    // WRES (one channel chunk and one N tile: the 64->64 layers): the 9-tap weight slab is the same for every
+    // item of the block -- it is staged once by the first stage and stays resident in LDS.
+    typedef std::integral_constant<bool, !WRES> LoopW;
+    auto load_stage = [&](const Item& itn, int cc, auto with_w) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(a.x + (int64_t)itn.n * a.H * a.W * a.in_stride), 0, img_bytes, 0x00020000);
         const unsigned sc = (unsigned)cc * 128u;                  // 64 channels x 2 bytes per chunk
+        if (decltype(with_w)::value) {
 #pragma unroll
-        for (int j = 0; j < WCH; ++j) {                           // row = rbase + 32 j = (j>>1)*64 + (rbase + 32 (j&1))
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wv[j & 1], sc + (unsigned)(j >> 1) * tap_stride, 0);
-            rw[j] = make_uint4(v[0], v[1], v[2], v[3]);
+            for (int j = 0; j < WCH; ++j) {                       // row = rbase + 32 j = (j>>1)*64 + (rbase + 32 (j&1))
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wv[j & 1], sc + (unsigned)(j >> 1) * tap_stride, 0);
+                rw[j] = make_uint4(v[0], v[1], v[2], v[3]);
+            }
         }
 #pragma unroll
         for (int j = 0; j < HCH; ++j) {
@@ -614,10 +618,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
             rh[j] = make_uint4(v[0], v[1], v[2], v[3]);
         }
     };
-    auto store_stage = [&]() __attribute__((always_inline)) {
+    auto store_stage = [&](auto with_w) __attribute__((always_inline)) {
+        if (decltype(with_w)::value) {
 #pragma unroll
-        for (int j = 0; j < WCH; ++j)
-            *reinterpret_cast<uint4*>(Ws + (rbase + 32 * j) * C3_LDR + chunk * 8) = rw[j];
+            for (int j = 0; j < WCH; ++j)
+                *reinterpret_cast<uint4*>(Ws + (rbase + 32 * j) * C3_LDR + chunk * 8) = rw[j];
+        }
 #pragma unroll
         for (int j = 0; j < HCH; ++j)
             if (rbase + 32 * j < HP) *reinterpret_cast<uint4*>(halo + (rbase + 32 * j) * C3_LDR + chunk * 8) = rh[j];
@@ -642,17 +648,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
     };
 
     // ---- epilogue (same scheme as conv3x3_persist_kernel, N tile = 64) ----
-    unsigned short* stg = Ws + wave * STG_EL;                     // staging overlays the (consumed) weights
-    float* red = reinterpret_cast<float*>(Ws + 4 * STG_EL);       // [4 waves][2][64]
+    static_assert(4 * STG_EL + 4 * 2 * BN * 2 <= HALO_EL, "epilogue staging must fit in the halo region");
+    unsigned short* stg = halo + wave * STG_EL;                   // staging overlays the consumed halo (the weights
+    float* red = reinterpret_cast<float*>(halo + 4 * STG_EL);     // may be resident); red = [4 waves][2][64]
     const bool odd = lane & 1;
     const unsigned int psel = odd ? 0x03020706u : 0x05040100u;
     const float neg_slope = act == GS_ACT_RELU ? 0.f : (act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
-    auto epilogue = [&](const Item& itc) __attribute__((always_inline)) {
-        float bv[2];
+    auto epilogue_t = [&](const Item& itc, auto plain_tag, auto full_tag) __attribute__((always_inline)) {
+        constexpr bool PLAIN = decltype(plain_tag)::value;        // no bias, no activation (every U-Net conv)
+        constexpr bool FULL = decltype(full_tag)::value;          // patch completely inside the image
+        float bv[2] = {0.f, 0.f};
+        if (!PLAIN) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int co = itc.n0 + j * 32 + l31;
-            bv[j] = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
+            for (int j = 0; j < 2; ++j) {
+                const int co = itc.n0 + j * 32 + l31;
+                bv[j] = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
+            }
         }
         float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
         const bool want_stats = a.bnp != nullptr;
@@ -664,7 +675,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
                 const int r0 = 2 * m;
                 const int rowa = (r0 & 3) + 8 * (r0 >> 2) + 4 * h;
                 float w0 = 1.f, w1 = 1.f;
-                if (want_stats) {
+                if (!FULL && want_stats) {
                     const int p0 = prow0 + rowa;
                     const int gy0 = itc.y0 + (p0 >> TWS), gx0 = itc.x0 + (p0 & (TW - 1));
                     const int gy1 = itc.y0 + ((p0 + 1) >> TWS), gx1 = itc.x0 + ((p0 + 1) & (TW - 1));
@@ -675,14 +686,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
                 for (int j = 0; j < 2; ++j) {
                     float v0 = acc[i][j][r0], v1 = acc[i][j][r0 + 1];
                     if (want_stats) {
-                        const float u0 = v0 * w0, u1 = v1 * w1;
-                        s1[j] += u0 + u1;
-                        s2[j] += u0 * u0 + u1 * u1;
+                        if (FULL) {
+                            s1[j] += v0 + v1;
+                            s2[j] += v0 * v0 + v1 * v1;
+                        } else {
+                            const float u0 = v0 * w0, u1 = v1 * w1;
+                            s1[j] += u0 + u1;
+                            s2[j] += u0 * u0 + u1 * u1;
+                        }
                     }
-                    v0 += bv[j];
-                    v1 += bv[j];
-                    v0 = v0 > 0.f ? v0 : v0 * neg_slope;
-                    v1 = v1 > 0.f ? v1 : v1 * neg_slope;
+                    if (!PLAIN) {
+                        v0 += bv[j];
+                        v1 += bv[j];
+                        v0 = v0 > 0.f ? v0 : v0 * neg_slope;
+                        v1 = v1 > 0.f ? v1 : v1 * neg_slope;
+                    }
                     const unsigned int own = (unsigned int)Elem<DT>::from_f(v0) | ((unsigned int)Elem<DT>::from_f(v1) << 16);
                     const unsigned int oth = dpp_xor1(own);
                     const unsigned int pk = __builtin_amdgcn_perm(oth, own, psel);
@@ -698,7 +716,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
                 const int p = prow0 + rrow;
                 const int gy = itc.y0 + (p >> TWS), gx = itc.x0 + (p & (TW - 1));
                 const int co = itc.n0 + ch * 8;
-                if (gy < a.H && gx < a.W && co < a.Cout && !(dbg & 1))
+                if ((FULL || (gy < a.H && gx < a.W)) && co < a.Cout && !(dbg & 1))
                     *reinterpret_cast<uint4*>(a.y + (int64_t)((itc.n * a.H + gy) * a.W + gx) * a.out_stride +
                                               a.out_coff + co) = v;
             }
@@ -716,6 +734,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
             }
         }
     };
+    const bool plain = (a.bias == nullptr && act == GS_ACT_NONE);
+    auto epilogue = [&](const Item& itc) __attribute__((always_inline)) {
+        const bool full = (itc.y0 + TH <= a.H) && (itc.x0 + TW <= a.W);
+        if (plain && full) epilogue_t(itc, std::true_type{}, std::true_type{});
+        else epilogue_t(itc, std::false_type{}, std::false_type{});
+    };
     auto finish_stats = [&](const Item& itc) __attribute__((always_inline)) {
         if (a.bnp != nullptr && t < BN && itc.n0 + t < a.Cout) {
             float v1 = 0.f, v2 = 0.f;
@@ -731,8 +755,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
     if (it >= nitems) return;
     Item cur = decode(it);
     setup_item(cur);
-    load_stage(cur, 0);
+    load_stage(cur, 0, std::true_type{});
     zero_acc();
+    bool first = true;
     for (;;) {
         const int nit = it + gridDim.x;
         const bool more_items = nit < nitems;
@@ -741,10 +766,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
         for (int cc = 0; cc < nchunks; ++cc) {
             const bool more_cc = cc + 1 < nchunks;
             __syncthreads();                       // previous stage fully consumed (and epilogue staging done)
-            store_stage();
+            if (WRES) {
+                if (first) store_stage(std::true_type{});         // only the very first stage carries the weights
+                else store_stage(std::false_type{});
+                first = false;
+            } else {
+                store_stage(std::true_type{});
+            }
             __syncthreads();
-            if (more_cc) load_stage(cur, cc + 1);
-            else if (more_items) { setup_item(nxt); load_stage(nxt, 0); }
+            if (more_cc) load_stage(cur, cc + 1, LoopW{});
+            else if (more_items) { setup_item(nxt); load_stage(nxt, 0, LoopW{}); }
             if (!(dbg & 2)) {
                 // 36 steps (tap, kk) of 4 MFMAs; the four fragment reads of step s+1 are issued BEFORE the MFMAs
                 // of step s (hipcc otherwise schedules them just-in-time behind lgkmcnt(0) and the LDS latency
@@ -773,7 +804,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
                 }
             }
             if (!more_cc) {
-                __syncthreads();                   // every wave is done reading the weights: staging may overlay them
+                __syncthreads();                   // every wave is done reading the halo: staging may overlay it
                 epilogue(cur);
                 zero_acc();
                 __syncthreads();
@@ -858,12 +889,23 @@ extern "C" int gs_conv3x3(const void* x, const void* w, void* y, const float* bi
         static const int big_blocks = getenv("GSSEG_C3_GRID") ? atoi(getenv("GSSEG_C3_GRID")) : 256;
         dim3 bgrid(a.nblocks < big_blocks ? a.nblocks : big_blocks);
         hipStream_t bs = (hipStream_t)stream;
+        const bool wres = (Cin <= 64 && a.ntn == 1);       // one chunk, one N tile: weights stay resident in LDS
         if (dtype == GS_F16) {
-            if (tw == 32) conv3x3_big_kernel<GS_F16, 32><<<bgrid, 256, 0, bs>>>(a);
-            else conv3x3_big_kernel<GS_F16, 16><<<bgrid, 256, 0, bs>>>(a);
+            if (wres) {
+                if (tw == 32) conv3x3_big_kernel<GS_F16, 32, true><<<bgrid, 256, 0, bs>>>(a);
+                else conv3x3_big_kernel<GS_F16, 16, true><<<bgrid, 256, 0, bs>>>(a);
+            } else {
+                if (tw == 32) conv3x3_big_kernel<GS_F16, 32, false><<<bgrid, 256, 0, bs>>>(a);
+                else conv3x3_big_kernel<GS_F16, 16, false><<<bgrid, 256, 0, bs>>>(a);
+            }
         } else {
-            if (tw == 32) conv3x3_big_kernel<GS_BF16, 32><<<bgrid, 256, 0, bs>>>(a);
-            else conv3x3_big_kernel<GS_BF16, 16><<<bgrid, 256, 0, bs>>>(a);
+            if (wres) {
+                if (tw == 32) conv3x3_big_kernel<GS_BF16, 32, true><<<bgrid, 256, 0, bs>>>(a);
+                else conv3x3_big_kernel<GS_BF16, 16, true><<<bgrid, 256, 0, bs>>>(a);
+            } else {
+                if (tw == 32) conv3x3_big_kernel<GS_BF16, 32, false><<<bgrid, 256, 0, bs>>>(a);
+                else conv3x3_big_kernel<GS_BF16, 16, false><<<bgrid, 256, 0, bs>>>(a);
+            }
         }
         GS_CHECK_LAUNCH("gs_conv3x3");
         return GS_OK;

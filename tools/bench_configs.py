@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Timings of the non-headline BASELINE configs on one MI355X (informational; bench.py is the contract):
+config 3: Generator / Discriminator / Unet training steps at 256x256 (batch 2 and 32);
+config 5: UNet3D(1,2) forward+backward at 64^3 and 128^3 (batch 1)."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle  # noqa: E402  (synthetic inputs only)
+from semantic_segmentation_amd import steps  # noqa: E402
+from semantic_segmentation_amd.losses import seg_loss  # noqa: E402
+from semantic_segmentation_amd.models_pix2pix import networks  # noqa: E402
+from semantic_segmentation_amd.unet import UNet  # noqa: E402
+from semantic_segmentation_amd.unet3d import UNet3D  # noqa: E402
+
+
+def timeit(fn, iters=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def zero(*nets):
+    for n in nets:
+        for p in n.parameters():
+            p.grad = None
+
+
+def main():
+    dev = torch.device("cuda:0")
+    norm = networks.get_norm_layer("batch")
+    G = networks.define_G(1, 1, 64, "unet_256", "batch", True).to(dev).train()
+    D = networks.define_D(2, 64, "basic", 3, "batch").to(dev).train()
+    U = UNet(1, 1).to(dev).train()
+    networks.upconv_arch = (1e-3 * torch.randn(8, 3)).to(dev).requires_grad_(True)
+    crit = networks.GANLoss("vanilla").to(dev)
+    for B in (2, 32):
+        x, mask = oracle.synthetic_batch(B, 256, seed=3)
+        x, mask = x.to(dev), mask.to(dev)
+        maskf = mask.float()
+        real = torch.rand(B, 1, 256, 256, device=dev)
+
+        def g_step():
+            zero(G, D); steps.generator_step_loss(G, D, crit, maskf, real).backward()
+
+        def d_step():
+            zero(G, D); steps.discriminator_step_loss(G, D, crit, maskf, real).backward()
+
+        def u_step():
+            zero(U); steps.unet_step_loss(U, G, x, mask, 1.0).backward()
+
+        tg, td, tu = timeit(g_step), timeit(d_step), timeit(u_step)
+        print(f"config3 B={B:3d}: generator step {tg * 1e3:8.2f} ms | discriminator step {td * 1e3:8.2f} ms | "
+              f"unet step (2 U-Net fwd+bwd + G fwd + post-proc) {tu * 1e3:8.2f} ms | trio {B / (tg + td + tu):8.1f} img/s")
+    del G, D, U
+    torch.cuda.empty_cache()
+    net = UNet3D(1, 2).to(dev).train()
+    for S in (64, 128):
+        xv = torch.randn(1, 1, S, S, S, device=dev)
+        mv = (torch.rand(1, S, S, S, device=dev) > 0.5).long()
+
+        def v_step():
+            zero(net)
+            lg = net(xv)
+            n, c, d, h, w = lg.shape
+            seg_loss(lg.reshape(n, c, d * h, w), mv.reshape(n, d * h, w)).backward()
+
+        t = timeit(v_step, iters=3, warm=1)
+        tf = 3 * 61.06e9 * (S / 32) ** 3 / t / 1e12
+        print(f"config5 UNet3D(1,2) {S}^3 batch 1: fwd+bwd {t * 1e3:9.2f} ms  = {1 / t:7.2f} volumes/s  ({tf:6.1f} TFLOP/s algorithmic)")
+
+
+if __name__ == "__main__":
+    main()
