@@ -29,7 +29,32 @@ sys.path.insert(0, ROOT)
 
 GF_PER_IMG_FWDBWD = {1: 288.48, 2: 288.50}     # conv/convT 2*MACs, 256x256
 MFMA_PEAK_TFLOPS = 2500.0                      # dense bf16/fp16, MI355X_MICROARCH.md
+MFMA_SUSTAINED_TFLOPS = 1560.0                 # tools/mfma_peak.hip on this part: 32x32x16 f16, random operands
 HBM_PEAK_GBS = 8000.0
+
+
+# KernelTimer class -> kernel-name prefix in the committed rocprofv3 PMC summary (tools/profile_step.sh)
+PMC_PREFIX = {"conv3x3_halo": "conv3x3_", "wgrad3x3_halo": "wgrad3x3_kernel", "igemm_fwd": "igemm_fwd_kernel",
+              "igemm_wgrad": "igemm_wgrad_kernel"}
+
+
+def pmc_traffic(kind):
+    """HBM bytes per launch of a kernel class, from the newest committed PMC summary under profiles/
+    (FETCH_SIZE x2 + WRITE_SIZE, launch-weighted over the class's template instances).  PMC counters cannot be
+    collected from inside this process, so this is the figure of the profiled run of the same command."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), key=os.path.getmtime)
+    pre = PMC_PREFIX.get(kind)
+    if not files or pre is None:
+        return None, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    n, b = 0.0, 0.0
+    for k, v in d.items():
+        if k.startswith(pre) and isinstance(v, dict) and v.get("write_MB_per_launch") is not None:
+            n += v["launches_per_step"]
+            b += v["launches_per_step"] * (v["fetch_MB_per_launch_corrected"] + v["write_MB_per_launch"]) * 1e6
+    return (round(b / n, 0), os.path.relpath(files[-1], ROOT)) if n else (None, None)
 
 
 def parse():
@@ -152,12 +177,18 @@ def main():
         tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
         kern[kind] = {"launches_per_step": d["launches"] / args.steps, "ms_per_step": round(d["ms"] / args.steps, 4),
                       "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2), "tflops": round(tf, 1),
-                      "tflop_per_step": round(d["flops"] / args.steps / 1e12, 4)}
+                      "tflop_per_step": round(d["flops"] / args.steps / 1e12, 4),
+                      "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"], 0)}
     dom = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
     roof = None
     if dom:
+        traffic, traffic_src = pmc_traffic(dom)
         roof = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": kern[dom]["algorithmic_bytes_per_launch"],
+                "measured_sustained_mfma_tflops": MFMA_SUSTAINED_TFLOPS,
+                "frac_of_sustained": round(kern[dom]["tflops"] / MFMA_SUSTAINED_TFLOPS, 4),
                 "avg_launch_us": kern[dom]["avg_launch_us"],
                 "flop_per_launch": round(kern[dom]["tflop_per_step"] * 1e12 / kern[dom]["launches_per_step"], 0)}
     out = {

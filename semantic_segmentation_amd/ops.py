@@ -191,7 +191,8 @@ def conv3x3(x, w, y, N, H, W, Cin, Cout, taps=TAPS3_FWD, bias=None, bn_partials=
               Cin if in_stride is None else in_stride, in_coff, Cout, Cout if out_stride is None else out_stride,
               out_coff, dy, dx, act, dt_code(x), _stream())
     if ev is not None:
-        TIMER.stop("conv3x3_halo", ev, 2.0 * N * H * W * Cout * 9 * Cin)
+        TIMER.stop("conv3x3_halo", ev, 2.0 * N * H * W * Cout * 9 * Cin,
+                   2.0 * (N * H * W * (Cin + Cout) + 9 * Cin * Cout))
 
 
 def conv3x3_wgrad(x, dy, dw, N, H, W, Cin, Cout, in_stride=None, in_coff=0, out_stride=None, out_coff=0):
@@ -206,7 +207,8 @@ def conv3x3_wgrad(x, dy, dw, N, H, W, Cin, Cout, in_stride=None, in_coff=0, out_
     _lib.call("gs_conv3x3_wgrad", _p(x), _p(dy), _p(dw), N, H, W, Cin, Cin if in_stride is None else in_stride,
               in_coff, Cout, Cout if out_stride is None else out_stride, out_coff, dt_code(x), _stream())
     if ev is not None:
-        TIMER.stop("wgrad3x3_halo", ev, 2.0 * N * H * W * Cout * 9 * Cin)
+        TIMER.stop("wgrad3x3_halo", ev, 2.0 * N * H * W * Cout * 9 * Cin,
+                   2.0 * N * H * W * (Cin + Cout) + 4.0 * 9 * Cin * Cout)
 
 
 def conv_igemm_mtiles(g: GsConvGeom) -> int:

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 output of `bench.py` into the small JSON / CSV files kept under profiles/.
+
+    python tools/pmc_summary.py stats  <dir-of-kernel-trace-run>  <steps+warmup>  out.csv
+    python tools/pmc_summary.py pmc    <dir-of-FETCH_SIZE-run> <dir-of-WRITE_SIZE-run> <steps+warmup> out.json
+
+The PMC passes are collected separately (FETCH_SIZE and WRITE_SIZE do not fit one TCC pass) and corrected as
+/opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: both counters are in KiB; FETCH_SIZE reports
+half of the bytes of wide (16 B/lane) streaming reads, so it is doubled; WRITE_SIZE is exact.
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"\.kd$", "", name)
+    name = re.sub(r"^void ", "", name)
+    return re.sub(r"\(.*$", "", name)
+
+
+def find(d, pat):
+    hits = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
+    if not hits:
+        raise SystemExit(f"no {pat} under {d}")
+    return hits[0]
+
+
+def stats(d, nsteps, out):
+    rows = defaultdict(lambda: [0, 0.0])
+    with open(find(d, "*kernel_trace.csv")) as f:
+        for r in csv.DictReader(f):
+            k = short(r["Kernel_Name"])
+            rows[k][0] += 1
+            rows[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    tot = sum(v[1] for v in rows.values())
+    with open(out, "w") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "launches_per_step", "avg_us", "ms_per_step", "percent"])
+        for k, (c, us) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+            w.writerow([k, round(c / nsteps, 2), round(us / c, 2), round(us / nsteps / 1e3, 4), round(100 * us / tot, 2)])
+        w.writerow(["TOTAL", "", "", round(tot / nsteps / 1e3, 4), 100.0])
+
+
+def counter(d, name):
+    acc = defaultdict(lambda: [0, 0.0])
+    with open(find(d, "*counter_collection.csv")) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != name:
+                continue
+            k = short(r["Kernel_Name"])
+            acc[k][0] += 1
+            acc[k][1] += float(r["Counter_Value"])
+    return acc
+
+
+def pmc(dfetch, dwrite, nsteps, out):
+    fe, wr = counter(dfetch, "FETCH_SIZE"), counter(dwrite, "WRITE_SIZE")
+    res = {"_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py; KiB -> MB; "
+                    "FETCH_SIZE doubled (gfx950 wide-read correction, MI355X_MICROARCH.md); averages per launch"}
+    for k in sorted(fe, key=lambda k: -fe[k][1]):
+        c, kib = fe[k]
+        wc, wkib = wr.get(k, (0, 0.0))
+        res[k] = {"launches_per_step": round(c / nsteps, 2),
+                  "fetch_MB_per_launch_corrected": round(2 * kib * 1024 / c / 1e6, 2),
+                  "write_MB_per_launch": round(wkib * 1024 / wc / 1e6, 2) if wc else None}
+    with open(out, "w") as f:
+        json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], int(sys.argv[3]), sys.argv[4])
+    else:
+        pmc(sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5])
