@@ -205,14 +205,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
     __shared__ float red[2][256 * 8 / 8][8];   // [stat][thread][8 channels] -- reduced below
     const int nch = a.C >> 3;
     const int PH = POOL ? (a.H + 1) / 2 : a.H, PW = POOL ? (a.W + 1) / 2 : a.W;
-    const int64_t units = (int64_t)a.N * PH * PW;
+    const int units = a.N * PH * PW;                       // host guarantees < 2^31
     // thread -> (chunk, unit-lane): chunk fastest so a wave reads contiguous channels
     const int lanes_per_unit = nch < 256 ? nch : 256;      // threads covering the channel chunks of one unit
     const int unit_lanes = 256 / lanes_per_unit;           // units processed concurrently per block
     const int chl = threadIdx.x % lanes_per_unit, ul = threadIdx.x / lanes_per_unit;
-    const int64_t u0 = (int64_t)blockIdx.x * a.tile_units;
-    int64_t u1 = u0 + a.tile_units < units ? u0 + a.tile_units : units;
+    const int u0 = blockIdx.x * a.tile_units;
+    int u1 = u0 + a.tile_units < units ? u0 + a.tile_units : units;
     if (ul >= unit_lanes) u1 = u0;   // leftover threads (256 % lanes_per_unit) only join the barriers
+    constexpr int UNR = 4;           // plain path: four pixels per lane in flight (memory-level parallelism)
 
     for (int ch = chl; ch < nch; ch += lanes_per_unit) {
         const int c0 = ch * 8;
@@ -230,71 +231,86 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
 
-        for (int64_t u = u0 + ul; u < u1; u += unit_lanes) {
-            int64_t r = u;
-            const int px = (int)(r % PW); r /= PW;
-            const int py = (int)(r % PH);
-            const int n = (int)(r / PH);
-            if (!POOL) {
-                const int64_t pix = ((int64_t)n * a.H + py) * a.W + px;
-                float yv[8], g[8];
-                unpack8<DT>(*reinterpret_cast<const uint4*>(a.y + pix * a.C + c0), yv);
-                if (a.dza) unpack8<DT>(*reinterpret_cast<const uint4*>(a.dza + pix * a.sa + a.ca + c0), g);
-                else {
+        if (!POOL) {
+            // a unit IS a pixel: no index decomposition at all
+            for (int ub = u0 + ul; ub < u1; ub += unit_lanes * UNR) {
+                uint4 ry[UNR], rg[UNR], rb[UNR];
+                uint2 rk[UNR];
+                bool ok[UNR];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) g[i] = 0.f;
+                for (int k = 0; k < UNR; ++k) {
+                    const int u = ub + k * unit_lanes;
+                    ok[k] = u < u1;
+                    const int64_t pix = ok[k] ? u : u0;
+                    ry[k] = *reinterpret_cast<const uint4*>(a.y + pix * a.C + c0);
+                    rg[k] = a.dza ? *reinterpret_cast<const uint4*>(a.dza + pix * a.sa + a.ca + c0) : make_uint4(0, 0, 0, 0);
+                    rb[k] = a.dzb ? *reinterpret_cast<const uint4*>(a.dzb + pix * a.C + c0) : make_uint4(0, 0, 0, 0);
+                    rk[k] = a.keep ? *reinterpret_cast<const uint2*>(a.keep + pix * a.C + c0) : make_uint2(0, 0);
                 }
-                if (a.keep) {
-                    const uint2 k = *reinterpret_cast<const uint2*>(a.keep + pix * a.C + c0);
-                    const unsigned int kw[2] = {k.x, k.y};
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) g[i] *= ((kw[i >> 2] >> (8 * (i & 3))) & 0xffu) ? a.keep_scale : 0.f;
-                }
-                float gb[8];
-                if (a.dzb) unpack8<DT>(*reinterpret_cast<const uint4*>(a.dzb + pix * a.C + c0), gb);
-                else {
+                for (int k = 0; k < UNR; ++k) {
+                    if (!ok[k]) continue;
+                    const int64_t pix = ub + k * unit_lanes;
+                    float yv[8], g[8], gb[8], out[8];
+                    unpack8<DT>(ry[k], yv);
+                    unpack8<DT>(rg[k], g);
+                    unpack8<DT>(rb[k], gb);
+                    if (a.keep) {
+                        const unsigned int kw[2] = {rk[k].x, rk[k].y};
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) gb[i] = 0.f;
-                }
-                float out[8];
+                        for (int i = 0; i < 8; ++i) g[i] *= ((kw[i >> 2] >> (8 * (i & 3))) & 0xffu) ? a.keep_scale : 0.f;
+                    }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float v = yv[i] * sc[i] + sh[i];
-                    const float gh = g[i] * act_grad(v, a.act) + (a.dzb ? gb[i] * act_grad(v, a.act_b) : 0.f);
-                    const float xh = (yv[i] - mu[i]) * is[i];
-                    if (APPLY) out[i] = a.bn ? sc[i] * (gh - k1[i] - xh * k2[i]) : gh;
-                    else { s1[i] += gh; s2[i] += gh * xh; }
+                    for (int i = 0; i < 8; ++i) {
+                        const float v = yv[i] * sc[i] + sh[i];
+                        const float gh = g[i] * act_grad(v, a.act) + (a.dzb ? gb[i] * act_grad(v, a.act_b) : 0.f);
+                        const float xh = (yv[i] - mu[i]) * is[i];
+                        if (APPLY) out[i] = a.bn ? sc[i] * (gh - k1[i] - xh * k2[i]) : gh;
+                        else { s1[i] += gh; s2[i] += gh * xh; }
+                    }
+                    if (APPLY) *reinterpret_cast<uint4*>(a.dy + pix * a.C + c0) = pack8<DT>(out);
                 }
-                if (APPLY) *reinterpret_cast<uint4*>(a.dy + pix * a.C + c0) = pack8<DT>(out);
-            } else {
-                // 2x2 window: recompute the stored (rounded) z of the 4 pixels, route dzp to the first max
-                float yv[4][8], zr[4][8];
+            }
+        } else {
+            const int PH2 = a.H / 2, PW2 = a.W / 2;
+            for (int u = u0 + ul; u < u1; u += unit_lanes) {
+                const int px = u % PW;
+                const int r = u / PW;
+                const int py = r % PH;
+                const int n = r / PH;
+                // 2x2 window: all nine loads are issued up front (clamped addresses; `ok` masks the results),
+                // then the stored (rounded) z of the 4 pixels is recomputed and dzp routed to the first max
+                uint4 ry[4], rg[4];
                 bool ok[4];
+                int64_t pixk[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int yy = 2 * py + (k >> 1), xx = 2 * px + (k & 1);
                     ok[k] = yy < a.H && xx < a.W;
-                    if (ok[k]) {
-                        const int64_t pix = ((int64_t)n * a.H + yy) * a.W + xx;
-                        unpack8<DT>(*reinterpret_cast<const uint4*>(a.y + pix * a.C + c0), yv[k]);
-                        float zt[8];
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) zt[i] = act_fwd(yv[k][i] * sc[i] + sh[i], a.act);
-                        const uint4 pk = pack8<DT>(zt);
-                        unpack8<DT>(pk, zr[k]);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) { yv[k][i] = 0.f; zr[k][i] = -INFINITY; }
-                    }
+                    pixk[k] = ((int64_t)n * a.H + (yy < a.H ? yy : a.H - 1)) * a.W + (xx < a.W ? xx : a.W - 1);
+                    ry[k] = *reinterpret_cast<const uint4*>(a.y + pixk[k] * a.C + c0);
+                    rg[k] = a.dza ? *reinterpret_cast<const uint4*>(a.dza + pixk[k] * a.sa + a.ca + c0) : make_uint4(0, 0, 0, 0);
                 }
-                const bool pooled = (py < a.H / 2) && (px < a.W / 2);
-                float gp[8];
+                const bool pooled = (py < PH2) && (px < PW2);
+                uint4 rp = make_uint4(0, 0, 0, 0);
                 if (pooled && a.dzp) {
-                    const int64_t pp = ((int64_t)n * (a.H / 2) + py) * (a.W / 2) + px;
-                    unpack8<DT>(*reinterpret_cast<const uint4*>(a.dzp + pp * a.C + c0), gp);
-                } else {
+                    const int64_t pp = ((int64_t)n * PH2 + py) * PW2 + px;
+                    rp = *reinterpret_cast<const uint4*>(a.dzp + pp * a.C + c0);
+                }
+                float yv[4][8], zr[4][8], gp[8];
+                unpack8<DT>(rp, gp);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) gp[i] = 0.f;
+                for (int k = 0; k < 4; ++k) {
+                    unpack8<DT>(ry[k], yv[k]);
+                    float zt[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) zt[i] = act_fwd(yv[k][i] * sc[i] + sh[i], a.act);
+                    const uint4 pk = pack8<DT>(zt);
+                    unpack8<DT>(pk, zr[k]);
+                    if (!ok[k]) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) zr[k][i] = -INFINITY;
+                    }
                 }
                 int amax[8];
 #pragma unroll
@@ -307,15 +323,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (!ok[k]) continue;
-                    const int yy = 2 * py + (k >> 1), xx = 2 * px + (k & 1);
-                    const int64_t pix = ((int64_t)n * a.H + yy) * a.W + xx;
-                    float g[8];
-                    if (a.dza) unpack8<DT>(*reinterpret_cast<const uint4*>(a.dza + pix * a.sa + a.ca + c0), g);
-                    else {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) g[i] = 0.f;
-                    }
-                    float out[8];
+                    float g[8], out[8];
+                    unpack8<DT>(rg[k], g);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const float gz = g[i] + (amax[i] == k ? gp[i] : 0.f);
@@ -325,7 +334,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
                         if (APPLY) out[i] = a.bn ? sc[i] * (gh - k1[i] - xh * k2[i]) : gh;
                         else { s1[i] += gh; s2[i] += gh * xh; }
                     }
-                    if (APPLY) *reinterpret_cast<uint4*>(a.dy + pix * a.C + c0) = pack8<DT>(out);
+                    if (APPLY) *reinterpret_cast<uint4*>(a.dy + pixk[k] * a.C + c0) = pack8<DT>(out);
                 }
             }
         }
@@ -543,6 +552,7 @@ extern "C" int gs_bn_act_bwd_reduce(const void* y, const void* dz_a, int sa, int
     GS_CHECK_ARG(y && partials && (dz_a || dzp || dz_b) && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= 2048,
                  "gs_bn_act_bwd_reduce: bad arguments");
     GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_bn_act_bwd_reduce: bad dtype");
+    GS_CHECK_ARG((int64_t)N * H * W < 2147483647LL, "gs_bn_act_bwd_reduce: more than 2^31 pixels");
     GS_CHECK_ARG(!dz_a || (sa >= coff_a + C && sa % 8 == 0 && coff_a % 8 == 0), "gs_bn_act_bwd_reduce: bad dz stride");
     BwdArgs a{};
     a.y = (const unsigned short*)y; a.dza = (const unsigned short*)dz_a; a.dzp = (const unsigned short*)dzp;
@@ -575,6 +585,7 @@ extern "C" int gs_bn_act_bwd_apply(const void* y, const void* dz_a, int sa, int 
     GS_CHECK_ARG(y && dy && (dz_a || dzp || dz_b) && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= 2048,
                  "gs_bn_act_bwd_apply: bad arguments");
     GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_bn_act_bwd_apply: bad dtype");
+    GS_CHECK_ARG((int64_t)N * H * W < 2147483647LL, "gs_bn_act_bwd_apply: more than 2^31 pixels");
     GS_CHECK_ARG(!bn || (scale && shift && mean && invstd && c1 && c2), "gs_bn_act_bwd_apply: bn=1 needs all coefficients");
     GS_CHECK_ARG(!dz_a || (sa >= coff_a + C && sa % 8 == 0 && coff_a % 8 == 0), "gs_bn_act_bwd_apply: bad dz stride");
     BwdArgs a{};
