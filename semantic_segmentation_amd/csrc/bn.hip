@@ -115,8 +115,10 @@ struct ApplyArgs {
     int act, N, H, W, C, zs, zc;
 };
 
-template <int DT, bool POOL>
+template <int DT, bool POOL, bool GENERIC>
 __global__ __launch_bounds__(256) void bn_act_apply_kernel(const ApplyArgs a) {
+    const float slope = a.act == GS_ACT_RELU ? 0.f : (a.act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
+    auto fwd_a = [&](float v) __attribute__((always_inline)) { return GENERIC ? act_fwd(v, a.act) : (v > 0.f ? v : v * slope); };
     const int nch = a.C >> 3;
     const int PH = POOL ? (a.H + 1) / 2 : a.H, PW = POOL ? (a.W + 1) / 2 : a.W;
     const int64_t total = (int64_t)a.N * PH * PW * nch;
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(const ApplyArgs a) {
             float v[8];
             unpack8<DT>(*reinterpret_cast<const uint4*>(a.y + pix * a.C + c0), v);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = act_fwd(v[i] * sc[i] + sh[i], a.act);
+            for (int i = 0; i < 8; ++i) v[i] = fwd_a(v[i] * sc[i] + sh[i]);
             if (a.keep) {
                 const uint2 k = *reinterpret_cast<const uint2*>(a.keep + pix * a.C + c0);
                 const unsigned int kw[2] = {k.x, k.y};
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(const ApplyArgs a) {
                         float v[8];
                         unpack8<DT>(*reinterpret_cast<const uint4*>(a.y + pix * a.C + c0), v);
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) v[i] = act_fwd(v[i] * sc[i] + sh[i], a.act);
+                        for (int i = 0; i < 8; ++i) v[i] = fwd_a(v[i] * sc[i] + sh[i]);
                         const uint4 pk = pack8<DT>(v);
                         *reinterpret_cast<uint4*>(a.z + pix * a.zs + a.zc + c0) = pk;
                         // pool the ROUNDED values: the next layer sees exactly max over the stored z
@@ -200,9 +202,17 @@ struct BwdArgs {
 // gradient w.r.t. z at one pixel for 8 channels: concat/skip part + max-pool routed part.
 // v[] are the pre-activation values (y*scale+shift) of THIS pixel; for the pool part the caller supplies
 // `win` = whether this pixel is the first arg-max of its window, per channel.
-template <int DT, bool POOL, bool APPLY>
+// GENERIC = some activation is tanh (runtime switch per element); otherwise the activations are the slope family
+// (identity / ReLU / LeakyReLU) and their value / derivative is one compare + select -- the per-element uniform
+// `switch` of act_fwd/act_grad costs a scalar branch per element and held these kernels at ~3 TB/s.
+template <int DT, bool POOL, bool APPLY, bool GENERIC>
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
     __shared__ float red[2][256 * 8 / 8][8];   // [stat][thread][8 channels] -- reduced below
+    const float slope_a = a.act == GS_ACT_RELU ? 0.f : (a.act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
+    const float slope_b = a.act_b == GS_ACT_RELU ? 0.f : (a.act_b == GS_ACT_LEAKY02 ? 0.2f : 1.f);
+    auto grad_a = [&](float v) __attribute__((always_inline)) { return GENERIC ? act_grad(v, a.act) : (v > 0.f ? 1.f : slope_a); };
+    auto grad_b = [&](float v) __attribute__((always_inline)) { return GENERIC ? act_grad(v, a.act_b) : (v > 0.f ? 1.f : slope_b); };
+    auto fwd_a = [&](float v) __attribute__((always_inline)) { return GENERIC ? act_fwd(v, a.act) : (v > 0.f ? v : v * slope_a); };
     const int nch = a.C >> 3;
     const int PH = POOL ? (a.H + 1) / 2 : a.H, PW = POOL ? (a.W + 1) / 2 : a.W;
     const int units = a.N * PH * PW;                       // host guarantees < 2^31
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const float v = yv[i] * sc[i] + sh[i];
-                        const float gh = g[i] * act_grad(v, a.act) + (a.dzb ? gb[i] * act_grad(v, a.act_b) : 0.f);
+                        const float gh = g[i] * grad_a(v) + (a.dzb ? gb[i] * grad_b(v) : 0.f);
                         const float xh = (yv[i] - mu[i]) * is[i];
                         if (APPLY) out[i] = a.bn ? sc[i] * (gh - k1[i] - xh * k2[i]) : gh;
                         else { s1[i] += gh; s2[i] += gh * xh; }
@@ -304,7 +314,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
                     unpack8<DT>(ry[k], yv[k]);
                     float zt[8];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) zt[i] = act_fwd(yv[k][i] * sc[i] + sh[i], a.act);
+                    for (int i = 0; i < 8; ++i) zt[i] = fwd_a(yv[k][i] * sc[i] + sh[i]);
                     const uint4 pk = pack8<DT>(zt);
                     unpack8<DT>(pk, zr[k]);
                     if (!ok[k]) {
@@ -329,7 +339,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
                     for (int i = 0; i < 8; ++i) {
                         const float gz = g[i] + (amax[i] == k ? gp[i] : 0.f);
                         const float v = yv[k][i] * sc[i] + sh[i];
-                        const float gh = gz * act_grad(v, a.act);
+                        const float gh = gz * grad_a(v);
                         const float xh = (yv[k][i] - mu[i]) * is[i];
                         if (APPLY) out[i] = a.bn ? sc[i] * (gh - k1[i] - xh * k2[i]) : gh;
                         else { s1[i] += gh; s2[i] += gh * xh; }
@@ -482,12 +492,23 @@ extern "C" int gs_bn_act_apply(const void* y, const float* scale, const float* s
     int64_t blocks = cdiv64(total, 256);
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipStream_t s = (hipStream_t)stream;
+    const bool generic = act == GS_ACT_TANH;
     if (dtype == GS_F16) {
-        if (pool) bn_act_apply_kernel<GS_F16, true><<<(int)blocks, 256, 0, s>>>(a);
-        else bn_act_apply_kernel<GS_F16, false><<<(int)blocks, 256, 0, s>>>(a);
+        if (generic) {
+            if (pool) bn_act_apply_kernel<GS_F16, true, true><<<(int)blocks, 256, 0, s>>>(a);
+            else bn_act_apply_kernel<GS_F16, false, true><<<(int)blocks, 256, 0, s>>>(a);
+        } else {
+            if (pool) bn_act_apply_kernel<GS_F16, true, false><<<(int)blocks, 256, 0, s>>>(a);
+            else bn_act_apply_kernel<GS_F16, false, false><<<(int)blocks, 256, 0, s>>>(a);
+        }
     } else if (dtype == GS_BF16) {
-        if (pool) bn_act_apply_kernel<GS_BF16, true><<<(int)blocks, 256, 0, s>>>(a);
-        else bn_act_apply_kernel<GS_BF16, false><<<(int)blocks, 256, 0, s>>>(a);
+        if (generic) {
+            if (pool) bn_act_apply_kernel<GS_BF16, true, true><<<(int)blocks, 256, 0, s>>>(a);
+            else bn_act_apply_kernel<GS_BF16, false, true><<<(int)blocks, 256, 0, s>>>(a);
+        } else {
+            if (pool) bn_act_apply_kernel<GS_BF16, true, false><<<(int)blocks, 256, 0, s>>>(a);
+            else bn_act_apply_kernel<GS_BF16, false, false><<<(int)blocks, 256, 0, s>>>(a);
+        }
     } else {
         GS_CHECK_ARG(false, "gs_bn_act_apply: bad dtype");
     }
@@ -518,18 +539,19 @@ static int launch_bwd(const BwdArgs& a0, bool apply, int dtype, hipStream_t s, i
     if (a.tile_units < 1) a.tile_units = 1;
     const int ntiles = (int)cdiv64(units, a.tile_units);
     if (ntiles_out) *ntiles_out = ntiles;
-#define LAUNCH(DT)                                                                                      \
+    const bool generic = a.act == GS_ACT_TANH || (a.dzb && a.act_b == GS_ACT_TANH);
+#define LAUNCH(DT, G)                                                                                   \
     do {                                                                                                \
         if (pool) {                                                                                     \
-            if (apply) bn_act_bwd_kernel<DT, true, true><<<ntiles, 256, 0, s>>>(a);                     \
-            else bn_act_bwd_kernel<DT, true, false><<<ntiles, 256, 0, s>>>(a);                          \
+            if (apply) bn_act_bwd_kernel<DT, true, true, G><<<ntiles, 256, 0, s>>>(a);                  \
+            else bn_act_bwd_kernel<DT, true, false, G><<<ntiles, 256, 0, s>>>(a);                       \
         } else {                                                                                        \
-            if (apply) bn_act_bwd_kernel<DT, false, true><<<ntiles, 256, 0, s>>>(a);                    \
-            else bn_act_bwd_kernel<DT, false, false><<<ntiles, 256, 0, s>>>(a);                         \
+            if (apply) bn_act_bwd_kernel<DT, false, true, G><<<ntiles, 256, 0, s>>>(a);                 \
+            else bn_act_bwd_kernel<DT, false, false, G><<<ntiles, 256, 0, s>>>(a);                      \
         }                                                                                               \
     } while (0)
-    if (dtype == GS_F16) LAUNCH(GS_F16);
-    else LAUNCH(GS_BF16);
+    if (dtype == GS_F16) { if (generic) LAUNCH(GS_F16, true); else LAUNCH(GS_F16, false); }
+    else { if (generic) LAUNCH(GS_BF16, true); else LAUNCH(GS_BF16, false); }
 #undef LAUNCH
     return 0;
 }

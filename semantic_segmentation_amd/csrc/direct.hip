@@ -88,23 +88,112 @@ __global__ __launch_bounds__(256) void smallcin_fwd_kernel(const SCArgs a) {
     }
 }
 
+// Cout == 64 specialisation: ONE THREAD PER OUTPUT PIXEL holding all 64 channels.  The [tap][64] weights are
+// read from LDS with wave-uniform addresses (broadcast ds_read_b128: 16 reads + 64 FMAs per tap) and every
+// lane stores its own full 128-byte output line; the generic kernel above spends 8 lanes (and 8x the index
+// arithmetic and image loads) per pixel.  BatchNorm partial sums go through a padded LDS transpose.
+constexpr int SC64_PAD = 33;
+template <int DT>
+__global__ __launch_bounds__(256) void smallcin_fwd64_kernel(const SCArgs a) {
+    extern __shared__ float sc64_smem[];
+    const int T = a.Cin * a.k * a.k;
+    float* wl = sc64_smem;                          // [tap][64]
+    float* stage = sc64_smem + T * 64;              // [256 pixels][33]
+    for (int i = threadIdx.x; i < T * 64; i += 256) {
+        const int co = i & 63, tap = i >> 6;
+        wl[i] = a.w[co * T + tap];
+    }
+    __syncthreads();
+    const int M = a.N * a.OH * a.OW;                // host guarantees < 2^31
+    const int m = blockIdx.x * SC_TILE + threadIdx.x;
+    const bool live = m < M;
+    const int mm = live ? m : M - 1;
+    const int ox = mm % a.OW;
+    const int r = mm / a.OW;
+    const int oy = r % a.OH;
+    const int n = r / a.OH;
+    float acc[64];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) acc[c] = 0.f;
+    const float* xn = a.x + (int64_t)n * a.Cin * a.IH * a.IW;
+    int tap = 0;
+    for (int ci = 0; ci < a.Cin; ++ci)
+        for (int ky = 0; ky < a.k; ++ky) {
+            const int iy = oy * a.stride - a.pad + ky;
+            for (int kx = 0; kx < a.k; ++kx, ++tap) {
+                const int ix = ox * a.stride - a.pad + kx;
+                float xv = 0.f;
+                if ((unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW)
+                    xv = xn[(ci * a.IH + iy) * a.IW + ix];
+                const float4* wp = reinterpret_cast<const float4*>(wl + tap * 64);
+#pragma unroll
+                for (int c4 = 0; c4 < 16; ++c4) {
+                    const float4 w4 = wp[c4];
+                    acc[4 * c4 + 0] += xv * w4.x;
+                    acc[4 * c4 + 1] += xv * w4.y;
+                    acc[4 * c4 + 2] += xv * w4.z;
+                    acc[4 * c4 + 3] += xv * w4.w;
+                }
+            }
+        }
+    if (live) {
+        unsigned short* dst = a.y + (int64_t)m * 64;
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) {
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                o[i] = act_fwd(acc[c8 * 8 + i] + (a.bias ? a.bias[c8 * 8 + i] : 0.f), a.act);
+            *reinterpret_cast<uint4*>(dst + c8 * 8) = pack8<DT>(o);
+        }
+    }
+    if (a.bnp) {
+        // two channel halves through a [256 pixels][33] transpose: lane (c, q) sums 64 pixels of channel c
+        const int c = threadIdx.x & 31, q = threadIdx.x >> 5;           // 8 pixel groups of 32
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 32; ++i) stage[threadIdx.x * SC64_PAD + i] = live ? acc[hf * 32 + i] : 0.f;
+            __syncthreads();
+            float t1 = 0.f, t2 = 0.f;
+            for (int i = 0; i < 32; ++i) {
+                const float v = stage[(q * 32 + i) * SC64_PAD + c];
+                t1 += v; t2 += v * v;
+            }
+            __syncthreads();
+            stage[q * 32 + c] = t1;
+            stage[256 + q * 32 + c] = t2;
+            __syncthreads();
+            if (threadIdx.x < 64) {
+                const int cc = threadIdx.x & 31, st = threadIdx.x >> 5;
+                const float* sp = stage + st * 256 + cc;
+                float t = 0.f;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) t += sp[g * 32];
+                a.bnp[(int64_t)blockIdx.x * 128 + st * 64 + hf * 32 + cc] = t;
+            }
+        }
+    }
+}
+
 struct SCWArgs {
     const float* x; const unsigned short* dy; float* dw;   // dw: partial slab [nblocks][Cout*T] (stage 1)
     int N, Cin, IH, IW, Cout, OH, OW, k, stride, pad;
     float gscale; int64_t pix_per_block;
 };
 
-constexpr int TG = 16;   // taps accumulated per pass
-
-template <int DT>
+// TG = taps accumulated per pass (template: 9 keeps the 3x3 / 1-channel stem at ~100 VGPRs)
+template <int DT, int TG>
 __global__ __launch_bounds__(256) void smallcin_wgrad_kernel(const SCWArgs a) {
     __shared__ float red[256][8];
     const int T = a.Cin * a.k * a.k, kk = a.k * a.k;
     const int nch = a.Cout >> 3, lanes = 256 / nch;
     const int ch = threadIdx.x % nch, pl = threadIdx.x / nch;
-    const int64_t M = (int64_t)a.N * a.OH * a.OW;
-    const int64_t m0 = (int64_t)blockIdx.x * a.pix_per_block;
-    const int64_t m1 = m0 + a.pix_per_block < M ? m0 + a.pix_per_block : M;
+    const int M = a.N * a.OH * a.OW;                               // host guarantees < 2^31
+    const int m0 = (int)(blockIdx.x * a.pix_per_block);
+    const int m1 = m0 + (int)a.pix_per_block < M ? m0 + (int)a.pix_per_block : M;
+    const int img = a.Cin * a.IH * a.IW;
     for (int t0 = 0; t0 < T; t0 += TG) {
         float acc[TG][8];
         int tdy[TG], tdx[TG], tco[TG];       // tap decode hoisted out of the pixel loop (integer divisions)
@@ -117,24 +206,36 @@ __global__ __launch_bounds__(256) void smallcin_wgrad_kernel(const SCWArgs a) {
             tdy[j] = ky - a.pad; tdx[j] = kx - a.pad; tco[j] = ci * a.IH * a.IW;
         }
         if (pl < lanes) {
-            for (int64_t m = m0 + pl; m < m1; m += lanes) {
-                const int ox = (int)(m % a.OW);
-                const int64_t r = m / a.OW;
-                const int oy = (int)(r % a.OH);
-                const int n = (int)(r / a.OH);
-                float g[8];
-                unpack8<DT>(*reinterpret_cast<const uint4*>(a.dy + m * a.Cout + ch * 8), g);
+            // two pixels per iteration: both gradient rows and all their image taps are in flight together
+            for (int mb = m0 + pl; mb < m1; mb += 2 * lanes) {
+                const bool two = mb + lanes < m1;
+                const int mq[2] = {mb, two ? mb + lanes : mb};
+                uint4 rg[2];
+                float xv[2][TG];
 #pragma unroll
-                for (int j = 0; j < TG; ++j) {
-                    const int tap = t0 + j;
-                    if (tap < T) {
+                for (int q = 0; q < 2; ++q) {
+                    rg[q] = *reinterpret_cast<const uint4*>(a.dy + (int64_t)mq[q] * a.Cout + ch * 8);
+                    const int ox = mq[q] % a.OW;
+                    const int r = mq[q] / a.OW;
+                    const int oy = r % a.OH;
+                    const int n = r / a.OH;
+                    const float* xn = a.x + (int64_t)n * img;
+#pragma unroll
+                    for (int j = 0; j < TG; ++j) {
                         const int iy = oy * a.stride + tdy[j], ix = ox * a.stride + tdx[j];
-                        float xv = 0.f;
-                        if ((unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW)
-                            xv = a.x[(int64_t)n * a.Cin * a.IH * a.IW + tco[j] + iy * a.IW + ix];
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) acc[j][i] += g[i] * xv;
+                        const bool ok = (t0 + j < T) && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+                        xv[q][j] = ok ? xn[tco[j] + iy * a.IW + ix] : 0.f;
                     }
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (q == 1 && !two) break;
+                    float g[8];
+                    unpack8<DT>(rg[q], g);
+#pragma unroll
+                    for (int j = 0; j < TG; ++j)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc[j][i] += g[i] * xv[q][j];
                 }
             }
         }
@@ -173,12 +274,12 @@ __global__ __launch_bounds__(256) void smallcin_dgrad_kernel(const SCDArgs a) {
         wl[i] = a.w[(int64_t)co * T + tap];
     }
     __syncthreads();
-    const int64_t total = (int64_t)a.N * a.IH * a.IW;
-    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (int64_t)gridDim.x * 256) {
-        const int ix = (int)(p % a.IW);
-        const int64_t r = p / a.IW;
-        const int iy = (int)(r % a.IH);
-        const int n = (int)(r / a.IH);
+    const int total = a.N * a.IH * a.IW;                 // host guarantees < 2^31
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < total; p += gridDim.x * 256) {
+        const int ix = p % a.IW;
+        const int r = p / a.IW;
+        const int iy = r % a.IH;
+        const int n = r / a.IH;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int ky = 0; ky < a.k; ++ky) {
             const int ty = iy + a.pad - ky;
@@ -237,16 +338,16 @@ __global__ __launch_bounds__(256) void smallcout_fwd_kernel(const HArgs a) {
     const int gl = nch < 64 ? nch : 64;           // lanes cooperating on one pixel (power of two)
     const int groups = 256 / gl;
     const int li = threadIdx.x % gl, grp = threadIdx.x / gl;
-    const int64_t M = (int64_t)a.N * a.OH * a.OW;
-    const int64_t nit = (M + groups - 1) / groups;
-    for (int64_t it = blockIdx.x; it < nit; it += gridDim.x) {
-        const int64_t m = it * groups + grp;
+    const int M = a.N * a.OH * a.OW;                     // host guarantees < 2^31
+    const int nit = (M + groups - 1) / groups;
+    for (int it = blockIdx.x; it < nit; it += gridDim.x) {
+        const int m = it * groups + grp;
         const bool valid = m < M;
-        const int64_t mm = valid ? m : 0;
-        const int ox = (int)(mm % a.OW);
-        const int64_t r = mm / a.OW;
-        const int oy = (int)(r % a.OH);
-        const int n = (int)(r / a.OH);
+        const int mm = valid ? m : 0;
+        const int ox = mm % a.OW;
+        const int r = mm / a.OW;
+        const int oy = r % a.OH;
+        const int n = r / a.OH;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int ky = 0; ky < a.k; ++ky)
             for (int kx = 0; kx < a.k; ++kx) {
@@ -281,10 +382,10 @@ __global__ __launch_bounds__(256) void smallcout_dgrad_kernel(const HArgs a) {
     __syncthreads();
     const int kk = a.k * a.k;
     const int nch = a.Cin >> 3;
-    const int64_t total = (int64_t)a.N * a.IH * a.IW * nch;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int ch = (int)(idx % nch);
-        int64_t p = idx / nch;
+    const int total = a.N * a.IH * a.IW * nch;           // host guarantees < 2^31
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int ch = idx % nch;
+        int p = idx / nch;
         const int ix = (int)(p % a.IW); p /= a.IW;
         const int iy = (int)(p % a.IH);
         const int n = (int)(p / a.IH);
@@ -322,16 +423,17 @@ __global__ __launch_bounds__(256) void smallcout_wgrad_kernel(const HArgs a) {
     const int nch = a.Cin >> 3;
     const int lpu = nch < 256 ? nch : 256, lanes = 256 / lpu;
     const int chl = threadIdx.x % lpu, pl = threadIdx.x / lpu;
-    const int64_t M = (int64_t)a.N * a.OH * a.OW;
-    const int64_t m0 = (int64_t)blockIdx.x * a.pix_per_block;
-    const int64_t m1 = m0 + a.pix_per_block < M ? m0 + a.pix_per_block : M;
+    const int M = a.N * a.OH * a.OW;                     // host guarantees < 2^31
+    const int m0 = (int)(blockIdx.x * a.pix_per_block);
+    const int m1 = m0 + (int)a.pix_per_block < M ? m0 + (int)a.pix_per_block : M;
+    const int ohw = a.OH * a.OW;
     // bias gradient: plain block reduction over this block's pixels
     if (a.db) {
         for (int c = 0; c < a.Cout; ++c) {
             float s = 0.f;
-            for (int64_t m = m0 + threadIdx.x; m < m1; m += 256) {
-                const int64_t hw = m % ((int64_t)a.OH * a.OW), n = m / ((int64_t)a.OH * a.OW);
-                s += a.dy[(n * a.Cout + c) * (int64_t)a.OH * a.OW + hw];
+            for (int m = m0 + threadIdx.x; m < m1; m += 256) {
+                const int hw = m % ohw, n = m / ohw;
+                s += a.dy[((int64_t)n * a.Cout + c) * ohw + hw];
             }
             s = wave_sum(s);
             __syncthreads();
@@ -349,11 +451,11 @@ __global__ __launch_bounds__(256) void smallcout_wgrad_kernel(const HArgs a) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) acc[c][i] = 0.f;
             if (pl < lanes) {
-                for (int64_t m = m0 + pl; m < m1; m += lanes) {
-                    const int ox = (int)(m % a.OW);
-                    const int64_t r = m / a.OW;
-                    const int oy = (int)(r % a.OH);
-                    const int n = (int)(r / a.OH);
+                for (int m = m0 + pl; m < m1; m += lanes) {
+                    const int ox = m % a.OW;
+                    const int r = m / a.OW;
+                    const int oy = r % a.OH;
+                    const int n = r / a.OH;
                     const int iy = oy * a.stride - a.pad + ky, ix = ox * a.stride - a.pad + kx;
                     if ((unsigned)iy >= (unsigned)a.IH || (unsigned)ix >= (unsigned)a.IW) continue;
                     float v[8];
@@ -443,8 +545,15 @@ extern "C" int gs_conv_smallcin_fwd(const float* x, const float* w, const float*
     SCArgs a{x, w, bias, (unsigned short*)y, bn_partials, N, Cin, IH, IW, Cout, OH, OW, k, stride, pad, act};
     const int nb = gs_conv_smallcin_mtiles(N, OH, OW);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GS_F16) smallcin_fwd_kernel<GS_F16><<<nb, 256, 0, s>>>(a);
-    else smallcin_fwd_kernel<GS_BF16><<<nb, 256, 0, s>>>(a);
+    GS_CHECK_ARG((int64_t)N * OH * OW < 2147483647LL && (int64_t)Cin * IH * IW < 2147483647LL, "gs_conv_smallcin_fwd: too many pixels");
+    const size_t lds = ((size_t)Cin * k * k * 64 + 256 * SC64_PAD) * sizeof(float);
+    if (Cout == 64 && lds <= 64 * 1024) {
+        if (dtype == GS_F16) smallcin_fwd64_kernel<GS_F16><<<nb, 256, lds, s>>>(a);
+        else smallcin_fwd64_kernel<GS_BF16><<<nb, 256, lds, s>>>(a);
+    } else {
+        if (dtype == GS_F16) smallcin_fwd_kernel<GS_F16><<<nb, 256, 0, s>>>(a);
+        else smallcin_fwd_kernel<GS_BF16><<<nb, 256, 0, s>>>(a);
+    }
     GS_CHECK_LAUNCH("gs_conv_smallcin_fwd");
     return GS_OK;
 }
@@ -461,8 +570,15 @@ extern "C" int gs_conv_smallcin_wgrad(const float* x, const void* dy, float* dw,
     SCWArgs a{x, (const unsigned short*)dy, ws, N, Cin, IH, IW, Cout, OH, OW, k, stride, pad, gscale, ppb};
     const int nb = (int)cdiv64(M, ppb);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GS_F16) smallcin_wgrad_kernel<GS_F16><<<nb, 256, 0, s>>>(a);
-    else smallcin_wgrad_kernel<GS_BF16><<<nb, 256, 0, s>>>(a);
+    GS_CHECK_ARG(M < 2147483647LL && (int64_t)Cin * IH * IW < 2147483647LL, "gs_conv_smallcin_wgrad: too many pixels");
+    const int T = Cin * k * k;
+    if (T <= 9) {
+        if (dtype == GS_F16) smallcin_wgrad_kernel<GS_F16, 9><<<nb, 256, 0, s>>>(a);
+        else smallcin_wgrad_kernel<GS_BF16, 9><<<nb, 256, 0, s>>>(a);
+    } else {
+        if (dtype == GS_F16) smallcin_wgrad_kernel<GS_F16, 16><<<nb, 256, 0, s>>>(a);
+        else smallcin_wgrad_kernel<GS_BF16, 16><<<nb, 256, 0, s>>>(a);
+    }
     const int n = Cout * Cin * k * k;
     slab_reduce_kernel<<<cdiv(n, 32), 256, 0, s>>>(ws, nb, n, n, gscale, dw);
     GS_CHECK_LAUNCH("gs_conv_smallcin_wgrad");
@@ -475,6 +591,7 @@ extern "C" int gs_conv_smallcin_dgrad(const void* dy, const float* w, float* dx,
     int rc = check_smallcin("gs_conv_smallcin_dgrad", N, Cin, IH, IW, Cout, OH, OW, k, stride, pad, dtype);
     if (rc) return rc;
     GS_CHECK_ARG(dy && w && dx, "gs_conv_smallcin_dgrad: null pointer");
+    GS_CHECK_ARG((int64_t)N * IH * IW + 4096 * 256 < 2147483647LL, "gs_conv_smallcin_dgrad: too many pixels");
     SCDArgs a{(const unsigned short*)dy, w, dx, N, Cin, IH, IW, Cout, OH, OW, k, stride, pad, gscale};
     int64_t nb = cdiv64((int64_t)N * IH * IW, 256);
     if (nb > 4096) nb = 4096;
@@ -503,6 +620,7 @@ extern "C" int gs_conv_smallcout_fwd(const void* x, const float* w, const float*
     int rc = check_head("gs_conv_smallcout_fwd", N, IH, IW, Cin, Cout, OH, OW, k, stride, pad, dtype);
     if (rc) return rc;
     GS_CHECK_ARG(x && w && y, "gs_conv_smallcout_fwd: null pointer");
+    GS_CHECK_ARG((int64_t)N * OH * OW + 256 < 2147483647LL, "gs_conv_smallcout_fwd: too many pixels");
     HArgs a{};
     a.x = (const unsigned short*)x; a.w = w; a.bias = bias; a.y = y;
     a.N = N; a.IH = IH; a.IW = IW; a.Cin = Cin; a.Cout = Cout; a.OH = OH; a.OW = OW; a.k = k; a.stride = stride; a.pad = pad;
@@ -522,6 +640,8 @@ extern "C" int gs_conv_smallcout_bwd(const void* x, const float* w, const float*
     int rc = check_head("gs_conv_smallcout_bwd", N, IH, IW, Cin, Cout, OH, OW, k, stride, pad, dtype);
     if (rc) return rc;
     GS_CHECK_ARG(w && dy, "gs_conv_smallcout_bwd: null pointer");
+    GS_CHECK_ARG((int64_t)N * IH * IW * (Cin / 8) < 2147483647LL && (int64_t)N * OH * OW < 2147483647LL,
+                 "gs_conv_smallcout_bwd: too many pixels");
     HArgs a{};
     a.x = (const unsigned short*)x; a.w = w; a.dy = dy; a.dx = (unsigned short*)dx; a.dw = dw; a.db = db;
     a.N = N; a.IH = IH; a.IW = IW; a.Cin = Cin; a.Cout = Cout; a.OH = OH; a.OW = OW; a.k = k; a.stride = stride; a.pad = pad;
