@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 5
+#define GS_ABI_VERSION 6
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -69,6 +69,16 @@ int gs_abi_version(void);
 int gs_conv_igemm_mtiles(const GsConvGeom* g);
 int gs_conv_igemm(const GsConvGeom* g, const void* x, const void* w, void* y, const float* bias,
                   float* bn_partials, int act, int dtype, void* stream);
+
+/* ---- stride-2 / kernel-2 transposed convolution as ONE pointwise GEMM + sub-pixel scatter ------
+ * replaces nn.ConvTranspose2d(C, C/2, kernel_size=2, stride=2) at unet/unet_parts.py:51 (Up.up) and
+ * nn.ConvTranspose3d(k=2, s=2) at GenSeg-3D/UNet3D/unet3d.py:68, including the zero F.pad offset of
+ * unet_parts.py:58-61 (ooy/oox) and the write into the concat buffer of torch.cat (out_coff).
+ * x: [N*D,IH,IW,*]; w: gs_pack_weight(transposed) slots [ncls][Cout][Cin], slot = (kz*2+ky)*2+kx, ncls = 4 (D == Dout
+ * == 1) or 8; y: [N*Dout,OH,OW,*], voxel (2z+kz+ooz, 2y+ky+ooy, 2x+kx+oox).  Cout, strides, offsets % 8 == 0. */
+int gs_upconv2x2_fwd(const void* x, const void* w, const float* bias, void* y, int N, int D, int IH, int IW, int Cin,
+                     int in_pix_stride, int in_coff, int Cout, int Dout, int OH, int OW, int out_pix_stride,
+                     int out_coff, int ooz, int ooy, int oox, int act, int dtype, void* stream);
 
 /* ---- 3x3 / stride 1 / pad 1 convolution with LDS halo reuse (the U-Net DoubleConv hot loop,
  * unet_parts.py:16,19) and its data gradient (pass flipped taps and the [9][Cin][Cout] pack).

@@ -28,6 +28,9 @@ struct IgemmArgs {
     int kchunks;  // ceil(Cin/64)
     int ntn;      // number of N tiles
     int nblocks;
+    int vec_store;     // 1: epilogue stages the tile through LDS and stores 16-byte channel chunks
+    int shuffle_cout;  // > 0: merged stride-2 transposed conv (kernel 2): GEMM column c' = cls * shuffle_cout + co is
+    int shuffle_cls;   //      written to output pixel (2z+cz, 2y+cy, 2x+cx), cls = (cz, cy, cx) bits; 4 or 8 classes
 };
 
 // bijective XCD-aware remap: blocks that share an XCD (bid % 8) get a contiguous range of logical ids
@@ -158,26 +161,27 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
         rowpix[t] = p;
     }
     __syncthreads();
+    const float slope = a.act == GS_ACT_RELU ? 0.f : (a.act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
+    const bool is_tanh = a.act == GS_ACT_TANH;
+    const int bmod = a.shuffle_cout > 0 ? a.shuffle_cout : g.Cout;    // bias / output channel = column mod bmod
+    float bvj[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int co = n0 + wn * (BN / 2) + j * 32 + l31;
-        const bool cok = co < g.Cout;
-        const float bv = (a.bias != nullptr && cok) ? a.bias[co] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
+        bvj[j] = (a.bias != nullptr && co < g.Cout) ? a.bias[co % bmod] : 0.f;
+    }
+    if (a.bnp != nullptr) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int j = 0; j < NT; ++j) {
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = acc[i][j][r];
-                s1 += v;
-                s2 += v * v;
-                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int p = rowpix[row];
-                if (cok && p >= 0)
-                    a.y[(int64_t)p * g.out_pix_stride + g.out_coff + co] = Elem<DT>::from_f(act_fwd(v + bv, a.act));
-            }
-        }
-        if (a.bnp != nullptr) {
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[i][j][r];
+                    s1 += v;
+                    s2 += v * v;
+                }
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
             if (h == 0) {
@@ -185,6 +189,73 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
                 red[(wm * 2 + 0) * BN + c] = s1;
                 red[(wm * 2 + 1) * BN + c] = s2;
             }
+        }
+    }
+    // bias + activation in place (slope family branch-free; tanh behind one uniform branch)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[i][j][r] + bvj[j];
+                acc[i][j][r] = v > 0.f ? v : v * slope;
+            }
+    if (is_tanh) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = tanhf(acc[i][j][r]);
+    }
+    if (a.vec_store) {
+        // stage 32 rows x BN/2 columns per wave in LDS, then every lane stores 16-byte channel chunks
+        constexpr int WCOLS = BN / 2, STG_LD = WCOLS + 8, CH = WCOLS / 8;
+        unsigned short* stg = smem + 2048 + wave * (32 * STG_LD);     // behind rowpix / red
+        const int ohw_out = g.OH * g.OW;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    stg[row * STG_LD + j * 32 + l31] = Elem<DT>::from_f(acc[i][j][r]);
+                }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < (32 * CH) / 64; ++q) {
+                const int idx = q * 64 + lane;
+                const int rrow = idx / CH, ch = idx - rrow * CH;
+                const uint4 v = *reinterpret_cast<const uint4*>(stg + rrow * STG_LD + ch * 8);
+                int p = rowpix[wm * 64 + i * 32 + rrow];
+                int co = n0 + wn * WCOLS + ch * 8;
+                if (p >= 0 && co < g.Cout) {
+                    if (a.shuffle_cout > 0) {
+                        const int cls = co / a.shuffle_cout;
+                        co -= cls * a.shuffle_cout;
+                        p += (cls & 1) + ((cls >> 1) & 1) * g.OW + (a.shuffle_cls == 8 ? (cls >> 2) * ohw_out : 0);
+                    }
+                    *reinterpret_cast<uint4*>(a.y + (int64_t)p * g.out_pix_stride + g.out_coff + co) = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int co = n0 + wn * (BN / 2) + j * 32 + l31;
+            const bool cok = co < g.Cout;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int p = rowpix[row];
+                    if (cok && p >= 0)
+                        a.y[(int64_t)p * g.out_pix_stride + g.out_coff + co] = Elem<DT>::from_f(acc[i][j][r]);
+                }
         }
     }
     if (a.bnp != nullptr) {
@@ -407,6 +478,23 @@ int check_geom(const GsConvGeom* g, const char* who) {
 
 }  // namespace
 
+static int launch_igemm(IgemmArgs& a, int dtype, hipStream_t s, const char* who) {
+    const int bn = (a.g.Cout <= 64) ? 64 : 128;
+    a.ntn = cdiv(a.g.Cout, bn);
+    const int mt = cdiv(a.M, FW_BM);
+    a.nblocks = mt * a.ntn;
+    dim3 grid(a.nblocks), block(256);
+    if (dtype == GS_F16) {
+        if (bn == 64) igemm_fwd_kernel<GS_F16, 64><<<grid, block, 0, s>>>(a);
+        else igemm_fwd_kernel<GS_F16, 128><<<grid, block, 0, s>>>(a);
+    } else {
+        if (bn == 64) igemm_fwd_kernel<GS_BF16, 64><<<grid, block, 0, s>>>(a);
+        else igemm_fwd_kernel<GS_BF16, 128><<<grid, block, 0, s>>>(a);
+    }
+    GS_CHECK_LAUNCH(who);
+    return GS_OK;
+}
+
 extern "C" int gs_conv_igemm_mtiles(const GsConvGeom* g) {
     if (!g) return GS_EINVAL;
     return (int)cdiv64((int64_t)g->N * (g->Dg > 0 ? g->Dg : 1) * g->OHg * g->OWg, FW_BM);
@@ -424,21 +512,55 @@ extern "C" int gs_conv_igemm(const GsConvGeom* g, const void* x, const void* w, 
     a.bias = bias; a.bnp = bn_partials; a.act = act;
     a.M = g->N * g->Dg * g->OHg * g->OWg;
     a.kchunks = cdiv(g->Cin, FW_BK);
-    const int bn = (g->Cout <= 64) ? 64 : 128;
-    a.ntn = cdiv(g->Cout, bn);
-    const int mt = cdiv(a.M, FW_BM);
-    a.nblocks = mt * a.ntn;
-    hipStream_t s = (hipStream_t)stream;
-    dim3 grid(a.nblocks), block(256);
-    if (dtype == GS_F16) {
-        if (bn == 64) igemm_fwd_kernel<GS_F16, 64><<<grid, block, 0, s>>>(a);
-        else igemm_fwd_kernel<GS_F16, 128><<<grid, block, 0, s>>>(a);
-    } else {
-        if (bn == 64) igemm_fwd_kernel<GS_BF16, 64><<<grid, block, 0, s>>>(a);
-        else igemm_fwd_kernel<GS_BF16, 128><<<grid, block, 0, s>>>(a);
+    a.vec_store = (g->Cout % 8 == 0 && g->out_pix_stride % 8 == 0 && g->out_coff % 8 == 0) ? 1 : 0;
+    a.shuffle_cout = 0; a.shuffle_cls = 0;
+    return launch_igemm(a, dtype, (hipStream_t)stream, "gs_conv_igemm");
+}
+
+// Merged stride-2 / kernel-2 transposed convolution (unet_parts.py:51 ConvTranspose2d(C, C/2, 2, 2);
+// GenSeg-3D/UNet3D/unet3d.py:68 ConvTranspose3d(k=2, s=2)): every input voxel produces a 2x2(x2) output patch,
+// i.e. ONE pointwise GEMM  [pixels x Cin] . [Cin x ncls*Cout]  with a sub-pixel scatter in the epilogue --
+// the input is read once instead of once per sub-pixel class.
+//   x  [N*D, IH, IW, Cin] 16-bit NHWC (strided);  w = gs_pack_weight slots [ncls][Cout][Cin], slot = (kz*2+ky)*2+kx
+//   y  [N*Dout, OH, OW, *] : voxel (2z+kz+ooz, 2y+ky+ooy, 2x+kx+oox), channels out_coff..out_coff+Cout
+extern "C" int gs_upconv2x2_fwd(const void* x, const void* w, const float* bias, void* y, int N, int D, int IH, int IW,
+                                int Cin, int in_pix_stride, int in_coff, int Cout, int Dout, int OH, int OW,
+                                int out_pix_stride, int out_coff, int ooz, int ooy, int oox, int act, int dtype,
+                                void* stream) {
+    GS_CHECK_ARG(x && w && y, "gs_upconv2x2_fwd: null pointer");
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_upconv2x2_fwd: bad dtype %d", dtype);
+    GS_CHECK_ARG(D >= 1 && Dout >= 1, "gs_upconv2x2_fwd: bad depth");
+    const bool is3d = D > 1 || Dout > 1;
+    const int ncls = is3d ? 8 : 4;
+    GS_CHECK_ARG(Cout > 0 && Cout % 8 == 0 && out_pix_stride % 8 == 0 && out_coff % 8 == 0 &&
+                     out_pix_stride >= out_coff + Cout,
+                 "gs_upconv2x2_fwd: Cout / output stride / offset must be multiples of 8");
+    GS_CHECK_ARG(2 * IH - 1 + ooy < OH && 2 * IW - 1 + oox < OW && (is3d ? 2 * D - 1 + ooz < Dout : (Dout == 1 && ooz == 0)),
+                 "gs_upconv2x2_fwd: output patch exceeds the output tensor");
+    GsConvGeom g{};
+    g.N = N; g.IH = IH; g.IW = IW; g.Cin = Cin; g.in_pix_stride = in_pix_stride; g.in_coff = in_coff;
+    g.OHg = IH; g.OWg = IW; g.Cout = ncls * Cout; g.OH = OH; g.OW = OW;
+    g.out_pix_stride = ncls * Cout > out_pix_stride ? ncls * Cout : out_pix_stride;   // checked below with the real one
+    g.out_coff = 0;
+    g.isy = 1; g.isx = 1; g.osy = 2; g.osx = 2; g.ooy = ooy; g.oox = oox;
+    g.ntaps = 1; g.tap_dy[0] = 0; g.tap_dx[0] = 0; g.tap_w[0] = 0; g.tap_dz[0] = 0;
+    g.Dg = D; g.Din = D; g.Dout = Dout; g.isz = 1; g.osz = is3d ? 2 : 1; g.ooz = ooz;
+    // geometry check on the logical (widened) GEMM, then the physical output layout is put back
+    {
+        GsConvGeom c = g;
+        c.OH = OH + 1; c.OW = OW + 1; c.Dout = Dout + 1;      // the +1 sub-pixel is checked explicitly above
+        int rc = check_geom(&c, "gs_upconv2x2_fwd");
+        if (rc) return rc;
     }
-    GS_CHECK_LAUNCH("gs_conv_igemm");
-    return GS_OK;
+    g.out_pix_stride = out_pix_stride; g.out_coff = out_coff;
+    IgemmArgs a;
+    a.g = g;
+    a.x = (const unsigned short*)x; a.w = (const unsigned short*)w; a.y = (unsigned short*)y;
+    a.bias = bias; a.bnp = nullptr; a.act = act;
+    a.M = N * D * IH * IW;
+    a.kchunks = cdiv(Cin, FW_BK);
+    a.vec_store = 1; a.shuffle_cout = Cout; a.shuffle_cls = ncls;
+    return launch_igemm(a, dtype, (hipStream_t)stream, "gs_upconv2x2_fwd");
 }
 
 extern "C" int gs_conv_wgrad(const GsConvGeom* g, const void* x, const void* dy, float* dw, int dtype,

@@ -211,6 +211,25 @@ def conv3x3_wgrad(x, dy, dw, N, H, W, Cin, Cout, in_stride=None, in_coff=0, out_
                    2.0 * N * H * W * (Cin + Cout) + 4.0 * 9 * Cin * Cout)
 
 
+def upconv2x2_fwd(x, w, bias, y, N, D, IH, IW, Cin, Cout, Dout, OH, OW, in_stride=None, in_coff=0, out_stride=None,
+                  out_coff=0, ooz=0, ooy=0, oox=0, act=ACT_NONE):
+    """ConvTranspose2d/3d(kernel 2, stride 2) forward as one pointwise MFMA GEMM with a sub-pixel scatter.
+    w: packed [4|8][Cout][Cin] (pack_weight(..., transposed=True)); y may be a concat buffer (out_coff)."""
+    _dev(x)
+    _f32(bias, "bias")
+    if not (x.dtype == w.dtype == y.dtype):
+        raise TypeError("upconv2x2_fwd: x, w, y must share one 16-bit dtype")
+    ncls = 8 if (D > 1 or Dout > 1) else 4
+    if w.numel() != ncls * Cout * Cin:
+        raise ValueError("upconv2x2_fwd: packed weight has the wrong size")
+    ev = TIMER.start() if TIMER is not None else None
+    _lib.call("gs_upconv2x2_fwd", _p(x), _p(w), _p(bias), _p(y), N, D, IH, IW, Cin,
+              Cin if in_stride is None else in_stride, in_coff, Cout, Dout, OH, OW,
+              Cout if out_stride is None else out_stride, out_coff, ooz, ooy, oox, act, dt_code(x), _stream())
+    if ev is not None:
+        TIMER.stop("igemm_fwd", ev, 2.0 * N * D * IH * IW * Cin * ncls * Cout)
+
+
 def conv_igemm_mtiles(g: GsConvGeom) -> int:
     return _lib.load().gs_conv_igemm_mtiles(g)
 

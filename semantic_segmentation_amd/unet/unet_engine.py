@@ -208,11 +208,9 @@ class UNetEngine:
             wf, wd = self._packed(wkey, params[wkey], True, need_grad)
             bias = params[prefix + ".up.bias"].detach()
             cat = cats[lvl]
-            for py in range(2):
-                for px in range(2):
-                    g = ops.make_geom(N, h, w, cin_t, h, w, cout_t, H2, W2, [(0, 0)], osy=2, osx=2,
-                                      ooy=py + pt, oox=px + pl, out_stride=2 * cout_t, out_coff=cout_t)
-                    ops.conv_igemm(g, inp, wf[py * 2 + px], cat, bias, None)
+            # all four sub-pixel classes in one pointwise GEMM: the input is read once
+            ops.upconv2x2_fwd(inp, wf, bias, cat, N, 1, h, w, cin_t, cout_t, 1, H2, W2, out_stride=2 * cout_t,
+                              out_coff=cout_t, ooy=pt, oox=pl)
             if need_grad:
                 u = _UpRec()
                 u.name, u.zin, u.cat, u.wd = prefix, inp, cat, wd

@@ -184,6 +184,56 @@ def test_conv_transpose2x2_fwd_bwd(dtn, dt, pad):
     assert rel_err(db.cpu(), b.grad) < 1e-4
 
 
+@pytest.mark.parametrize("dtn,dt", DTS)
+@pytest.mark.parametrize("N,h,w,Cin,Cout,pad", [(2, 5, 6, 128, 64, (0, 0)), (2, 5, 6, 128, 64, (1, 1)),
+                                                 (1, 16, 16, 1024, 512, (0, 0)), (3, 7, 3, 64, 8, (2, 3))])
+def test_upconv2x2_merged_fwd(dtn, dt, N, h, w, Cin, Cout, pad):
+    """gs_upconv2x2_fwd: the four sub-pixel classes of ConvTranspose2d(k2,s2)+bias in ONE pointwise GEMM, written
+    (with the F.pad offset of unet_parts.py:58-61) into the second half of a zeroed concat buffer."""
+    from semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(6)
+    H2, W2 = 2 * h + pad[0], 2 * w + pad[1]
+    pt, pl = pad[0] // 2, pad[1] // 2
+    x = rnd(g, N, Cin, h, w, dt=dt)
+    wt = rnd(g, Cin, Cout, 2, 2, dt=dt, scale=0.05)
+    b = rnd(g, Cout)
+    ref = F.pad(F.conv_transpose2d(x, wt, b, stride=2), [pl, pad[1] - pl, pt, pad[0] - pt])
+    wf = torch.empty(4, Cout, Cin, dtype=dt, device=dev())
+    ops.pack_weight(wt.to(dev()), wf, None, True)
+    cat = torch.zeros(N, H2, W2, 2 * Cout, dtype=dt, device=dev())
+    ops.upconv2x2_fwd(nhwc(x, dt), wf, b.to(dev()), cat, N, 1, h, w, Cin, Cout, 1, H2, W2, out_stride=2 * Cout,
+                      out_coff=Cout, ooy=pt, oox=pl)
+    torch.cuda.synchronize()
+    got = from_nhwc(cat[..., Cout:])
+    # the padded border is never written; inside, compare with the torch result
+    inner = torch.zeros_like(ref, dtype=torch.bool)
+    inner[:, :, pt:pt + 2 * h, pl:pl + 2 * w] = True
+    assert rel_err(got[inner], ref[inner]) < tol(dt)
+    assert float(got[~inner].abs().max() if (~inner).any() else 0.0) == 0.0
+    assert float(cat[..., :Cout].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtn,dt", DTS)
+def test_upconv2x2x2_merged_fwd_3d(dtn, dt):
+    """ConvTranspose3d(k2,s2)+bias (GenSeg-3D/UNet3D/unet3d.py:68) as one GEMM with 8 sub-voxel classes."""
+    from semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(7)
+    N, D, h, w, Cin, Cout = 2, 3, 4, 5, 64, 64
+    x = rnd(g, N, Cin, D, h, w, dt=dt)
+    wt = rnd(g, Cin, Cout, 2, 2, 2, dt=dt, scale=0.05)
+    b = rnd(g, Cout)
+    ref = F.conv_transpose3d(x, wt, b, stride=2)                       # [N,Cout,2D,2h,2w]
+    # pack: slot (kz*2+ky)*2+kx of [8][Cout][Cin]
+    wf = wt.permute(2, 3, 4, 1, 0).reshape(8, Cout, Cin).contiguous().to(dt).to(dev())
+    xd = x.permute(0, 2, 3, 4, 1).contiguous().to(dt).to(dev())       # [N,D,h,w,Cin]
+    y = torch.zeros(N, 2 * D, 2 * h, 2 * w, Cout + 8, dtype=dt, device=dev())
+    ops.upconv2x2_fwd(xd, wf, b.to(dev()), y, N, D, h, w, Cin, Cout, 2 * D, 2 * h, 2 * w, out_stride=Cout + 8, out_coff=8)
+    torch.cuda.synchronize()
+    got = y[..., 8:].float().cpu().permute(0, 4, 1, 2, 3)
+    assert rel_err(got, ref) < tol(dt)
+    assert float(y[..., :8].abs().max()) == 0.0
+
+
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtn,dt", DTS)
 @pytest.mark.parametrize("N,H,W,C,pool", [(2, 8, 6, 64, True), (2, 9, 7, 64, True), (3, 5, 5, 128, False),
