@@ -161,11 +161,8 @@ class UNet3DEngine:
             wd = empty(8, ccur, cu) if need_grad else None
             ops.pack_weight(wt, wf, wd, True)
             bias = sb.upconv1.bias.detach()
-            for cls in range(8):
-                pz, py, px = cls >> 2, (cls >> 1) & 1, cls & 1
-                g = ops.make_geom(NB, h, w, ccur, h, w, cu, H, W, [(0, 0)], osy=2, osx=2, ooy=py, oox=px,
-                                  out_stride=ctot, out_coff=0, Dg=d, Din=d, Dout=D, osz=2, ooz=pz)
-                ops.conv_igemm(g, cur, wf[cls], cats[k], bias, None)
+            # all eight sub-voxel classes in one pointwise GEMM (the input volume is read once)
+            ops.upconv2x2_fwd(cur, wf, bias, cats[k], NB, d, h, w, ccur, cu, D, H, W, out_stride=ctot, out_coff=0)
             if need_grad:
                 taps = [((c >> 1) & 1, c & 1) for c in range(8)]
                 gb = ops.make_geom(NB, H, W, cu, h, w, ccur, h, w, taps, isy=2, isx=2, in_stride=ctot, in_coff=0,
