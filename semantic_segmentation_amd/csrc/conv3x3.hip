@@ -561,6 +561,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
     const int nchunks = (a.Cin + 63) >> 6;
     const unsigned img_bytes = (unsigned)a.H * a.W * a.in_stride * 2u;
 
+#ifdef GS_C3_PHASE_TIMING
+    long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tq = clock64();
+#define PH(i) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = clock64(); ph[i] += t_ - tq; tq = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PH(i) do {} while (0)
+#endif
     struct Item { int n, y0, x0, n0, mtile; };
     auto decode = [&](int it) __attribute__((always_inline)) {
         Item r;
@@ -583,20 +589,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
     uint4 rh[HCH], rw[WCH];
     unsigned wv[2], hv[HCH];
     const unsigned tap_stride = (unsigned)a.Cout * a.Cin * 2u;
-    auto setup_item = [&](const Item& itn) __attribute__((always_inline)) {
+    auto setup_w = [&](int n0) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int co = itn.n0 + rbase + 32 * j;
+            const int co = n0 + rbase + 32 * j;
             wv[j] = co < a.Cout ? (unsigned)((co * a.Cin + chunk * 8) * 2) : VOOB;
         }
+    };
+    auto setup_h = [&](int y0, int x0, int j) __attribute__((always_inline)) {      // j compile-time
+        const int hp = rbase + 32 * j;
+        const int hy = hp / HWD, hx = hp - hy * HWD;
+        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool ok = hp < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        hv[j] = ok ? (unsigned)(((gy * a.W + gx) * a.in_stride + a.in_coff + chunk * 8) * 2) : VOOB;
+    };
+    auto setup_item = [&](const Item& itn) __attribute__((always_inline)) {
+        setup_w(itn.n0);
 #pragma unroll
-        for (int j = 0; j < HCH; ++j) {
-            const int hp = rbase + 32 * j;
-            const int hy = hp / HWD, hx = hp - hy * HWD;
-            const int gy = itn.y0 + hy - 1, gx = itn.x0 + hx - 1;
-            const bool ok = hp < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-            hv[j] = ok ? (unsigned)(((gy * a.W + gx) * a.in_stride + a.in_coff + chunk * 8) * 2) : VOOB;
-        }
+        for (int j = 0; j < HCH; ++j) setup_h(itn.y0, itn.x0, j);
     };
     // WRES (one channel chunk and one N tile: the 64->64 layers): the 9-tap weight slab is the same for every
     // item of the block -- it is staged once by the first stage and stays resident in LDS.
@@ -657,11 +667,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
     auto epilogue_t = [&](const Item& itc, auto plain_tag, auto full_tag) __attribute__((always_inline)) {
         constexpr bool PLAIN = decltype(plain_tag)::value;        // no bias, no activation (every U-Net conv)
         constexpr bool FULL = decltype(full_tag)::value;          // patch completely inside the image
+        // opaque copies: hipcc otherwise hoists the per-item edge weights and store addresses of BOTH
+        // instantiations into the item loop header (~600 VALU instructions per item, measured 23% of the
+        // 64->64 layers) although only one path runs
+        int e_y0 = itc.y0, e_x0 = itc.x0, e_n = itc.n, e_n0 = itc.n0;
+        asm volatile("" : "+s"(e_y0), "+s"(e_x0), "+s"(e_n), "+s"(e_n0));
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.y + (int64_t)e_n * a.H * a.W * a.out_stride), 0, (unsigned)a.H * a.W * a.out_stride * 2u, 0x00020000);
         float bv[2] = {0.f, 0.f};
         if (!PLAIN) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int co = itc.n0 + j * 32 + l31;
+                const int co = e_n0 + j * 32 + l31;
                 bv[j] = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
             }
         }
@@ -677,8 +694,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
                 float w0 = 1.f, w1 = 1.f;
                 if (!FULL && want_stats) {
                     const int p0 = prow0 + rowa;
-                    const int gy0 = itc.y0 + (p0 >> TWS), gx0 = itc.x0 + (p0 & (TW - 1));
-                    const int gy1 = itc.y0 + ((p0 + 1) >> TWS), gx1 = itc.x0 + ((p0 + 1) & (TW - 1));
+                    const int gy0 = e_y0 + (p0 >> TWS), gx0 = e_x0 + (p0 & (TW - 1));
+                    const int gy1 = e_y0 + ((p0 + 1) >> TWS), gx1 = e_x0 + ((p0 + 1) & (TW - 1));
                     w0 = (float)((unsigned)((gy0 - a.H) & (gx0 - a.W)) >> 31);
                     w1 = (float)((unsigned)((gy1 - a.H) & (gx1 - a.W)) >> 31);
                 }
@@ -709,18 +726,26 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            PH(8 + 2 * i);
+            // buffer stores: 32-bit offsets inside the image, out-of-range lanes get an out-of-range offset (the
+            // hardware drops them) -- no exec-mask branch per store, so the four LDS reads are issued back to back
+            uint4 sv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                sv[q] = *reinterpret_cast<const uint4*>(stg + (q * 8 + (lane >> 3)) * C3_LDR + (lane & 7) * 8);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int rrow = q * 8 + (lane >> 3), ch = lane & 7;
-                const uint4 v = *reinterpret_cast<const uint4*>(stg + rrow * C3_LDR + ch * 8);
-                const int p = prow0 + rrow;
-                const int gy = itc.y0 + (p >> TWS), gx = itc.x0 + (p & (TW - 1));
-                const int co = itc.n0 + ch * 8;
-                if ((FULL || (gy < a.H && gx < a.W)) && co < a.Cout && !(dbg & 1))
-                    *reinterpret_cast<uint4*>(a.y + (int64_t)((itc.n * a.H + gy) * a.W + gx) * a.out_stride +
-                                              a.out_coff + co) = v;
+                const int p = prow0 + q * 8 + (lane >> 3);
+                const int gy = e_y0 + (p >> TWS), gx = e_x0 + (p & (TW - 1));
+                const int co = e_n0 + (lane & 7) * 8;
+                const bool ok = (FULL || (gy < a.H && gx < a.W)) && co < a.Cout && !(dbg & 1);
+                const unsigned off = ok ? (unsigned)(((gy * a.W + gx) * a.out_stride + a.out_coff + co) * 2) : VOOB;
+                u32x4 d;
+                d[0] = sv[q].x; d[1] = sv[q].y; d[2] = sv[q].z; d[3] = sv[q].w;
+                __builtin_amdgcn_raw_buffer_store_b128(d, ry, off, 0, 0);
             }
             __builtin_amdgcn_wave_barrier();
+            PH(9 + 2 * i);
         }
         if (want_stats) {
 #pragma unroll
@@ -754,6 +779,31 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
     int it = blockIdx.x;
     if (it >= nitems) return;
     Item cur = decode(it);
+    // items advance by gridDim.x: the (ntile, tx, ty, n) digits are stepped with carries instead of being
+    // re-derived with six integer divisions per item (measured: ~3.5k cycles per item, 23% of the 64->64 layers)
+    int dg0 = it % a.ntn, dg1, dg2, dg3;
+    {
+        int r = it / a.ntn;
+        dg1 = r % a.tiles_x; r /= a.tiles_x;
+        dg2 = r % a.tiles_y; dg3 = r / a.tiles_y;
+    }
+    int st0, st1, st2, st3;
+    {
+        int r = gridDim.x;
+        st0 = r % a.ntn; r /= a.ntn;
+        st1 = r % a.tiles_x; r /= a.tiles_x;
+        st2 = r % a.tiles_y; st3 = r / a.tiles_y;
+    }
+    auto advance_item = [&]() __attribute__((always_inline)) {
+        Item r;
+        dg0 += st0; int c = dg0 >= a.ntn ? 1 : 0; dg0 -= c * a.ntn;
+        dg1 += st1 + c; c = dg1 >= a.tiles_x ? 1 : 0; dg1 -= c * a.tiles_x;
+        dg2 += st2 + c; c = dg2 >= a.tiles_y ? 1 : 0; dg2 -= c * a.tiles_y;
+        dg3 += st3 + c;
+        r.n = dg3; r.y0 = dg2 * TH; r.x0 = dg1 * TW; r.n0 = dg0 * BN;
+        r.mtile = (dg3 * a.tiles_y + dg2) * a.tiles_x + dg1;
+        return r;
+    };
     setup_item(cur);
     load_stage(cur, 0, std::true_type{});
     zero_acc();
@@ -762,10 +812,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
         const int nit = it + gridDim.x;
         const bool more_items = nit < nitems;
         Item nxt = cur;
-        if (more_items) nxt = decode(nit);
+        if (more_items) nxt = advance_item();
         for (int cc = 0; cc < nchunks; ++cc) {
             const bool more_cc = cc + 1 < nchunks;
+#ifdef GS_C3_PHASE_TIMING
+            PH(6);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PH(7);
+#endif
             __syncthreads();                       // previous stage fully consumed (and epilogue staging done)
+            PH(0);
             if (WRES) {
                 if (first) store_stage(std::true_type{});         // only the very first stage carries the weights
                 else store_stage(std::false_type{});
@@ -774,8 +830,47 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
                 store_stage(std::true_type{});
             }
             __syncthreads();
-            if (more_cc) load_stage(cur, cc + 1, LoopW{});
-            else if (more_items) { setup_item(nxt); load_stage(nxt, 0, LoopW{}); }
+            PH(1);
+            // The prefetch of the next stage is spread over the K loop (one 16-byte load per lane per MFMA
+            // step): issued in one burst in front of the loop, its 29 loads per lane keep the wave in the
+            // memory-issue queue (~2k cycles per CU) before the first MFMA can start.  No next stage: the
+            // voffsets are forced out of range and the loads return zeros that nobody reads.
+            // With one wave per SIMD nothing hides ALU latency: in the single-chunk (WRES) kernel, where a new
+            // item starts every stage, the ~250 address instructions of the next item's halo offsets are
+            // interleaved with the first SH MFMA steps as well and the loads follow.  (Multi-chunk layers change
+            // item once per nchunks stages; recomputing the offsets every stage costs more than it hides.)
+            const bool have_next = more_cc || more_items;
+            const Item& ldi = more_cc ? cur : nxt;
+            constexpr int SH = WRES ? (HCH + 1) / 2 : 0;
+            if (!WRES && !more_cc && more_items) setup_item(nxt);
+            const __amdgpu_buffer_rsrc_t rx_n = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(a.x + (int64_t)ldi.n * a.H * a.W * a.in_stride), 0, img_bytes, 0x00020000);
+            const unsigned sc_n = more_cc ? (unsigned)(cc + 1) * 128u : 0u;
+            const unsigned kill = have_next ? 0u : VOOB;
+            auto issue_load = [&](int j) __attribute__((always_inline)) {       // j is a compile-time constant
+                constexpr int NW = WRES ? 0 : WCH;
+                if (j < NW) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wv[j & 1] | kill,
+                                                                          sc_n + (unsigned)(j >> 1) * tap_stride, 0);
+                    rw[j < NW ? j : 0] = make_uint4(v[0], v[1], v[2], v[3]);
+                } else if (j - NW < HCH) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx_n, hv[j - NW < HCH ? j - NW : 0] | kill, sc_n, 0);
+                    rh[j - NW < HCH ? j - NW : 0] = make_uint4(v[0], v[1], v[2], v[3]);
+                }
+            };
+            static_assert(SH + (WRES ? 0 : WCH) + HCH <= 36, "address setup + prefetch loads must fit the 36 MFMA steps");
+            auto setup_step = [&](int step) __attribute__((always_inline)) {    // step compile-time, < SH
+                int py0 = ldi.y0, px0 = ldi.x0, pn0 = ldi.n0;
+                asm volatile("" : "+s"(py0), "+s"(px0), "+s"(pn0));              // keep this arithmetic in the K loop
+                if (step == 0) setup_w(pn0);
+                if (2 * step < HCH) setup_h(py0, px0, 2 * step < HCH ? 2 * step : 0);
+                if (2 * step + 1 < HCH) setup_h(py0, px0, 2 * step + 1 < HCH ? 2 * step + 1 : 0);
+            };
+            if (dbg & 2) {
+                if (WRES) setup_item(ldi);
+#pragma unroll
+                for (int j = 0; j < 36; ++j) issue_load(j);
+            }
             if (!(dbg & 2)) {
                 // 36 steps (tap, kk) of 4 MFMAs; the four fragment reads of step s+1 are issued BEFORE the MFMAs
                 // of step s (hipcc otherwise schedules them just-in-time behind lgkmcnt(0) and the LDS latency
@@ -795,6 +890,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
                 for (int step = 0; step < 36; ++step) {
                     const int cur = step & 1;
                     if (step + 1 < 36) frag_load(step + 1, af[cur ^ 1], bf[cur ^ 1]);
+                    if (step < SH) setup_step(step);
+                    else issue_load(step - SH);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
@@ -803,18 +900,29 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            PH(2);
             if (!more_cc) {
                 __syncthreads();                   // every wave is done reading the halo: staging may overlay it
-                epilogue(cur);
+                PH(3);
+                if (!(dbg & 4)) epilogue(cur);
                 zero_acc();
+                PH(4);
                 __syncthreads();
                 finish_stats(cur);
+                PH(5);
             }
         }
         if (!more_items) break;
         it = nit;
         cur = nxt;
     }
+#ifdef GS_C3_PHASE_TIMING
+    if (blockIdx.x == 0 && lane == 0 && (a.bias != nullptr || a.bnp != nullptr)) {   // debug build only
+        float* sink = a.bias != nullptr ? const_cast<float*>(a.bias) : a.bnp;      // bias / partials double as sink
+        for (int i = 0; i < 16; ++i) sink[wave * 16 + i] = (float)ph[i];
+    }
+#endif
+#undef PH
 }
 
 struct C3Plan { int bn, tw, th, tiles_x, tiles_y; };
@@ -845,8 +953,10 @@ namespace { int c3_variant_get() { return c3_variant(); } }
 static bool c3_use_big(int Cout, int out_pix_stride, int out_coff) {
     return c3_variant() == 2 && (Cout % 8) == 0 && (out_pix_stride % 8) == 0 && (out_coff % 8) == 0;
 }
-static bool c3_big_ok(int H, int W, int Cin, int in_pix_stride, int Cout) {
-    return (Cin % 64) == 0 && (int64_t)H * W * in_pix_stride * 2 < 2147483000LL && (int64_t)9 * Cout * Cin * 2 < 2147483000LL;
+static bool c3_big_ok(int H, int W, int Cin, int in_pix_stride, int Cout, int out_pix_stride) {
+    // 32-bit buffer offsets with bit 31 as the "out of range" marker: one image and the weights stay below 2 GiB
+    return (Cin % 64) == 0 && (int64_t)H * W * in_pix_stride * 2 < 2147483000LL &&
+           (int64_t)H * W * out_pix_stride * 2 < 2147483000LL && (int64_t)9 * Cout * Cin * 2 < 2147483000LL;
 }
 
 extern "C" int gs_conv3x3_mtiles(int N, int H, int W, int Cout) {
@@ -881,7 +991,7 @@ extern "C" int gs_conv3x3(const void* x, const void* w, void* y, const float* bi
     hipStream_t s = (hipStream_t)stream;
     GS_CHECK_ARG((act & 0xff) == GS_ACT_NONE || (act & 0xff) == GS_ACT_RELU || (act & 0xff) == GS_ACT_LEAKY02,
                  "gs_conv3x3: activation %d not supported (use gs_conv_igemm)", act & 0xff);
-    if (c3_use_big(Cout, out_pix_stride, out_coff) && c3_big_ok(H, W, Cin, in_pix_stride, Cout)) {
+    if (c3_use_big(Cout, out_pix_stride, out_coff) && c3_big_ok(H, W, Cin, in_pix_stride, Cout, out_pix_stride)) {
         const int tw = (W >= 24) ? 32 : 16, th = 256 / tw;
         a.tiles_x = cdiv(W, tw); a.tiles_y = cdiv(H, th);
         a.ntn = cdiv(Cout, 64);
