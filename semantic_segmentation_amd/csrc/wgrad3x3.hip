@@ -43,7 +43,13 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const W3Args a) {
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    int bid = blockIdx.x;
+    // XCD-aware: the (co, ci) channel-block pairs that share one patch range read the same dY / X tiles, so
+    // they get consecutive logical ids inside ONE XCD (blocks with equal id % 8 share an XCD and its L2)
+    int bid;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
     const int cob = bid % a.ncob; bid /= a.ncob;
     const int cib = bid % a.ncib; bid /= a.ncib;
     const int ks = bid;
@@ -58,34 +64,42 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const W3Args a) {
     const bool ci_ok = ci0 + chunk * 8 < a.Cin, co_ok = co0 + chunk * 8 < a.Cout;
 
     uint4 rd[4], rh[HCH];
-    auto load_patch = [&](int patch) __attribute__((always_inline)) {
+    // prefetch of the next patch, split so that the loads can be spread over the MFMA steps of the current one
+    struct Pf { int y0, x0; __amdgpu_buffer_rsrc_t rx, rdy; unsigned kill; };
+    auto prep_patch = [&](int patch, bool live) __attribute__((always_inline)) {
+        Pf f;
         const int tx = patch % a.tiles_x;
         const int r = patch / a.tiles_x;
         const int ty = r % a.tiles_y, n = r / a.tiles_y;
-        const int y0 = ty * TH, x0 = tx * TW;
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(a.x + (int64_t)n * a.H * a.W * a.in_stride), 0, x_img_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(a.dy + (int64_t)n * a.H * a.W * a.out_stride), 0, dy_img_bytes, 0x00020000);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        f.y0 = ty * TH; f.x0 = tx * TW;
+        f.rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)n * a.H * a.W * a.in_stride), 0, x_img_bytes, 0x00020000);
+        f.rdy = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + (int64_t)n * a.H * a.W * a.out_stride), 0, dy_img_bytes, 0x00020000);
+        f.kill = live ? 0u : OOB;                  // no next patch: every offset out of range (loads return zeros)
+        return f;
+    };
+    auto issue_load = [&](const Pf& f, int j) __attribute__((always_inline)) {      // j compile-time, 0 .. 4+HCH-1
+        if (j < 4) {
             const int p = row0 + 32 * j;
-            const int gy = y0 + (p >> TWS), gx = x0 + (p & (TW - 1));
+            const int gy = f.y0 + (p >> TWS), gx = f.x0 + (p & (TW - 1));
             const bool ok = co_ok && gy < a.H && gx < a.W;
             const unsigned off = ok ? (unsigned)(((gy * a.W + gx) * a.out_stride + a.out_coff + co0 + chunk * 8) * 2) : OOB;
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0);
-            rd[j] = make_uint4(v[0], v[1], v[2], v[3]);
-        }
-#pragma unroll
-        for (int j = 0; j < HCH; ++j) {
-            const int hp = row0 + 32 * j;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(f.rdy, off | f.kill, 0, 0);
+            rd[j < 4 ? j : 0] = make_uint4(v[0], v[1], v[2], v[3]);
+        } else if (j - 4 < HCH) {
+            const int jj = j - 4 < HCH ? j - 4 : 0;
+            const int hp = row0 + 32 * jj;
             const int hy = hp / HWD, hx = hp - hy * HWD;
-            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+            const int gy = f.y0 + hy - 1, gx = f.x0 + hx - 1;
             const bool ok = ci_ok && hp < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
             const unsigned off = ok ? (unsigned)(((gy * a.W + gx) * a.in_stride + a.in_coff + ci0 + chunk * 8) * 2) : OOB;
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
-            rh[j] = make_uint4(v[0], v[1], v[2], v[3]);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(f.rx, off | f.kill, 0, 0);
+            rh[jj] = make_uint4(v[0], v[1], v[2], v[3]);
         }
+    };
+    auto load_patch = [&](int patch) __attribute__((always_inline)) {
+        const Pf f = prep_patch(patch, true);
+#pragma unroll
+        for (int j = 0; j < 4 + HCH; ++j) issue_load(f, j);
     };
     auto store_patch = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -115,12 +129,16 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const W3Args a) {
         __syncthreads();                 // previous patch fully consumed
         store_patch();
         __syncthreads();
-        if (patch + 1 < p_end) load_patch(patch + 1);
-#pragma unroll 2
+        const bool more = patch + 1 < p_end;
+        const Pf pf = prep_patch(more ? patch + 1 : patch, more);
+        static_assert(4 + HCH <= 2 * (W3_BM / 16), "prefetch loads must fit two per k16 step");
+#pragma unroll
         for (int k16 = 0; k16 < W3_BM / 16; ++k16) {
             const int pb = k16 * 16;
             const int py = pb >> TWS, px0 = pb & (TW - 1);
             const V8 af = tr_read8<DT>(a_base + pb * W3_LDR, a_base + (pb + 4) * W3_LDR);
+            issue_load(pf, 2 * k16);               // two 16-byte loads of the next patch per 9 MFMAs
+            issue_load(pf, 2 * k16 + 1);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int hrow = (py + tap / 3) * HWD + px0 + tap % 3;      // (py+1+dy)*HWD + px0+1+dx
