@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--classes", type=int, default=2)
     ap.add_argument("--dtype", default=os.environ.get("GSSEG_DTYPE", "f16"), choices=["f16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-input", action="store_true",
+                    help="PCIe-inclusive variant: copy the batch from pinned host memory inside every timed step")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=2)
     return ap.parse_args()
@@ -134,13 +136,18 @@ def main():
     if world > 1:
         reducer = GradReducer(net.named_parameters()).attach(net.engine)
     x, mask = oracle.synthetic_batch(args.batch, args.size, seed=1234 + rank)
+    if args.host_input:
+        x_host, mask_host = x.pin_memory(), mask.pin_memory()
     x, mask = x.to(dev), mask.to(dev)
 
     def step():
         for p in net.parameters():
             p.grad = None
         net.engine.invalidate_packs()      # weights change every step in training: re-pack inside the timed region
-        loss = seg_loss(net(x), mask)
+        xs, ms = x, mask
+        if args.host_input:
+            xs, ms = x_host.to(dev, non_blocking=True), mask_host.to(dev, non_blocking=True)
+        loss = seg_loss(net(xs), ms)
         loss.backward()
         return loss
 
@@ -198,6 +205,7 @@ def main():
         "config": {"workload": f"unet.UNet(1,{args.classes}) {args.size}x{args.size} fwd+bwd, CE+Dice loss, "
                                f"batch {args.batch}/GPU (BASELINE configs[1])",
                    "global_batch": world * args.batch, "parallelism": f"dp{world}", "loss": float(loss.item())},
+        "input": "pinned host memory, copied every step (PCIe-inclusive)" if args.host_input else "resident in HBM",
         "whole_step_tflops": round(value * gf / 1e3, 1),
         "whole_step_frac_of_mfma_peak": round(value * gf / 1e3 / (MFMA_PEAK_TFLOPS * world), 4),
         "roofline": roof, "kernels": kern,

@@ -25,3 +25,14 @@ def install(force: bool = True) -> None:
         put("util", util)
     util.dice_score = _dice
     put("util.dice_score", _dice)
+    # Pix2Pix side: `from models_pix2pix import create_model, networks` (train_end2end_jsrt.py:17,55-59) and the
+    # architecture package networks.py imports (networks.py:8-9)
+    from . import architecture_pix2pix as _arch, models_pix2pix as _mp
+    from .architecture_pix2pix import genotypes as _geno, operations as _opsmod
+    from .models_pix2pix import networks as _networks, pix2pix_model as _pm
+    put("models_pix2pix", _mp)
+    put("models_pix2pix.networks", _networks)
+    put("models_pix2pix.pix2pix_model", _pm)
+    put("architecture_pix2pix", _arch)
+    put("architecture_pix2pix.genotypes", _geno)
+    put("architecture_pix2pix.operations", _opsmod)

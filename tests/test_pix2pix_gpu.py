@@ -2,6 +2,7 @@
 reference (tests/golden/pix2pix_256.npz: seeded weights, dropout disabled) and vs the CPU oracle.  GPU only.
 Measured deltas are written to gpurun_out/parity_pix2pix.json."""
 import json
+import math
 import os
 
 import numpy as np
@@ -228,3 +229,60 @@ def test_generator_train_forward_vs_oracle_batch8():
                                        "worst": float(max(rel)), "arch": arel}
     _dump()
     assert np.median(rel) < 0.15 and arel < 0.1, REPORT["G_train_b8_grad_rel_l2"]
+
+
+def _pix2pix_opt(tmp_path, ngf=64):
+    import argparse
+    return argparse.Namespace(model="pix2pix", input_nc=1, output_nc=1, ngf=ngf, ndf=64, netG="unet_256", netD="basic",
+                              n_layers_D=3, norm="batch", no_dropout=False, init_type="normal", init_gain=0.02,
+                              gpu_ids=[0], cuda_index=0, isTrain=True, gan_mode="vanilla", lr=2e-4, beta1=0.5,
+                              arch_lr=3e-4, lambda_L1=100.0, lr_policy="linear", n_epochs=2, n_epochs_decay=2,
+                              epoch_count=1, checkpoints_dir=str(tmp_path), name="p2p", continue_train=False,
+                              verbose=False)
+
+
+def test_create_model_surface_and_stage1_steps(tmp_path):
+    """`create_model(opt)` object of the reference (models_pix2pix/pix2pix_model.py, base_model.py): one
+    optimize_parameters + optimize_architect iteration runs on the HIP engines, updates G, D and the up-conv
+    architecture tensor, and save_model / load_model round-trips bit-exactly (train_pix2pix_lung.py:65-103)."""
+    import semantic_segmentation_amd.compat as compat
+    compat.install()
+    from models_pix2pix import create_model, networks as nw
+    torch.manual_seed(3)
+    model = create_model(_pix2pix_opt(tmp_path))
+    model.setup(model.opt)
+    for attr in ("netG", "netD", "optimizer_G", "optimizer_D", "optimizer_arch_upconv", "optimizer_arch_conv",
+                 "criterionGAN", "set_input", "set_input_1", "optimize_parameters", "optimize_architect",
+                 "save_model", "load_model", "eval", "test", "update_learning_rate", "get_current_losses"):
+        assert hasattr(model, attr), attr
+    g = torch.Generator().manual_seed(5)
+    mask = (torch.rand(2, 1, 256, 256, generator=g) > 0.6).float()
+    image = torch.rand(2, 1, 256, 256, generator=g) * 2 - 1
+    g0 = [p.detach().clone() for p in list(model.netG.parameters())[:3]]
+    d0 = [p.detach().clone() for p in list(model.netD.parameters())[:3]]
+    a0 = nw.upconv_arch.detach().clone()
+    model.set_input_1({"image": image, "mask": mask})
+    model.optimize_parameters()
+    losses = model.get_current_losses()
+    assert set(losses) == {"G_GAN", "G_L1", "D_real", "D_fake"} and all(math.isfinite(v) for v in losses.values())
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(g0, list(model.netG.parameters())[:3]))
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(d0, list(model.netD.parameters())[:3]))
+    model.optimize_architect(image, mask)
+    assert not torch.equal(a0, nw.upconv_arch.detach())            # the arch optimiser really owns the leaf tensor
+    model.update_learning_rate()
+    # checkpoint round trip
+    out = tmp_path / "ckpt"
+    model.save_model(str(out))
+    sdG = {k: v.detach().clone() for k, v in model.netG.state_dict().items()}
+    arch_saved = nw.upconv_arch.detach().clone()
+    with torch.no_grad():
+        for p in model.netG.parameters():
+            p.add_(1.0)
+        nw.upconv_arch.add_(1.0)
+    model.load_model(str(out / "pix2pix_discriminator.pkl"), str(out / "pix2pix_generator.pkl"))
+    for k, v in model.netG.state_dict().items():
+        assert torch.equal(v, sdG[k]), k
+    assert torch.equal(nw.upconv_arch.detach(), arch_saved)
+    model.eval()
+    model.test()
+    assert model.fake_image.shape == (2, 1, 256, 256) and torch.isfinite(model.fake_image).all()
