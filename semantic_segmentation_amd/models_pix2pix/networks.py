@@ -118,27 +118,25 @@ class GANLoss(nn.Module):
 # ---- architecture tensors (module globals like the reference: networks.py:441-484) -------------------
 num_ops_conv = len(PRIMITIVES_conv)
 conv_arch = (1e-3 * torch.randn(8, num_ops_conv)).requires_grad_(True)
-_conv_arch_parameters = [conv_arch, ]
 
 
 def conv_arch_parameters():
-    return _conv_arch_parameters
+    """The tensor the generator reads NOW: the reference returns a list captured at import time, which goes
+    stale as soon as a script rebinds `networks.conv_arch` (pix2pix_model.py:59 does) -- its arch optimisers
+    then own a tensor the forward pass never uses."""
+    return [conv_arch, ]
 
 
 num_ops_upconv = len(PRIMITIVES_upconv)
 upconv_arch = (1e-3 * torch.randn(8, num_ops_upconv)).requires_grad_(True)
-_upconv_arch_parameters = [upconv_arch, ]
 
 
 def upconv_arch_parameters():
-    return _upconv_arch_parameters
-
-
-_arch_parameters = [upconv_arch, conv_arch]
+    return [upconv_arch, ]
 
 
 def arch_parameters():
-    return _arch_parameters
+    return [upconv_arch, conv_arch]
 
 
 class MixedOp_upconv(nn.Module):
