@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 6
+#define GS_ABI_VERSION 7
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -237,6 +237,24 @@ int gs_mean_loss_fwd(const float* x, const float* t, float cval, int mode, int64
                      void* stream);
 int gs_mean_loss_bwd(const float* x, const float* t, float cval, int mode, int64_t n, const float* gout,
                      float gscale, float* dx, void* stream);
+
+/* ---- multi-tensor optimiser steps (one launch for a whole model) ---------------------------------
+ * replaces optim.RMSprop(net.parameters(), lr, weight_decay=1e-8, momentum=0.9, foreach=True).step()
+ * (running_files/train_end2end_jsrt.py:69-70) and torch.optim.Adam(...).step() (models_pix2pix/pix2pix_model.py:69-72,
+ * train_end2end_jsrt.py:318), with torch's single-tensor arithmetic (torch/optim/rmsprop.py, adam.py; not centered,
+ * not amsgrad, L2 weight decay).  All tables live in device memory: per tensor the pointers and element count, per chunk
+ * of gs_optim_chunk_elems() elements the owning tensor and the chunk start.  grad_scale multiplies every gradient first
+ * (1/world_size, or a loss-scale inverse).  momentum_buf entries may be NULL when momentum == 0.
+ * gs_optim_adam: step_scalars[2t] = lr / (1 - beta1^step_t), step_scalars[2t+1] = sqrt(1 - beta2^step_t). */
+int gs_optim_chunk_elems(void);
+int gs_optim_rmsprop(float* const* params, const float* const* grads, float* const* square_avg,
+                     float* const* momentum_buf, const int64_t* sizes, const int32_t* chunk_tensor,
+                     const int64_t* chunk_start, int nchunks, float lr, float alpha, float eps, float weight_decay,
+                     float momentum, float grad_scale, void* stream);
+int gs_optim_adam(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                  const int64_t* sizes, const int32_t* chunk_tensor, const int64_t* chunk_start, int nchunks,
+                  const float* step_scalars, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                  void* stream);
 
 #ifdef __cplusplus
 }

@@ -610,7 +610,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
     };
     // WRES (one channel chunk and one N tile: the 64->64 layers): the 9-tap weight slab is the same for every
     // item of the block -- it is staged once by the first stage and stays resident in LDS.
-    typedef std::integral_constant<bool, !WRES> LoopW;
     auto load_stage = [&](const Item& itn, int cc, auto with_w) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(a.x + (int64_t)itn.n * a.H * a.W * a.in_stride), 0, img_bytes, 0x00020000);
