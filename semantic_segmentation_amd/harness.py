@@ -1,0 +1,195 @@
+"""Betty-free end-to-end training harness: the four problems of
+running_files/train_end2end_jsrt.py (Generator :141-154, Discriminator :157-172, Unet :176-226, Arch :229-236),
+their optimisers (:69-71, pix2pix_model.py:69-72, :318), `SSEngine.validation` (:239-255: Dice on the validation
+loader, best-checkpoint save, ReduceLROnPlateau) and the final save (:345) -- without betty / wandb / imgaug.
+
+What is reproduced is the PER-STEP MATH with first-order updates, in the order Betty's engine visits the problems
+(lower problems every iteration, the upper `arch` problem every `unroll_steps` iterations).  Betty's scheduling
+and its darts finite-difference hypergradient are NOT reproduced (betty-ml is not vendored by the reference and no
+reference test pins it -- SURVEY section 8c): the architecture step here is the plain gradient of its own loss;
+as written in the reference that loss (validation loss of the U-Net) does not depend on the architecture tensors
+in first order, so the step is a no-op unless `arch_through_generator=True` routes the validation masks through
+G first (the dependency the reference's `l2u` table intends, :329).
+
+Everything heavy (U-Net, generator, discriminator, fused losses, fused RMSprop/Adam) runs on the HIP kernels.
+
+    python -m semantic_segmentation_amd.harness --synthetic --iters 20 --batch-size 2
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import time
+from typing import Callable, Dict, Iterable, Iterator, Optional
+
+import torch
+
+from . import optim as gs_optim
+from . import steps
+from .models_pix2pix import networks
+from .unet import UNet
+from .unet.evaluate import evaluate
+
+
+def _cycle(loader: Iterable) -> Iterator:
+    while True:
+        for batch in loader:
+            yield batch
+
+
+class EndToEndTrainer:
+    def __init__(self, net, netG, netD, criterionGAN, train_loader, val_loader, device, *, unet_lr=1e-5, gan_lr=2e-4,
+                 beta1=0.5, arch_lr=3e-4, lambda_L1=100.0, loss_lambda=1.0, unroll_steps=1, valid_every=10,
+                 mask_augment: Optional[Callable] = None, save_dir: Optional[str] = None,
+                 arch_through_generator: bool = False, train_gan: bool = True):
+        self.net, self.netG, self.netD, self.criterionGAN = net, netG, netD, criterionGAN
+        self.device, self.train_loader, self.val_loader = device, train_loader, val_loader
+        self.lambda_L1, self.loss_lambda, self.unroll_steps, self.valid_every = lambda_L1, loss_lambda, unroll_steps, valid_every
+        self.mask_augment, self.save_dir, self.train_gan = mask_augment, save_dir, train_gan
+        self.arch_through_generator = arch_through_generator
+        # optimisers of the reference, fused
+        self.optimizer_unet = gs_optim.RMSprop(net.parameters(), lr=unet_lr, weight_decay=1e-8, momentum=0.9)
+        self.scheduler_unet = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer_unet, "max", patience=5)
+        self.optimizer_G = gs_optim.Adam(netG.parameters(), lr=gan_lr, betas=(beta1, 0.999))
+        self.optimizer_D = gs_optim.Adam(netD.parameters(), lr=gan_lr, betas=(beta1, 0.999))
+        self.optimizer_arch = torch.optim.Adam(networks.arch_parameters(), lr=arch_lr, betas=(0.5, 0.999), weight_decay=1e-5)
+        self.global_step, self.val_best_score, self.history = 0, -1.0, []
+        self._train_iter, self._val_iter = _cycle(train_loader), _cycle(val_loader)
+
+    # ---- one batch to the device in the layout the steps expect (JSRT_loader dict keys) ----
+    def _batch(self, batch: Dict[str, torch.Tensor]):
+        image = batch["image"].to(self.device, dtype=torch.float32, non_blocking=True)
+        mask = batch["mask"].to(self.device, non_blocking=True)
+        if mask.dim() == 3:
+            mask = mask.unsqueeze(1)
+        return image, mask
+
+    def _set_requires_grad(self, module, flag: bool):
+        for p in module.parameters():
+            p.requires_grad = flag
+
+    def train_iteration(self) -> Dict[str, float]:
+        image, mask = self._batch(next(self._train_iter))
+        real_mask, real_image = mask.float(), image
+        out: Dict[str, float] = {}
+        if self.train_gan:
+            # Generator problem (:141-154): D frozen, GAN + lambda*L1
+            self._set_requires_grad(self.netD, False)
+            self.optimizer_G.zero_grad(set_to_none=True)
+            loss_g = steps.generator_step_loss(self.netG, self.netD, self.criterionGAN, real_mask, real_image, self.lambda_L1)
+            loss_g.backward()
+            self.optimizer_G.step()
+            # Discriminator problem (:157-172)
+            self._set_requires_grad(self.netD, True)
+            self.optimizer_D.zero_grad(set_to_none=True)
+            loss_d = steps.discriminator_step_loss(self.netG, self.netD, self.criterionGAN, real_mask, real_image)
+            loss_d.backward()
+            self.optimizer_D.step()
+            out.update(loss_G=float(loss_g.detach()), loss_D=float(loss_d.detach()))
+        # Unet problem (:176-226): real pair + generated pair from the (augmented) masks
+        self.optimizer_unet.zero_grad(set_to_none=True)
+        loss_u = steps.unet_step_loss(self.net, self.netG, image, mask, self.loss_lambda, self.mask_augment)
+        loss_u.backward()
+        self.optimizer_unet.step()
+        out["loss_unet"] = float(loss_u.detach())
+        self.global_step += 1
+        # Arch problem (:229-236) on validation data, every unroll_steps lower iterations
+        if self.global_step % self.unroll_steps == 0:
+            v_image, v_mask = self._batch(next(self._val_iter))
+            self.optimizer_arch.zero_grad(set_to_none=True)
+            if self.arch_through_generator:
+                fake = self.netG(v_mask.float())
+                loss_a = steps.arch_step_loss(self.net, fake, v_mask)
+            else:
+                loss_a = steps.arch_step_loss(self.net, v_image, v_mask)
+            for p in self.net.parameters():                    # the arch optimiser owns only the arch tensors
+                p.grad = None
+            loss_a.backward()
+            if any(a.grad is not None for a in networks.arch_parameters()):
+                self.optimizer_arch.step()
+            for p in list(self.net.parameters()) + list(self.netG.parameters()):
+                p.grad = None
+            out["loss_arch"] = float(loss_a.detach())
+        if self.valid_every and self.global_step % self.valid_every == 0:
+            out["val_score"] = self.validation()
+        self.history.append(out)
+        return out
+
+    @torch.no_grad()
+    def validation(self) -> float:
+        """SSEngine.validation (:239-255)."""
+        score = float(evaluate(self.net, self.val_loader, self.device, False))
+        if score > self.val_best_score:
+            self.val_best_score = score
+            if self.save_dir:
+                os.makedirs(self.save_dir, exist_ok=True)
+                torch.save(self.net.state_dict(), os.path.join(self.save_dir, "unet.pkl"))
+        n_train = max(len(self.train_loader), 1)
+        if self.global_step % n_train == 0 and self.global_step:
+            self.scheduler_unet.step(self.val_best_score)
+        return score
+
+    def run(self, iters: int, log_every: int = 10) -> None:
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            out = self.train_iteration()
+            if log_every and self.global_step % log_every == 0:
+                msg = " ".join(f"{k}={v:.4f}" for k, v in out.items())
+                print(f"[{self.global_step:6d}] {msg}  ({(time.perf_counter() - t0) / self.global_step * 1e3:.1f} ms/iter)", flush=True)
+        if self.save_dir:
+            os.makedirs(self.save_dir, exist_ok=True)
+            torch.save(self.net.state_dict(), os.path.join(self.save_dir, "final.pkl"))      # :345
+
+
+class SyntheticLungDataset(torch.utils.data.Dataset):
+    """Stand-in for util/JSRT_loader.py's BasicDataset (needs torchvision + private data): emits the same dict keys
+    (`image` float [1,H,W] in [0,1], `mask` int64 [1,H,W]) with 1-3 filled ellipses per image."""
+
+    def __init__(self, n: int, size: int = 256, seed: int = 0):
+        self.n, self.size, self.seed = n, size, seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 100003 + i)
+        s = self.size
+        yy, xx = torch.meshgrid(torch.arange(s, dtype=torch.float32), torch.arange(s, dtype=torch.float32), indexing="ij")
+        mask = torch.zeros(s, s, dtype=torch.bool)
+        for _ in range(int(torch.randint(1, 4, (1,), generator=g))):
+            cy, cx = (torch.rand(2, generator=g) * 0.6 + 0.2) * s
+            ry, rx = (torch.rand(2, generator=g) * 0.27 + 0.08) * s
+            mask |= ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0
+        m = mask.float()
+        image = (0.25 + 0.5 * m + 0.1 * torch.randn(s, s, generator=g)).clamp(0, 1)
+        return {"image": image.unsqueeze(0), "mask": mask.long().unsqueeze(0)}
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="Betty-free GenSeg end-to-end loop on the MI355X kernels")
+    ap.add_argument("--synthetic", action="store_true", help="synthetic lung-like data (no dataset ships with the repo)")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--batch-size", type=int, default=2)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--classes", type=int, default=1)
+    ap.add_argument("--ngf", type=int, default=64)
+    ap.add_argument("--unet-lr", type=float, default=1e-5)
+    ap.add_argument("--save-dir", default=None)
+    ap.add_argument("--no-gan", action="store_true", help="freeze the Pix2Pix pair (only the Unet / Arch problems step)")
+    args = ap.parse_args(argv)
+    if not args.synthetic:
+        raise SystemExit("only --synthetic data ships with this repository; build the loaders of your dataset and use EndToEndTrainer")
+    dev = torch.device("cuda", 0)
+    net = UNet(1, args.classes).to(dev)
+    netG = networks.define_G(1, 1, args.ngf, "unet_256", "batch", True, "normal", 0.02, [0])
+    netD = networks.define_D(2, 64, "basic", 3, "batch", "normal", 0.02, [0])
+    crit = networks.GANLoss("vanilla").to(dev)
+    mk = lambda n, seed: torch.utils.data.DataLoader(SyntheticLungDataset(n, args.size, seed), batch_size=args.batch_size,
+                                                     shuffle=True, drop_last=True)
+    trainer = EndToEndTrainer(net, netG, netD, crit, mk(8 * args.batch_size, 1), mk(2 * args.batch_size, 2), dev,
+                              unet_lr=args.unet_lr, save_dir=args.save_dir, train_gan=not args.no_gan)
+    trainer.run(args.iters, log_every=5)
+
+
+if __name__ == "__main__":
+    main()
