@@ -421,8 +421,20 @@ __global__ __launch_bounds__(256) void colsum_stage2(const float* ws, int nblock
     const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double s = 0.0;
-    if (c < C)
-        for (int i = tl; i < nblocks; i += 8) s += (double)ws[(int64_t)i * C + c];
+    if (c < C) {
+        // eight independent loads in flight per lane (the chain of dependent adds was latency bound: 34 us for 1024 rows)
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int i = tl;
+        for (; i + 56 < nblocks; i += 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ws[(int64_t)(i + 8 * u) * C + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += (double)v[u];
+        }
+        for (; i < nblocks; i += 8) a[0] += (double)ws[(int64_t)i * C + c];
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
     red[tl][cl] = s;
     __syncthreads();
     if (tl == 0 && c < C) {

@@ -9,7 +9,7 @@
 
 namespace {
 
-constexpr int SC_TILE = 256;        // output pixels per block / BN tile (small-Cin fwd)
+constexpr int SC_TILE = 1024;       // output pixels per block / BN tile (small-Cin fwd)
 constexpr int SC_MAX_W = 8192;      // floats of weights cached in LDS
 
 struct SCArgs {
@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256) void smallcin_fwd64_kernel(const SCArgs a) {
     }
     __syncthreads();
     const int M = a.N * a.OH * a.OW;                // host guarantees < 2^31
-    const int m = blockIdx.x * SC_TILE + threadIdx.x;
+    for (int sub = 0; sub < SC_TILE / 256; ++sub) {  // a BN tile (SC_TILE pixels) = four passes of 256 pixels
+    const int m = blockIdx.x * SC_TILE + sub * 256 + threadIdx.x;
     const bool live = m < M;
     const int mm = live ? m : M - 1;
     const int ox = mm % a.OW;
@@ -171,7 +172,112 @@ __global__ __launch_bounds__(256) void smallcin_fwd64_kernel(const SCArgs a) {
                 float t = 0.f;
 #pragma unroll
                 for (int g = 0; g < 8; ++g) t += sp[g * 32];
-                a.bnp[(int64_t)blockIdx.x * 128 + st * 64 + hf * 32 + cc] = t;
+                float* dst = a.bnp + (int64_t)blockIdx.x * 128 + st * 64 + hf * 32 + cc;
+                *dst = sub == 0 ? t : *dst + t;      // same thread, same address on every pass
+            }
+        }
+    }
+    __syncthreads();
+    }
+}
+
+// Cout == 64, <= TT taps (the 3x3 one-channel U-Net stem: TT = 9; the generator's 4x4 one-channel stem: TT = 16),
+// slope-family activation: FOUR pixels per thread, the 64 output channels in four passes of 16.  The image taps of
+// the four pixels are loaded once into registers; each weight vector read from LDS (wave-uniform address) feeds
+// 4 x 16 FMAs, so LDS traffic is a quarter of the one-pixel kernel's.
+template <int DT, int TT>
+__global__ __launch_bounds__(256) void smallcin_fwd64x4_kernel(const SCArgs a) {
+    extern __shared__ float sc4_smem[];
+    const int T = a.Cin * a.k * a.k, kk = a.k * a.k;
+    float* wl = sc4_smem;                           // [TT][64]
+    float* stage = sc4_smem + TT * 64;              // [256][17]
+    for (int i = threadIdx.x; i < TT * 64; i += 256) {
+        const int co = i & 63, tap = i >> 6;
+        wl[i] = tap < T ? a.w[co * T + tap] : 0.f;
+    }
+    const int M = a.N * a.OH * a.OW;                // host guarantees < 2^31
+    const int m0 = blockIdx.x * SC_TILE + threadIdx.x;
+    float xv[4][TT];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int m = m0 + 256 * k;
+        const bool live = m < M;
+        const int mm = live ? m : 0;
+        const int ox = mm % a.OW;
+        const int r = mm / a.OW;
+        const int oy = r % a.OH;
+        const int n = r / a.OH;
+        const float* xn = a.x + (int64_t)n * a.Cin * a.IH * a.IW;
+#pragma unroll
+        for (int tap = 0; tap < TT; ++tap) {
+            const int ci = tap / kk, rr = tap - ci * kk, ky = rr / a.k, kx = rr - ky * a.k;
+            const int iy = oy * a.stride - a.pad + ky, ix = ox * a.stride - a.pad + kx;
+            const bool ok = live && tap < T && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+            xv[k][tap] = ok ? xn[(ci * a.IH + iy) * a.IW + ix] : 0.f;
+        }
+    }
+    const float slope = a.act == GS_ACT_RELU ? 0.f : (a.act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
+    __syncthreads();
+    for (int g = 0; g < 4; ++g) {
+        float acc[4][16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[k][c] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < TT; ++tap) {
+            const float4* wp = reinterpret_cast<const float4*>(wl + tap * 64 + g * 16);
+            float w16[16];
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const float4 w4 = wp[c4];
+                w16[4 * c4] = w4.x; w16[4 * c4 + 1] = w4.y; w16[4 * c4 + 2] = w4.z; w16[4 * c4 + 3] = w4.w;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int c = 0; c < 16; ++c) acc[k][c] += xv[k][tap] * w16[c];
+        }
+        float s1[16], s2[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            s1[c] = (acc[0][c] + acc[1][c]) + (acc[2][c] + acc[3][c]);
+            s2[c] = (acc[0][c] * acc[0][c] + acc[1][c] * acc[1][c]) + (acc[2][c] * acc[2][c] + acc[3][c] * acc[3][c]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int m = m0 + 256 * k;
+            if (m < M) {
+                float o[2][8];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const float v = acc[k][c] + (a.bias ? a.bias[g * 16 + c] : 0.f);
+                    o[c >> 3][c & 7] = v > 0.f ? v : v * slope;
+                }
+                unsigned short* dst = a.y + (int64_t)m * 64 + g * 16;
+                *reinterpret_cast<uint4*>(dst) = pack8<DT>(o[0]);
+                *reinterpret_cast<uint4*>(dst + 8) = pack8<DT>(o[1]);
+            }
+        }
+        if (a.bnp) {
+            const int c = threadIdx.x & 15, q = threadIdx.x >> 4;        // 16 groups of 16 threads
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 16; ++i) stage[threadIdx.x * 17 + i] = st == 0 ? s1[i] : s2[i];
+                __syncthreads();
+                float t = 0.f;
+                for (int i = 0; i < 16; ++i) t += stage[(q * 16 + i) * 17 + c];
+                __syncthreads();
+                stage[q * 16 + c] = t;
+                __syncthreads();
+                if (threadIdx.x < 16) {
+                    float u = 0.f;
+#pragma unroll
+                    for (int gq = 0; gq < 16; ++gq) u += stage[gq * 16 + threadIdx.x];
+                    a.bnp[(int64_t)blockIdx.x * 128 + st * 64 + g * 16 + threadIdx.x] = u;
+                }
             }
         }
     }
@@ -415,6 +521,157 @@ __global__ __launch_bounds__(256) void smallcout_dgrad_kernel(const HArgs a) {
     }
 }
 
+// ---- pointwise head, Cin == 64 (OutConv of the U-Net, unet_parts.py:74): 8 lanes per pixel (one 16-byte chunk
+// each: a wave reads 1 KB contiguous), the <= 4 x 8 weights of a lane's chunk live in registers, four pixels per lane
+// are in flight, the 8-lane dot-product reduction is DPP only (quad_perm / row_half_mirror: no LDS round trips).
+__device__ __forceinline__ float sum8_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    return v;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void head1x1_fwd_kernel(const HArgs a) {
+    const int ch = threadIdx.x & 7, pl = threadIdx.x >> 3;           // 32 pixels per block pass
+    float w[4][8], bv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        bv[c] = (c < a.Cout && a.bias) ? a.bias[c] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[c][i] = c < a.Cout ? a.w[c * 64 + ch * 8 + i] : 0.f;
+    }
+    const int M = a.N * a.OH * a.OW, ohw = a.OH * a.OW;              // host guarantees < 2^31
+    constexpr int UNR = 4;
+    for (int mb = blockIdx.x * (32 * UNR) + pl; mb < M; mb += gridDim.x * (32 * UNR)) {
+        uint4 r[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int m = mb + 32 * u;
+            r[u] = *reinterpret_cast<const uint4*>(a.x + (int64_t)(m < M ? m : mb) * 64 + ch * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int m = mb + 32 * u;
+            float v[8], s[4];
+            unpack8<DT>(r[u], v);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float t = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t += v[i] * w[c][i];
+                s[c] = sum8_dpp(t);
+            }
+            if (ch == 0 && m < M) {
+                const int n = m / ohw, hw = m - n * ohw;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < a.Cout) a.y[((int64_t)n * a.Cout + c) * ohw + hw] = s[c] + bv[c];
+            }
+        }
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void head1x1_dgrad_kernel(const HArgs a) {
+    const int ch = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    float w[4][8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[c][i] = c < a.Cout ? a.w[c * 64 + ch * 8 + i] : 0.f;
+    const int M = a.N * a.IH * a.IW, hw_n = a.IH * a.IW;
+    constexpr int UNR = 4;
+    for (int mb = blockIdx.x * (32 * UNR) + pl; mb < M; mb += gridDim.x * (32 * UNR)) {
+        float g[UNR][4];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int m = mb + 32 * u < M ? mb + 32 * u : mb;
+            const int n = m / hw_n, hw = m - n * hw_n;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) g[u][c] = c < a.Cout ? a.dy[((int64_t)n * a.Cout + c) * hw_n + hw] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int m = mb + 32 * u;
+            if (m >= M) continue;
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = g[u][0] * w[0][i] + g[u][1] * w[1][i] + g[u][2] * w[2][i] + g[u][3] * w[3][i];
+            *reinterpret_cast<uint4*>(a.dx + (int64_t)m * 64 + ch * 8) = pack8<DT>(o);
+        }
+    }
+}
+
+// weight + bias gradient of the pointwise head (Cin == 64): same slab layout as smallcout_wgrad_kernel
+template <int DT>
+__global__ __launch_bounds__(256) void head1x1_wgrad_kernel(const HArgs a) {
+    __shared__ float red[256][8];
+    __shared__ float redb[4][4];
+    const int ch = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int M = a.N * a.OH * a.OW, ohw = a.OH * a.OW;
+    const int m0 = (int)(blockIdx.x * a.pix_per_block);
+    const int m1 = m0 + (int)a.pix_per_block < M ? m0 + (int)a.pix_per_block : M;
+    float acc[4][8], sb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[c][i] = 0.f;
+    constexpr int UNR = 4;
+    for (int mb = m0 + pl; mb < m1; mb += 32 * UNR) {
+        uint4 r[UNR];
+        float g[UNR][4];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int m = mb + 32 * u;
+            const bool ok = m < m1;
+            const int mm = ok ? m : mb;
+            r[u] = *reinterpret_cast<const uint4*>(a.x + (int64_t)mm * 64 + ch * 8);
+            const int n = mm / ohw, hw = mm - n * ohw;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) g[u][c] = (ok && c < a.Cout) ? a.dy[((int64_t)n * a.Cout + c) * ohw + hw] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            float v[8];
+            unpack8<DT>(r[u], v);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                sb[c] += g[u][c];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[c][i] += g[u][c] * v[i];
+            }
+        }
+    }
+    if (a.db) {                                   // every 8-lane group saw each pixel once: lanes ch == 0 carry the bias sums
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float s = wave_sum(ch == 0 ? sb[c] : 0.f);
+            if ((threadIdx.x & 63) == 0) redb[c][threadIdx.x >> 6] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) a.db[(int64_t)blockIdx.x * 4 + threadIdx.x] =
+            redb[threadIdx.x][0] + redb[threadIdx.x][1] + redb[threadIdx.x][2] + redb[threadIdx.x][3];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c < a.Cout) {                         // uniform
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = acc[c][i];
+            __syncthreads();
+            if (pl == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float t = 0.f;
+                    for (int q = 0; q < 32; ++q) t += red[q * 8 + ch][i];
+                    a.dw[(int64_t)blockIdx.x * a.Cout * 64 + c * 64 + ch * 8 + i] = t;
+                }
+            }
+        }
+    }
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void smallcout_wgrad_kernel(const HArgs a) {
     __shared__ float red[256][8];
@@ -498,8 +755,19 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     const int jl = threadIdx.x & 31, bl = threadIdx.x >> 5;
     const int j = blockIdx.x * 32 + jl;
     double s = 0.0;
-    if (j < n)
-        for (int b = bl; b < nb; b += 8) s += (double)slab[(int64_t)b * stride + j];
+    if (j < n) {
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // eight independent loads in flight per lane
+        int b = bl;
+        for (; b + 56 < nb; b += 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slab[(int64_t)(b + 8 * u) * stride + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += (double)v[u];
+        }
+        for (; b < nb; b += 8) a[0] += (double)slab[(int64_t)b * stride + j];
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
     red[bl][jl] = s;
     __syncthreads();
     if (bl == 0 && j < n) {
@@ -547,7 +815,18 @@ extern "C" int gs_conv_smallcin_fwd(const float* x, const float* w, const float*
     hipStream_t s = (hipStream_t)stream;
     GS_CHECK_ARG((int64_t)N * OH * OW < 2147483647LL && (int64_t)Cin * IH * IW < 2147483647LL, "gs_conv_smallcin_fwd: too many pixels");
     const size_t lds = ((size_t)Cin * k * k * 64 + 256 * SC64_PAD) * sizeof(float);
-    if (Cout == 64 && lds <= 64 * 1024) {
+    const int T = Cin * k * k;
+    if (Cout == 64 && T <= 16 && act != GS_ACT_TANH) {
+        const int tt = T <= 9 ? 9 : 16;
+        const size_t lds4 = ((size_t)tt * 64 + 256 * 17) * sizeof(float);
+        if (dtype == GS_F16) {
+            if (tt == 9) smallcin_fwd64x4_kernel<GS_F16, 9><<<nb, 256, lds4, s>>>(a);
+            else smallcin_fwd64x4_kernel<GS_F16, 16><<<nb, 256, lds4, s>>>(a);
+        } else {
+            if (tt == 9) smallcin_fwd64x4_kernel<GS_BF16, 9><<<nb, 256, lds4, s>>>(a);
+            else smallcin_fwd64x4_kernel<GS_BF16, 16><<<nb, 256, lds4, s>>>(a);
+        }
+    } else if (Cout == 64 && lds <= 64 * 1024) {
         if (dtype == GS_F16) smallcin_fwd64_kernel<GS_F16><<<nb, 256, lds, s>>>(a);
         else smallcin_fwd64_kernel<GS_BF16><<<nb, 256, lds, s>>>(a);
     } else {
@@ -628,7 +907,12 @@ extern "C" int gs_conv_smallcout_fwd(const void* x, const float* w, const float*
     int64_t nb = cdiv64((int64_t)N * OH * OW, groups);
     if (nb > 8192) nb = 8192;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GS_F16) smallcout_fwd_kernel<GS_F16><<<(int)nb, 256, 0, s>>>(a);
+    if (k == 1 && stride == 1 && pad == 0 && Cin == 64) {
+        int64_t hb = cdiv64((int64_t)N * OH * OW, 128);
+        if (hb > 4096) hb = 4096;
+        if (dtype == GS_F16) head1x1_fwd_kernel<GS_F16><<<(int)hb, 256, 0, s>>>(a);
+        else head1x1_fwd_kernel<GS_BF16><<<(int)hb, 256, 0, s>>>(a);
+    } else if (dtype == GS_F16) smallcout_fwd_kernel<GS_F16><<<(int)nb, 256, 0, s>>>(a);
     else smallcout_fwd_kernel<GS_BF16><<<(int)nb, 256, 0, s>>>(a);
     GS_CHECK_LAUNCH("gs_conv_smallcout_fwd");
     return GS_OK;
@@ -650,7 +934,12 @@ extern "C" int gs_conv_smallcout_bwd(const void* x, const float* w, const float*
     if (dx) {
         int64_t nb = cdiv64((int64_t)N * IH * IW * (Cin / 8), 256);
         if (nb > 8192) nb = 8192;
-        if (dtype == GS_F16) smallcout_dgrad_kernel<GS_F16><<<(int)nb, 256, 0, s>>>(a);
+        if (k == 1 && stride == 1 && pad == 0 && Cin == 64) {
+            int64_t hb = cdiv64((int64_t)N * IH * IW, 128);
+            if (hb > 4096) hb = 4096;
+            if (dtype == GS_F16) head1x1_dgrad_kernel<GS_F16><<<(int)hb, 256, 0, s>>>(a);
+            else head1x1_dgrad_kernel<GS_BF16><<<(int)hb, 256, 0, s>>>(a);
+        } else if (dtype == GS_F16) smallcout_dgrad_kernel<GS_F16><<<(int)nb, 256, 0, s>>>(a);
         else smallcout_dgrad_kernel<GS_BF16><<<(int)nb, 256, 0, s>>>(a);
     }
     if (dw) {
@@ -664,7 +953,10 @@ extern "C" int gs_conv_smallcout_bwd(const void* x, const float* w, const float*
         HArgs b = a;
         b.dw = ws;                                   // partial slabs [nb][n], then bias partials [nb][4]
         b.db = db ? ws + (int64_t)nb * n : nullptr;
-        if (dtype == GS_F16) smallcout_wgrad_kernel<GS_F16><<<nb, 256, 0, s>>>(b);
+        if (k == 1 && stride == 1 && pad == 0 && Cin == 64) {
+            if (dtype == GS_F16) head1x1_wgrad_kernel<GS_F16><<<nb, 256, 0, s>>>(b);
+            else head1x1_wgrad_kernel<GS_BF16><<<nb, 256, 0, s>>>(b);
+        } else if (dtype == GS_F16) smallcout_wgrad_kernel<GS_F16><<<nb, 256, 0, s>>>(b);
         else smallcout_wgrad_kernel<GS_BF16><<<nb, 256, 0, s>>>(b);
         slab_reduce_kernel<<<cdiv(n, 32), 256, 0, s>>>(ws, nb, n, n, gscale, dw);
         if (db) slab_reduce_kernel<<<1, 256, 0, s>>>(ws + (int64_t)nb * n, nb, 4, Cout, gscale, db);
