@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 7
+#define GS_ABI_VERSION 8
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -237,6 +237,16 @@ int gs_mean_loss_fwd(const float* x, const float* t, float cval, int mode, int64
                      void* stream);
 int gs_mean_loss_bwd(const float* x, const float* t, float cval, int mode, int64_t n, const float* gout,
                      float gscale, float* dx, void* stream);
+
+/* ---- bilinear x2 up-sampling, align_corners=True -----------------------------------------------
+ * replaces nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) + F.pad + torch.cat of the bilinear=True
+ * U-Net (unet/unet_parts.py:49-50,58-67) and its autograd.  x: [N,IH,IW,*] 16-bit NHWC (pixel stride / channel
+ * offset); y: the [N,OH,OW,*] concat buffer, the 2IH x 2IW result lands at (ooy, oox) in channels out_coff...
+ * _bwd reads the same slice of the concat-buffer gradient and writes d(x) (gather form, deterministic). */
+int gs_upsample2x_bilinear_fwd(const void* x, void* y, int N, int IH, int IW, int C, int in_pix_stride, int in_coff,
+                               int OH, int OW, int out_pix_stride, int out_coff, int ooy, int oox, int dtype, void* stream);
+int gs_upsample2x_bilinear_bwd(const void* dy, void* dx, int N, int IH, int IW, int C, int dy_pix_stride, int dy_coff,
+                               int OH, int OW, int dx_pix_stride, int dx_coff, int ooy, int oox, int dtype, void* stream);
 
 /* ---- multi-tensor optimiser steps (one launch for a whole model) ---------------------------------
  * replaces optim.RMSprop(net.parameters(), lr, weight_decay=1e-8, momentum=0.9, foreach=True).step()

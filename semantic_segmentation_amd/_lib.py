@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 GS_F16, GS_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH = 0, 1, 2, 3
 GS_MAX_TAPS = 64
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class GsConvGeom(ctypes.Structure):
@@ -38,6 +38,8 @@ PROTOTYPES = {
     "gs_conv_igemm": (c_int, [POINTER(GsConvGeom), _P, _P, _P, _F, _F, c_int, c_int, c_void_p]),
     "gs_upconv2x2_fwd": (c_int, [_P, _P, _F, _P] + [c_int] * 18 + [c_void_p]),
     "gs_conv3x3_mtiles": (c_int, [c_int, c_int, c_int, c_int]),
+    "gs_upsample2x_bilinear_fwd": (c_int, [_P, _P] + [c_int] * 13 + [c_void_p]),
+    "gs_upsample2x_bilinear_bwd": (c_int, [_P, _P] + [c_int] * 13 + [c_void_p]),
     "gs_optim_chunk_elems": (c_int, []),
     "gs_optim_rmsprop": (c_int, [_P] * 7 + [c_int] + [c_float] * 6 + [c_void_p]),
     "gs_optim_adam": (c_int, [_P] * 7 + [c_int, _P] + [c_float] * 5 + [c_void_p]),

@@ -230,6 +230,25 @@ def upconv2x2_fwd(x, w, bias, y, N, D, IH, IW, Cin, Cout, Dout, OH, OW, in_strid
         TIMER.stop("igemm_fwd", ev, 2.0 * N * D * IH * IW * Cin * ncls * Cout)
 
 
+def upsample2x_bilinear_fwd(x, y, N, IH, IW, C, OH, OW, in_stride=None, in_coff=0, out_stride=None, out_coff=0,
+                            ooy=0, oox=0):
+    """nn.Upsample(scale_factor=2, bilinear, align_corners=True) into a channel slice of the [N,OH,OW,*] buffer y."""
+    _dev(x)
+    if x.dtype != y.dtype:
+        raise TypeError("upsample2x_bilinear_fwd: x and y must share one 16-bit dtype")
+    _lib.call("gs_upsample2x_bilinear_fwd", _p(x), _p(y), N, IH, IW, C, C if in_stride is None else in_stride, in_coff,
+              OH, OW, C if out_stride is None else out_stride, out_coff, ooy, oox, dt_code(x), _stream())
+
+
+def upsample2x_bilinear_bwd(dy, dx, N, IH, IW, C, OH, OW, dy_stride=None, dy_coff=0, dx_stride=None, dx_coff=0,
+                            ooy=0, oox=0):
+    _dev(dy)
+    if dy.dtype != dx.dtype:
+        raise TypeError("upsample2x_bilinear_bwd: dy and dx must share one 16-bit dtype")
+    _lib.call("gs_upsample2x_bilinear_bwd", _p(dy), _p(dx), N, IH, IW, C, C if dy_stride is None else dy_stride, dy_coff,
+              OH, OW, C if dx_stride is None else dx_stride, dx_coff, ooy, oox, dt_code(dy), _stream())
+
+
 def conv_igemm_mtiles(g: GsConvGeom) -> int:
     return _lib.load().gs_conv_igemm_mtiles(g)
 

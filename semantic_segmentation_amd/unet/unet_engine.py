@@ -91,8 +91,6 @@ class UNetEngine:
         if not x.is_cuda:
             raise RuntimeError("UNet (semantic_segmentation_amd) runs on the MI355X only: move the input and the "
                                "module to cuda; there is no CPU / ATen fallback")
-        if net.bilinear:
-            raise NotImplementedError("bilinear=True up-sampling path is not implemented on the HIP engine yet")
         if x.dim() != 4 or x.shape[1] != net.n_channels:
             raise ValueError(f"expected input [N,{net.n_channels},H,W], got {tuple(x.shape)}")
         N, _, H, W = x.shape
@@ -105,7 +103,8 @@ class UNetEngine:
         bufs = dict(net.named_buffers())
         hs = [H >> i for i in range(5)]
         ws_ = [W >> i for i in range(5)]
-        C = [64, 128, 256, 512, 1024]
+        bilinear = bool(net.bilinear)
+        C = [64, 128, 256, 512, 1024 // (2 if bilinear else 1)]      # unet_model.py:18-19
 
         def empty(*shape, dtype=tdt):
             return torch.empty(shape, dtype=dtype, device=dev)
@@ -200,30 +199,41 @@ class UNetEngine:
         for j in range(1, 5):
             lvl = 4 - j                      # output level of up_j
             prefix = f"up{j}"
-            cin_t, cout_t = C[lvl + 1], C[lvl]
+            cout_t = C[lvl]                                           # skip channels == up-sampled channels
+            cin_t = inp.shape[3]                                      # decoder input: 2*cout_t (convT) / cout_t (bilinear)
             h, w = hs[lvl + 1], ws_[lvl + 1]
             H2, W2 = hs[lvl], ws_[lvl]
             pt, pl = (H2 - 2 * h) // 2, (W2 - 2 * w) // 2
-            wkey = prefix + ".up.weight"
-            wf, wd = self._packed(wkey, params[wkey], True, need_grad)
-            bias = params[prefix + ".up.bias"].detach()
             cat = cats[lvl]
-            # all four sub-pixel classes in one pointwise GEMM: the input is read once
-            ops.upconv2x2_fwd(inp, wf, bias, cat, N, 1, h, w, cin_t, cout_t, 1, H2, W2, out_stride=2 * cout_t,
-                              out_coff=cout_t, ooy=pt, oox=pl)
+            wd = None
+            if bilinear:
+                # nn.Upsample(scale_factor=2, bilinear, align_corners=True) straight into the concat buffer
+                ops.upsample2x_bilinear_fwd(inp, cat, N, h, w, cin_t, H2, W2, out_stride=2 * cout_t, out_coff=cout_t,
+                                            ooy=pt, oox=pl)
+            else:
+                wkey = prefix + ".up.weight"
+                wf, wd = self._packed(wkey, params[wkey], True, need_grad)
+                bias = params[prefix + ".up.bias"].detach()
+                # all four sub-pixel classes in one pointwise GEMM: the input is read once
+                ops.upconv2x2_fwd(inp, wf, bias, cat, N, 1, h, w, cin_t, cout_t, 1, H2, W2, out_stride=2 * cout_t,
+                                  out_coff=cout_t, ooy=pt, oox=pl)
             if need_grad:
                 u = _UpRec()
                 u.name, u.zin, u.cat, u.wd = prefix, inp, cat, wd
                 u.cin, u.cout, u.h, u.w, u.H2, u.W2, u.pt, u.pl = cin_t, cout_t, h, w, H2, W2, pt, pl
-                taps = [(py + pt, px + pl) for py in range(2) for px in range(2)]
-                # the ConvTranspose2d seen from its output side: a stride-2, 4-tap conv dU -> x
-                u.geom_bwd = ops.make_geom(N, H2, W2, cout_t, h, w, cin_t, h, w, taps, isy=2, isx=2,
-                                           in_stride=2 * cout_t, in_coff=cout_t)
+                u.geom_bwd = None
+                if not bilinear:
+                    taps = [(py + pt, px + pl) for py in range(2) for px in range(2)]
+                    # the ConvTranspose2d seen from its output side: a stride-2, 4-tap conv dU -> x
+                    u.geom_bwd = ops.make_geom(N, H2, W2, cout_t, h, w, cin_t, h, w, taps, isy=2, isx=2,
+                                               in_stride=2 * cout_t, in_coff=cout_t)
                 ups.append(u)
-            zmid = empty(N, H2, W2, cout_t)
-            conv_bn_relu(prefix + ".conv", 0, cat, 2 * cout_t, cout_t, H2, W2, zmid, cout_t, 0, None)
-            zout = empty(N, H2, W2, cout_t)
-            conv_bn_relu(prefix + ".conv", 3, zmid, cout_t, cout_t, H2, W2, zout, cout_t, 0, None)
+            cmid = params[prefix + ".conv.double_conv.0.weight"].shape[0]     # in_channels // 2 when bilinear
+            cout3 = params[prefix + ".conv.double_conv.3.weight"].shape[0]
+            zmid = empty(N, H2, W2, cmid)
+            conv_bn_relu(prefix + ".conv", 0, cat, 2 * cout_t, cmid, H2, W2, zmid, cmid, 0, None)
+            zout = empty(N, H2, W2, cout3)
+            conv_bn_relu(prefix + ".conv", 3, zmid, cmid, cout3, H2, W2, zout, cout3, 0, None)
             inp = zout
 
         logits = empty(N, net.n_classes, H, W, dtype=torch.float32)
@@ -331,10 +341,16 @@ class UNetEngine:
             lvl = 4 - j
             prefix = f"up{j}"
             cout_t = C[lvl]
-            dmid = conv_stage_bwd(recs[prefix + ".conv.3"], dz, cout_t, 0, None, True)
-            dcat = conv_stage_bwd(recs[prefix + ".conv.0"], dmid, cout_t, 0, None, True)
+            r3, r0 = recs[prefix + ".conv.3"], recs[prefix + ".conv.0"]
+            dmid = conv_stage_bwd(r3, dz, r3.cout, 0, None, True)
+            dcat = conv_stage_bwd(r0, dmid, r0.cout, 0, None, True)
             dcats[lvl] = dcat
             u = ups[prefix]
+            if u.geom_bwd is None:                                    # bilinear up-sampling: transposed interpolation
+                dz = empty(N, u.h, u.w, u.cin)
+                ops.upsample2x_bilinear_bwd(dcat, dz, N, u.h, u.w, u.cin, u.H2, u.W2, dy_stride=2 * cout_t,
+                                            dy_coff=cout_t, ooy=u.pt, oox=u.pl)
+                continue
             wkey = prefix + ".up.weight"
             wparam = params[wkey]
             db = galloc(prefix + ".up.bias", params[prefix + ".up.bias"])

@@ -50,14 +50,14 @@ def ref_seg_loss(logits, mask, dice_loss):
     return ce, dl
 
 
-def make_unet(name, n_classes, batch, h, w, seed, mask_mode="ellipse"):
+def make_unet(name, n_classes, batch, h, w, seed, mask_mode="ellipse", bilinear=False):
     from unet import UNet
     from unet.evaluate import evaluate  # noqa: F401  (import check only)
     from util.dice_score import dice_loss, dice_coeff, multiclass_dice_coeff
     import torch.nn.functional as F
 
-    sd = oracle.unet_state_dict(1, n_classes, seed=seed)
-    net = UNet(1, n_classes)
+    sd = oracle.unet_state_dict(1, n_classes, seed=seed, bilinear=bilinear)
+    net = UNet(1, n_classes, bilinear=bilinear)
     net.load_state_dict(sd, strict=True)
     net.train()
     size = max(h, w)
@@ -72,7 +72,7 @@ def make_unet(name, n_classes, batch, h, w, seed, mask_mode="ellipse"):
     loss = l1 + l2
     loss.backward()
     out = {
-        "n_classes": n_classes, "seed": seed, "x": x.numpy(), "mask": mask.numpy().astype(np.uint8),
+        "n_classes": n_classes, "seed": seed, "bilinear": int(bilinear), "x": x.numpy(), "mask": mask.numpy().astype(np.uint8),
         "logits": logits.detach().numpy(), "loss_ce": l1.item(), "loss_dice": l2.item(), "loss": loss.item(),
     }
     for k, p in net.named_parameters():
@@ -301,6 +301,9 @@ if __name__ == "__main__":
         make_unet("unet_c1_odd", 1, 2, 70, 52, seed=4)               # non-zero F.pad through Up
         make_unet("unet_c1_zeros", 1, 2, 32, 32, seed=5, mask_mode="zeros")
         make_unet("unet_c1_ones", 1, 2, 32, 32, seed=6, mask_mode="ones")
+    if a.only in ("", "unet", "bilinear"):
+        make_unet("unet_c1_bilinear_64", 1, 2, 64, 64, seed=7, bilinear=True)      # nn.Upsample path, unet_parts.py:49-51
+        make_unet("unet_c2_bilinear_odd", 2, 2, 70, 52, seed=8, bilinear=True)     # + non-zero F.pad
     if a.only in ("", "ops"):
         make_dice_cases()
         make_ops_micro()

@@ -214,6 +214,30 @@ def test_upconv2x2_merged_fwd(dtn, dt, N, h, w, Cin, Cout, pad):
 
 
 @pytest.mark.parametrize("dtn,dt", DTS)
+@pytest.mark.parametrize("N,h,w,C,pad", [(2, 5, 6, 64, (0, 0)), (1, 8, 8, 128, (1, 1)), (3, 1, 4, 8, (0, 2)), (2, 16, 13, 72, (3, 0))])
+def test_upsample2x_bilinear_fwd_bwd(dtn, dt, N, h, w, C, pad):
+    """nn.Upsample(scale_factor=2, bilinear, align_corners=True) + F.pad into the second half of the concat buffer
+    (bilinear=True U-Net, unet_parts.py:49-50,58-67) and its gradient, vs ATen on the same 16-bit-rounded inputs."""
+    from semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(8)
+    H2, W2 = 2 * h + pad[0], 2 * w + pad[1]
+    pt, pl = pad[0] // 2, pad[1] // 2
+    x = rnd(g, N, C, h, w, dt=dt).requires_grad_(True)
+    up = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    ref = F.pad(up, [pl, pad[1] - pl, pt, pad[0] - pt])
+    dcat = rnd(g, N, 2 * C, H2, W2, dt=dt)
+    ref.backward(dcat[:, C:])
+    cat = torch.zeros(N, H2, W2, 2 * C, dtype=dt, device=dev())
+    ops.upsample2x_bilinear_fwd(nhwc(x.detach(), dt), cat, N, h, w, C, H2, W2, out_stride=2 * C, out_coff=C, ooy=pt, oox=pl)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(cat[..., C:]), ref.detach()) < tol(dt)
+    assert float(cat[..., :C].abs().max()) == 0.0
+    dx = torch.empty(N, h, w, C, dtype=dt, device=dev())
+    ops.upsample2x_bilinear_bwd(nhwc(dcat, dt), dx, N, h, w, C, H2, W2, dy_stride=2 * C, dy_coff=C, ooy=pt, oox=pl)
+    assert rel_err(from_nhwc(dx), x.grad) < tol(dt)
+
+
+@pytest.mark.parametrize("dtn,dt", DTS)
 def test_upconv2x2x2_merged_fwd_3d(dtn, dt):
     """ConvTranspose3d(k2,s2)+bias (GenSeg-3D/UNet3D/unet3d.py:68) as one GEMM with 8 sub-voxel classes."""
     from semantic_segmentation_amd import ops

@@ -18,17 +18,18 @@ def load(golden_dir, name):
 
 
 @pytest.mark.parametrize("name", ["unet_c1_64", "unet_c2_64", "unet_c1_odd", "unet_c1_zeros", "unet_c1_ones",
-                                  "unet_c2_128_b4"])
+                                  "unet_c2_128_b4", "unet_c1_bilinear_64", "unet_c2_bilinear_odd"])
 def test_unet_step_matches_reference(golden_dir, name):
     z = load(golden_dir, name)
     n_classes, seed = int(z["n_classes"]), int(z["seed"])
-    sd = oracle.unet_state_dict(1, n_classes, seed=seed)
+    bilinear = bool(int(z["bilinear"])) if "bilinear" in z.files else False
+    sd = oracle.unet_state_dict(1, n_classes, seed=seed, bilinear=bilinear)
     for k, v in sd.items():                      # PRNG stream drift guard
         if v.is_floating_point():
             np.testing.assert_allclose(tensor_checksum(v), z["wsum/" + k], rtol=1e-12, atol=0)
     x = torch.from_numpy(z["x"])
     mask = torch.from_numpy(z["mask"].astype(np.int64))
-    logits, loss, grads, updates = oracle.unet_step(sd, x, mask, train=True)
+    logits, loss, grads, updates = oracle.unet_step(sd, x, mask, train=True, bilinear=bilinear)
     assert np.abs(logits.numpy() - z["logits"]).max() < 2e-5
     assert abs(loss.item() - float(z["loss"])) < 2e-6
     for k, g in grads.items():
@@ -47,7 +48,7 @@ def test_unet_step_matches_reference(golden_dir, name):
     # eval mode with the updated running statistics, and the evaluate.py Dice
     sd2 = dict(sd)
     sd2.update(updates)
-    lg = oracle.unet_forward(sd2, x, train=False)
+    lg = oracle.unet_forward(sd2, x, train=False, bilinear=bilinear)
     assert np.abs(lg.numpy() - z["logits_eval"]).max() < 5e-4 * max(1.0, np.abs(z["logits_eval"]).max())
     assert abs(oracle.evaluate_dice(lg, mask).item() - float(z["eval_dice"])) < 1e-6
 
