@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 8
+#define GS_ABI_VERSION 9
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -237,6 +237,21 @@ int gs_mean_loss_fwd(const float* x, const float* t, float cval, int mode, int64
                      void* stream);
 int gs_mean_loss_bwd(const float* x, const float* t, float cval, int mode, int64_t n, const float* gout,
                      float gscale, float* dx, void* stream);
+
+/* ---- 3x3x3 / stride 1 / pad 1 Conv3d on the halo-reuse kernels ------------------------------------
+ * replaces nn.Conv3d(kernel_size=3, padding=1) forward / data gradient / weight gradient of
+ * GenSeg-3D/UNet3D/unet3d.py:28-31 (Conv3DBlock) and :69-71 (UpConv3DBlock).  Volumes are NB*D depth slices
+ * [NB*D, H, W, *]; w / dw: [27][Cout][Cin], slot = kd*9 + kh*3 + kw.  tap_dz[kd] / tap_dy,tap_dx[kh*3+kw] are the
+ * input offsets each slot reads (forward: kd-1, kh-1, kw-1; data gradient: the negated offsets with the [27][Cin][Cout]
+ * pack).  bn_partials: [gs_conv3d_3x3x3_mtiles][2][Cout].  Requires Cin % 64 == 0, Cout % 8 == 0, 16-byte aligned
+ * output channel slices (other shapes: gs_conv_igemm with depth taps). */
+int gs_conv3d_3x3x3_mtiles(int NB, int D, int H, int W, int Cout);
+int gs_conv3d_3x3x3(const void* x, const void* w, void* y, const float* bias, float* bn_partials, int NB, int D, int H,
+                    int W, int Cin, int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff,
+                    const int32_t* tap_dz, const int32_t* tap_dy, const int32_t* tap_dx, int act, int dtype, void* stream);
+int gs_conv3d_3x3x3_wgrad(const void* x, const void* dy, float* dw, int NB, int D, int H, int W, int Cin,
+                          int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff, int dtype,
+                          void* stream);
 
 /* ---- bilinear x2 up-sampling, align_corners=True -----------------------------------------------
  * replaces nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) + F.pad + torch.cat of the bilinear=True

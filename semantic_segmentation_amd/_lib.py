@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 GS_F16, GS_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH = 0, 1, 2, 3
 GS_MAX_TAPS = 64
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class GsConvGeom(ctypes.Structure):
@@ -38,6 +38,9 @@ PROTOTYPES = {
     "gs_conv_igemm": (c_int, [POINTER(GsConvGeom), _P, _P, _P, _F, _F, c_int, c_int, c_void_p]),
     "gs_upconv2x2_fwd": (c_int, [_P, _P, _F, _P] + [c_int] * 18 + [c_void_p]),
     "gs_conv3x3_mtiles": (c_int, [c_int, c_int, c_int, c_int]),
+    "gs_conv3d_3x3x3_mtiles": (c_int, [c_int] * 5),
+    "gs_conv3d_3x3x3": (c_int, [_P, _P, _P, _F, _F] + [c_int] * 10 + [POINTER(c_int32)] * 3 + [c_int, c_int, c_void_p]),
+    "gs_conv3d_3x3x3_wgrad": (c_int, [_P, _P, _F] + [c_int] * 11 + [c_void_p]),
     "gs_upsample2x_bilinear_fwd": (c_int, [_P, _P] + [c_int] * 13 + [c_void_p]),
     "gs_upsample2x_bilinear_bwd": (c_int, [_P, _P] + [c_int] * 13 + [c_void_p]),
     "gs_optim_chunk_elems": (c_int, []),

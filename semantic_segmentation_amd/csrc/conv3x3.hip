@@ -30,6 +30,9 @@ struct C3Args {
     int N, H, W, Cin, in_stride, in_coff, Cout, out_stride, out_coff;
     int tiles_x, tiles_y, ntn, nblocks;
     int tap_dy[9], tap_dx[9];
+    // 3-D (3x3x3) convolution: images are the N = volumes*D depth slices; stage (dz index, channel chunk) reads slice
+    // n + tap_dz and the weight slots [dzi*9 .. dzi*9+8].  2-D: D = 1, ndz = 1, tap_dz = {0}.
+    int D, ndz, tap_dz[3];
 };
 
 __device__ __forceinline__ int xcd_remap3(int bid, int nwg) {
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_persist_kernel(const C3Args a)
         return __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)n * a.H * a.W * a.in_stride), 0, img_bytes, 0x00020000);
     };
     const __amdgpu_buffer_rsrc_t w_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)(9u * a.Cout * a.Cin * 2u), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)(9u * a.ndz * a.Cout * a.Cin * 2u), 0x00020000);
 
     // ---- halo staging: byte offsets inside the image (OOB when the halo pixel is outside) ----
     unsigned h_off[HCH];
@@ -558,7 +561,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
     const int dbg = a.act >> 8;
     const int act = a.act & 0xff;
     const int chunk = t & 7, rbase = t >> 3;
-    const int nchunks = (a.Cin + 63) >> 6;
+    const int nchunks_c = (a.Cin + 63) >> 6;               // 64-channel chunks of one slice
+    const int nchunks = a.ndz * nchunks_c;                  // K stages per item: (depth tap, channel chunk)
+    // stage cc of an item that lives in slice n: source slice, weight-slot offset, validity (zero padding in depth)
+    struct StageSrc { int n; unsigned sc, wsc; unsigned kill; };
     const unsigned img_bytes = (unsigned)a.H * a.W * a.in_stride * 2u;
 
 #ifdef GS_C3_PHASE_TIMING
@@ -580,7 +586,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
         return r;
     };
     const __amdgpu_buffer_rsrc_t w_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)(9u * a.Cout * a.Cin * 2u), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)(9u * a.ndz * a.Cout * a.Cin * 2u), 0x00020000);
 
     // Staging addresses are strength reduced: per ITEM each lane keeps the byte offsets of its two weight rows
     // and of its halo pixels (voffset; 0x80000000 = out of range -> the buffer load returns zeros), the per-tap
@@ -610,20 +616,33 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
     };
     // WRES (one channel chunk and one N tile: the 64->64 layers): the 9-tap weight slab is the same for every
     // item of the block -- it is staged once by the first stage and stays resident in LDS.
+    const unsigned tap_stride_c = (unsigned)a.Cout * a.Cin * 2u;
+    auto stage_src = [&](int n, int cc) __attribute__((always_inline)) {
+        StageSrc r;
+        int dzi = 0, c = cc;
+        if (a.ndz > 1) { dzi = cc / nchunks_c; c = cc - dzi * nchunks_c; }
+        const int dz = a.tap_dz[dzi];
+        const int d = a.D > 1 ? n % a.D : 0;
+        r.n = n + dz;
+        r.kill = ((unsigned)(d + dz) < (unsigned)a.D) ? 0u : VOOB;
+        r.sc = (unsigned)c * 128u;                                // 64 channels x 2 bytes per chunk
+        r.wsc = r.sc + (unsigned)(dzi * 9) * tap_stride_c;
+        return r;
+    };
     auto load_stage = [&](const Item& itn, int cc, auto with_w) __attribute__((always_inline)) {
+        const StageSrc ss = stage_src(itn.n, cc);
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(a.x + (int64_t)itn.n * a.H * a.W * a.in_stride), 0, img_bytes, 0x00020000);
-        const unsigned sc = (unsigned)cc * 128u;                  // 64 channels x 2 bytes per chunk
+            (void*)(a.x + (int64_t)(ss.kill ? itn.n : ss.n) * a.H * a.W * a.in_stride), 0, img_bytes, 0x00020000);
         if (decltype(with_w)::value) {
 #pragma unroll
             for (int j = 0; j < WCH; ++j) {                       // row = rbase + 32 j = (j>>1)*64 + (rbase + 32 (j&1))
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wv[j & 1], sc + (unsigned)(j >> 1) * tap_stride, 0);
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wv[j & 1], ss.wsc + (unsigned)(j >> 1) * tap_stride, 0);
                 rw[j] = make_uint4(v[0], v[1], v[2], v[3]);
             }
         }
 #pragma unroll
         for (int j = 0; j < HCH; ++j) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, hv[j], sc, 0);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, hv[j] | ss.kill, ss.sc, 0);
             rh[j] = make_uint4(v[0], v[1], v[2], v[3]);
         }
     };
@@ -842,18 +861,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
             const Item& ldi = more_cc ? cur : nxt;
             constexpr int SH = WRES ? (HCH + 1) / 2 : 0;
             if (!WRES && !more_cc && more_items) setup_item(nxt);
+            const StageSrc ssn = stage_src(ldi.n, more_cc ? cc + 1 : 0);
             const __amdgpu_buffer_rsrc_t rx_n = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(a.x + (int64_t)ldi.n * a.H * a.W * a.in_stride), 0, img_bytes, 0x00020000);
-            const unsigned sc_n = more_cc ? (unsigned)(cc + 1) * 128u : 0u;
+                (void*)(a.x + (int64_t)(ssn.kill ? ldi.n : ssn.n) * a.H * a.W * a.in_stride), 0, img_bytes, 0x00020000);
+            const unsigned sc_n = ssn.sc, wsc_n = ssn.wsc;
             const unsigned kill = have_next ? 0u : VOOB;
+            const unsigned killh = kill | ssn.kill;              // depth tap outside the volume: zero slice
             auto issue_load = [&](int j) __attribute__((always_inline)) {       // j is a compile-time constant
                 constexpr int NW = WRES ? 0 : WCH;
                 if (j < NW) {
                     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wv[j & 1] | kill,
-                                                                          sc_n + (unsigned)(j >> 1) * tap_stride, 0);
+                                                                          wsc_n + (unsigned)(j >> 1) * tap_stride, 0);
                     rw[j < NW ? j : 0] = make_uint4(v[0], v[1], v[2], v[3]);
                 } else if (j - NW < HCH) {
-                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx_n, hv[j - NW < HCH ? j - NW : 0] | kill, sc_n, 0);
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx_n, hv[j - NW < HCH ? j - NW : 0] | killh, sc_n, 0);
                     rh[j - NW < HCH ? j - NW : 0] = make_uint4(v[0], v[1], v[2], v[3]);
                 }
             };
@@ -963,9 +984,10 @@ extern "C" int gs_conv3x3_mtiles(int N, int H, int W, int Cout) {
     return N * p.tiles_x * p.tiles_y;
 }
 
-extern "C" int gs_conv3x3(const void* x, const void* w, void* y, const float* bias, float* bn_partials, int N, int H,
+static int conv3x3_launch(const void* x, const void* w, void* y, const float* bias, float* bn_partials, int N, int H,
                           int W, int Cin, int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff,
-                          const int32_t* tap_dy, const int32_t* tap_dx, int act, int dtype, void* stream) {
+                          const int32_t* tap_dy, const int32_t* tap_dx, int act, int dtype, void* stream, int D, int ndz,
+                          const int32_t* tap_dz) {
     GS_CHECK_ARG(x && w && y && tap_dy && tap_dx, "gs_conv3x3: null pointer");
     GS_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0 && Cout > 0, "gs_conv3x3: bad dims");
     GS_CHECK_ARG(in_pix_stride >= in_coff + Cin && in_pix_stride % 8 == 0 && in_coff % 8 == 0, "gs_conv3x3: bad input stride");
@@ -983,6 +1005,8 @@ extern "C" int gs_conv3x3(const void* x, const void* w, void* y, const float* bi
         GS_CHECK_ARG(tap_dy[i] >= -1 && tap_dy[i] <= 1 && tap_dx[i] >= -1 && tap_dx[i] <= 1, "gs_conv3x3: tap offsets must be in [-1,1]");
         a.tap_dy[i] = tap_dy[i]; a.tap_dx[i] = tap_dx[i];
     }
+    a.D = D; a.ndz = ndz;
+    for (int i = 0; i < 3; ++i) a.tap_dz[i] = (tap_dz && i < ndz) ? tap_dz[i] : 0;
     const C3Plan p = c3_plan(H, W, Cout);
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y;
     a.ntn = cdiv(Cout, p.bn);
@@ -990,7 +1014,10 @@ extern "C" int gs_conv3x3(const void* x, const void* w, void* y, const float* bi
     hipStream_t s = (hipStream_t)stream;
     GS_CHECK_ARG((act & 0xff) == GS_ACT_NONE || (act & 0xff) == GS_ACT_RELU || (act & 0xff) == GS_ACT_LEAKY02,
                  "gs_conv3x3: activation %d not supported (use gs_conv_igemm)", act & 0xff);
-    if (c3_use_big(Cout, out_pix_stride, out_coff) && c3_big_ok(H, W, Cin, in_pix_stride, Cout, out_pix_stride)) {
+    const bool big = c3_use_big(Cout, out_pix_stride, out_coff) && c3_big_ok(H, W, Cin, in_pix_stride, Cout, out_pix_stride) &&
+                     (int64_t)9 * ndz * Cout * Cin * 2 < 2147483000LL;
+    GS_CHECK_ARG(big || ndz == 1, "gs_conv3d_3x3x3: needs Cin %% 64 == 0, Cout %% 8 == 0 and 16-byte aligned output channels");
+    if (big) {
         const int tw = (W >= 24) ? 32 : 16, th = 256 / tw;
         a.tiles_x = cdiv(W, tw); a.tiles_y = cdiv(H, th);
         a.ntn = cdiv(Cout, 64);
@@ -998,7 +1025,7 @@ extern "C" int gs_conv3x3(const void* x, const void* w, void* y, const float* bi
         static const int big_blocks = getenv("GSSEG_C3_GRID") ? atoi(getenv("GSSEG_C3_GRID")) : 256;
         dim3 bgrid(a.nblocks < big_blocks ? a.nblocks : big_blocks);
         hipStream_t bs = (hipStream_t)stream;
-        const bool wres = (Cin <= 64 && a.ntn == 1);       // one chunk, one N tile: weights stay resident in LDS
+        const bool wres = (Cin <= 64 && a.ntn == 1 && ndz == 1);   // one stage, one N tile: weights stay resident in LDS
         if (dtype == GS_F16) {
             if (wres) {
                 if (tw == 32) conv3x3_big_kernel<GS_F16, 32, true><<<bgrid, 256, 0, bs>>>(a);
@@ -1057,4 +1084,30 @@ extern "C" int gs_conv3x3(const void* x, const void* w, void* y, const float* bi
 #undef C3_LAUNCH
     GS_CHECK_LAUNCH("gs_conv3x3");
     return GS_OK;
+}
+
+extern "C" int gs_conv3x3(const void* x, const void* w, void* y, const float* bias, float* bn_partials, int N, int H,
+                          int W, int Cin, int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff,
+                          const int32_t* tap_dy, const int32_t* tap_dx, int act, int dtype, void* stream) {
+    return conv3x3_launch(x, w, y, bias, bn_partials, N, H, W, Cin, in_pix_stride, in_coff, Cout, out_pix_stride, out_coff,
+                          tap_dy, tap_dx, act, dtype, stream, 1, 1, nullptr);
+}
+
+// 3x3x3 / stride 1 / pad 1 Conv3d (GenSeg-3D/UNet3D/unet3d.py:28-31,69-71) and its data gradient on the same halo-reuse
+// kernel: the volumes are NB*D depth slices [NB*D, H, W, *]; per output patch the K loop runs over (depth tap, channel
+// chunk) stages, stage (dz, c) staging the halo of slice d + tap_dz[dz] (zeros outside the volume) and the nine
+// weights of slot dz*9 .. dz*9+8 of the [27][Cout][Cin] pack.  Requires Cin % 64 == 0, Cout % 8 == 0.
+extern "C" int gs_conv3d_3x3x3_mtiles(int NB, int D, int H, int W, int Cout) {
+    return gs_conv3x3_mtiles(NB * D, H, W, Cout);
+}
+
+extern "C" int gs_conv3d_3x3x3(const void* x, const void* w, void* y, const float* bias, float* bn_partials, int NB, int D,
+                               int H, int W, int Cin, int in_pix_stride, int in_coff, int Cout, int out_pix_stride,
+                               int out_coff, const int32_t* tap_dz, const int32_t* tap_dy, const int32_t* tap_dx, int act,
+                               int dtype, void* stream) {
+    GS_CHECK_ARG(NB > 0 && D > 0 && tap_dz, "gs_conv3d_3x3x3: bad depth arguments");
+    for (int i = 0; i < 3; ++i) GS_CHECK_ARG(tap_dz[i] >= -1 && tap_dz[i] <= 1, "gs_conv3d_3x3x3: depth tap offsets must be in [-1,1]");
+    GS_CHECK_ARG(c3_variant_get() == 2, "gs_conv3d_3x3x3: needs the big-K-step kernel (GSSEG_C3=2)");
+    return conv3x3_launch(x, w, y, bias, bn_partials, NB * D, H, W, Cin, in_pix_stride, in_coff, Cout, out_pix_stride,
+                          out_coff, tap_dy, tap_dx, act, dtype, stream, D, 3, tap_dz);
 }

@@ -23,6 +23,7 @@ struct W3Args {
     float* dw;                  // [9][Cout][Cin]
     int N, H, W, Cin, in_stride, in_coff, Cout, out_stride, out_coff;
     int tiles_x, tiles_y, npatches, ncob, ncib, ksplit, pps;   // pps = patches per split
+    int D, dz;                  // 3-D: images are depth slices; X is read from slice n + dz (zeros outside the volume)
 };
 
 constexpr int W3_LDR = 96;      // 64 channels + 32 pad elements = 192-byte rows
@@ -65,16 +66,19 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const W3Args a) {
 
     uint4 rd[4], rh[HCH];
     // prefetch of the next patch, split so that the loads can be spread over the MFMA steps of the current one
-    struct Pf { int y0, x0; __amdgpu_buffer_rsrc_t rx, rdy; unsigned kill; };
+    struct Pf { int y0, x0; __amdgpu_buffer_rsrc_t rx, rdy; unsigned kill, killx; };
     auto prep_patch = [&](int patch, bool live) __attribute__((always_inline)) {
         Pf f;
         const int tx = patch % a.tiles_x;
         const int r = patch / a.tiles_x;
         const int ty = r % a.tiles_y, n = r / a.tiles_y;
         f.y0 = ty * TH; f.x0 = tx * TW;
-        f.rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)n * a.H * a.W * a.in_stride), 0, x_img_bytes, 0x00020000);
+        const int d = a.D > 1 ? n % a.D : 0;
+        const bool xin = (unsigned)(d + a.dz) < (unsigned)a.D;
+        f.rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)(xin ? n + a.dz : n) * a.H * a.W * a.in_stride), 0, x_img_bytes, 0x00020000);
         f.rdy = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + (int64_t)n * a.H * a.W * a.out_stride), 0, dy_img_bytes, 0x00020000);
         f.kill = live ? 0u : OOB;                  // no next patch: every offset out of range (loads return zeros)
+        f.killx = (live && xin) ? 0u : OOB;
         return f;
     };
     auto issue_load = [&](const Pf& f, int j) __attribute__((always_inline)) {      // j compile-time, 0 .. 4+HCH-1
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const W3Args a) {
             const int gy = f.y0 + hy - 1, gx = f.x0 + hx - 1;
             const bool ok = ci_ok && hp < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
             const unsigned off = ok ? (unsigned)(((gy * a.W + gx) * a.in_stride + a.in_coff + ci0 + chunk * 8) * 2) : OOB;
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(f.rx, off | f.kill, 0, 0);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(f.rx, off | f.killx, 0, 0);
             rh[jj] = make_uint4(v[0], v[1], v[2], v[3]);
         }
     };
@@ -163,9 +167,9 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const W3Args a) {
 
 }  // namespace
 
-extern "C" int gs_conv3x3_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin,
-                                int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff, int dtype,
-                                void* stream) {
+static int wgrad3x3_launch(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin,
+                           int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff, int dtype,
+                           void* stream, int D, int dz) {
     GS_CHECK_ARG(x && dy && dw, "gs_conv3x3_wgrad: null pointer");
     GS_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 8 == 0, "gs_conv3x3_wgrad: bad dims");
     GS_CHECK_ARG(in_pix_stride >= in_coff + Cin && in_pix_stride % 8 == 0 && in_coff % 8 == 0, "gs_conv3x3_wgrad: bad x stride");
@@ -177,6 +181,7 @@ extern "C" int gs_conv3x3_wgrad(const void* x, const void* dy, float* dw, int N,
     a.x = (const unsigned short*)x; a.dy = (const unsigned short*)dy; a.dw = dw;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.in_stride = in_pix_stride; a.in_coff = in_coff;
     a.Cout = Cout; a.out_stride = out_pix_stride; a.out_coff = out_coff;
+    a.D = D; a.dz = dz;
     const int tw = (W >= 24) ? 32 : 16, th = W3_BM / tw;
     a.tiles_x = cdiv(W, tw); a.tiles_y = cdiv(H, th);
     a.npatches = N * a.tiles_x * a.tiles_y;
@@ -198,5 +203,26 @@ extern "C" int gs_conv3x3_wgrad(const void* x, const void* dy, float* dw, int N,
         else wgrad3x3_kernel<GS_BF16, 16><<<grid, block, 0, s>>>(a);
     }
     GS_CHECK_LAUNCH("gs_conv3x3_wgrad");
+    return GS_OK;
+}
+
+extern "C" int gs_conv3x3_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin,
+                                int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff, int dtype,
+                                void* stream) {
+    return wgrad3x3_launch(x, dy, dw, N, H, W, Cin, in_pix_stride, in_coff, Cout, out_pix_stride, out_coff, dtype, stream, 1, 0);
+}
+
+// weight gradient of the 3x3x3 Conv3d: dw [27][Cout][Cin] (fp32, caller zeroes); depth tap kd = 0..2 pairs dY slice d
+// with X slice d + kd - 1 -- three launches of the 2-D halo kernel, each into its own nine weight slots.
+extern "C" int gs_conv3d_3x3x3_wgrad(const void* x, const void* dy, float* dw, int NB, int D, int H, int W, int Cin,
+                                     int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff, int dtype,
+                                     void* stream) {
+    GS_CHECK_ARG(NB > 0 && D > 0 && dw, "gs_conv3d_3x3x3_wgrad: bad arguments");
+    for (int kd = 0; kd < 3; ++kd) {
+        if (D == 1 && kd != 1) continue;               // a one-slice volume only sees the centre depth tap
+        int rc = wgrad3x3_launch(x, dy, dw + (int64_t)kd * 9 * Cout * Cin, NB * D, H, W, Cin, in_pix_stride, in_coff, Cout,
+                                 out_pix_stride, out_coff, dtype, stream, D, kd - 1);
+        if (rc) return rc;
+    }
     return GS_OK;
 }

@@ -230,6 +230,55 @@ def upconv2x2_fwd(x, w, bias, y, N, D, IH, IW, Cin, Cout, Dout, OH, OW, in_strid
         TIMER.stop("igemm_fwd", ev, 2.0 * N * D * IH * IW * Cin * ncls * Cout)
 
 
+def conv3d3_eligible(Cin, Cout, out_stride=None, out_coff=0) -> bool:
+    """shapes the 3-D halo kernels take (others go through conv_igemm with depth taps)"""
+    os_ = Cout if out_stride is None else out_stride
+    return USE_HALO_CONV and Cin % 64 == 0 and Cout % 8 == 0 and os_ % 8 == 0 and out_coff % 8 == 0
+
+
+def conv3d3_mtiles(NB, D, H, W, Cout) -> int:
+    return int(_lib.load().gs_conv3d_3x3x3_mtiles(NB, D, H, W, Cout))
+
+
+def conv3d3(x, w, y, NB, D, H, W, Cin, Cout, dgrad=False, bias=None, bn_partials=None, act=ACT_NONE, in_stride=None,
+            in_coff=0, out_stride=None, out_coff=0):
+    """Conv3d(k3, p1) forward (w = [27][Cout][Cin] pack) or data gradient (dgrad=True: x = dY, w = [27][Cin][Cout]
+    pack, Cin/Cout given from the kernel's point of view: Cin = channels of x) on depth-slice NHWC tensors."""
+    _dev(x)
+    _f32(bias, "bias"); _f32(bn_partials, "bn_partials")
+    if not (x.dtype == w.dtype == y.dtype):
+        raise TypeError("conv3d3: x, w, y must share one 16-bit dtype")
+    if w.numel() != 27 * Cout * Cin:
+        raise ValueError("conv3d3: packed weight has the wrong size")
+    if bn_partials is not None and bn_partials.numel() < bn_partials_numel(conv3d3_mtiles(NB, D, H, W, Cout), Cout):
+        raise ValueError("conv3d3: bn_partials too small")
+    sgn = -1 if dgrad else 1
+    dz = (ctypes.c_int32 * 3)(*[sgn * (k - 1) for k in range(3)])
+    dy = (ctypes.c_int32 * 9)(*[sgn * (k // 3 - 1) for k in range(9)])
+    dx = (ctypes.c_int32 * 9)(*[sgn * (k % 3 - 1) for k in range(9)])
+    ev = TIMER.start() if TIMER is not None else None
+    _lib.call("gs_conv3d_3x3x3", _p(x), _p(w), _p(y), _p(bias), _p(bn_partials), NB, D, H, W, Cin,
+              Cin if in_stride is None else in_stride, in_coff, Cout, Cout if out_stride is None else out_stride, out_coff,
+              dz, dy, dx, act, dt_code(x), _stream())
+    if ev is not None:
+        TIMER.stop("conv3x3_halo", ev, 2.0 * NB * D * H * W * Cout * 27 * Cin)
+
+
+def conv3d3_wgrad(x, dy, dw, NB, D, H, W, Cin, Cout, in_stride=None, in_coff=0, out_stride=None, out_coff=0):
+    """dw[27][Cout][Cin] (fp32, caller zeroes) += weight gradient of Conv3d(k3, p1)."""
+    _dev(x)
+    _f32(dw, "dw")
+    if x.dtype != dy.dtype:
+        raise TypeError("conv3d3_wgrad: x and dy must share one 16-bit dtype")
+    if dw.numel() < 27 * Cout * Cin:
+        raise ValueError("conv3d3_wgrad: dw too small")
+    ev = TIMER.start() if TIMER is not None else None
+    _lib.call("gs_conv3d_3x3x3_wgrad", _p(x), _p(dy), _p(dw), NB, D, H, W, Cin, Cin if in_stride is None else in_stride,
+              in_coff, Cout, Cout if out_stride is None else out_stride, out_coff, dt_code(x), _stream())
+    if ev is not None:
+        TIMER.stop("wgrad3x3_halo", ev, 2.0 * NB * D * H * W * Cout * 27 * Cin)
+
+
 def upsample2x_bilinear_fwd(x, y, N, IH, IW, C, OH, OW, in_stride=None, in_coff=0, out_stride=None, out_coff=0,
                             ooy=0, oox=0):
     """nn.Upsample(scale_factor=2, bilinear, align_corners=True) into a channel slice of the [N,OH,OW,*] buffer y."""

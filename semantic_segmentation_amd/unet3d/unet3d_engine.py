@@ -34,7 +34,7 @@ def geom_conv3d(NB, D, H, W, Cin, Cout, dgrad=False, **kw):
 
 class _Stage:
     __slots__ = ("conv", "bn", "inp", "in_stride", "in_coff", "y", "coef", "stats", "geom", "wd", "cin", "cout",
-                 "D", "H", "W", "first", "x3")
+                 "D", "H", "W", "first", "x3", "halo")
 
 
 class UNet3DEngine:
@@ -98,15 +98,23 @@ class UNet3DEngine:
                 part = empty(ops.bn_partials_numel(nt, cout), dtype=torch.float32) if batch else None
                 ops.conv_smallcin_fwd(x3, conv.weight.detach().reshape(cout, 3, 3, 3).contiguous(), None, y, part, 3, 1, 1)
                 st.geom = st.wd = None
+                st.halo = False
             else:
                 w4 = conv.weight.detach().reshape(cout, cin, 27, 1)
                 wf = empty(27, cout, cin)
                 wd = empty(27, cin, cout) if need_grad else None
                 ops.pack_weight(w4, wf, wd, False)
-                g = geom_conv3d(NB, D, H, W, cin, cout, in_stride=in_stride, in_coff=in_coff)
-                nt = ops.conv_igemm_mtiles(g)
-                part = empty(ops.bn_partials_numel(nt, cout), dtype=torch.float32) if batch else None
-                ops.conv_igemm(g, inp, wf, y, None, part)
+                st.halo = ops.conv3d3_eligible(cin, cout)
+                if st.halo:                      # halo-reuse kernel: (depth tap, channel chunk) K stages
+                    g = None
+                    nt = ops.conv3d3_mtiles(NB, D, H, W, cout)
+                    part = empty(ops.bn_partials_numel(nt, cout), dtype=torch.float32) if batch else None
+                    ops.conv3d3(inp, wf, y, NB, D, H, W, cin, cout, bn_partials=part, in_stride=in_stride, in_coff=in_coff)
+                else:
+                    g = geom_conv3d(NB, D, H, W, cin, cout, in_stride=in_stride, in_coff=in_coff)
+                    nt = ops.conv_igemm_mtiles(g)
+                    part = empty(ops.bn_partials_numel(nt, cout), dtype=torch.float32) if batch else None
+                    ops.conv_igemm(g, inp, wf, y, None, part)
                 st.geom, st.wd = g, wd
             st.coef, st.stats = bn_coeffs(bn, conv.bias, part, nt, cout, NB * D * H * W)
             ops.bn_act_apply(y, st.coef[0], st.coef[1], ACT_RELU, z, z_stride, z_coff)
@@ -236,13 +244,19 @@ class UNet3DEngine:
                 emit(wparam, dw.view(wparam.shape))
             else:
                 dwp = torch.zeros((27, cout, cin), dtype=torch.float32, device=dev)
-                ops.conv_wgrad(st.geom, st.inp, dy, dwp)
+                if st.halo:
+                    ops.conv3d3_wgrad(st.inp, dy, dwp, NB, D, H, W, cin, cout, in_stride=st.in_stride, in_coff=st.in_coff)
+                else:
+                    ops.conv_wgrad(st.geom, st.inp, dy, dwp)
                 dw = torch.empty((cout, cin, 27), dtype=torch.float32, device=dev)
                 ops.unpack_wgrad(dwp, dw, cout, cin, 27, False, inv_s)
                 emit(wparam, dw.view(wparam.shape))
                 if need_dinp:
                     dinp = empty(n2, H, W, cin)
-                    ops.conv_igemm(geom_conv3d(NB, D, H, W, cin, cout, dgrad=True), dy, st.wd, dinp)
+                    if ops.conv3d3_eligible(cout, cin):
+                        ops.conv3d3(dy, st.wd, dinp, NB, D, H, W, cout, cin, dgrad=True)
+                    else:
+                        ops.conv_igemm(geom_conv3d(NB, D, H, W, cin, cout, dgrad=True), dy, st.wd, dinp)
             return dinp
 
         stages = {id(s): s for s in ctx["stages"]}

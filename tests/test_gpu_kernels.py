@@ -519,3 +519,49 @@ def test_conv3x3_halo_wgrad(dtn, dt, N, H, W, Cin, Cout):
     torch.cuda.synchronize()
     got = dwp.cpu().view(3, 3, Cout, Cin).permute(2, 3, 0, 1)
     assert rel_err(got, w.grad) < 2e-3, rel_err(got, w.grad)
+
+
+@pytest.mark.parametrize("dtn,dt", DTS)
+@pytest.mark.parametrize("NB,D,H,W,Cin,Cout", [(1, 4, 8, 8, 64, 64), (2, 3, 9, 13, 128, 72), (1, 1, 16, 16, 64, 8),
+                                               (1, 5, 33, 20, 192, 64)])
+def test_conv3d_3x3x3_halo_fwd_dgrad_wgrad(dtn, dt, NB, D, H, W, Cin, Cout):
+    """gs_conv3d_3x3x3 / _wgrad: Conv3d(k3,p1) of GenSeg-3D/UNet3D/unet3d.py:28-31 forward, data gradient and weight
+    gradient on the halo-reuse kernels ((depth tap, channel chunk) K stages), plus the BatchNorm partial sums."""
+    from semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = rnd(g, NB, Cin, D, H, W, dt=dt).requires_grad_(True)
+    w = rnd(g, Cout, Cin, 3, 3, 3, dt=dt, scale=0.05).requires_grad_(True)
+    y = F.conv3d(x, w, None, padding=1)
+    dyt = rnd(g, NB, Cout, D, H, W, dt=dt)
+    y.backward(dyt)
+
+    def to_slices(t):                       # [NB,C,D,H,W] -> [NB*D,H,W,C]
+        return t.permute(0, 2, 3, 4, 1).reshape(NB * D, H, W, t.shape[1]).contiguous().to(dt).to(dev())
+
+    def from_slices(t, C):
+        return t.float().cpu().reshape(NB, D, H, W, C).permute(0, 4, 1, 2, 3)
+
+    wf = torch.empty(27, Cout, Cin, dtype=dt, device=dev())
+    wd = torch.empty(27, Cin, Cout, dtype=dt, device=dev())
+    ops.pack_weight(w.detach().reshape(Cout, Cin, 27, 1).to(dev()), wf, wd, False)
+    xs, dys = to_slices(x.detach()), to_slices(dyt)
+    nt = ops.conv3d3_mtiles(NB, D, H, W, Cout)
+    part = torch.empty(ops.bn_partials_numel(nt, Cout), dtype=torch.float32, device=dev())
+    yo = torch.empty(NB * D, H, W, Cout, dtype=dt, device=dev())
+    ops.conv3d3(xs, wf, yo, NB, D, H, W, Cin, Cout, bn_partials=part)
+    torch.cuda.synchronize()
+    assert rel_err(from_slices(yo, Cout), y.detach()) < tol(dt)
+    p = part[: nt * 2 * Cout].view(nt, 2, Cout).double().sum(0).cpu()
+    ref1 = y.detach().double().sum(dim=(0, 2, 3, 4))
+    ref2 = (y.detach().double() ** 2).sum(dim=(0, 2, 3, 4))
+    assert float((p[0] - ref1).abs().max() / (ref1.abs().max() + 1e-6)) < 2e-3
+    assert float((p[1] - ref2).abs().max() / (ref2.abs().max() + 1e-6)) < 2e-3
+    if Cout % 64 == 0:                      # data gradient runs on the same kernel when its K (= Cout) allows it
+        dxo = torch.empty(NB * D, H, W, Cin, dtype=dt, device=dev())
+        ops.conv3d3(dys, wd, dxo, NB, D, H, W, Cout, Cin, dgrad=True)
+        assert rel_err(from_slices(dxo, Cin), x.grad) < tol(dt)
+    dwp = torch.zeros(27, Cout, Cin, dtype=torch.float32, device=dev())
+    ops.conv3d3_wgrad(xs, dys, dwp, NB, D, H, W, Cin, Cout)
+    dw = torch.empty(Cout, Cin, 27, dtype=torch.float32, device=dev())
+    ops.unpack_wgrad(dwp, dw, Cout, Cin, 27, False, 1.0)
+    assert rel_err(dw.cpu().view(Cout, Cin, 3, 3, 3), w.grad) < 2e-3
