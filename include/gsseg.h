@@ -243,7 +243,7 @@ int gs_mean_loss_bwd(const float* x, const float* t, float cval, int mode, int64
  * GenSeg-3D/UNet3D/unet3d.py:28-31 (Conv3DBlock) and :69-71 (UpConv3DBlock).  Volumes are NB*D depth slices
  * [NB*D, H, W, *]; w / dw: [27][Cout][Cin], slot = kd*9 + kh*3 + kw.  tap_dz[kd] / tap_dy,tap_dx[kh*3+kw] are the
  * input offsets each slot reads (forward: kd-1, kh-1, kw-1; data gradient: the negated offsets with the [27][Cin][Cout]
- * pack).  bn_partials: [gs_conv3d_3x3x3_mtiles][2][Cout].  Requires Cin % 64 == 0, Cout % 8 == 0, 16-byte aligned
+ * pack).  bn_partials: [gs_conv3d_3x3x3_mtiles][2][Cout].  Requires Cin % 8 == 0, Cout % 8 == 0, 16-byte aligned
  * output channel slices (other shapes: gs_conv_igemm with depth taps). */
 int gs_conv3d_3x3x3_mtiles(int NB, int D, int H, int W, int Cout);
 int gs_conv3d_3x3x3(const void* x, const void* w, void* y, const float* bias, float* bn_partials, int NB, int D, int H,

@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
     const int nchunks_c = (a.Cin + 63) >> 6;               // 64-channel chunks of one slice
     const int nchunks = a.ndz * nchunks_c;                  // K stages per item: (depth tap, channel chunk)
     // stage cc of an item that lives in slice n: source slice, weight-slot offset, validity (zero padding in depth)
-    struct StageSrc { int n; unsigned sc, wsc; unsigned kill; };
+    struct StageSrc { int n; unsigned sc, wsc; unsigned kill; unsigned ckill; };   // ckill: this lane's 8 channels >= Cin
     const unsigned img_bytes = (unsigned)a.H * a.W * a.in_stride * 2u;
 
 #ifdef GS_C3_PHASE_TIMING
@@ -627,6 +627,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
         r.kill = ((unsigned)(d + dz) < (unsigned)a.D) ? 0u : VOOB;
         r.sc = (unsigned)c * 128u;                                // 64 channels x 2 bytes per chunk
         r.wsc = r.sc + (unsigned)(dzi * 9) * tap_stride_c;
+        r.ckill = (c * 64 + chunk * 8 < a.Cin) ? 0u : VOOB;       // Cin % 64 != 0: the tail chunk is zero padded
         return r;
     };
     auto load_stage = [&](const Item& itn, int cc, auto with_w) __attribute__((always_inline)) {
@@ -636,13 +637,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
         if (decltype(with_w)::value) {
 #pragma unroll
             for (int j = 0; j < WCH; ++j) {                       // row = rbase + 32 j = (j>>1)*64 + (rbase + 32 (j&1))
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wv[j & 1], ss.wsc + (unsigned)(j >> 1) * tap_stride, 0);
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wv[j & 1] | ss.ckill, ss.wsc + (unsigned)(j >> 1) * tap_stride, 0);
                 rw[j] = make_uint4(v[0], v[1], v[2], v[3]);
             }
         }
 #pragma unroll
         for (int j = 0; j < HCH; ++j) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, hv[j] | ss.kill, ss.sc, 0);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, hv[j] | ss.kill | ss.ckill, ss.sc, 0);
             rh[j] = make_uint4(v[0], v[1], v[2], v[3]);
         }
     };
@@ -865,7 +866,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
             const __amdgpu_buffer_rsrc_t rx_n = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(a.x + (int64_t)(ssn.kill ? ldi.n : ssn.n) * a.H * a.W * a.in_stride), 0, img_bytes, 0x00020000);
             const unsigned sc_n = ssn.sc, wsc_n = ssn.wsc;
-            const unsigned kill = have_next ? 0u : VOOB;
+            const unsigned kill = (have_next ? 0u : VOOB) | ssn.ckill;
             const unsigned killh = kill | ssn.kill;              // depth tap outside the volume: zero slice
             auto issue_load = [&](int j) __attribute__((always_inline)) {       // j is a compile-time constant
                 constexpr int NW = WRES ? 0 : WCH;
@@ -975,7 +976,7 @@ static bool c3_use_big(int Cout, int out_pix_stride, int out_coff) {
 }
 static bool c3_big_ok(int H, int W, int Cin, int in_pix_stride, int Cout, int out_pix_stride) {
     // 32-bit buffer offsets with bit 31 as the "out of range" marker: one image and the weights stay below 2 GiB
-    return (Cin % 64) == 0 && (int64_t)H * W * in_pix_stride * 2 < 2147483000LL &&
+    return (Cin % 8) == 0 && (int64_t)H * W * in_pix_stride * 2 < 2147483000LL &&
            (int64_t)H * W * out_pix_stride * 2 < 2147483000LL && (int64_t)9 * Cout * Cin * 2 < 2147483000LL;
 }
 
@@ -1016,7 +1017,7 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
                  "gs_conv3x3: activation %d not supported (use gs_conv_igemm)", act & 0xff);
     const bool big = c3_use_big(Cout, out_pix_stride, out_coff) && c3_big_ok(H, W, Cin, in_pix_stride, Cout, out_pix_stride) &&
                      (int64_t)9 * ndz * Cout * Cin * 2 < 2147483000LL;
-    GS_CHECK_ARG(big || ndz == 1, "gs_conv3d_3x3x3: needs Cin %% 64 == 0, Cout %% 8 == 0 and 16-byte aligned output channels");
+    GS_CHECK_ARG(big || ndz == 1, "gs_conv3d_3x3x3: needs Cin %% 8 == 0, Cout %% 8 == 0 and 16-byte aligned output channels");
     if (big) {
         const int tw = (W >= 24) ? 32 : 16, th = 256 / tw;
         a.tiles_x = cdiv(W, tw); a.tiles_y = cdiv(H, th);
@@ -1096,7 +1097,7 @@ extern "C" int gs_conv3x3(const void* x, const void* w, void* y, const float* bi
 // 3x3x3 / stride 1 / pad 1 Conv3d (GenSeg-3D/UNet3D/unet3d.py:28-31,69-71) and its data gradient on the same halo-reuse
 // kernel: the volumes are NB*D depth slices [NB*D, H, W, *]; per output patch the K loop runs over (depth tap, channel
 // chunk) stages, stage (dz, c) staging the halo of slice d + tap_dz[dz] (zeros outside the volume) and the nine
-// weights of slot dz*9 .. dz*9+8 of the [27][Cout][Cin] pack.  Requires Cin % 64 == 0, Cout % 8 == 0.
+// weights of slot dz*9 .. dz*9+8 of the [27][Cout][Cin] pack.  Requires Cin % 8 == 0, Cout % 8 == 0 (a tail channel chunk is zero padded).
 extern "C" int gs_conv3d_3x3x3_mtiles(int NB, int D, int H, int W, int Cout) {
     return gs_conv3x3_mtiles(NB * D, H, W, Cout);
 }

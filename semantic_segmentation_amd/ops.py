@@ -233,7 +233,7 @@ def upconv2x2_fwd(x, w, bias, y, N, D, IH, IW, Cin, Cout, Dout, OH, OW, in_strid
 def conv3d3_eligible(Cin, Cout, out_stride=None, out_coff=0) -> bool:
     """shapes the 3-D halo kernels take (others go through conv_igemm with depth taps)"""
     os_ = Cout if out_stride is None else out_stride
-    return USE_HALO_CONV and Cin % 64 == 0 and Cout % 8 == 0 and os_ % 8 == 0 and out_coff % 8 == 0
+    return USE_HALO_CONV and Cin % 8 == 0 and Cout % 8 == 0 and os_ % 8 == 0 and out_coff % 8 == 0
 
 
 def conv3d3_mtiles(NB, D, H, W, Cout) -> int:
