@@ -75,10 +75,39 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
         }
     }
     uint4 ra[4], rb[BROWS];
-    const int nk = g.ntaps * a.kchunks;
+    // Taps none of this tile's 128 rows can see (out of the image for every row) are dropped from the K loop: at the
+    // 1x1 .. 8x8 bottom of the Pix2Pix generator 75-94 % of the 4x4 / 8x8 taps fall outside the feature map, and with
+    // M = a few pixels the kernel otherwise streams (and multiplies by zero) the whole multi-megabyte weight pack.
+    __shared__ int act_taps[GS_MAX_TAPS + 1];
+    {
+        unsigned long long mask = 0ull;              // ntaps <= 64
+        for (int tp = 0; tp < g.ntaps; ++tp) {
+            const int dy = g.tap_dy[tp], dx = g.tap_dx[tp], dz = g.tap_dz[tp];
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                any = any || (a_n[j] >= 0 && (unsigned)(a_iy0[j] + dy) < (unsigned)g.IH &&
+                              (unsigned)(a_ix0[j] + dx) < (unsigned)g.IW && (unsigned)(a_d0[j] + dz) < (unsigned)g.Din);
+            if (__any(any)) mask |= 1ull << tp;
+        }
+        // OR over the four waves, then a compact list in tap order
+        unsigned long long* wmask = reinterpret_cast<unsigned long long*>(smem);
+        if (lane == 0) wmask[wave] = mask;
+        __syncthreads();
+        if (t == 0) {
+            const unsigned long long m4 = wmask[0] | wmask[1] | wmask[2] | wmask[3];
+            int n = 0;
+            for (int tp = 0; tp < g.ntaps; ++tp)
+                if ((m4 >> tp) & 1ull) act_taps[1 + n++] = tp;
+            act_taps[0] = n;
+        }
+        __syncthreads();
+    }
+    const int nk = act_taps[0] * a.kchunks;
 
     auto load_tile = [&](int ks) {
-        const int tap = ks / a.kchunks, cc = ks - tap * a.kchunks;
+        const int ti = ks / a.kchunks, cc = ks - ti * a.kchunks;
+        const int tap = act_taps[1 + ti];
         const int ci = cc * FW_BK + chunk * 8;
         const int dy = g.tap_dy[tap], dx = g.tap_dx[tap], dz = g.tap_dz[tap];
         const bool cok = ci < g.Cin;
@@ -122,8 +151,10 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tile(0);
-    store_tile(0);
+    if (nk > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
     __syncthreads();
     for (int ks = 0; ks < nk; ++ks) {
         const int cur = ks & 1;
