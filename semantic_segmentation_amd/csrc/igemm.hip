@@ -31,6 +31,12 @@ struct IgemmArgs {
     int vec_store;     // 1: epilogue stages the tile through LDS and stores 16-byte channel chunks
     int shuffle_cout;  // > 0: merged stride-2 transposed conv (kernel 2): GEMM column c' = cls * shuffle_cout + co is
     int shuffle_cls;   //      written to output pixel (2z+cz, 2y+cy, 2x+cx), cls = (cz, cy, cx) bits; 4 or 8 classes
+    // split-K (skinny GEMMs: few M/N tiles, long K): blockIdx = tile * ksplit + part; every part stores its fp32
+    // accumulators in its slab ws_acc[tile][part][256 threads][regs]; the LAST part to arrive (ticket in ws_cnt[tile])
+    // sums the slabs, runs the normal epilogue and resets the ticket counter.
+    int ksplit;
+    float* ws_acc;
+    unsigned int* ws_cnt;
 };
 
 // bijective XCD-aware remap: blocks that share an XCD (bid % 8) get a contiguous range of logical ids
@@ -54,7 +60,9 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
     const GsConvGeom& g = a.g;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
-    const int lid = xcd_remap(blockIdx.x, a.nblocks);
+    const int ksplit = a.ksplit;
+    const int kpart = ksplit > 1 ? (int)(blockIdx.x % ksplit) : 0;
+    const int lid = ksplit > 1 ? (int)(blockIdx.x / ksplit) : xcd_remap(blockIdx.x, a.nblocks);
     const int ntile = lid % a.ntn, mtile = lid / a.ntn;
     const int m0 = mtile * FW_BM, n0 = ntile * BN;
 
@@ -103,10 +111,13 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
         }
         __syncthreads();
     }
-    const int nk = act_taps[0] * a.kchunks;
+    const int nk_all = act_taps[0] * a.kchunks;
+    const int ks_begin = ksplit > 1 ? (int)((int64_t)nk_all * kpart / ksplit) : 0;
+    const int ks_end = ksplit > 1 ? (int)((int64_t)nk_all * (kpart + 1) / ksplit) : nk_all;
+    const int nk = ks_end - ks_begin;
 
     auto load_tile = [&](int ks) {
-        const int ti = ks / a.kchunks, cc = ks - ti * a.kchunks;
+        const int ti = (ks + ks_begin) / a.kchunks, cc = (ks + ks_begin) - ti * a.kchunks;
         const int tap = act_taps[1 + ti];
         const int ci = cc * FW_BK + chunk * 8;
         const int dy = g.tap_dy[tap], dx = g.tap_dx[tap], dz = g.tap_dz[tap];
@@ -174,6 +185,49 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
                 for (int j = 0; j < NT; ++j) acc[i][j] = Elem<DT>::mfma32(af[i], bf[j], acc[i][j]);
         }
         if (ks + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    if (ksplit > 1) {
+        // every part stores its partial tile in its own slab (plain 16-byte stores: same-address atomics from dozens
+        // of blocks serialise in L2); the LAST part to take a ticket sums the slabs in part order (deterministic)
+        constexpr int REGS = 2 * NT * 16;
+        float* slab = a.ws_acc + (((int64_t)lid * ksplit + kpart) * 256 + t) * REGS;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+                    *reinterpret_cast<float4*>(slab + (i * NT + j) * 16 + r4 * 4) =
+                        make_float4(acc[i][j][r4 * 4], acc[i][j][r4 * 4 + 1], acc[i][j][r4 * 4 + 2], acc[i][j][r4 * 4 + 3]);
+        __threadfence();                                           // release: the slab is visible device-wide
+        __syncthreads();
+        __shared__ unsigned int ticket;
+        if (t == 0) ticket = __hip_atomic_fetch_add(a.ws_cnt + lid, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (ticket != (unsigned)(ksplit - 1)) return;             // not the last part of this tile
+        __threadfence();                                           // acquire: see the other parts' slabs
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int pp = 0; pp < ksplit; ++pp) {
+            const float* q = a.ws_acc + (((int64_t)lid * ksplit + pp) * 256 + t) * REGS;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const float4 v = *reinterpret_cast<const float4*>(q + (i * NT + j) * 16 + r4 * 4);
+                        acc[i][j][r4 * 4] += v.x; acc[i][j][r4 * 4 + 1] += v.y;
+                        acc[i][j][r4 * 4 + 2] += v.z; acc[i][j][r4 * 4 + 3] += v.w;
+                    }
+        }
+        if (t == 0) __hip_atomic_store(a.ws_cnt + lid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ticket counter back to 0
         __syncthreads();
     }
 
@@ -509,12 +563,41 @@ int check_geom(const GsConvGeom* g, const char* who) {
 
 }  // namespace
 
-static int launch_igemm(IgemmArgs& a, int dtype, hipStream_t s, const char* who) {
+float* g_splitk_ws = nullptr;                             // set by gs_conv_igemm_set_workspace (caller-owned memory)
+int64_t g_splitk_ws_floats = 0;
+constexpr int64_t SPLITK_TILE_FLOATS = 256 * 64;          // 256 threads x (2 x 2 x 16) accumulators of a 128x128 tile
+
+constexpr int SPLITK_MAX_TILES = 16, SPLITK_MAX_PARTS = 16;
+
+// ksplit for a launch with `tiles` output tiles and up to `ksteps` K steps: only really skinny GEMMs (<= 16 tiles on
+// 256 CUs), >= 8 K steps per part, ~256 blocks in total
+static int choose_ksplit(int tiles, int ksteps, int64_t ws_floats, int64_t cnt_slots) {
+    if (tiles > SPLITK_MAX_TILES || ksteps < 32) return 1;
+    int k = 256 / tiles;
+    if (k > ksteps / 8) k = ksteps / 8;
+    if (k > SPLITK_MAX_PARTS) k = SPLITK_MAX_PARTS;
+    if ((int64_t)tiles * k * SPLITK_TILE_FLOATS > ws_floats || tiles > cnt_slots) return 1;
+    return k < 2 ? 1 : k;
+}
+
+static int launch_igemm(IgemmArgs& a, int dtype, hipStream_t s, const char* who, float* ws = nullptr,
+                        int64_t ws_floats = 0) {
     const int bn = (a.g.Cout <= 64) ? 64 : 128;
     a.ntn = cdiv(a.g.Cout, bn);
     const int mt = cdiv(a.M, FW_BM);
     a.nblocks = mt * a.ntn;
-    dim3 grid(a.nblocks), block(256);
+    a.ksplit = 1; a.ws_acc = nullptr; a.ws_cnt = nullptr;
+    if (ws != nullptr) {
+        // layout of the caller's (zero-initialised, self-cleaning) workspace: [4096 tile counters][tile accumulators]
+        const int64_t cnt_slots = 4096;
+        const int k = choose_ksplit(a.nblocks, a.g.ntaps * a.kchunks, ws_floats - cnt_slots, cnt_slots);
+        if (k > 1) {
+            a.ksplit = k;
+            a.ws_cnt = reinterpret_cast<unsigned int*>(ws);
+            a.ws_acc = ws + cnt_slots;
+        }
+    }
+    dim3 grid(a.nblocks * a.ksplit), block(256);
     if (dtype == GS_F16) {
         if (bn == 64) igemm_fwd_kernel<GS_F16, 64><<<grid, block, 0, s>>>(a);
         else igemm_fwd_kernel<GS_F16, 128><<<grid, block, 0, s>>>(a);
@@ -545,7 +628,22 @@ extern "C" int gs_conv_igemm(const GsConvGeom* g, const void* x, const void* w, 
     a.kchunks = cdiv(g->Cin, FW_BK);
     a.vec_store = (g->Cout % 8 == 0 && g->out_pix_stride % 8 == 0 && g->out_coff % 8 == 0) ? 1 : 0;
     a.shuffle_cout = 0; a.shuffle_cls = 0;
-    return launch_igemm(a, dtype, (hipStream_t)stream, "gs_conv_igemm");
+    return launch_igemm(a, dtype, (hipStream_t)stream, "gs_conv_igemm", g_splitk_ws, g_splitk_ws_floats);
+}
+
+// Optional split-K workspace for gs_conv_igemm (skinny GEMMs: the 1x1 .. 16x16 levels of the Pix2Pix generator at
+// the script's batch size 2 run 4-8 blocks over multi-megabyte weight packs otherwise).  The caller owns the memory
+// (fp32, zero-initialised once; the kernels leave it zeroed); pass NULL / 0 to switch split-K off.  One workspace per
+// process: launches that share it must be ordered on one stream.
+extern "C" int gs_conv_igemm_set_workspace(float* ws, int64_t ws_floats) {
+    GS_CHECK_ARG(ws == nullptr || ws_floats >= 4096 + SPLITK_TILE_FLOATS, "gs_conv_igemm_set_workspace: workspace too small");
+    g_splitk_ws = ws;
+    g_splitk_ws_floats = ws ? ws_floats : 0;
+    return GS_OK;
+}
+
+extern "C" int64_t gs_conv_igemm_workspace_floats(void) {
+    return 4096 + (int64_t)SPLITK_MAX_TILES * SPLITK_MAX_PARTS * SPLITK_TILE_FLOATS;
 }
 
 // Merged stride-2 / kernel-2 transposed convolution (unet_parts.py:51 ConvTranspose2d(C, C/2, 2, 2);

@@ -149,6 +149,19 @@ def geom_conv_s2_dgrad_class(N, IH, IW, Cin, Cout, k, pad, py, px, **kw) -> GsCo
 
 
 # ---------------------------------------------------------------------------- MFMA engine
+_SPLITK_WS = {}      # device index -> zeroed fp32 workspace handed to the library (kept alive here)
+
+
+def _ensure_splitk_workspace(device: torch.device) -> None:
+    """gs_conv_igemm's split-K workspace: allocated (zeroed) once per process; the kernels leave it zeroed."""
+    if os.environ.get("GSSEG_SPLITK", "1") == "0" or device.index in _SPLITK_WS:
+        return
+    n = int(_lib.load().gs_conv_igemm_workspace_floats())
+    ws = torch.zeros(n, dtype=torch.float32, device=device)
+    _lib.call("gs_conv_igemm_set_workspace", _p(ws), n)
+    _SPLITK_WS[device.index] = ws
+
+
 def conv_igemm(g: GsConvGeom, x, w, y, bias=None, bn_partials=None, act=ACT_NONE):
     _dev(x)
     _f32(bias, "bias"); _f32(bn_partials, "bn_partials")
@@ -158,6 +171,7 @@ def conv_igemm(g: GsConvGeom, x, w, y, bias=None, bn_partials=None, act=ACT_NONE
         need = _lib.load().gs_bn_partials_floats(conv_igemm_mtiles(g), g.Cout)
         if bn_partials.numel() < need:
             raise ValueError(f"bn_partials too small: {bn_partials.numel()} < {need}")
+    _ensure_splitk_workspace(x.device)
     ev = TIMER.start() if TIMER is not None else None
     _lib.call("gs_conv_igemm", g, _p(x), _p(w), _p(y), _p(bias), _p(bn_partials), act, dt_code(x), _stream())
     if ev is not None:

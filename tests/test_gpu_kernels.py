@@ -565,3 +565,42 @@ def test_conv3d_3x3x3_halo_fwd_dgrad_wgrad(dtn, dt, NB, D, H, W, Cin, Cout):
     dw = torch.empty(Cout, Cin, 27, dtype=torch.float32, device=dev())
     ops.unpack_wgrad(dwp, dw, Cout, Cin, 27, False, 1.0)
     assert rel_err(dw.cpu().view(Cout, Cin, 3, 3, 3), w.grad) < 2e-3
+
+
+@pytest.mark.parametrize("dtn,dt", DTS)
+@pytest.mark.parametrize("N,h,Cin,Cout,k,s,p", [(2, 2, 512, 512, 4, 2, 1), (2, 4, 512, 256, 4, 2, 1), (1, 8, 1024, 128, 3, 1, 1)])
+def test_igemm_split_k_skinny(dtn, dt, N, h, Cin, Cout, k, s, p):
+    """Skinny GEMMs (a few output pixels, K = taps x 512..1024 channels: the bottom of the Pix2Pix generator at batch 2,
+    networks.py:582-602) go through the split-K path of gs_conv_igemm: partial tiles in the fp32 workspace, the last
+    part runs bias / activation / BatchNorm partial sums; the workspace must come back zeroed (two calls agree)."""
+    from semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(13)
+    x = rnd(g, N, Cin, h, h, dt=dt)
+    w = rnd(g, Cout, Cin, k, k, dt=dt, scale=0.03)
+    b = rnd(g, Cout)
+    ref_raw = F.conv2d(x, w, None, stride=s, padding=p)
+    ref = F.leaky_relu(ref_raw + b.view(1, -1, 1, 1), 0.2)
+    oh = ref.shape[2]
+    wf = torch.empty(k * k, Cout, Cin, dtype=dt, device=dev())
+    ops.pack_weight(w.to(dev()), wf, None, False)
+    geom = ops.geom_conv(N, h, h, Cin, Cout, k, s, p)
+    from semantic_segmentation_amd._lib import ACT_LEAKY02
+    outs = []
+    for _ in range(2):
+        y = torch.empty(N, oh, oh, Cout, dtype=dt, device=dev())
+        ops.conv_igemm(geom, nhwc(x, dt), wf, y, b.to(dev()), None, ACT_LEAKY02)
+        torch.cuda.synchronize()
+        outs.append(from_nhwc(y))
+    assert rel_err(outs[0], ref) < tol(dt)
+    assert rel_err(outs[1], ref) < tol(dt)
+    # BatchNorm partial sums come from the full (summed) accumulators
+    nt = ops.conv_igemm_mtiles(geom)
+    part = torch.empty(ops.bn_partials_numel(nt, Cout), dtype=torch.float32, device=dev())
+    y = torch.empty(N, oh, oh, Cout, dtype=dt, device=dev())
+    ops.conv_igemm(geom, nhwc(x, dt), wf, y, None, part)
+    torch.cuda.synchronize()
+    ps = part[: nt * 2 * Cout].view(nt, 2, Cout).double().sum(0).cpu()
+    r1 = ref_raw.double().sum(dim=(0, 2, 3))
+    assert float((ps[0] - r1).abs().max() / (r1.abs().max() + 1e-6)) < 3e-3
+    ws = ops._SPLITK_WS[0]
+    assert int(ws[:4096].view(torch.int32).abs().max()) == 0        # the tile ticket counters are back to zero
