@@ -92,6 +92,42 @@ class GradReducer:
         return self
 
 
+def all_reduce_gradients(params, bucket_bytes: int = 64 << 20, group=None, average: bool = True) -> int:
+    """Post-backward gradient exchange for modules whose engines have no bucket hooks (UNet3D, the Pix2Pix pair,
+    multi-forward steps such as harness.EndToEndTrainer): the `.grad`s are packed into flat fp32 buckets in reverse
+    registration order, each bucket all-reduced asynchronously (the copies of the next bucket overlap the
+    collective of the previous one) and scattered back.  Parameters without gradient are skipped on EVERY rank
+    alike (the set must match across ranks, as in DDP).  Returns the number of elements exchanged."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 0
+    world = dist.get_world_size(group)
+    plist = [p for p in params if p.grad is not None][::-1]
+    if not plist:
+        return 0
+    use_avg = average and dist.get_backend(group) == "nccl"
+    op = dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM
+    pending, total, i = [], 0, 0
+    while i < len(plist):
+        chunk, nbytes = [], 0
+        while i < len(plist) and (not chunk or nbytes + plist[i].numel() * 4 <= bucket_bytes):
+            chunk.append(plist[i])
+            nbytes += plist[i].numel() * 4
+            i += 1
+        flat = torch.cat([p.grad.reshape(-1).float() for p in chunk])
+        pending.append((dist.all_reduce(flat, op=op, group=group, async_op=True), flat, chunk))
+        total += flat.numel()
+    for work, flat, chunk in pending:
+        work.wait()
+        if average and not use_avg:
+            flat.mul_(1.0 / world)
+        off = 0
+        for p in chunk:
+            n = p.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n
+    return total
+
+
 def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None):
     """Replicas start identical: parameters and buffers of rank `src` (DDP broadcast_buffers semantics)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:

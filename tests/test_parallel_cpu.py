@@ -55,6 +55,19 @@ def _worker(rank, world, port, q):
         assert torch.allclose(red.flat, torch.full_like(red.flat, (world + 1) / 2))
         lo, hi = shard_batch(8, rank, world)
         assert (lo, hi) == (rank * 4, rank * 4 + 4)
+        # generic post-backward exchange (UNet3D / Pix2Pix / harness): rank-dependent gradients are averaged in
+        # place, a parameter without gradient is skipped, small buckets force several collectives
+        from semantic_segmentation_amd.parallel import all_reduce_gradients
+        plist = list(net.parameters())
+        for i, p in enumerate(plist):
+            p.grad = None if i == 1 else torch.full_like(p, float((rank + 1) * (i + 1)))
+        n = all_reduce_gradients(plist, bucket_bytes=48)
+        assert n == sum(p.numel() for i, p in enumerate(plist) if i != 1)
+        for i, p in enumerate(plist):
+            if i == 1:
+                assert p.grad is None
+            else:
+                assert torch.allclose(p.grad, torch.full_like(p, (i + 1) * (world + 1) / 2)), i
         q.put((rank, "ok"))
     except Exception as e:      # noqa: BLE001
         q.put((rank, repr(e)))
