@@ -213,3 +213,46 @@ def test_evaluate_matches_reference(golden_dir, name):
     score = evaluate(net, loader, torch.device("cuda:0"), amp=True)
     assert net.training                        # evaluate() restores train mode (evaluate.py:42)
     assert abs(float(score) - float(z["eval_dice"])) < 1e-3
+
+
+def test_full_size_properties_bs32_256():
+    """Size-independent properties at BASELINE's full configuration (UNet(1,2), 256x256, batch 32), where the oracle
+    is too slow to run as a checker:
+      * eval-mode shard equivalence: the logits of a sample do not depend on which other samples share its batch
+        (bit-exact) -- the property the data-parallel parity definition of SURVEY 8e rests on;
+      * the loss gradient is linear in the loss scale: grads(4*loss) == 4*grads(loss) (a power of two passes through
+        the 16-bit gradient tensors exactly; the backward itself carries a power-of-two scale S and divides at the end);
+      * train-mode statistics: after one step the running mean of the first BatchNorm equals momentum * batch mean
+        of the first conv's output, checked against a direct fp32 evaluation of that one layer."""
+    from semantic_segmentation_amd.losses import seg_loss
+    net, sd = build_net(2, seed=21)
+    x, mask = oracle.synthetic_batch(32, 256, seed=77)
+    x, mask = x.cuda(), mask.cuda()
+    net.eval()
+    with torch.no_grad():
+        full = net(x)
+        part = net(x[8:16].contiguous())
+        single = net(x[31:32].contiguous())
+    assert torch.equal(full[8:16], part)
+    assert torch.equal(full[31:32], single)
+    net.train()
+    g1, g3 = {}, {}
+    for scale, store in ((1.0, g1), (4.0, g3)):
+        for p in net.parameters():
+            p.grad = None
+        net.load_state_dict(sd, strict=True)            # same running statistics for both passes
+        (seg_loss(net(x), mask) * scale).backward()
+        for k, p in net.named_parameters():
+            store[k] = p.grad.detach().clone()
+    # whole-gradient relative L2 (single tensors such as the up-conv biases, whose exact gradient nearly cancels
+    # in front of a BatchNorm, move by ~1e-2 of their own tiny norm when the fp16 subnormal tail shifts by 4x)
+    num = sum(float(((g3[k] - 4.0 * g1[k]).double() ** 2).sum()) for k in g1)
+    den = sum(float(((4.0 * g1[k]).double() ** 2).sum()) for k in g1)
+    assert (num / den) ** 0.5 < 2e-3, (num / den) ** 0.5
+    # running mean of inc.double_conv.1 after exactly one training step from zero: 0.1 * batch mean of conv(x)
+    net.load_state_dict(sd, strict=True)
+    net(x)
+    w = sd["inc.double_conv.0.weight"].cuda()
+    ref_mean = torch.nn.functional.conv2d(x, w, padding=1).mean(dim=(0, 2, 3)) * 0.1
+    got = net.inc.double_conv[1].running_mean
+    assert float((got - ref_mean).abs().max()) < 2e-5 + 2e-3 * float(ref_mean.abs().max())
