@@ -999,6 +999,10 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
     GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_conv3x3: bad dtype");
     C3Args a;
     a.x = (const unsigned short*)x; a.w = (const unsigned short*)w; a.y = (unsigned short*)y;
+    // bits 8.. of `act` are ablation switches of the big kernel (0x100 skip stores, 0x200 skip the K loop, 0x400 skip the
+    // epilogue: tools/bench_layers.py); they are honoured only when GSSEG_C3_DEBUG=1 is set in the environment
+    static const bool dbg_env = getenv("GSSEG_C3_DEBUG") && atoi(getenv("GSSEG_C3_DEBUG")) != 0;
+    if (!dbg_env) act &= 0xff;
     a.bias = bias; a.bnp = bn_partials; a.act = act;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.in_stride = in_pix_stride; a.in_coff = in_coff;
     a.Cout = Cout; a.out_stride = out_pix_stride; a.out_coff = out_coff;

@@ -6,6 +6,8 @@ import argparse
 import os
 import sys
 
+import os
+os.environ.setdefault("GSSEG_C3_DEBUG", "1")   # honour the ablation bits of gs_conv3x3 in this tool
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
