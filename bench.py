@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--classes", type=int, default=2)
     ap.add_argument("--dtype", default=os.environ.get("GSSEG_DTYPE", "f16"), choices=["f16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--global-dice", action="store_true",
+                    help="exact global-batch Dice across ranks (all-reduce of three scalars); default: per-rank Dice")
     ap.add_argument("--host-input", action="store_true",
                     help="PCIe-inclusive variant: copy the batch from pinned host memory inside every timed step")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -147,7 +149,7 @@ def main():
         xs, ms = x, mask
         if args.host_input:
             xs, ms = x_host.to(dev, non_blocking=True), mask_host.to(dev, non_blocking=True)
-        loss = seg_loss(net(xs), ms)
+        loss = seg_loss(net(xs), ms, global_dice=True if (args.global_dice and world > 1) else None)
         loss.backward()
         return loss
 
@@ -204,7 +206,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"unet.UNet(1,{args.classes}) {args.size}x{args.size} fwd+bwd, CE+Dice loss, "
                                f"batch {args.batch}/GPU (BASELINE configs[1])",
-                   "global_batch": world * args.batch, "parallelism": f"dp{world}", "loss": float(loss.item())},
+                   "global_batch": world * args.batch, "parallelism": f"dp{world}", "loss": float(loss.item()),
+                   "dice": "global-batch (3-scalar all-reduce)" if (args.global_dice and world > 1) else "per-rank"},
         "input": "pinned host memory, copied every step (PCIe-inclusive)" if args.host_input else "resident in HBM",
         "whole_step_tflops": round(value * gf / 1e3, 1),
         "whole_step_frac_of_mfma_peak": round(value * gf / 1e3 / (MFMA_PEAK_TFLOPS * world), 4),

@@ -227,7 +227,9 @@ int gs_nhwc_to_nchw(const void* src, int src_pix_stride, int src_coff, float* ds
  * seg loss forward: logits fp32 NCHW [N,C,H,W], mask uint8 [N,H,W] (class index; {0,1} for C==1).
  *   C==1: BCEWithLogits(mean) + 1 - dice(sigmoid(x), t) with ONE global sum over the batch;
  *   C>1 : CrossEntropy(mean) + 1 - dice(softmax(x), onehot(t)) (global sum over N*C*H*W).
- *   out[0]=loss out[1]=ce/bce out[2]=dice_loss out[3..5]=inter(2*sum p t), sum p, sum t.  ws: fp32 [4*1024].
+ *   out[0]=loss out[1]=ce/bce out[2]=dice_loss out[3..5]=inter(2*sum p t), sum p, sum t, out[6]=1 (multiplier of the
+ *   Dice gradient: data-parallel callers all-reduce out[3..5], rewrite out[0], out[2] and set out[6]=world for the exact
+ *   global-batch Dice of dice_score.py:10).  out has 8 floats.  ws: fp32 [4*1024].
  * backward: dlogits fp32 NCHW = dloss/dlogits * gscale * gout[0]  (gout: device scalar, upstream grad). */
 int gs_seg_loss_fwd(const float* logits, const uint8_t* mask, int N, int C, int H, int W, float* ws, float* out,
                     void* stream);

@@ -97,6 +97,8 @@ __global__ __launch_bounds__(256) void seg_loss_finalize_kernel(const float* ws,
         out[3] = inter;
         out[4] = (float)sp;
         out[5] = (float)st;
+        out[6] = 1.f;       // multiplier of the Dice part of the gradient (world size in global-batch Dice mode)
+        out[7] = 0.f;
     }
 }
 
@@ -108,7 +110,8 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restri
     const float inter = out[3], sp = out[4], st = out[5];
     const float S = sp + st;
     const bool degenerate = (S == 0.f);               // torch.where(sets_sum == 0, inter, sets_sum): dice == 1, grad 0
-    const float den = (S + DICE_EPS), inv2 = 1.f / (den * den);
+    const float dmul = out[6];                         // 1, or the world size when out[3..5] are global sums
+    const float den = (S + DICE_EPS), inv2 = dmul / (den * den);
     const float inv_m = 1.f / (float)total;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int t = m[i];

@@ -16,12 +16,37 @@ def _ws(dev):
     return torch.empty(ops.LOSS_WS, dtype=torch.float32, device=dev)
 
 
+DICE_EPS = 1e-6
+
+
+def apply_global_dice(out: torch.Tensor, global_sums: torch.Tensor, world: int) -> None:
+    """Turn the per-rank result of gs_seg_loss_fwd into the EXACT global-batch Dice of the reference's bs = world*B
+    step (dice_score.py:10-17 sums over the whole batch): `global_sums` = (2*sum p t, sum p, sum t) summed over the
+    ranks.  Rewrites out[0], out[2..5] in place and sets the Dice-gradient multiplier out[6] = world, so that the
+    gradient AVERAGE the data-parallel exchange computes equals the gradient of the global loss."""
+    inter, sp, st = global_sums[0], global_sums[1], global_sums[2]
+    sets = sp + st
+    sets = torch.where(sets == 0, inter, sets)
+    dice_loss = 1.0 - (inter + DICE_EPS) / (sets + DICE_EPS)
+    out[2] = dice_loss
+    out[0] = out[1] + dice_loss
+    out[3:6] = global_sums
+    out[6] = float(world)
+
+
 class _SegLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, mask_u8):
+    def forward(ctx, logits, mask_u8, group):
         logits = logits.contiguous().float()
         out = torch.empty(8, dtype=torch.float32, device=logits.device)
         ops.seg_loss_fwd(logits, mask_u8, _ws(logits.device), out)
+        if group is not None:
+            import torch.distributed as dist
+            world = dist.get_world_size(None if group is True else group)
+            if world > 1:
+                sums = out[3:6].clone()
+                dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=None if group is True else group)   # 12 bytes
+                apply_global_dice(out, sums, world)
         ctx.save_for_backward(logits, mask_u8, out)
         return out[0].clone(), out.detach()
 
@@ -30,7 +55,7 @@ class _SegLoss(torch.autograd.Function):
         logits, mask_u8, out = ctx.saved_tensors
         d = torch.empty_like(logits)
         ops.seg_loss_bwd(logits, mask_u8, out, gout.contiguous().float().reshape(1), 1.0, d)
-        return d, None
+        return d, None, None
 
 
 def _mask_u8(mask: torch.Tensor, n: int, h: int, w: int) -> torch.Tensor:
@@ -43,13 +68,16 @@ def _mask_u8(mask: torch.Tensor, n: int, h: int, w: int) -> torch.Tensor:
     return mask.to(torch.uint8).contiguous()
 
 
-def seg_loss(logits: torch.Tensor, mask: torch.Tensor, return_parts: bool = False):
+def seg_loss(logits: torch.Tensor, mask: torch.Tensor, return_parts: bool = False, global_dice=None):
     """loss = criterion(logits, mask) + dice_loss(prob(logits), mask) in one pass over the logits.
 
     logits fp32 [N,C,H,W]; mask integer class indices ([N,1,H,W] or [N,H,W]; {0,1} when C == 1).
-    parts = [loss, ce_or_bce, dice_loss, 2*sum(p t), sum p, sum t, -, -] (device tensor)."""
+    parts = [loss, ce_or_bce, dice_loss, 2*sum(p t), sum p, sum t, dice-grad multiplier, -] (device tensor).
+    global_dice: None = per-rank Dice (DDP semantics, the default); True or a process group = the three Dice sums are
+    all-reduced (12 bytes) so that loss and averaged gradient are exactly those of the reference's global batch
+    (SURVEY 8e); the CE/BCE mean needs no exchange (mean of equal-sized rank means)."""
     n, c, h, w = logits.shape
-    loss, parts = _SegLoss.apply(logits, _mask_u8(mask, n, h, w))
+    loss, parts = _SegLoss.apply(logits, _mask_u8(mask, n, h, w), global_dice)
     return (loss, parts) if return_parts else loss
 
 

@@ -604,3 +604,40 @@ def test_igemm_split_k_skinny(dtn, dt, N, h, Cin, Cout, k, s, p):
     assert float((ps[0] - r1).abs().max() / (r1.abs().max() + 1e-6)) < 3e-3
     ws = ops._SPLITK_WS[0]
     assert int(ws[:4096].view(torch.int32).abs().max()) == 0        # the tile ticket counters are back to zero
+
+
+@pytest.mark.parametrize("C", [1, 2])
+def test_seg_loss_global_dice_equals_full_batch(C):
+    """Data-parallel exact global-batch Dice: two 'ranks' each hold half of a batch; with the three Dice
+    sums exchanged (emulated here by adding them) and the Dice-gradient multiplier = world, every rank reports the
+    full-batch loss's Dice term and the AVERAGE of the rank gradients equals the full-batch gradient."""
+    from semantic_segmentation_amd import ops
+    from semantic_segmentation_amd.losses import _mask_u8, _ws, apply_global_dice, seg_loss
+    g = torch.Generator().manual_seed(17)
+    N, H, W = 4, 24, 20
+    logits = torch.randn(N, C, H, W, generator=g).to(dev()).requires_grad_(True)
+    mask = (torch.rand(N, 1, H, W, generator=g) > 0.6).long().to(dev())
+    loss_full, parts_full = seg_loss(logits, mask, return_parts=True)
+    loss_full.backward()
+    g_full = logits.grad.detach().clone()
+    world, per = 2, N // 2
+    outs, halves = [], []
+    for r in range(world):
+        lg = logits.detach()[r * per:(r + 1) * per].contiguous()
+        mu = _mask_u8(mask[r * per:(r + 1) * per], per, H, W)
+        out = torch.empty(8, dtype=torch.float32, device=dev())
+        ops.seg_loss_fwd(lg, mu, _ws(dev()), out)
+        outs.append(out)
+        halves.append((lg, mu))
+    sums = outs[0][3:6] + outs[1][3:6]                     # what dist.all_reduce(SUM) would produce
+    grads = []
+    for r in range(world):
+        apply_global_dice(outs[r], sums, world)
+        assert abs(float(outs[r][2]) - float(parts_full[2].detach())) < 1e-6   # global Dice loss on every rank
+        d = torch.empty_like(halves[r][0])
+        ops.seg_loss_bwd(halves[r][0], halves[r][1], outs[r], torch.ones(1, device=dev()), 1.0, d)
+        grads.append(d)
+    avg_equiv = torch.cat(grads, 0) / world                # gradient AVERAGE over ranks, sample by sample
+    assert float((avg_equiv - g_full).abs().max()) < 1e-7 + 1e-5 * float(g_full.abs().max())
+    ce_mean = 0.5 * (float(outs[0][1]) + float(outs[1][1]))
+    assert abs(ce_mean - float(parts_full[1].detach())) < 1e-6
