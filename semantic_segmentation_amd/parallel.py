@@ -24,9 +24,12 @@ class GradReducer:
     buckets of ~bucket_bytes.  When the last gradient of a bucket is announced its all-reduce is issued
     asynchronously; `finish()` makes the current stream wait for all of them."""
 
-    def __init__(self, named_params, bucket_bytes: int = 32 << 20, group=None, average: bool = True):
+    def __init__(self, named_params, bucket_bytes: int = 32 << 20, group=None, average: bool = True,
+                 force_collective: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # force_collective: issue the all-reduces even in a 1-rank group (exercises the RCCL path on one GPU)
+        self.collective = (self.world > 1) or (force_collective and dist.is_initialized())
         items = [(n, p) for n, p in named_params if p.requires_grad][::-1]
         if not items:
             raise ValueError("no trainable parameters")
@@ -73,7 +76,7 @@ class GradReducer:
         if grad.data_ptr() != self.views[name].data_ptr():
             self.views[name].copy_(grad)
         self._pending[b] -= 1
-        if self._pending[b] == 0 and self.world > 1:
+        if self._pending[b] == 0 and self.collective:
             a, e = self.buckets[b]["range"]
             self._works.append(dist.all_reduce(self.flat[a:e], op=self.op, group=self.group, async_op=True))
 
