@@ -272,8 +272,16 @@ class UNetEngine:
             return (torch.zeros_like if zero else torch.empty_like)(like, memory_format=torch.contiguous_format)
 
         # workspaces
-        max_w = max(p.numel() for k, p in params.items() if k.endswith("weight") and p.dim() == 4)
-        dw_ws = empty(max_w, dtype=torch.float32)
+        # one zeroed arena for every MFMA weight-gradient accumulator of this backward (fp32 atomics need zeros):
+        # ONE fill of 124 MB instead of a small fill in front of each of the 22 wgrad launches
+        tot_w = sum(p.numel() for k, p in params.items() if k.endswith("weight") and p.dim() == 4)
+        dw_arena = torch.zeros(tot_w, dtype=torch.float32, device=dev)
+        arena_off = [0]
+
+        def dw_take(numel):
+            a = arena_off[0]
+            arena_off[0] = a + numel
+            return dw_arena[a:a + numel]
         npart = 0
         for i in range(5):
             npart = max(npart, ops.bn_partials_numel(ops.bn_bwd_tiles(N, hs[i], ws_[i]), C[i]))
@@ -316,8 +324,7 @@ class UNetEngine:
                     dinp = torch.empty_like(rec.inp)
                     ops.conv_smallcin_dgrad(dy, wparam.detach().contiguous(), dinp, 3, 1, 1, inv_s)
             else:
-                dwp = dw_ws[: wparam.numel()]
-                dwp.zero_()
+                dwp = dw_take(wparam.numel())
                 if ops.USE_HALO_CONV and cin % 8 == 0 and cout % 8 == 0:
                     ops.conv3x3_wgrad(rec.inp, dy, dwp, N, h, w, cin, cout)
                 else:
@@ -355,8 +362,7 @@ class UNetEngine:
             wparam = params[wkey]
             db = galloc(prefix + ".up.bias", params[prefix + ".up.bias"])
             ops.colsum(dcat, 2 * cout_t, cout_t, N, u.H2, u.W2, u.pt, u.pl, 2 * u.h, 2 * u.w, cout_t, inv_s, col_ws, db)
-            dwp = dw_ws[: wparam.numel()]
-            dwp.zero_()
+            dwp = dw_take(wparam.numel())
             ops.conv_wgrad(u.geom_bwd, dcat, u.zin, dwp)
             dw = galloc(wkey, wparam)
             ops.unpack_wgrad(dwp, dw, u.cin, u.cout, 4, False, inv_s)
