@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 10
+#define GS_ABI_VERSION 11
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -246,6 +246,18 @@ int gs_mean_loss_fwd(const float* x, const float* t, float cval, int mode, int64
                      void* stream);
 int gs_mean_loss_bwd(const float* x, const float* t, float cval, int mode, int64_t n, const float* gout,
                      float gscale, float* dx, void* stream);
+
+/* Deterministic weight gradient of the 3x3 conv without atomics: gs_conv3x3_wgrad_slabs stores every split-K part's
+ * tile into its own slab ws[part][9][Cout][Cin] (fp32, gs_conv3x3_wgrad_ws_floats() elements, no zero fill needed,
+ * gs_conv3x3_wgrad_parts() parts); gs_wgrad_reduce_unpack sums the parts in order, scales by gscale and writes the
+ * gradient in the reference layout ([A][B][taps]; [B][A][taps] when transposed) -- it replaces the zero fill, the
+ * atomics of gs_conv3x3_wgrad and the gs_unpack_wgrad pass (autograd of unet_parts.py:16,19). */
+int64_t gs_conv3x3_wgrad_ws_floats(int N, int H, int W, int Cin, int Cout);
+int gs_conv3x3_wgrad_parts(int N, int H, int W, int Cin, int Cout);
+int gs_conv3x3_wgrad_slabs(const void* x, const void* dy, float* ws, int N, int H, int W, int Cin, int in_pix_stride,
+                           int in_coff, int Cout, int out_pix_stride, int out_coff, int dtype, void* stream);
+int gs_wgrad_reduce_unpack(const float* ws, int nparts, float* grad, int A, int B, int taps, int transposed,
+                           float gscale, void* stream);
 
 /* ---- 3x3x3 / stride 1 / pad 1 Conv3d on the halo-reuse kernels ------------------------------------
  * replaces nn.Conv3d(kernel_size=3, padding=1) forward / data gradient / weight gradient of

@@ -312,6 +312,30 @@ def upsample2x_bilinear_bwd(dy, dx, N, IH, IW, C, OH, OW, dy_stride=None, dy_cof
               OH, OW, C if dx_stride is None else dx_stride, dx_coff, ooy, oox, dt_code(dy), _stream())
 
 
+def conv3x3_wgrad_ws_floats(N, H, W, Cin, Cout) -> int:
+    return int(_lib.load().gs_conv3x3_wgrad_ws_floats(N, H, W, Cin, Cout))
+
+
+def conv3x3_wgrad_det(x, dy, ws, grad, N, H, W, Cin, Cout, gscale, in_stride=None, in_coff=0, out_stride=None,
+                      out_coff=0):
+    """Deterministic 3x3 weight gradient straight into the reference layout: split-K parts in fp32 slabs (ws, no zero
+    fill), then an ordered reduction fused with the scale + [Cout][Cin][3][3] unpack.  No atomics."""
+    _dev(x)
+    _f32(ws, "ws"); _f32(grad, "grad")
+    if x.dtype != dy.dtype:
+        raise TypeError("conv3x3_wgrad_det: x and dy must share one 16-bit dtype")
+    if ws.numel() < conv3x3_wgrad_ws_floats(N, H, W, Cin, Cout) or grad.numel() != 9 * Cout * Cin:
+        raise ValueError("conv3x3_wgrad_det: workspace / gradient size")
+    ev = TIMER.start() if TIMER is not None else None
+    _lib.call("gs_conv3x3_wgrad_slabs", _p(x), _p(dy), _p(ws), N, H, W, Cin, Cin if in_stride is None else in_stride,
+              in_coff, Cout, Cout if out_stride is None else out_stride, out_coff, dt_code(x), _stream())
+    if ev is not None:
+        TIMER.stop("wgrad3x3_halo", ev, 2.0 * N * H * W * Cout * 9 * Cin,
+                   2.0 * N * H * W * (Cin + Cout) + 4.0 * 9 * Cin * Cout)
+    parts = int(_lib.load().gs_conv3x3_wgrad_parts(N, H, W, Cin, Cout))
+    _lib.call("gs_wgrad_reduce_unpack", _p(ws), parts, _p(grad), Cout, Cin, 9, 0, float(gscale), _stream())
+
+
 def conv_igemm_mtiles(g: GsConvGeom) -> int:
     return _lib.load().gs_conv_igemm_mtiles(g)
 

@@ -274,8 +274,16 @@ class UNetEngine:
         # workspaces
         # one zeroed arena for every MFMA weight-gradient accumulator of this backward (fp32 atomics need zeros):
         # ONE fill of 124 MB instead of a small fill in front of each of the 22 wgrad launches
-        tot_w = sum(p.numel() for k, p in params.items() if k.endswith("weight") and p.dim() == 4)
-        dw_arena = torch.zeros(tot_w, dtype=torch.float32, device=dev)
+        halo_w = ops.USE_HALO_CONV
+        tot_w = sum(p.numel() for k, p in params.items() if k.endswith("weight") and p.dim() == 4 and
+                    not (halo_w and p.shape[2] == 3 and p.shape[1] % 8 == 0 and p.shape[0] % 8 == 0))
+        dw_arena = torch.zeros(max(tot_w, 1), dtype=torch.float32, device=dev)
+        # slab workspace of the deterministic 3x3 weight gradient (largest layer), reused by every layer
+        wg_need = 1
+        for r in ctx["recs"]:
+            if not r.inp_is_image and r.cin % 8 == 0 and r.cout % 8 == 0:
+                wg_need = max(wg_need, ops.conv3x3_wgrad_ws_floats(N, r.h, r.w, r.cin, r.cout))
+        wg_ws = empty(wg_need, dtype=torch.float32)
         arena_off = [0]
 
         def dw_take(numel):
@@ -324,13 +332,14 @@ class UNetEngine:
                     dinp = torch.empty_like(rec.inp)
                     ops.conv_smallcin_dgrad(dy, wparam.detach().contiguous(), dinp, 3, 1, 1, inv_s)
             else:
-                dwp = dw_take(wparam.numel())
-                if ops.USE_HALO_CONV and cin % 8 == 0 and cout % 8 == 0:
-                    ops.conv3x3_wgrad(rec.inp, dy, dwp, N, h, w, cin, cout)
-                else:
-                    ops.conv_wgrad(rec.geom, rec.inp, dy, dwp)
                 dw = galloc(rec.wkey, wparam)
-                ops.unpack_wgrad(dwp, dw, cout, cin, 9, False, inv_s)
+                if ops.USE_HALO_CONV and cin % 8 == 0 and cout % 8 == 0:
+                    # split-K parts in slabs + ordered reduction fused with scale / unpack: deterministic, no atomics
+                    ops.conv3x3_wgrad_det(rec.inp, dy, wg_ws, dw, N, h, w, cin, cout, inv_s)
+                else:
+                    dwp = dw_take(wparam.numel())
+                    ops.conv_wgrad(rec.geom, rec.inp, dy, dwp)
+                    ops.unpack_wgrad(dwp, dw, cout, cin, 9, False, inv_s)
                 if need_dinp:
                     dinp = empty(N, h, w, cin)
                     if ops.USE_HALO_CONV:
