@@ -57,14 +57,6 @@ struct Elem<GS_F16> {
     static __device__ __forceinline__ f32x16 mfma32(V8 a, V8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
-    // explicit register class of the accumulator (the builtin leaves it to the allocator, which keeps every
-    // accumulator in the AGPR half and spills once a wave needs more than 256 of them)
-    static __device__ __forceinline__ void mfma32_agpr(V8 a, V8 b, f32x16& c) {
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-    }
-    static __device__ __forceinline__ void mfma32_vgpr(V8 a, V8 b, f32x16& c) {
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-    }
 
 };
 
@@ -81,12 +73,6 @@ struct Elem<GS_BF16> {
     }
     static __device__ __forceinline__ f32x16 mfma32(V8 a, V8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-    }
-    static __device__ __forceinline__ void mfma32_agpr(V8 a, V8 b, f32x16& c) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-    }
-    static __device__ __forceinline__ void mfma32_vgpr(V8 a, V8 b, f32x16& c) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
     }
 
 };

@@ -170,187 +170,13 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const W3Args a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// "wide" variant for Cout >= 128: a block owns a (128 co x 64 ci) pair, every wave a 64 co x 32 ci tile for all
-// nine taps = 18 accumulator tiles (288 registers; one 4-wave block per CU with the full 512-register budget: nine
-// tiles pinned to the AGPR half, nine to the VGPR half by explicit-class MFMAs).  In the kernel above each X fragment
-// read from LDS (the heavy operand: nine shifted windows per k step) feeds ONE MFMA and the transposing LDS reads
-// (1.1 KB per MFMA) take longer than the MFMAs; here it feeds two (0.6 KB per MFMA).  With one wave per SIMD the
-// fragment reads run RD-1 steps ahead of the MFMAs that use them.
-// ---------------------------------------------------------------------------------------------------
-constexpr int W3W_DLD = 160;    // dY rows: 128 couts + 32 pad elements = 320 bytes (== 64 mod 256: conflict-free tr reads)
-
-template <int DT, int TW>
-__global__ __launch_bounds__(256, 1) void wgrad3x3_wide_kernel(const W3Args a) {
-    typedef typename Elem<DT>::V8 V8;
-    constexpr int TH = W3_BM / TW;
-    constexpr int HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;
-    constexpr int DY_EL = W3_BM * W3W_DLD, H_EL = HP * W3_LDR;
-    constexpr int HCH = (HP * 8 + 255) / 256;
-    constexpr int DCH = W3_BM * 16 / 256;            // 8 dY loads per lane (16 chunks of 8 couts per pixel)
-    constexpr int TWS = (TW == 32) ? 5 : 4;
-    constexpr unsigned OOB = 0xFFFFFFFFu;
-    __shared__ __attribute__((aligned(16))) unsigned short smem[DY_EL + H_EL];
-    unsigned short* dyt = smem;
-    unsigned short* halo = smem + DY_EL;
-
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    int bid;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
-        bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-    }
-    const int cob = bid % a.ncob; bid /= a.ncob;
-    const int cib = bid % a.ncib; bid /= a.ncib;
-    const int ks = bid;
-    const int co0 = cob * 128, ci0 = cib * 64;
-    const int p_begin = ks * a.pps;
-    const int p_end = min(a.npatches, p_begin + a.pps);
-    if (p_begin >= p_end) return;
-
-    const unsigned x_img_bytes = (unsigned)a.H * a.W * a.in_stride * 2u;
-    const unsigned dy_img_bytes = (unsigned)a.H * a.W * a.out_stride * 2u;
-    const int chunk = t & 7, row0 = t >> 3;          // halo staging: 8 chunks x 32 rows per pass
-    const int dchunk = t & 15, drow0 = t >> 4;       // dY staging: 16 chunks x 16 rows per pass
-    const bool ci_ok = ci0 + chunk * 8 < a.Cin, co_ok = co0 + dchunk * 8 < a.Cout;
-
-    uint4 rd[DCH], rh[HCH];
-    struct Pf { int y0, x0; __amdgpu_buffer_rsrc_t rx, rdy; unsigned kill, killx; };
-    auto prep_patch = [&](int patch, bool live) __attribute__((always_inline)) {
-        Pf f;
-        const int tx = patch % a.tiles_x;
-        const int r = patch / a.tiles_x;
-        const int ty = r % a.tiles_y, n = r / a.tiles_y;
-        f.y0 = ty * TH; f.x0 = tx * TW;
-        const int d = a.D > 1 ? n % a.D : 0;
-        const bool xin = (unsigned)(d + a.dz) < (unsigned)a.D;
-        f.rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)(xin ? n + a.dz : n) * a.H * a.W * a.in_stride), 0, x_img_bytes, 0x00020000);
-        f.rdy = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + (int64_t)n * a.H * a.W * a.out_stride), 0, dy_img_bytes, 0x00020000);
-        f.kill = live ? 0u : OOB;
-        f.killx = (live && xin) ? 0u : OOB;
-        return f;
-    };
-    auto issue_load = [&](const Pf& f, int j) __attribute__((always_inline)) {      // j compile-time, 0 .. DCH+HCH-1
-        if (j < DCH) {
-            const int p = drow0 + 16 * j;
-            const int gy = f.y0 + (p >> TWS), gx = f.x0 + (p & (TW - 1));
-            const bool ok = co_ok && gy < a.H && gx < a.W;
-            const unsigned off = ok ? (unsigned)(((gy * a.W + gx) * a.out_stride + a.out_coff + co0 + dchunk * 8) * 2) : OOB;
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(f.rdy, off | f.kill, 0, 0);
-            rd[j < DCH ? j : 0] = make_uint4(v[0], v[1], v[2], v[3]);
-        } else if (j - DCH < HCH) {
-            const int jj = j - DCH < HCH ? j - DCH : 0;
-            const int hp = row0 + 32 * jj;
-            const int hy = hp / HWD, hx = hp - hy * HWD;
-            const int gy = f.y0 + hy - 1, gx = f.x0 + hx - 1;
-            const bool ok = ci_ok && hp < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-            const unsigned off = ok ? (unsigned)(((gy * a.W + gx) * a.in_stride + a.in_coff + ci0 + chunk * 8) * 2) : OOB;
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(f.rx, off | f.killx, 0, 0);
-            rh[jj] = make_uint4(v[0], v[1], v[2], v[3]);
-        }
-    };
-    auto load_patch = [&](int patch) __attribute__((always_inline)) {
-        const Pf f = prep_patch(patch, true);
-#pragma unroll
-        for (int j = 0; j < DCH + HCH; ++j) issue_load(f, j);
-    };
-    auto store_patch = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < DCH; ++j)
-            *reinterpret_cast<uint4*>(dyt + (drow0 + 16 * j) * W3W_DLD + dchunk * 8) = rd[j];
-#pragma unroll
-        for (int j = 0; j < HCH; ++j)
-            if (row0 + 32 * j < HP) *reinterpret_cast<uint4*>(halo + (row0 + 32 * j) * W3_LDR + chunk * 8) = rh[j];
-    };
-
-    f32x16 acc[2][9];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int tp = 0; tp < 9; ++tp)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][tp][r] = 0.f;
-
-    const int G = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-    const int krow = 8 * (G >> 1) + q;
-    const int chn = 16 * (G & 1) + 4 * pp;
-    const LDS_AS unsigned short* lds = (const LDS_AS unsigned short*)smem;
-    const LDS_AS unsigned short* a_base = lds + krow * W3W_DLD + wm * 64 + chn;
-    const LDS_AS unsigned short* b_base = lds + DY_EL + krow * W3_LDR + wn * 32 + chn;
-
-    load_patch(p_begin);
-    static_assert(DCH + HCH <= 2 * (W3_BM / 16), "prefetch loads must fit two per k16 step");
-    for (int patch = p_begin; patch < p_end; ++patch) {
-        __syncthreads();                 // previous patch fully consumed
-        store_patch();
-        __syncthreads();
-        const bool more = patch + 1 < p_end;
-        const Pf pf = prep_patch(more ? patch + 1 : patch, more);
-        auto b_frag = [&](int k16, int tap) __attribute__((always_inline)) {
-            const int pb = k16 * 16;
-            const int hrow = ((pb >> TWS) + tap / 3) * HWD + (pb & (TW - 1)) + tap % 3;
-            return tr_read8<DT>(b_base + hrow * W3_LDR, b_base + (hrow + 4) * W3_LDR);
-        };
-        constexpr int RD = 4, NK = W3_BM / 16;
-        V8 af[2], bf[RD];
-#pragma unroll
-        for (int d = 0; d < RD - 1; ++d) bf[d] = b_frag(0, d);
-#pragma unroll
-        for (int k16 = 0; k16 < NK; ++k16) {
-            const int pb = k16 * 16;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                af[i] = tr_read8<DT>(a_base + pb * W3W_DLD + i * 32, a_base + (pb + 4) * W3W_DLD + i * 32);
-            issue_load(pf, 2 * k16);               // two 16-byte loads of the next patch per 18 MFMAs
-            issue_load(pf, 2 * k16 + 1);
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int step = k16 * 9 + tap;
-                int nt = tap + (RD - 1), nk = k16;           // (k16, tap) of step + RD - 1, without a division
-                if (nt >= 9) { nt -= 9; nk += 1; }
-                if (nk < NK) bf[(step + RD - 1) % RD] = b_frag(nk, nt);
-                __builtin_amdgcn_sched_barrier(0);
-                Elem<DT>::mfma32_agpr(af[0], bf[step % RD], acc[0][tap]);
-                Elem<DT>::mfma32_vgpr(af[1], bf[step % RD], acc[1][tap]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-
-    const int l31 = lane & 31, h = lane >> 5;
-    const int ci = ci0 + wn * 32 + l31;
-    if (ci < a.Cin) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (co < a.Cout) {
-                        float* qd = a.dw + ((int64_t)tap * a.Cout + co) * a.Cin + ci;
-                        if (a.slab_stride > 0) qd[(int64_t)ks * a.slab_stride] = acc[i][tap][r];
-                        else atomicAdd(qd, acc[i][tap][r]);
-                    }
-                }
-    }
-}
-
 }  // namespace
-
-static bool w3_wide(int Cout) {
-    static const int wide_env = getenv("GSSEG_W3_WIDE") ? atoi(getenv("GSSEG_W3_WIDE")) : 1;
-    return wide_env && Cout >= 128;                      // 128 co x 64 ci per block, one block per CU
-}
 
 static int w3_ksplit(int N, int H, int W, int Cin, int Cout, int* pps_out, int* npatches_out) {
     const int tw = (W >= 24) ? 32 : 16, th = W3_BM / tw;
     const int npatches = N * cdiv(W, tw) * cdiv(H, th);
-    const bool wide = w3_wide(Cout);
-    const int pairs = cdiv(Cout, wide ? 128 : 64) * cdiv(Cin, 64);
-    static const int target_env = getenv("GSSEG_W3_GRID") ? atoi(getenv("GSSEG_W3_GRID")) : 0;
-    const int target = target_env ? target_env : (wide ? 256 : 512);
+    const int pairs = cdiv(Cout, 64) * cdiv(Cin, 64);
+    static const int target = getenv("GSSEG_W3_GRID") ? atoi(getenv("GSSEG_W3_GRID")) : 512;
     int ksplit = cdiv(target, pairs);
     if (ksplit > npatches) ksplit = npatches;
     if (ksplit < 1) ksplit = 1;
@@ -378,8 +204,7 @@ static int wgrad3x3_launch(const void* x, const void* dy, float* dw, int N, int 
     const int tw = (W >= 24) ? 32 : 16, th = W3_BM / tw;
     a.tiles_x = cdiv(W, tw); a.tiles_y = cdiv(H, th);
     a.npatches = N * a.tiles_x * a.tiles_y;
-    const bool wide = w3_wide(Cout);
-    a.ncob = cdiv(Cout, wide ? 128 : 64); a.ncib = cdiv(Cin, 64);
+    a.ncob = cdiv(Cout, 64); a.ncib = cdiv(Cin, 64);
     const int pairs = a.ncob * a.ncib;
     {
         int pps = 0, np = 0;
@@ -388,15 +213,7 @@ static int wgrad3x3_launch(const void* x, const void* dy, float* dw, int N, int 
     }
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(pairs * a.ksplit), block(256);
-    if (wide) {
-        if (dtype == GS_F16) {
-            if (tw == 32) wgrad3x3_wide_kernel<GS_F16, 32><<<grid, block, 0, s>>>(a);
-            else wgrad3x3_wide_kernel<GS_F16, 16><<<grid, block, 0, s>>>(a);
-        } else {
-            if (tw == 32) wgrad3x3_wide_kernel<GS_BF16, 32><<<grid, block, 0, s>>>(a);
-            else wgrad3x3_wide_kernel<GS_BF16, 16><<<grid, block, 0, s>>>(a);
-        }
-    } else if (dtype == GS_F16) {
+    if (dtype == GS_F16) {
         if (tw == 32) wgrad3x3_kernel<GS_F16, 32><<<grid, block, 0, s>>>(a);
         else wgrad3x3_kernel<GS_F16, 16><<<grid, block, 0, s>>>(a);
     } else {
