@@ -312,6 +312,10 @@ def upsample2x_bilinear_bwd(dy, dx, N, IH, IW, C, OH, OW, dy_stride=None, dy_cof
               OH, OW, C if dx_stride is None else dx_stride, dx_coff, ooy, oox, dt_code(dy), _stream())
 
 
+def conv3x3_wgrad_parts(N, H, W, Cin, Cout) -> int:
+    return int(_lib.load().gs_conv3x3_wgrad_parts(N, H, W, Cin, Cout))
+
+
 def conv3x3_wgrad_ws_floats(N, H, W, Cin, Cout) -> int:
     return int(_lib.load().gs_conv3x3_wgrad_ws_floats(N, H, W, Cin, Cout))
 
