@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 11
+#define GS_ABI_VERSION 12
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -283,6 +283,15 @@ int gs_upsample2x_bilinear_fwd(const void* x, void* y, int N, int IH, int IW, in
                                int OH, int OW, int out_pix_stride, int out_coff, int ooy, int oox, int dtype, void* stream);
 int gs_upsample2x_bilinear_bwd(const void* dy, void* dx, int N, int IH, int IW, int C, int dy_pix_stride, int dy_coff,
                                int OH, int OW, int dx_pix_stride, int dx_coff, int ooy, int oox, int dtype, void* stream);
+
+/* ---- on-device mask augmentation: one affine warp per sample ----------------------------------------
+ * replaces the host-side imgaug pipeline of running_files/train_end2end_jsrt.py:99-112 applied at :186-190 (Fliplr,
+ * CropAndPad, Affine scale / translate / rotate / shear in random order -- every stage is an affine map, their
+ * composition is one) and the re-binarisation of :191-193.  src/dst: fp32 [N,C,H,W]; mats: [N][6] row-major 2x3,
+ * mapping DESTINATION pixel centres to source coordinates: (sx, sy) = M (x+.5, y+.5, 1) - .5; bilinear taps, zeros
+ * outside; thresh >= 0: dst = (value > thresh) ? 1 : 0, thresh < 0: the interpolated value. */
+int gs_affine_warp(const float* src, float* dst, const float* mats, int N, int C, int H, int W, float thresh,
+                   void* stream);
 
 /* ---- multi-tensor optimiser steps (one launch for a whole model) ---------------------------------
  * replaces optim.RMSprop(net.parameters(), lr, weight_decay=1e-8, momentum=0.9, foreach=True).step()

@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 GS_F16, GS_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH = 0, 1, 2, 3
 GS_MAX_TAPS = 64
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class GsConvGeom(ctypes.Structure):
@@ -45,6 +45,7 @@ PROTOTYPES = {
     "gs_conv3d_3x3x3_wgrad": (c_int, [_P, _P, _F] + [c_int] * 11 + [c_void_p]),
     "gs_upsample2x_bilinear_fwd": (c_int, [_P, _P] + [c_int] * 13 + [c_void_p]),
     "gs_upsample2x_bilinear_bwd": (c_int, [_P, _P] + [c_int] * 13 + [c_void_p]),
+    "gs_affine_warp": (c_int, [_F, _F, _F, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "gs_optim_chunk_elems": (c_int, []),
     "gs_optim_rmsprop": (c_int, [_P] * 7 + [c_int] + [c_float] * 6 + [c_void_p]),
     "gs_optim_adam": (c_int, [_P] * 7 + [c_int, _P] + [c_float] * 5 + [c_void_p]),

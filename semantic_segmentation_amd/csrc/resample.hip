@@ -146,3 +146,44 @@ extern "C" int gs_upsample2x_bilinear_bwd(const void* dy, void* dx, int N, int I
     GS_CHECK_LAUNCH("gs_upsample2x_bilinear_bwd");
     return GS_OK;
 }
+
+// ---- on-device mask augmentation -------------------------------------------------
+// The reference augments the generator's input masks on the HOST with imgaug (Fliplr, CropAndPad, Affine scale /
+// translate / rotate / shear in random order: running_files/train_end2end_jsrt.py:99-112), which costs a
+// GPU -> CPU -> GPU round trip per Unet step (:186-190).  Every one of those operations is an affine map of the image
+// plane, so their composition is ONE affine map per sample: this kernel applies it (dst pixel centre -> src
+// coordinates, bilinear taps, zeros outside) and re-binarises (:191-193, threshold 0.1) in a single pass.
+namespace {
+__global__ __launch_bounds__(256) void affine_warp_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                          const float* __restrict__ mats, int N, int C, int H, int W,
+                                                          float thresh) {
+    const int total = N * C * H * W;                      // host guarantees < 2^31
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int x = idx % W;
+        int r = idx / W;
+        const int y = r % H; r /= H;
+        const int n = r / C;
+        const float* m = mats + n * 6;                   // [a b c; d e f]: (sx, sy) = M * (x + .5, y + .5, 1) - .5
+        const float fx = x + 0.5f, fy = y + 0.5f;
+        const float sx = m[0] * fx + m[1] * fy + m[2] - 0.5f;
+        const float sy = m[3] * fx + m[4] * fy + m[5] - 0.5f;
+        const float x0f = floorf(sx), y0f = floorf(sy);
+        const int x0 = (int)x0f, y0 = (int)y0f;
+        const float lx = sx - x0f, ly = sy - y0f;
+        const float* img = src + (int64_t)(idx / (H * W)) * H * W;
+        auto tap = [&](int yy, int xx) { return ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? img[yy * W + xx] : 0.f; };
+        const float v = (1.f - ly) * ((1.f - lx) * tap(y0, x0) + lx * tap(y0, x0 + 1)) +
+                        ly * ((1.f - lx) * tap(y0 + 1, x0) + lx * tap(y0 + 1, x0 + 1));
+        dst[idx] = thresh >= 0.f ? (v > thresh ? 1.f : 0.f) : v;
+    }
+}
+}  // namespace
+
+extern "C" int gs_affine_warp(const float* src, float* dst, const float* mats, int N, int C, int H, int W, float thresh,
+                              void* stream) {
+    GS_CHECK_ARG(src && dst && mats && src != dst && N > 0 && C > 0 && H > 0 && W > 0, "gs_affine_warp: bad arguments");
+    GS_CHECK_ARG((int64_t)N * C * H * W < 2147483647LL, "gs_affine_warp: too many elements");
+    affine_warp_kernel<<<grid_for((int64_t)N * C * H * W), 256, 0, (hipStream_t)stream>>>(src, dst, mats, N, C, H, W, thresh);
+    GS_CHECK_LAUNCH("gs_affine_warp");
+    return GS_OK;
+}

@@ -25,6 +25,7 @@ from typing import Callable, Dict, Iterable, Iterator, Optional
 import torch
 
 from . import optim as gs_optim
+from .augment import MaskAugmenter
 from . import steps
 from .models_pix2pix import networks
 from .unet import UNet
@@ -175,6 +176,7 @@ def main(argv=None):
     ap.add_argument("--ngf", type=int, default=64)
     ap.add_argument("--unet-lr", type=float, default=1e-5)
     ap.add_argument("--save-dir", default=None)
+    ap.add_argument("--no-augment", action="store_true", help="do not augment the masks that feed the generator")
     ap.add_argument("--no-gan", action="store_true", help="freeze the Pix2Pix pair (only the Unet / Arch problems step)")
     args = ap.parse_args(argv)
     if not args.synthetic:
@@ -187,7 +189,8 @@ def main(argv=None):
     mk = lambda n, seed: torch.utils.data.DataLoader(SyntheticLungDataset(n, args.size, seed), batch_size=args.batch_size,
                                                      shuffle=True, drop_last=True)
     trainer = EndToEndTrainer(net, netG, netD, crit, mk(8 * args.batch_size, 1), mk(2 * args.batch_size, 2), dev,
-                              unet_lr=args.unet_lr, save_dir=args.save_dir, train_gan=not args.no_gan)
+                              unet_lr=args.unet_lr, save_dir=args.save_dir, train_gan=not args.no_gan,
+                              mask_augment=None if args.no_augment else MaskAugmenter(seed=0))
     trainer.run(args.iters, log_every=5)
 
 
