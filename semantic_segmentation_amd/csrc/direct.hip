@@ -353,13 +353,12 @@ __global__ __launch_bounds__(256) void smallcin_wgrad_kernel(const SCWArgs a) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = acc[j][i];
                 __syncthreads();
-                if (pl == 0) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        float s = 0.f;
-                        for (int q = 0; q < lanes; ++q) s += red[q * nch + ch][i];
-                        a.dw[(int64_t)blockIdx.x * a.Cout * T + (int64_t)(ch * 8 + i) * T + tap] = s;
-                    }
+                // one thread per output channel sums the pixel lanes (64 threads x 32 reads; eight threads doing
+                // 256 dependent reads each made this tail as long as the whole pixel loop)
+                for (int co = threadIdx.x; co < a.Cout; co += 256) {
+                    float s = 0.f;
+                    for (int q = 0; q < lanes; ++q) s += red[q * nch + (co >> 3)][co & 7];
+                    a.dw[(int64_t)blockIdx.x * a.Cout * T + (int64_t)co * T + tap] = s;
                 }
             }
         }
@@ -660,13 +659,11 @@ __global__ __launch_bounds__(256) void head1x1_wgrad_kernel(const HArgs a) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = acc[c][i];
             __syncthreads();
-            if (pl == 0) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    float t = 0.f;
-                    for (int q = 0; q < 32; ++q) t += red[q * 8 + ch][i];
-                    a.dw[(int64_t)blockIdx.x * a.Cout * 64 + c * 64 + ch * 8 + i] = t;
-                }
+            if (threadIdx.x < 64) {                  // one thread per input channel sums the 32 pixel lanes
+                const int ci = threadIdx.x;
+                float t = 0.f;
+                for (int q = 0; q < 32; ++q) t += red[q * 8 + (ci >> 3)][ci & 7];
+                a.dw[(int64_t)blockIdx.x * a.Cout * 64 + c * 64 + ci] = t;
             }
         }
     }
@@ -734,12 +731,13 @@ __global__ __launch_bounds__(256) void smallcout_wgrad_kernel(const HArgs a) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = acc[c][i];
                     __syncthreads();
-                    if (pl == 0) {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
+                    for (int xt = threadIdx.x; xt < lpu * 8; xt += 256) {   // one thread per input channel of this trip
+                        const int cl = xt >> 3, i = xt & 7;
+                        const int chx = ch - chl + cl;         // chunk handled by lane cl in this trip
+                        if (chx < nch) {
                             float s = 0.f;
-                            for (int q = 0; q < lanes; ++q) s += red[q * lpu + chl][i];
-                            a.dw[(int64_t)blockIdx.x * a.Cout * a.Cin * kk + ((int64_t)c * a.Cin + ch * 8 + i) * kk + tap] = s;
+                            for (int q = 0; q < lanes; ++q) s += red[q * lpu + cl][i];
+                            a.dw[(int64_t)blockIdx.x * a.Cout * a.Cin * kk + ((int64_t)c * a.Cin + chx * 8 + i) * kk + tap] = s;
                         }
                     }
                 }
