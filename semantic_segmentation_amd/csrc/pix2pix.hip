@@ -103,6 +103,32 @@ __device__ __forceinline__ int tap_slot(int tap) {                     // class-
     return ((1 - (ky & 1)) * 2 + (1 - (kx & 1))) * 16 + (ky >> 1) * 4 + (kx >> 1);
 }
 
+// U merged taps per lane with every load issued up front: the k6 / k4 windows are read unconditionally from a clamped
+// index and weighted by 0 outside the window (per-iteration conditional loads left one load in flight per lane)
+template <int U>
+__device__ __forceinline__ void merged_taps_batch(const float* __restrict__ W4, const float* __restrict__ W6,
+                                                  const float* __restrict__ W8, const int64_t (&pair)[U], const int (&tap)[U],
+                                                  float s0, float s1, float s2, float (&out)[U]) {
+    float a8[U], a6[U], a4[U], m6[U], m4[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int ky = tap[u] >> 3, kx = tap[u] & 7;
+        const bool in6 = ky >= 1 && ky <= 6 && kx >= 1 && kx <= 6, in4 = ky >= 2 && ky <= 5 && kx >= 2 && kx <= 5;
+        a8[u] = W8[pair[u] * 64 + tap[u]];
+        a6[u] = W6[pair[u] * 36 + (in6 ? (ky - 1) * 6 + kx - 1 : 0)];
+        a4[u] = W4[pair[u] * 16 + (in4 ? (ky - 2) * 4 + kx - 2 : 0)];
+        m6[u] = in6 ? s1 : 0.f;
+        m4[u] = in4 ? s0 : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        float v = s2 * a8[u];                      // same association as merged_tap()
+        v += m6[u] * a6[u];
+        v += m4[u] * a4[u];
+        out[u] = v;
+    }
+}
+
 // forward pack: tile 8 co x 64 ci, LDS [64 slots][8 co][64 ci]
 template <int DT>
 __global__ __launch_bounds__(256) void upconv_merge_pack_fwd_tiled(const float* __restrict__ W4, const float* __restrict__ W6,
@@ -111,12 +137,21 @@ __global__ __launch_bounds__(256) void upconv_merge_pack_fwd_tiled(const float* 
     __shared__ unsigned short lds[64 * 8 * 64];
     const int co0 = blockIdx.x * 8, ci0 = blockIdx.y * 64;
     const float s0 = sm[0], s1 = sm[1], s2 = sm[2];
-    for (int idx = threadIdx.x; idx < 64 * 8 * 64; idx += 256) {
-        const int tap = idx & 63, co_l = (idx >> 6) & 7, ci_l = idx >> 9;
-        const int64_t pair = (int64_t)(ci0 + ci_l) * Cout + co0 + co_l;
-        const float v = merged_tap(W4 + pair * 16, W6 + pair * 36, W8 + pair * 64, tap >> 3, tap & 7, s0, s1, s2);
-        const int slot = tap_slot(tap);
-        lds[(slot * 8 + co_l) * 64 + (ci_l ^ ((slot & 31) << 1))] = Elem<DT>::from_f(v);
+    constexpr int U = 8;
+    for (int base = threadIdx.x; base < 64 * 8 * 64; base += 256 * U) {
+        int64_t pair[U]; int tap[U], dst[U]; float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * 256;
+            tap[u] = idx & 63;
+            const int co_l = (idx >> 6) & 7, ci_l = idx >> 9;
+            pair[u] = (int64_t)(ci0 + ci_l) * Cout + co0 + co_l;
+            const int slot = tap_slot(tap[u]);
+            dst[u] = (slot * 8 + co_l) * 64 + (ci_l ^ ((slot & 31) << 1));
+        }
+        merged_taps_batch<U>(W4, W6, W8, pair, tap, s0, s1, s2, v);
+#pragma unroll
+        for (int u = 0; u < U; ++u) lds[dst[u]] = Elem<DT>::from_f(v[u]);
     }
     __syncthreads();
     const int64_t plane = (int64_t)Cout * Cin;
@@ -134,11 +169,20 @@ __global__ __launch_bounds__(256) void upconv_merge_pack_dgrad_tiled(const float
     __shared__ unsigned short lds[64 * 8 * 64];
     const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 8;
     const float s0 = sm[0], s1 = sm[1], s2 = sm[2];
-    for (int idx = threadIdx.x; idx < 64 * 8 * 64; idx += 256) {
-        const int tap = idx & 63, co_l = (idx >> 6) & 63, ci_l = idx >> 12;
-        const int64_t pair = (int64_t)(ci0 + ci_l) * Cout + co0 + co_l;
-        const float v = merged_tap(W4 + pair * 16, W6 + pair * 36, W8 + pair * 64, tap >> 3, tap & 7, s0, s1, s2);
-        lds[(tap * 8 + ci_l) * 64 + (co_l ^ ((tap & 31) << 1))] = Elem<DT>::from_f(v);
+    constexpr int U = 8;
+    for (int base = threadIdx.x; base < 64 * 8 * 64; base += 256 * U) {
+        int64_t pair[U]; int tap[U], dst[U]; float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * 256;
+            tap[u] = idx & 63;
+            const int co_l = (idx >> 6) & 63, ci_l = idx >> 12;
+            pair[u] = (int64_t)(ci0 + ci_l) * Cout + co0 + co_l;
+            dst[u] = (tap[u] * 8 + ci_l) * 64 + (co_l ^ ((tap[u] & 31) << 1));
+        }
+        merged_taps_batch<U>(W4, W6, W8, pair, tap, s0, s1, s2, v);
+#pragma unroll
+        for (int u = 0; u < U; ++u) lds[dst[u]] = Elem<DT>::from_f(v[u]);
     }
     __syncthreads();
     const int64_t plane = (int64_t)Cout * Cin;
@@ -157,6 +201,7 @@ __global__ __launch_bounds__(256) void upconv_split_wgrad_tiled(const float* __r
     __shared__ float red[3][4];
     const int co0 = blockIdx.x * 8, ci0 = blockIdx.y * 32;
     const int64_t plane = (int64_t)Cout * Cin;
+#pragma unroll 8
     for (int idx = threadIdx.x; idx < 64 * 8 * 32; idx += 256) {
         const int ci_l = idx & 31, co_l = (idx >> 5) & 7, slot = idx >> 8;
         lds[(slot * 8 + co_l) * 32 + (ci_l ^ (slot & 31))] = dWm[slot * plane + (int64_t)(co0 + co_l) * Cin + ci0 + ci_l];
@@ -164,23 +209,32 @@ __global__ __launch_bounds__(256) void upconv_split_wgrad_tiled(const float* __r
     __syncthreads();
     const float s0 = sm[0] * gscale, s1 = sm[1] * gscale, s2 = sm[2] * gscale;
     float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-    for (int idx = threadIdx.x; idx < 64 * 8 * 32; idx += 256) {
-        const int tap = idx & 63, co_l = (idx >> 6) & 7, ci_l = idx >> 9;
-        const int ky = tap >> 3, kx = tap & 7;
-        const int slot = tap_slot(tap);
-        const float g = lds[(slot * 8 + co_l) * 32 + (ci_l ^ (slot & 31))];
-        const int64_t pair = (int64_t)(ci0 + ci_l) * Cout + co0 + co_l;
-        dW8[pair * 64 + tap] = s2 * g;
-        d2 += g * W8[pair * 64 + tap];
-        if (ky >= 1 && ky <= 6 && kx >= 1 && kx <= 6) {
-            const int o = (ky - 1) * 6 + kx - 1;
-            dW6[pair * 36 + o] = s1 * g;
-            d1 += g * W6[pair * 36 + o];
+    constexpr int U = 8;
+    for (int base = threadIdx.x; base < 64 * 8 * 32; base += 256 * U) {
+        int64_t pair[U]; int tap[U]; float g[U], a8[U], a6[U], a4[U]; bool in6[U], in4[U]; int o6[U], o4[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                    // every load up front (clamped indices, masked later)
+            const int idx = base + u * 256;
+            tap[u] = idx & 63;
+            const int co_l = (idx >> 6) & 7, ci_l = idx >> 9;
+            const int ky = tap[u] >> 3, kx = tap[u] & 7;
+            const int slot = tap_slot(tap[u]);
+            g[u] = lds[(slot * 8 + co_l) * 32 + (ci_l ^ (slot & 31))];
+            pair[u] = (int64_t)(ci0 + ci_l) * Cout + co0 + co_l;
+            in6[u] = ky >= 1 && ky <= 6 && kx >= 1 && kx <= 6;
+            in4[u] = ky >= 2 && ky <= 5 && kx >= 2 && kx <= 5;
+            o6[u] = in6[u] ? (ky - 1) * 6 + kx - 1 : 0;
+            o4[u] = in4[u] ? (ky - 2) * 4 + kx - 2 : 0;
+            a8[u] = W8[pair[u] * 64 + tap[u]];
+            a6[u] = W6[pair[u] * 36 + o6[u]];
+            a4[u] = W4[pair[u] * 16 + o4[u]];
         }
-        if (ky >= 2 && ky <= 5 && kx >= 2 && kx <= 5) {
-            const int o = (ky - 2) * 4 + kx - 2;
-            dW4[pair * 16 + o] = s0 * g;
-            d0 += g * W4[pair * 16 + o];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            dW8[pair[u] * 64 + tap[u]] = s2 * g[u];
+            d2 += g[u] * a8[u];
+            if (in6[u]) { dW6[pair[u] * 36 + o6[u]] = s1 * g[u]; d1 += g[u] * a6[u]; }
+            if (in4[u]) { dW4[pair[u] * 16 + o4[u]] = s0 * g[u]; d0 += g[u] * a4[u]; }
         }
     }
     d0 = wave_sum(d0); d1 = wave_sum(d1); d2 = wave_sum(d2);
