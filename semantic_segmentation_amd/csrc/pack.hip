@@ -23,6 +23,31 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     }
 }
 
+// Row-wise variant for the common tap counts: a lane owns one (a, b) pair of the source [A][B][T] and reads its T
+// contiguous floats back to back (T loads in flight, the wave covers one contiguous run when b is the fast index), then
+// writes one pack with the fast index along the lanes (128-byte runs).  blockIdx.y picks the pack: 0 -> P_ab [T][A][B]
+// (lanes along b: perfectly coalesced source), 1 -> P_ba [T][B][A] (lanes along a: 36-byte segments of the source).
+// The element-wise kernel above reads the source with a stride of T elements: ~T x over-fetch on the big layers.
+template <int DT, int T>
+__global__ __launch_bounds__(256) void pack_weight_rows_kernel(const float* __restrict__ w, unsigned short* p_ab,
+                                                               unsigned short* p_ba, int A, int B) {
+    const int64_t n = (int64_t)A * B;
+    const bool ba = blockIdx.y == 1;
+    unsigned short* dst = ba ? p_ba : p_ab;
+    if (dst == nullptr) return;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        int a, b;
+        if (!ba) { b = (int)(i % B); a = (int)(i / B); }
+        else { a = (int)(i % A); b = (int)(i / A); }
+        const float* src = w + ((int64_t)a * B + b) * T;
+        float v[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) v[t] = src[t];
+#pragma unroll
+        for (int t = 0; t < T; ++t) dst[(int64_t)t * n + i] = Elem<DT>::from_f(v[t]);
+    }
+}
+
 __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ dw, float* __restrict__ grad,
                                                            int A, int B, int T, int transposed, float gscale) {
     const int64_t total = (int64_t)A * B * T;
@@ -77,6 +102,29 @@ extern "C" int gs_pack_weight(const float* w, void* w_fwd, void* w_dgrad, int Co
     GS_CHECK_ARG(w && (w_fwd || w_dgrad) && Cout > 0 && Cin > 0 && taps > 0, "gs_pack_weight: bad arguments");
     const int64_t total = (int64_t)Cout * Cin * taps;
     hipStream_t s = (hipStream_t)stream;
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_pack_weight: bad dtype");
+    if (taps == 1 || taps == 4 || taps == 9 || taps == 16 || taps == 27) {
+        // source [A][B][T]: Conv2d A=Cout,B=Cin (P_ab = fwd pack, P_ba = dgrad pack); ConvTranspose2d A=Cin,B=Cout
+        // (P_ab = dgrad pack [T][Cin][Cout], P_ba = fwd pack [T][Cout][Cin])
+        const int A = transposed ? Cin : Cout, B = transposed ? Cout : Cin;
+        unsigned short* p_ab = (unsigned short*)(transposed ? w_dgrad : w_fwd);
+        unsigned short* p_ba = (unsigned short*)(transposed ? w_fwd : w_dgrad);
+        dim3 grid(ew_blocks((int64_t)A * B), 2);
+#define GS_PACK_ROWS(DT, TT) pack_weight_rows_kernel<DT, TT><<<grid, 256, 0, s>>>(w, p_ab, p_ba, A, B)
+#define GS_PACK_T(DT)                                    \
+        switch (taps) {                                  \
+            case 1: GS_PACK_ROWS(DT, 1); break;          \
+            case 4: GS_PACK_ROWS(DT, 4); break;          \
+            case 9: GS_PACK_ROWS(DT, 9); break;          \
+            case 16: GS_PACK_ROWS(DT, 16); break;        \
+            default: GS_PACK_ROWS(DT, 27); break;        \
+        }
+        if (dtype == GS_F16) { GS_PACK_T(GS_F16) } else { GS_PACK_T(GS_BF16) }
+#undef GS_PACK_T
+#undef GS_PACK_ROWS
+        GS_CHECK_LAUNCH("gs_pack_weight");
+        return GS_OK;
+    }
     if (dtype == GS_F16)
         pack_weight_kernel<GS_F16><<<ew_blocks(total), 256, 0, s>>>(w, (unsigned short*)w_fwd, (unsigned short*)w_dgrad,
                                                                     Cout, Cin, taps, transposed);
