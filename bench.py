@@ -43,7 +43,7 @@ def pmc_traffic(kind):
     (FETCH_SIZE x2 + WRITE_SIZE, launch-weighted over the class's template instances).  PMC counters cannot be
     collected from inside this process, so this is the figure of the profiled run of the same command."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))     # r01_v7 > r01_v4: newest by name
     pre = PMC_PREFIX.get(kind)
     if not files or pre is None:
         return None, None
