@@ -54,6 +54,13 @@ struct Elem<GS_F16> {
     static __device__ __forceinline__ unsigned short from_f(float f) {
         return __builtin_bit_cast(unsigned short, (_Float16)f);
     }
+    // two values -> one dword (lo = a, hi = b): a single v_cvt_pk_f16_f32 (RNE, same results as two scalar converts)
+    static __device__ __forceinline__ unsigned int pack2(float a, float b) {
+        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+        typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+        const f32x2_ v = {a, b};
+        return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, f16x2_));
+    }
     static __device__ __forceinline__ f32x16 mfma32(V8 a, V8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
@@ -70,6 +77,12 @@ struct Elem<GS_BF16> {
     }
     static __device__ __forceinline__ unsigned short from_f(float f) {
         return __builtin_bit_cast(unsigned short, (__bf16)f);   // v_cvt_pk_bf16_f32: RNE, NaN-safe
+    }
+    static __device__ __forceinline__ unsigned int pack2(float a, float b) {
+        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+        const f32x2_ v = {a, b};
+        return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_));
     }
     static __device__ __forceinline__ f32x16 mfma32(V8 a, V8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -103,7 +116,7 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
     unsigned int w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-        w[i] = (unsigned int)Elem<DT>::from_f(f[2 * i]) | ((unsigned int)Elem<DT>::from_f(f[2 * i + 1]) << 16);
+        w[i] = Elem<DT>::pack2(f[2 * i], f[2 * i + 1]);
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 

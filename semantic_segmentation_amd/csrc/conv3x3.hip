@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_persist_kernel(const C3Args a)
                     v1 += bv[j];
                     v0 = v0 > 0.f ? v0 : v0 * neg_slope;      // NONE: slope 1, RELU: 0, LEAKY: 0.2 (branch free)
                     v1 = v1 > 0.f ? v1 : v1 * neg_slope;
-                    const unsigned int own = (unsigned int)Elem<DT>::from_f(v0) | ((unsigned int)Elem<DT>::from_f(v1) << 16);
+                    const unsigned int own = Elem<DT>::pack2(v0, v1);
                     const unsigned int oth = dpp_xor1(own);
                     const unsigned int pk = __builtin_amdgcn_perm(oth, own, psel);
                     const int row = rowa + (odd ? 1 : 0);
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
                         v0 = v0 > 0.f ? v0 : v0 * neg_slope;
                         v1 = v1 > 0.f ? v1 : v1 * neg_slope;
                     }
-                    const unsigned int own = (unsigned int)Elem<DT>::from_f(v0) | ((unsigned int)Elem<DT>::from_f(v1) << 16);
+                    const unsigned int own = Elem<DT>::pack2(v0, v1);
                     const unsigned int oth = dpp_xor1(own);
                     const unsigned int pk = __builtin_amdgcn_perm(oth, own, psel);
                     const int row = rowa + (odd ? 1 : 0);
