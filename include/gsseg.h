@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 12
+#define GS_ABI_VERSION 13
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -273,6 +273,12 @@ int gs_conv3d_3x3x3(const void* x, const void* w, void* y, const float* bias, fl
 int gs_conv3d_3x3x3_wgrad(const void* x, const void* dy, float* dw, int NB, int D, int H, int W, int Cin,
                           int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff, int dtype,
                           void* stream);
+/* deterministic form (slabs ws[part][27][Cout][Cin], then gs_wgrad_reduce_unpack with taps = 27) */
+int64_t gs_conv3d_3x3x3_wgrad_ws_floats(int NB, int D, int H, int W, int Cin, int Cout);
+int gs_conv3d_3x3x3_wgrad_parts(int NB, int D, int H, int W, int Cin, int Cout);
+int gs_conv3d_3x3x3_wgrad_slabs(const void* x, const void* dy, float* ws, int NB, int D, int H, int W, int Cin,
+                                int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff, int dtype,
+                                void* stream);
 
 /* ---- bilinear x2 up-sampling, align_corners=True -----------------------------------------------
  * replaces nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) + F.pad + torch.cat of the bilinear=True

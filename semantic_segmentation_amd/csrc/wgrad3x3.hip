@@ -329,3 +329,36 @@ extern "C" int gs_wgrad_reduce_unpack(const float* ws, int nparts, float* grad, 
 extern "C" int gs_conv3x3_wgrad_parts(int N, int H, int W, int Cin, int Cout) {
     return w3_ksplit(N, H, W, Cin, Cout, nullptr, nullptr);
 }
+
+// 3-D form of the deterministic weight gradient: the three depth-tap launches store their parts into one set of slabs
+// ws[part][27][Cout][Cin]; gs_wgrad_reduce_unpack(taps = 27) then writes [Cout][Cin][3][3][3].
+extern "C" int64_t gs_conv3d_3x3x3_wgrad_ws_floats(int NB, int D, int H, int W, int Cin, int Cout) {
+    if (NB <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    return (int64_t)w3_ksplit(NB * D, H, W, Cin, Cout, nullptr, nullptr) * 27 * Cout * Cin;
+}
+
+extern "C" int gs_conv3d_3x3x3_wgrad_parts(int NB, int D, int H, int W, int Cin, int Cout) {
+    return w3_ksplit(NB * D, H, W, Cin, Cout, nullptr, nullptr);
+}
+
+extern "C" int gs_conv3d_3x3x3_wgrad_slabs(const void* x, const void* dy, float* ws, int NB, int D, int H, int W, int Cin,
+                                           int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff,
+                                           int dtype, void* stream) {
+    GS_CHECK_ARG(NB > 0 && D > 0 && ws, "gs_conv3d_3x3x3_wgrad_slabs: bad arguments");
+    const int64_t slab = (int64_t)27 * Cout * Cin;
+    for (int kd = 0; kd < 3; ++kd) {
+        if (D == 1 && kd != 1) {
+            // a one-slice volume never pairs with the outer depth taps: their slots must still be defined (zeros)
+            const int parts = w3_ksplit(NB * D, H, W, Cin, Cout, nullptr, nullptr);
+            for (int p = 0; p < parts; ++p)
+                if (hipMemsetAsync(ws + p * slab + (int64_t)kd * 9 * Cout * Cin, 0, (size_t)9 * Cout * Cin * 4, (hipStream_t)stream) != hipSuccess)
+                    return GS_ELAUNCH;
+            continue;
+        }
+        int rc = wgrad3x3_launch(x, dy, ws + (int64_t)kd * 9 * Cout * Cin, NB * D, H, W, Cin, in_pix_stride, in_coff, Cout,
+                                 out_pix_stride, out_coff, dtype, stream, D, kd - 1, slab);
+        if (rc) return rc;
+    }
+    return GS_OK;
+}
+

@@ -293,6 +293,29 @@ def conv3d3_wgrad(x, dy, dw, NB, D, H, W, Cin, Cout, in_stride=None, in_coff=0, 
         TIMER.stop("wgrad3x3_halo", ev, 2.0 * NB * D * H * W * Cout * 27 * Cin)
 
 
+def conv3d3_wgrad_ws_floats(NB, D, H, W, Cin, Cout) -> int:
+    return int(_lib.load().gs_conv3d_3x3x3_wgrad_ws_floats(NB, D, H, W, Cin, Cout))
+
+
+def conv3d3_wgrad_det(x, dy, ws, grad, NB, D, H, W, Cin, Cout, gscale, in_stride=None, in_coff=0, out_stride=None,
+                      out_coff=0):
+    """Deterministic Conv3d(k3,p1) weight gradient into the reference layout [Cout][Cin][3][3][3] (27 taps fastest):
+    split-K parts in fp32 slabs (no zero fill), ordered reduction fused with scale + unpack.  No atomics."""
+    _dev(x)
+    _f32(ws, "ws"); _f32(grad, "grad")
+    if x.dtype != dy.dtype:
+        raise TypeError("conv3d3_wgrad_det: x and dy must share one 16-bit dtype")
+    if ws.numel() < conv3d3_wgrad_ws_floats(NB, D, H, W, Cin, Cout) or grad.numel() != 27 * Cout * Cin:
+        raise ValueError("conv3d3_wgrad_det: workspace / gradient size")
+    ev = TIMER.start() if TIMER is not None else None
+    _lib.call("gs_conv3d_3x3x3_wgrad_slabs", _p(x), _p(dy), _p(ws), NB, D, H, W, Cin, Cin if in_stride is None else in_stride,
+              in_coff, Cout, Cout if out_stride is None else out_stride, out_coff, dt_code(x), _stream())
+    if ev is not None:
+        TIMER.stop("wgrad3x3_halo", ev, 2.0 * NB * D * H * W * Cout * 27 * Cin)
+    parts = int(_lib.load().gs_conv3d_3x3x3_wgrad_parts(NB, D, H, W, Cin, Cout))
+    _lib.call("gs_wgrad_reduce_unpack", _p(ws), parts, _p(grad), Cout, Cin, 27, 0, float(gscale), _stream())
+
+
 def upsample2x_bilinear_fwd(x, y, N, IH, IW, C, OH, OW, in_stride=None, in_coff=0, out_stride=None, out_coff=0,
                             ooy=0, oox=0):
     """nn.Upsample(scale_factor=2, bilinear, align_corners=True) into a channel slice of the [N,OH,OW,*] buffer y."""

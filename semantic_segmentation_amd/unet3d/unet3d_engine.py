@@ -243,13 +243,16 @@ class UNet3DEngine:
                 ops.conv_smallcin_wgrad(st.x3, dy, dw, 3, 1, 1, inv_s)
                 emit(wparam, dw.view(wparam.shape))
             else:
-                dwp = torch.zeros((27, cout, cin), dtype=torch.float32, device=dev)
-                if st.halo:
-                    ops.conv3d3_wgrad(st.inp, dy, dwp, NB, D, H, W, cin, cout, in_stride=st.in_stride, in_coff=st.in_coff)
-                else:
-                    ops.conv_wgrad(st.geom, st.inp, dy, dwp)
                 dw = torch.empty((cout, cin, 27), dtype=torch.float32, device=dev)
-                ops.unpack_wgrad(dwp, dw, cout, cin, 27, False, inv_s)
+                if st.halo:
+                    # split-K parts in slabs + ordered reduction fused with scale / unpack: deterministic, no atomics
+                    wsl = empty(ops.conv3d3_wgrad_ws_floats(NB, D, H, W, cin, cout), dtype=torch.float32)
+                    ops.conv3d3_wgrad_det(st.inp, dy, wsl, dw, NB, D, H, W, cin, cout, inv_s, in_stride=st.in_stride,
+                                          in_coff=st.in_coff)
+                else:
+                    dwp = torch.zeros((27, cout, cin), dtype=torch.float32, device=dev)
+                    ops.conv_wgrad(st.geom, st.inp, dy, dwp)
+                    ops.unpack_wgrad(dwp, dw, cout, cin, 27, False, inv_s)
                 emit(wparam, dw.view(wparam.shape))
                 if need_dinp:
                     dinp = empty(n2, H, W, cin)

@@ -565,6 +565,15 @@ def test_conv3d_3x3x3_halo_fwd_dgrad_wgrad(dtn, dt, NB, D, H, W, Cin, Cout):
     dw = torch.empty(Cout, Cin, 27, dtype=torch.float32, device=dev())
     ops.unpack_wgrad(dwp, dw, Cout, Cin, 27, False, 1.0)
     assert rel_err(dw.cpu().view(Cout, Cin, 3, 3, 3), w.grad) < 2e-3
+    # deterministic form: slabs + ordered reduction straight into [Cout][Cin][27], twice -> bit-identical
+    ws = torch.empty(ops.conv3d3_wgrad_ws_floats(NB, D, H, W, Cin, Cout), dtype=torch.float32, device=dev())
+    d1 = torch.empty(Cout, Cin, 27, dtype=torch.float32, device=dev())
+    d2 = torch.empty_like(d1)
+    ops.conv3d3_wgrad_det(xs, dys, ws, d1, NB, D, H, W, Cin, Cout, 0.5)
+    ws.fill_(float("nan"))                      # the workspace needs no initialisation
+    ops.conv3d3_wgrad_det(xs, dys, ws, d2, NB, D, H, W, Cin, Cout, 0.5)
+    assert torch.equal(d1, d2)
+    assert rel_err(d1.cpu().view(Cout, Cin, 3, 3, 3) * 2, w.grad) < 2e-3
 
 
 @pytest.mark.parametrize("dtn,dt", DTS)
