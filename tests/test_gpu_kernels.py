@@ -519,6 +519,15 @@ def test_conv3x3_halo_wgrad(dtn, dt, N, H, W, Cin, Cout):
     torch.cuda.synchronize()
     got = dwp.cpu().view(3, 3, Cout, Cin).permute(2, 3, 0, 1)
     assert rel_err(got, w.grad) < 2e-3, rel_err(got, w.grad)
+    # deterministic form (slabs + ordered reduction fused with scale / unpack): reference layout, bit-reproducible
+    ws = torch.full((ops.conv3x3_wgrad_ws_floats(N, H, W, Cin, Cout),), float("nan"), dtype=torch.float32, device=dev())
+    g1 = torch.empty(Cout, Cin, 3, 3, dtype=torch.float32, device=dev())
+    g2 = torch.empty_like(g1)
+    for gg in (g1, g2):
+        ops.conv3x3_wgrad_det(xb, db, ws, gg, N, H, W, Cin, Cout, 0.25, in_stride=Cin + 8, in_coff=8, out_stride=Cout + 16,
+                              out_coff=0)
+    assert torch.equal(g1, g2)
+    assert rel_err(g1.cpu() * 4, w.grad) < 2e-3
 
 
 @pytest.mark.parametrize("dtn,dt", DTS)
