@@ -124,8 +124,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
-    from oracle import oracle          # synthetic data generator only (inputs), never the measured path
     from semantic_segmentation_amd import ops
+    from semantic_segmentation_amd.harness import synthetic_batch
     from semantic_segmentation_amd.losses import seg_loss
     from semantic_segmentation_amd.parallel import GradReducer, broadcast_module_state
     from semantic_segmentation_amd.unet import UNet
@@ -137,7 +137,7 @@ def main():
     reducer = None
     if world > 1:
         reducer = GradReducer(net.named_parameters()).attach(net.engine)
-    x, mask = oracle.synthetic_batch(args.batch, args.size, seed=1234 + rank)
+    x, mask = synthetic_batch(args.batch, args.size, seed=1234 + rank)
     if args.host_input:
         x_host, mask_host = x.pin_memory(), mask.pin_memory()
     x, mask = x.to(dev), mask.to(dev)

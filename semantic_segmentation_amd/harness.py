@@ -166,6 +166,22 @@ class SyntheticLungDataset(torch.utils.data.Dataset):
         return {"image": image.unsqueeze(0), "mask": mask.long().unsqueeze(0)}
 
 
+def synthetic_batch(batch: int, size: int, seed: int = 1234, n_channels: int = 1):
+    """SURVEY 8(d) synthetic inputs for the benchmarks: standard-normal images [B,C,S,S] and int64 masks [B,1,S,S]
+    holding 1-3 random filled ellipses each (host tensors; the caller moves them to the GPU)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(batch, n_channels, size, size, generator=g)
+    yy, xx = torch.meshgrid(torch.arange(size, dtype=torch.float32), torch.arange(size, dtype=torch.float32), indexing="ij")
+    mask = torch.zeros(batch, 1, size, size, dtype=torch.long)
+    sc = size / 256.0
+    for b in range(batch):
+        for _ in range(int(torch.randint(1, 4, (1,), generator=g))):
+            cy, cx = (torch.rand(2, generator=g) * size).tolist()
+            ry, rx = ((torch.rand(2, generator=g) * 70 + 20) * sc).tolist()
+            mask[b, 0] |= (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0).long()
+    return x, mask
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description="Betty-free GenSeg end-to-end loop on the MI355X kernels")
     ap.add_argument("--synthetic", action="store_true", help="synthetic lung-like data (no dataset ships with the repo)")
