@@ -225,8 +225,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
     if (ul >= unit_lanes) u1 = u0;   // leftover threads (256 % lanes_per_unit) only join the barriers
     constexpr int UNR = 4;           // plain path: four pixels per lane in flight (memory-level parallelism)
 
-    for (int ch = chl; ch < nch; ch += lanes_per_unit) {
-        const int c0 = ch * 8;
+    for (int ch = chl; ch - chl < nch; ch += lanes_per_unit) {      // uniform trip count: the block barriers below
+        const bool ch_ok = ch < nch;
+        const int c0 = ch_ok ? ch * 8 : 0;
+        if (!ch_ok) u1 = u0;
         float sc[8], sh[8], mu[8], is[8], k1[8], k2[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -354,19 +356,16 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) { red[0][threadIdx.x][i] = s1[i]; red[1][threadIdx.x][i] = s2[i]; }
             __syncthreads();
-            if (ul == 0) {
-                float t1[8], t2[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { t1[i] = 0.f; t2[i] = 0.f; }
-                for (int k = 0; k < unit_lanes; ++k)
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        t1[i] += red[0][k * lanes_per_unit + chl][i];
-                        t2[i] += red[1][k * lanes_per_unit + chl][i];
-                    }
-                float* dst = a.partials + (int64_t)blockIdx.x * 2 * a.C + c0;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { dst[i] = t1[i]; dst[a.C + i] = t2[i]; }
+            // one lane per (statistic, channel): unit_lanes LDS reads each, summed in ascending unit-lane order (the
+            // order of the former 8-lane serial loop, which was 6-10 % of the kernel on the 64-channel layers)
+            const int nv = lanes_per_unit * 8;
+            for (int v = threadIdx.x; v < 2 * nv; v += 256) {
+                const int st = v >= nv ? 1 : 0, idx = v - st * nv;
+                const int cl = idx >> 3, i = idx & 7;
+                if (ch - chl + cl >= nch) continue;
+                float tsum = 0.f;
+                for (int k = 0; k < unit_lanes; ++k) tsum += red[st][k * lanes_per_unit + cl][i];
+                a.partials[(int64_t)blockIdx.x * 2 * a.C + st * a.C + (ch - chl + cl) * 8 + i] = tsum;
             }
         }
     }
@@ -384,10 +383,11 @@ __global__ __launch_bounds__(256) void colsum_stage1(const unsigned short* __res
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     int64_t p1 = p0 + pix_per_block < npix ? p0 + pix_per_block : npix;
     if (ul >= ulanes) p1 = p0;
-    for (int ch = chl; ch < nch; ch += lpu) {
+    for (int ch = chl; ch - chl < nch; ch += lpu) {                 // uniform trip count (block barriers below)
         float s[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) s[i] = 0.f;
+        if (ch >= nch) p1 = p0;
         for (int64_t p = p0 + ul; p < p1; p += ulanes) {
             float v[8];
             const int xx = (int)(p % w);
@@ -403,15 +403,12 @@ __global__ __launch_bounds__(256) void colsum_stage1(const unsigned short* __res
 #pragma unroll
         for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = s[i];
         __syncthreads();
-        if (ul == 0) {
-            float tt[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) tt[i] = 0.f;
-            for (int k = 0; k < ulanes; ++k)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) tt[i] += red[k * lpu + chl][i];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) ws[(int64_t)blockIdx.x * C + ch * 8 + i] = tt[i];
+        for (int v = threadIdx.x; v < lpu * 8; v += 256) {            // one lane per channel, ascending unit-lane order
+            const int cl = v >> 3, i = v & 7;
+            if (ch - chl + cl >= nch) continue;
+            float tt = 0.f;
+            for (int k = 0; k < ulanes; ++k) tt += red[k * lpu + cl][i];
+            ws[(int64_t)blockIdx.x * C + (ch - chl + cl) * 8 + i] = tt;
         }
     }
 }
