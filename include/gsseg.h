@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 13
+#define GS_ABI_VERSION 14
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -184,6 +184,12 @@ int gs_maxpool3d_fwd(const void* z, int z_pix_stride, int z_coff, void* zp, int 
 int gs_maxpool3d_bwd(const void* z, int z_pix_stride, int z_coff, const void* dzp, const void* dres,
                      int res_pix_stride, int res_coff, void* dz, int NB, int D, int H, int W, int C, int dtype,
                      void* stream);
+
+/* MaxPool2d(2) forward on its own (unet/unet_parts.py:34): z [N,H,W,*] (strided, e.g. the skip half of a concat buffer)
+ * -> zp [N,H/2,W/2,C] dense (floor: an odd last row/column is dropped, as in ATen).  Used by the inference path, where
+ * conv + folded BatchNorm + ReLU is ONE gs_conv3x3 call (bias + activation epilogue) and gs_bn_act_apply is not run. */
+int gs_maxpool2x2_fwd(const void* z, int z_pix_stride, int z_coff, void* zp, int N, int H, int W, int C, int dtype,
+                      void* stream);
 
 /* per-channel column sums over the sub-rectangle [y0,y0+h) x [x0,x0+w) of a (strided) NHWC tensor
  * [N,H,W,*]: out[c] (OVERWRITE) = gscale * sum t[pix*s + coff + c]  (bias gradient of ConvTranspose2d,

@@ -103,6 +103,54 @@ int launch(const P3Args& a, bool bwd, int dtype, hipStream_t s) {
 
 }  // namespace
 
+namespace {
+// MaxPool2d(2) forward alone (unet_parts.py:34) for the inference path, where conv + folded BatchNorm + ReLU is one
+// kernel and nothing else touches the activation: z [N,H,W,*] (strided: a concat buffer) -> zp [N,H/2,W/2,C] dense.
+template <int DT>
+__global__ __launch_bounds__(256) void maxpool2x2_kernel(const unsigned short* __restrict__ z, int zs, int zc,
+                                                         unsigned short* __restrict__ zp, int N, int H, int W, int C) {
+    const int nch = C >> 3, PH = H / 2, PW = W / 2;
+    const int total = N * PH * PW * nch;                  // host guarantees < 2^31
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int ch = idx % nch;
+        int r = idx / nch;
+        const int px = r % PW; r /= PW;
+        const int py = r % PH;
+        const int n = r / PH;
+        const int64_t p00 = ((int64_t)n * H + 2 * py) * W + 2 * px;
+        const unsigned short* src = z + p00 * zs + zc + ch * 8;
+        const uint4 r0 = *reinterpret_cast<const uint4*>(src);
+        const uint4 r1 = *reinterpret_cast<const uint4*>(src + zs);
+        const uint4 r2 = *reinterpret_cast<const uint4*>(src + (int64_t)W * zs);
+        const uint4 r3 = *reinterpret_cast<const uint4*>(src + (int64_t)(W + 1) * zs);
+        float a[8], b[8], c[8], d[8], m[8];
+        unpack8<DT>(r0, a); unpack8<DT>(r1, b); unpack8<DT>(r2, c); unpack8<DT>(r3, d);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m[i] = fmaxf(fmaxf(a[i], b[i]), fmaxf(c[i], d[i]));
+        *reinterpret_cast<uint4*>(zp + (int64_t)(idx / nch) * C + ch * 8) = pack8<DT>(m);
+    }
+}
+}  // namespace
+
+extern "C" int gs_maxpool2x2_fwd(const void* z, int z_pix_stride, int z_coff, void* zp, int N, int H, int W, int C,
+                                 int dtype, void* stream) {
+    GS_CHECK_ARG(z && zp && N > 0 && H > 1 && W > 1 && C > 0 && C % 8 == 0, "gs_maxpool2x2_fwd: bad arguments");
+    GS_CHECK_ARG(z_pix_stride >= z_coff + C && z_pix_stride % 8 == 0 && z_coff % 8 == 0, "gs_maxpool2x2_fwd: bad z stride");
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_maxpool2x2_fwd: bad dtype");
+    const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 8);
+    GS_CHECK_ARG(total < 2147483000LL, "gs_maxpool2x2_fwd: output too large for 32-bit indexing");
+    int64_t nb = cdiv64(total, 256);
+    if (nb > 16384) nb = 16384;
+    if (dtype == GS_F16)
+        maxpool2x2_kernel<GS_F16><<<(int)nb, 256, 0, (hipStream_t)stream>>>((const unsigned short*)z, z_pix_stride, z_coff,
+                                                                            (unsigned short*)zp, N, H, W, C);
+    else
+        maxpool2x2_kernel<GS_BF16><<<(int)nb, 256, 0, (hipStream_t)stream>>>((const unsigned short*)z, z_pix_stride, z_coff,
+                                                                             (unsigned short*)zp, N, H, W, C);
+    GS_CHECK_LAUNCH("gs_maxpool2x2_fwd");
+    return GS_OK;
+}
+
 extern "C" int gs_maxpool3d_fwd(const void* z, int z_pix_stride, int z_coff, void* zp, int NB, int D, int H, int W, int C,
                                 int dtype, void* stream) {
     GS_CHECK_ARG(z && zp && NB > 0 && D > 1 && H > 1 && W > 1 && C > 0 && C % 8 == 0, "gs_maxpool3d_fwd: bad arguments");

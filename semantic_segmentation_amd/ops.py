@@ -447,6 +447,10 @@ def bn_finalize(partials, ntiles, C, count, gamma, beta, running_mean, running_v
         _f32(t, n)
     _lib.call("gs_bn_finalize", _p(partials), ntiles, C, float(count), _p(gamma), _p(beta), _p(running_mean),
               _p(running_var), float(momentum), float(eps), _p(scale), _p(shift), _p(mean), _p(invstd), _stream())
+    # the kernel wrote the running statistics through raw pointers: tell torch (version counters key the engines' caches)
+    for t in (running_mean, running_var):
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
 
 
 def bn_eval_coeffs(C, gamma, beta, running_mean, running_var, eps, scale, shift, mean, invstd):
@@ -494,6 +498,15 @@ def bn_act_bwd_apply(y, dz_a, sa, ca, dzp, scale, shift, mean, invstd, c1, c2, a
 def maxpool3d_fwd(z, zp, NB, D, H, W, C, z_stride=None, z_coff=0):
     _dev(z)
     _lib.call("gs_maxpool3d_fwd", _p(z), C if z_stride is None else z_stride, z_coff, _p(zp), NB, D, H, W, C,
+              dt_code(z), _stream())
+
+
+def maxpool2x2_fwd(z, zp, N, H, W, C, z_stride=None, z_coff=0):
+    """MaxPool2d(2) of a (strided) NHWC tensor into a dense one: the inference path's stand-alone pool."""
+    _dev(z)
+    if z.dtype != zp.dtype:
+        raise TypeError("maxpool2x2_fwd: z and zp must share one 16-bit dtype")
+    _lib.call("gs_maxpool2x2_fwd", _p(z), C if z_stride is None else z_stride, z_coff, _p(zp), N, H, W, C,
               dt_code(z), _stream())
 
 

@@ -62,6 +62,12 @@ class _FusedMixin:
         return dict(p=base, g=base + 8 * T, s1=base + 16 * T, s2=base + 24 * T, n=cache["n"].data_ptr(),
                     ct=cache["ct"].data_ptr(), cs=cache["cs"].data_ptr(), nchunks=cache["nchunks"])
 
+    @staticmethod
+    def _mark_updated(params):
+        """The kernel wrote the parameters through raw pointers: bump their version counters, which is what the engines'
+        16-bit weight-pack caches (and autograd's saved-tensor checks) key on."""
+        torch.autograd.graph.increment_version(params)
+
     def state_dict(self):
         sd = super().state_dict()
         for g in sd["param_groups"]:
@@ -108,6 +114,7 @@ class RMSprop(_FusedMixin, torch.optim.RMSprop):
                       tb["nchunks"], float(group["lr"]),
                       float(group["alpha"]), float(group["eps"]), float(group["weight_decay"]), float(group["momentum"]),
                       float(self.grad_scale), _stream())
+            self._mark_updated(params)
         return loss
 
 
@@ -153,6 +160,7 @@ class Adam(_FusedMixin, torch.optim.Adam):
                       float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), float(self.grad_scale),
                       _stream())
             group["_gs_keepalive"] = sc          # the launch is asynchronous: keep the scalars alive until the next step
+            self._mark_updated(params)
         return loss
 
     def state_dict(self):

@@ -27,6 +27,8 @@ from .. import ops
 from .._lib import ACT_NONE, ACT_RELU
 
 _TORCH_DT = {"f16": torch.float16, "bf16": torch.bfloat16}
+# eval-mode forward without a graph: fold BatchNorm into the conv weights (GSSEG_FOLD_BN=0 keeps the two-pass form)
+FOLD_BN_INFERENCE = os.environ.get("GSSEG_FOLD_BN", "1") != "0"
 
 
 class _ConvRec:
@@ -86,6 +88,25 @@ class UNetEngine:
         self._packs[name] = (key, wf, wd)
         return wf, wd
 
+    def _folded(self, wkey: str, bnkey: str, w, gamma, beta, rm, rv, eps: float, image: bool):
+        """Inference: BatchNorm(eval) folded into the conv -- w' = w * gamma/sqrt(var+eps) per output channel and a bias
+        beta - mean*gamma/sqrt(var+eps).  Cached until a Parameter or running statistic changes."""
+        key = tuple(_pack_key(t) for t in (w, gamma, beta, rm, rv)) + (eps,)
+        ent = self._packs.get(wkey + "|folded")
+        if ent is not None and ent[0] == key:
+            return ent[1], ent[2]
+        with torch.no_grad():
+            s = gamma.detach().float() * torch.rsqrt(rv.float() + eps)
+            w_eff = (w.detach().float() * s.view(-1, 1, 1, 1)).contiguous()
+            bias = (beta.detach().float() - rm.float() * s).contiguous()
+            if image:
+                wf = w_eff                                   # the direct first-layer kernel reads fp32 [Cout,Cin,3,3]
+            else:
+                wf = torch.empty((9, w.shape[0], w.shape[1]), dtype=self.tdt, device=w.device)
+                ops.pack_weight(w_eff, wf, None, False)
+        self._packs[wkey + "|folded"] = (key, wf, bias)
+        return wf, bias
+
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, params: Dict[str, torch.Tensor], training: bool, need_grad: bool):
         net = self.net
@@ -143,6 +164,21 @@ class UNetEngine:
             wparam = params[wkey]
             rm = bufs.get(bnkey + ".running_mean")
             batch_stats = training or rm is None
+            if FOLD_BN_INFERENCE and not batch_stats and not need_grad and ops.USE_HALO_CONV:
+                # inference: one kernel per conv block (folded BN as bias, ReLU in the epilogue, written where the
+                # consumer reads it); the 2x2 pool of the Down blocks is a read-only pass over the skip tensor
+                wf, bias = self._folded(wkey, bnkey, wparam, params[bnkey + ".weight"], params[bnkey + ".bias"], rm,
+                                        bufs[bnkey + ".running_var"], net.get_submodule(bnkey).eps, image)
+                if image:
+                    if z_stride != cout or z_coff != 0:
+                        raise RuntimeError("first-layer output must be dense")
+                    ops.conv_smallcin_fwd(inp, wf, bias, z, None, 3, 1, 1, act=ACT_RELU)
+                else:
+                    ops.conv3x3(inp, wf, z, N, h, w, cin, cout, ops.TAPS3_FWD, bias, None, act=ACT_RELU,
+                                out_stride=z_stride, out_coff=z_coff)
+                if zp is not None:
+                    ops.maxpool2x2_fwd(z, zp, N, h, w, cout, z_stride=z_stride, z_coff=z_coff)
+                return None
             y = empty(N, h, w, cout)
             rec = _ConvRec()
             rec.name, rec.wkey, rec.bnkey = f"{prefix}.{idx}", wkey, bnkey

@@ -659,3 +659,41 @@ def test_seg_loss_global_dice_equals_full_batch(C):
     assert float((avg_equiv - g_full).abs().max()) < 1e-7 + 1e-5 * float(g_full.abs().max())
     ce_mean = 0.5 * (float(outs[0][1]) + float(outs[1][1]))
     assert abs(ce_mean - float(parts_full[1].detach())) < 1e-6
+
+
+@pytest.mark.parametrize("dtn,dt", DTS)
+@pytest.mark.parametrize("N,H,W,C,pad", [(2, 16, 24, 64, 0), (1, 17, 9, 72, 8), (3, 64, 64, 128, 128)])
+def test_maxpool2x2_standalone_strided(dtn, dt, N, H, W, C, pad):
+    """gs_maxpool2x2_fwd (unet_parts.py:34) reading the skip half of a concat buffer: bit-exact against F.max_pool2d."""
+    from semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(5)
+    z = rnd(g, N, C, H, W, dt=dt)
+    buf = torch.zeros(N, H, W, C + pad, dtype=dt, device=dev())
+    buf[..., :C] = nhwc(z, dt)
+    zp = torch.empty(N, H // 2, W // 2, C, dtype=dt, device=dev())
+    ops.maxpool2x2_fwd(buf, zp, N, H, W, C, z_stride=C + pad, z_coff=0)
+    torch.cuda.synchronize()
+    assert torch.equal(from_nhwc(zp), F.max_pool2d(z, 2))
+
+
+@pytest.mark.parametrize("dtn,dt", DTS)
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 13, 9, 64, 64), (1, 40, 33, 128, 64), (2, 32, 32, 128, 256)])
+def test_conv3x3_halo_bias_relu_epilogue(dtn, dt, N, H, W, Cin, Cout):
+    """the inference form of a conv block: bias (folded BatchNorm) + ReLU in the halo kernel's epilogue, written into a
+    channel slice of a wider buffer"""
+    from semantic_segmentation_amd import ops
+    from semantic_segmentation_amd._lib import ACT_RELU
+    g = torch.Generator().manual_seed(31)
+    x = rnd(g, N, Cin, H, W, dt=dt)
+    w = rnd(g, Cout, Cin, 3, 3, dt=dt, scale=0.05)
+    b = torch.randn(Cout, generator=g)
+    ref = F.relu(F.conv2d(x, w, b, padding=1))
+    wf = torch.empty(9, Cout, Cin, dtype=dt, device=dev())
+    ops.pack_weight(w.to(dev()), wf, None, False)
+    y = torch.zeros(N, H, W, 2 * Cout, dtype=dt, device=dev())
+    ops.conv3x3(nhwc(x, dt), wf, y, N, H, W, Cin, Cout, ops.TAPS3_FWD, b.to(dev()), None, act=ACT_RELU,
+                out_stride=2 * Cout, out_coff=Cout)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(y[..., Cout:]), ref) < tol(dt)
+    assert float(y[..., :Cout].abs().max()) == 0.0
+    assert float(y.min()) >= 0.0

@@ -86,3 +86,39 @@ def test_cpu_parameters_raise():
     q.grad = torch.ones(4)
     with pytest.raises(RuntimeError):
         Adam([q]).step()
+
+
+@pytest.mark.parametrize("which", ["rmsprop", "adam"])
+def test_fused_step_refreshes_engine_weight_packs(which):
+    """The optimiser kernels write the parameters through raw pointers; the engines cache 16-bit packs of the weights
+    keyed on the tensors' version counters.  After a fused step the network must compute with the NEW weights: its
+    output has to equal that of a freshly built network loaded with the updated state dict (train mode and the
+    folded-BatchNorm inference path)."""
+    from semantic_segmentation_amd.losses import seg_loss
+    from semantic_segmentation_amd.optim import Adam, RMSprop
+    from semantic_segmentation_amd.unet import UNet
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    net = UNet(1, 2).to(dev).train()
+    x = torch.randn(2, 1, 32, 32, device=dev)
+    mask = (torch.rand(2, 1, 32, 32, device=dev) > 0.5).long()
+    opt = RMSprop(net.parameters(), lr=1e-4, momentum=0.9) if which == "rmsprop" else Adam(net.parameters(), lr=1e-3)
+    v0 = [p._version for p in net.parameters()]
+    with torch.no_grad():
+        net.eval()
+        before = net(x).clone()
+        net.train()
+    seg_loss(net(x), mask).backward()
+    opt.step()
+    assert all(p._version > v for p, v in zip(net.parameters(), v0))
+    fresh = UNet(1, 2).to(dev)
+    fresh.load_state_dict(net.state_dict(), strict=True)
+    for mode in ("eval", "train"):
+        getattr(net, mode)()
+        getattr(fresh, mode)()
+        with torch.no_grad():
+            a, b = net(x), fresh(x)
+        assert torch.equal(a, b), mode
+        if mode == "eval":
+            assert torch.isfinite(a).all()
+            assert float((a - before).abs().max()) > 1e-4      # the step moved every weight by ~1e-3: stale packs would give `before`

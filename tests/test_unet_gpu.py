@@ -258,6 +258,44 @@ def test_full_size_properties_bs32_256():
     assert float((got - ref_mean).abs().max()) < 2e-5 + 2e-3 * float(ref_mean.abs().max())
 
 
+@pytest.mark.parametrize("n_classes,bilinear,H,W", [(2, False, 64, 64), (1, True, 48, 80), (1, False, 33, 47)])
+def test_inference_folded_bn_matches_two_pass(n_classes, bilinear, H, W):
+    """eval-mode forward with BatchNorm folded into the convs (one kernel per conv block, stand-alone
+    pool) against the two-pass eval forward (conv -> bn_act_apply with running statistics) and against the oracle."""
+    from semantic_segmentation_amd.unet import unet_engine
+    net, sd = build_net(n_classes, seed=13, bilinear=bilinear)
+    x, mask = oracle.synthetic_batch(3, max(H, W), seed=9)
+    x = x[:, :, :H, :W].contiguous().cuda()
+    net.train()
+    with torch.no_grad():
+        for _ in range(2):
+            net(x)                                       # move the running statistics away from (0, 1)
+    net.eval()
+    assert unet_engine.FOLD_BN_INFERENCE
+    with torch.no_grad():
+        folded = net(x)
+    unet_engine.FOLD_BN_INFERENCE = False
+    try:
+        with torch.no_grad():
+            two_pass = net(x)
+    finally:
+        unet_engine.FOLD_BN_INFERENCE = True
+    ref = oracle.unet_forward({k: v.detach().cpu() for k, v in net.state_dict().items()}, x.cpu(), False, {}, bilinear)
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((folded - two_pass).abs().max()) < 1e-2 * scale
+    assert float((folded.cpu() - ref).abs().mean()) < 2.5e-3 * scale
+    assert float((folded.cpu() - ref).abs().max()) < 2e-2 * scale
+    # the weight packs are cached per (parameter, running statistics) version: another training step must refresh them
+    net.train()
+    with torch.no_grad():
+        net(x)
+    net.eval()
+    with torch.no_grad():
+        again = net(x)
+    ref2 = oracle.unet_forward({k: v.detach().cpu() for k, v in net.state_dict().items()}, x.cpu(), False, {}, bilinear)
+    assert float((again.cpu() - ref2).abs().max()) < 2e-2 * max(1.0, float(ref2.abs().max()))
+
+
 @pytest.mark.parametrize("N,H,W,C", [(1, 16, 16, 1), (3, 17, 31, 2), (1, 48, 200, 3), (2, 384, 512, 1)])
 def test_unet_extreme_shapes_vs_oracle(N, H, W, C):
     """Edge shapes of the reference's `forward` (unet_model.py:26-37): the minimum 16x16 (1x1 bottleneck), odd sizes

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timings of the non-headline BASELINE configs on one MI355X (informational; bench.py is the contract):
 config 3: Generator / Discriminator / Unet training steps at 256x256 (batch 2 and 32);
-config 5: UNet3D(1,2) forward+backward at 64^3 and 128^3 (batch 1)."""
+config 5: UNet3D(1,2) forward+backward at 64^3 and 128^3 (batch 1); plus the eval-mode (inference) forward of the U-Net."""
 import os
 import sys
 import time
@@ -60,7 +60,19 @@ def main():
         tg, td, tu = timeit(g_step), timeit(d_step), timeit(u_step)
         print(f"config3 B={B:3d}: generator step {tg * 1e3:8.2f} ms | discriminator step {td * 1e3:8.2f} ms | "
               f"unet step (2 U-Net fwd+bwd + G fwd + post-proc) {tu * 1e3:8.2f} ms | trio {B / (tg + td + tu):8.1f} img/s")
-    del G, D, U
+    # inference: eval-mode U-Net forward, BatchNorm folded into the convs vs the two-pass form
+    from semantic_segmentation_amd.unet import unet_engine
+    U2 = UNet(1, 2).to(dev).eval()
+    xe, _ = synthetic_batch(32, 256, seed=5)
+    xe = xe.to(dev)
+    with torch.no_grad():
+        for fold in (True, False):
+            unet_engine.FOLD_BN_INFERENCE = fold
+            t = timeit(lambda: U2(xe), iters=10, warm=3)
+            print(f"inference UNet(1,2) 256x256 B=32 eval forward, BatchNorm {'folded into the convs' if fold else 'as a second pass':24s}: "
+                  f"{t * 1e3:7.2f} ms = {32 / t:8.1f} img/s ({32 * 96.19e9 / t / 1e12:6.1f} TFLOP/s)")
+    unet_engine.FOLD_BN_INFERENCE = True
+    del G, D, U, U2
     torch.cuda.empty_cache()
     net = UNet3D(1, 2).to(dev).train()
     for S in (64, 128):
