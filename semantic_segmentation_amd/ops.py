@@ -27,7 +27,15 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_RAW_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """Handle of torch's current HIP stream on the current device.  torch.cuda.current_stream() builds a Stream object
+    (~9 us per call, a third of the host time of a small-batch step); the raw accessors return the same handle."""
+    if _RAW_STREAM is not None and _RAW_DEVICE is not None:
+        return _RAW_STREAM(_RAW_DEVICE())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -63,9 +63,32 @@ class UNetEngine:
         self.after_backward: Optional[Callable[[], None]] = None
 
     # ------------------------------------------------------------------ parameters
+    def _index(self):
+        """(owner module, leaf name) of every parameter and buffer, in registration order.  Walking the module tree costs
+        ~0.7 ms per call; the tree of a UNet is static, while the tensors themselves may be swapped (`.to()`, `.half()`)
+        -- so the owners are cached and the tensors are read from them on every call."""
+        idx = self.__dict__.get("_idx")
+        if idx is None:
+            mods = dict(self.net.named_modules())
+            def owners(named):
+                out = []
+                for name, _ in named:
+                    head, _, leaf = name.rpartition(".")
+                    out.append((name, mods[head], leaf))
+                return out
+            idx = (owners(self.net.named_parameters()), owners(self.net.named_buffers()), mods)
+            self.__dict__["_idx"] = idx
+        return idx
+
     def param_items(self):
         """(name, Parameter) in registration order -- the order autograd sees them."""
-        return list(self.net.named_parameters())
+        return [(n, m._parameters[leaf]) for n, m, leaf in self._index()[0]]
+
+    def buffer_dict(self):
+        return {n: m._buffers[leaf] for n, m, leaf in self._index()[1]}
+
+    def submodule(self, key: str):
+        return self._index()[2][key]
 
     def invalidate_packs(self):
         """Drop the cached 16-bit weight packs (they are otherwise reused until a Parameter changes)."""
@@ -122,7 +145,8 @@ class UNetEngine:
             raise NotImplementedError("n_channels / n_classes above 4 are not supported by the direct end kernels")
         dev, tdt = x.device, self.tdt
         x = x.contiguous().float()
-        bufs = dict(net.named_buffers())
+        bufs = self.buffer_dict()
+        nbt_pending = []                 # num_batches_tracked counters of this pass: ONE foreach increment at the end
         hs = [H >> i for i in range(5)]
         ws_ = [W >> i for i in range(5)]
         bilinear = bool(net.bilinear)
@@ -143,18 +167,21 @@ class UNetEngine:
             batch_stats = training or rm is None
             if batch_stats:
                 nbt = bufs.get(bnkey + ".num_batches_tracked")
-                bn_mod = net.get_submodule(bnkey)
+                bn_mod = self.submodule(bnkey)
                 mom = bn_mod.momentum
                 if training and nbt is not None:
-                    nbt.add_(1)
+                    if mom is None:
+                        nbt.add_(1)                      # cumulative average: the factor needs the new count now
+                    else:
+                        nbt_pending.append(nbt)
                 if mom is None:
                     mom = 1.0 / float(nbt.item()) if nbt is not None else 0.0
                 upd = training and rm is not None
                 ops.bn_finalize(partials, ntiles, cout, count, gamma.detach(), beta.detach(),
-                                rm if upd else None, rv if upd else None, mom, net.get_submodule(bnkey).eps,
+                                rm if upd else None, rv if upd else None, mom, bn_mod.eps,
                                 coef[0], coef[1], coef[2], coef[3])
             else:
-                ops.bn_eval_coeffs(cout, gamma.detach(), beta.detach(), rm, rv, net.get_submodule(bnkey).eps,
+                ops.bn_eval_coeffs(cout, gamma.detach(), beta.detach(), rm, rv, self.submodule(bnkey).eps,
                                    coef[0], coef[1], coef[2], coef[3])
             return coef, batch_stats
 
@@ -168,7 +195,7 @@ class UNetEngine:
                 # inference: one kernel per conv block (folded BN as bias, ReLU in the epilogue, written where the
                 # consumer reads it); the 2x2 pool of the Down blocks is a read-only pass over the skip tensor
                 wf, bias = self._folded(wkey, bnkey, wparam, params[bnkey + ".weight"], params[bnkey + ".bias"], rm,
-                                        bufs[bnkey + ".running_var"], net.get_submodule(bnkey).eps, image)
+                                        bufs[bnkey + ".running_var"], self.submodule(bnkey).eps, image)
                 if image:
                     if z_stride != cout or z_coff != 0:
                         raise RuntimeError("first-layer output must be dense")
@@ -276,6 +303,8 @@ class UNetEngine:
         logits = empty(N, net.n_classes, H, W, dtype=torch.float32)
         ops.conv_smallcout_fwd(inp, params["outc.conv.weight"].detach().contiguous(),
                                params["outc.conv.bias"].detach(), logits)
+        if nbt_pending:
+            torch._foreach_add_(nbt_pending, 1)
         ctx = None
         if need_grad:
             ctx = dict(recs=recs, ups=ups, x=x, z_last=inp, N=N, H=H, W=W, hs=hs, ws=ws_, C=C, training=training)
