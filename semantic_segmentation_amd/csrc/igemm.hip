@@ -12,6 +12,8 @@
 //   GEMM view M = Cout, N = (tap, ci), K = pixels.  Both operands are pixel-major in memory but the
 //   MFMA wants K(=pixel)-minor fragments: tiles are staged as [pixel][channel] and read with the
 //   gfx950 transposing LDS read (ds_read_b64_tr_b16).  Split-K over pixels, fp32 atomics into dW.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
@@ -193,14 +195,21 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
         // of blocks serialise in L2); the LAST part to take a ticket sums the slabs in part order (deterministic)
         constexpr int REGS = 2 * NT * 16;
         float* slab = a.ws_acc + (((int64_t)lid * ksplit + kpart) * 256 + t) * REGS;
+        // a 32-row block of the tile that lies wholly beyond M (skinny GEMMs fill 8..32 of the 128 rows) is neither
+        // stored nor summed: its accumulators are never written to y
+        bool rows_ok[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) rows_ok[i] = m0 + wm * 64 + i * 32 < a.M;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (!rows_ok[i]) continue;
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4)
                     *reinterpret_cast<float4*>(slab + (i * NT + j) * 16 + r4 * 4) =
                         make_float4(acc[i][j][r4 * 4], acc[i][j][r4 * 4 + 1], acc[i][j][r4 * 4 + 2], acc[i][j][r4 * 4 + 3]);
+        }
         __threadfence();                                           // release: the slab is visible device-wide
         __syncthreads();
         __shared__ unsigned int ticket;
@@ -217,7 +226,8 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
         for (int pp = 0; pp < ksplit; ++pp) {
             const float* q = a.ws_acc + (((int64_t)lid * ksplit + pp) * 256 + t) * REGS;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {
+                if (!rows_ok[i]) continue;
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -226,6 +236,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
                         acc[i][j][r4 * 4] += v.x; acc[i][j][r4 * 4 + 1] += v.y;
                         acc[i][j][r4 * 4 + 2] += v.z; acc[i][j][r4 * 4 + 3] += v.w;
                     }
+            }
         }
         if (t == 0) __hip_atomic_store(a.ws_cnt + lid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ticket counter back to 0
         __syncthreads();
@@ -567,15 +578,24 @@ float* g_splitk_ws = nullptr;                             // set by gs_conv_igem
 int64_t g_splitk_ws_floats = 0;
 constexpr int64_t SPLITK_TILE_FLOATS = 256 * 64;          // 256 threads x (2 x 2 x 16) accumulators of a 128x128 tile
 
-constexpr int SPLITK_MAX_TILES = 16, SPLITK_MAX_PARTS = 16;
+constexpr int SPLITK_MAX_PARTS = 16, SPLITK_MAX_SLABS = 512;
 
-// ksplit for a launch with `tiles` output tiles and up to `ksteps` K steps: only really skinny GEMMs (<= 16 tiles on
-// 256 CUs), >= 8 K steps per part, ~256 blocks in total
+// ksplit for a launch with `tiles` output tiles and up to `ksteps` K steps.  Skinny GEMMs (few M/N tiles, long K: the
+// batch-2 Pix2Pix layers) are latency bound -- one block walks 128 K steps of ~0.5 us with 64 blocks on 256 CUs --
+// so K is cut until ~512 blocks exist, at most 16 parts.  Row blocks of a tile beyond M are not stored in the slabs.
 static int choose_ksplit(int tiles, int ksteps, int64_t ws_floats, int64_t cnt_slots) {
-    if (tiles > SPLITK_MAX_TILES || ksteps < 32) return 1;
-    int k = 256 / tiles;
-    if (k > ksteps / 8) k = ksteps / 8;
+    static const int max_tiles = getenv("GSSEG_SPLITK_TILES") ? atoi(getenv("GSSEG_SPLITK_TILES")) : 128;
+    static const int target = getenv("GSSEG_SPLITK_BLOCKS") ? atoi(getenv("GSSEG_SPLITK_BLOCKS")) : 512;
+    if (tiles > max_tiles || ksteps < 32) return 1;
+    int k = target / tiles;
+    static const int min_steps = getenv("GSSEG_SPLITK_MINSTEPS") ? atoi(getenv("GSSEG_SPLITK_MINSTEPS")) : 32;
+    // K steps per part: 8 for the really skinny launches, 32 once whole 128-row tiles travel through the slabs (measured
+    // on the Pix2Pix step trio: 16 tiles/8 steps 73.2 | 412 img/s at batch 2 | 32; 128 tiles/8 steps 69.3 | 425;
+    // 128 tiles/32 steps 74.2 | 436)
+    const int per = tiles > 16 ? min_steps : 8;
+    if (k > ksteps / per) k = ksteps / per;
     if (k > SPLITK_MAX_PARTS) k = SPLITK_MAX_PARTS;
+    while (k > 1 && (int64_t)tiles * k > SPLITK_MAX_SLABS) --k;
     if ((int64_t)tiles * k * SPLITK_TILE_FLOATS > ws_floats || tiles > cnt_slots) return 1;
     return k < 2 ? 1 : k;
 }
@@ -643,7 +663,7 @@ extern "C" int gs_conv_igemm_set_workspace(float* ws, int64_t ws_floats) {
 }
 
 extern "C" int64_t gs_conv_igemm_workspace_floats(void) {
-    return 4096 + (int64_t)SPLITK_MAX_TILES * SPLITK_MAX_PARTS * SPLITK_TILE_FLOATS;
+    return 4096 + (int64_t)SPLITK_MAX_SLABS * SPLITK_TILE_FLOATS;
 }
 
 // Merged stride-2 / kernel-2 transposed convolution (unet_parts.py:51 ConvTranspose2d(C, C/2, 2, 2);
