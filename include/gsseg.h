@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 14
+#define GS_ABI_VERSION 15
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -107,6 +107,12 @@ int gs_conv3x3_wgrad(const void* x, const void* dy, float* dw, int N, int H, int
  * (N,OH,OW,out_pix_stride,out_coff), x on the INPUT side.  Replaces the autograd weight gradient of
  * the same call sites.  Requires Cin % 8 == 0 and Cout % 8 == 0. */
 int gs_conv_wgrad(const GsConvGeom* g, const void* x, const void* dy, float* dw, int dtype, void* stream);
+/* Same weight gradient WRITTEN instead of accumulated: dw[tap_w[t]][co][ci] = ... for the taps of g (other taps of dw
+ * are not touched), so the caller need not zero dw.  Only valid when the launch does not split K
+ * (gs_conv_wgrad_single_pass(g) == 1: the few-pixel layers of the batch-2 Pix2Pix step, where zero-filling and
+ * read-modify-writing the fp32 gradient of a 512x1024x8x8 kernel costs more than computing it); otherwise GS_EINVAL. */
+int gs_conv_wgrad_single_pass(const GsConvGeom* g);
+int gs_conv_wgrad_assign(const GsConvGeom* g, const void* x, const void* dy, float* dw, int dtype, void* stream);
 
 /* ---- direct (VALU) convolutions for 1..4-channel ends of the nets ----------------------------
  * gs_conv_smallcin_fwd: x fp32 NCHW [N,Cin,IH,IW] (the image / mask as the loader hands it,

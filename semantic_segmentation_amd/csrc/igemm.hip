@@ -378,6 +378,7 @@ struct WgradArgs {
     int n_cotiles, n_cbgroups, ksplit;
     int kper;      // pixels per K split (multiple of 64)
     int d_n, d_oy, d_ox;   // mixed-radix decomposition of 64 pixels
+    int assign;            // ksplit == 1 only: plain stores instead of atomic adds (dw need not be zeroed)
 };
 
 constexpr int WG_KP = 64;   // pixels per K step
@@ -540,7 +541,11 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (co < g.Cout) atomicAdd(a.dw + ((int64_t)g.tap_w[tap] * g.Cout + co) * g.Cin + ci, acc[i][j][r]);
+                if (co < g.Cout) {
+                    float* q = a.dw + ((int64_t)g.tap_w[tap] * g.Cout + co) * g.Cin + ci;
+                    if (a.assign) *q = acc[i][j][r];
+                    else atomicAdd(q, acc[i][j][r]);
+                }
             }
         }
 }
@@ -712,14 +717,16 @@ extern "C" int gs_upconv2x2_fwd(const void* x, const void* w, const float* bias,
     return launch_igemm(a, dtype, (hipStream_t)stream, "gs_upconv2x2_fwd");
 }
 
-extern "C" int gs_conv_wgrad(const GsConvGeom* g, const void* x, const void* dy, float* dw, int dtype,
-                             void* stream) {
+// plan only (x == nullptr): returns the K split of this geometry through *ksplit_out
+static int conv_wgrad_launch(const GsConvGeom* g, const void* x, const void* dy, float* dw, int dtype, void* stream,
+                             int assign, int* ksplit_out) {
     int rc = check_geom(g, "gs_conv_wgrad");
     if (rc) return rc;
-    GS_CHECK_ARG(x && dy && dw, "gs_conv_wgrad: null pointer");
+    const bool plan = ksplit_out != nullptr;
+    GS_CHECK_ARG(plan || (x && dy && dw), "gs_conv_wgrad: null pointer");
     GS_CHECK_ARG(g->Cout % 8 == 0 && g->out_pix_stride % 8 == 0 && g->out_coff % 8 == 0,
                  "gs_conv_wgrad: Cout/out stride/offset must be multiples of 8");
-    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_conv_wgrad: bad dtype %d", dtype);
+    GS_CHECK_ARG(plan || dtype == GS_F16 || dtype == GS_BF16, "gs_conv_wgrad: bad dtype %d", dtype);
     WgradArgs a;
     a.g = *g;
     a.x = (const unsigned short*)x; a.dy = (const unsigned short*)dy; a.dw = dw;
@@ -737,6 +744,9 @@ extern "C" int gs_conv_wgrad(const GsConvGeom* g, const void* x, const void* dy,
     if (ksplit < 1) ksplit = 1;
     a.kper = cdiv(ksteps, ksplit) * WG_KP;
     a.ksplit = cdiv(a.M, a.kper);
+    if (plan) { *ksplit_out = a.ksplit; return GS_OK; }
+    GS_CHECK_ARG(!assign || a.ksplit == 1, "gs_conv_wgrad_assign: this geometry splits K (%d parts): zero dw and use gs_conv_wgrad", a.ksplit);
+    a.assign = assign;
     const int ohw = g->OHg * g->OWg;
     a.d_n = WG_KP / ohw;
     const int rem = WG_KP - a.d_n * ohw;
@@ -753,4 +763,18 @@ extern "C" int gs_conv_wgrad(const GsConvGeom* g, const void* x, const void* dy,
     }
     GS_CHECK_LAUNCH("gs_conv_wgrad");
     return GS_OK;
+}
+
+extern "C" int gs_conv_wgrad(const GsConvGeom* g, const void* x, const void* dy, float* dw, int dtype, void* stream) {
+    return conv_wgrad_launch(g, x, dy, dw, dtype, stream, 0, nullptr);
+}
+
+extern "C" int gs_conv_wgrad_single_pass(const GsConvGeom* g) {
+    int ks = 0;
+    if (conv_wgrad_launch(g, nullptr, nullptr, nullptr, 0, nullptr, 0, &ks) != GS_OK) return 0;
+    return ks == 1 ? 1 : 0;
+}
+
+extern "C" int gs_conv_wgrad_assign(const GsConvGeom* g, const void* x, const void* dy, float* dw, int dtype, void* stream) {
+    return conv_wgrad_launch(g, x, dy, dw, dtype, stream, 1, nullptr);
 }

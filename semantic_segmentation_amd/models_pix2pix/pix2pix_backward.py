@@ -69,11 +69,16 @@ def generator_backward(engine, ctx, arch, dout, need_dx):
         h, w = hs[d + 1], ws[d + 1]
         w4, w6, w8 = (cell._ops._ops[j].op.weight for j in range(3))
         # weight gradient of the merged kernel, one sub-pixel class at a time
-        dwm = torch.zeros((4, 16, cpad, cin_t), dtype=torch.float32, device=dev)
+        geoms = []
         for cls in range(4):
             g = ops.geom_convT_class(N, h, w, cin_t, cpad, 8, 3, cls >> 1, cls & 1)
             g_tapw_identity(g)
-            ops.conv_wgrad(g, R[d + 1], du, dwm[cls])
+            geoms.append(g)
+        # few-pixel layers: no K split, so every element is written exactly once -- no zero fill, no atomic adds
+        single = all(ops.conv_wgrad_single_pass(g) for g in geoms)
+        dwm = (torch.empty if single else torch.zeros)((4, 16, cpad, cin_t), dtype=torch.float32, device=dev)
+        for cls in range(4):
+            ops.conv_wgrad(geoms[cls], R[d + 1], du, dwm[cls], assign=single)
         if cpad != cout_t:
             dwm = dwm[:, :, :cout_t, :].contiguous()
         dw4 = torch.empty_like(w4, memory_format=torch.contiguous_format)
@@ -142,8 +147,9 @@ def generator_backward(engine, ctx, arch, dout, need_dx):
                 ops.conv_smallcin_dgrad(dy, conv.weight.detach().contiguous(), dx, 4, 2, 1, inv_s)
         else:
             cin, cout = c[k - 1], c[k]
-            dwp = torch.zeros((16, cout, cin), dtype=torch.float32, device=dev)
-            ops.conv_wgrad(lv["geom"], lv["inp"], dy, dwp)
+            single = ops.conv_wgrad_single_pass(lv["geom"])
+            dwp = (torch.empty if single else torch.zeros)((16, cout, cin), dtype=torch.float32, device=dev)
+            ops.conv_wgrad(lv["geom"], lv["inp"], dy, dwp, assign=single)
             dw = torch.empty_like(conv.weight, memory_format=torch.contiguous_format)
             ops.unpack_wgrad(dwp, dw, cout, cin, 16, False, inv_s)
             emit(conv.weight, dw)

@@ -422,8 +422,9 @@ class DiscriminatorEngine:
             ops.bn_act_bwd_apply(y, dz, cout, 0, None, coef[0], coef[1], coef[2], coef[3], c12[0], c12[1],
                                  ACT_LEAKY02, True, dy)
             k, s, p, cin = rec["k"], rec["s"], rec["p"], rec["cin"]
-            dwp = torch.zeros((k * k, cout, cin), dtype=torch.float32, device=dev)
-            ops.conv_wgrad(rec["geom"], rec["inp"], dy, dwp)
+            single = ops.conv_wgrad_single_pass(rec["geom"])
+            dwp = (torch.empty if single else torch.zeros)((k * k, cout, cin), dtype=torch.float32, device=dev)
+            ops.conv_wgrad(rec["geom"], rec["inp"], dy, dwp, assign=single)
             dw = torch.empty_like(conv.weight, memory_format=torch.contiguous_format)
             ops.unpack_wgrad(dwp, dw, cout, cin, k * k, False, inv_s)
             grads[rec["name"] + ".weight"] = dw

@@ -375,7 +375,14 @@ def conv_igemm_mtiles(g: GsConvGeom) -> int:
     return _lib.load().gs_conv_igemm_mtiles(g)
 
 
-def conv_wgrad(g: GsConvGeom, x, dy, dw):
+def conv_wgrad_single_pass(g: GsConvGeom) -> bool:
+    """True when the weight gradient of this geometry is computed without a K split, i.e. conv_wgrad(assign=True) may
+    write into an un-zeroed dw."""
+    return bool(_lib.load().gs_conv_wgrad_single_pass(g))
+
+
+def conv_wgrad(g: GsConvGeom, x, dy, dw, assign: bool = False):
+    """dw[tap][Cout][Cin] (fp32) += weight gradient (caller zeroes dw); assign=True writes instead (single-pass only)."""
     _dev(x)
     _f32(dw, "dw")
     if x.dtype != dy.dtype:
@@ -383,7 +390,7 @@ def conv_wgrad(g: GsConvGeom, x, dy, dw):
     if dw.numel() < g.ntaps * g.Cout * g.Cin:
         raise ValueError("conv_wgrad: dw too small")
     ev = TIMER.start() if TIMER is not None else None
-    _lib.call("gs_conv_wgrad", g, _p(x), _p(dy), _p(dw), dt_code(x), _stream())
+    _lib.call("gs_conv_wgrad_assign" if assign else "gs_conv_wgrad", g, _p(x), _p(dy), _p(dw), dt_code(x), _stream())
     if ev is not None:
         TIMER.stop("igemm_wgrad", ev, _geom_flops(g))
 

@@ -697,3 +697,30 @@ def test_conv3x3_halo_bias_relu_epilogue(dtn, dt, N, H, W, Cin, Cout):
     assert rel_err(from_nhwc(y[..., Cout:]), ref) < tol(dt)
     assert float(y[..., :Cout].abs().max()) == 0.0
     assert float(y.min()) >= 0.0
+
+
+@pytest.mark.parametrize("dtn,dt", DTS)
+@pytest.mark.parametrize("N,h,Cin,Cout,k,s,p", [(2, 4, 128, 256, 4, 2, 1), (2, 8, 512, 512, 4, 2, 1), (1, 3, 64, 72, 3, 1, 1)])
+def test_conv_wgrad_assign_mode(dtn, dt, N, h, Cin, Cout, k, s, p):
+    """gs_conv_wgrad_assign: few-pixel layers (no K split) write the weight gradient into an UN-zeroed buffer; a geometry
+    that does split K is refused."""
+    from semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(8)
+    x = rnd(g, N, Cin, h, h, dt=dt)
+    w = rnd(g, Cout, Cin, k, k, dt=dt, scale=0.05).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=s, padding=p)
+    dy = rnd(g, *y.shape, dt=dt)
+    y.backward(dy)
+    geom = ops.geom_conv(N, h, h, Cin, Cout, k, s, p)
+    assert ops.conv_wgrad_single_pass(geom)
+    dwp = torch.full((k * k, Cout, Cin), float("nan"), dtype=torch.float32, device=dev())
+    ops.conv_wgrad(geom, nhwc(x, dt), nhwc(dy, dt), dwp, assign=True)
+    torch.cuda.synchronize()
+    got = dwp.cpu().view(k, k, Cout, Cin).permute(2, 3, 0, 1)
+    assert torch.isfinite(got).all()
+    assert rel_err(got, w.grad) < tol(dt)
+    big = ops.geom_conv(8, 64, 64, 64, 64, 3, 1, 1)
+    assert not ops.conv_wgrad_single_pass(big)
+    xb = torch.zeros(8, 64, 64, 64, dtype=dt, device=dev())
+    with pytest.raises(RuntimeError):
+        ops.conv_wgrad(big, xb, xb, torch.zeros(9, 64, 64, device=dev()), assign=True)
