@@ -177,8 +177,11 @@ static int w3_ksplit(int N, int H, int W, int Cin, int Cout, int* pps_out, int* 
     const int npatches = N * cdiv(W, tw) * cdiv(H, th);
     const int pairs = cdiv(Cout, 64) * cdiv(Cin, 64);
     static const int target = getenv("GSSEG_W3_GRID") ? atoi(getenv("GSSEG_W3_GRID")) : 512;
+    // every part writes a 9 x 64 x 64 fp32 tile per (co, ci) pair (147 KB) that the ordered reduction reads back: a part
+    // must cover a few patches for that to be worth it (batch 2: 512 one-patch parts cost more than the MFMAs)
+    static const int min_pps = getenv("GSSEG_W3_MINPPS") ? atoi(getenv("GSSEG_W3_MINPPS")) : 4;
     int ksplit = cdiv(target, pairs);
-    if (ksplit > npatches) ksplit = npatches;
+    if (ksplit > npatches / min_pps) ksplit = npatches / min_pps;
     if (ksplit < 1) ksplit = 1;
     const int pps = cdiv(npatches, ksplit);
     if (pps_out) *pps_out = pps;
