@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 15
+#define GS_ABI_VERSION 16
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -113,6 +113,13 @@ int gs_conv_wgrad(const GsConvGeom* g, const void* x, const void* dy, float* dw,
  * read-modify-writing the fp32 gradient of a 512x1024x8x8 kernel costs more than computing it); otherwise GS_EINVAL. */
 int gs_conv_wgrad_single_pass(const GsConvGeom* g);
 int gs_conv_wgrad_assign(const GsConvGeom* g, const void* x, const void* dy, float* dw, int dtype, void* stream);
+/* Deterministic form of gs_conv_wgrad: the gs_conv_wgrad_parts(g) K parts of the launch store their partial gradients in
+ * slabs ws[part][tap][Cout][Cin] (gs_conv_wgrad_ws_floats(g) floats, no zero fill, no atomics); gs_wgrad_reduce_unpack
+ * then sums the parts in order, scales and writes the reference layout.  Used for ConvTranspose2d(k2,s2) of `Up`
+ * (unet/unet_parts.py:51): with it every gradient of the U-Net step is bit-reproducible. */
+int gs_conv_wgrad_parts(const GsConvGeom* g);
+int64_t gs_conv_wgrad_ws_floats(const GsConvGeom* g);
+int gs_conv_wgrad_slabs(const GsConvGeom* g, const void* x, const void* dy, float* ws, int dtype, void* stream);
 
 /* ---- direct (VALU) convolutions for 1..4-channel ends of the nets ----------------------------
  * gs_conv_smallcin_fwd: x fp32 NCHW [N,Cin,IH,IW] (the image / mask as the loader hands it,

@@ -378,7 +378,8 @@ struct WgradArgs {
     int n_cotiles, n_cbgroups, ksplit;
     int kper;      // pixels per K split (multiple of 64)
     int d_n, d_oy, d_ox;   // mixed-radix decomposition of 64 pixels
-    int assign;            // ksplit == 1 only: plain stores instead of atomic adds (dw need not be zeroed)
+    int assign;            // plain stores instead of atomic adds: ksplit == 1 (dw need not be zeroed) or slab mode
+    int64_t slab_stride;   // > 0: K part ks writes its own slab dw + ks*slab_stride (ordered reduction afterwards)
 };
 
 constexpr int WG_KP = 64;   // pixels per K step
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (co < g.Cout) {
-                    float* q = a.dw + ((int64_t)g.tap_w[tap] * g.Cout + co) * g.Cin + ci;
+                    float* q = a.dw + (int64_t)ks_id * a.slab_stride + ((int64_t)g.tap_w[tap] * g.Cout + co) * g.Cin + ci;
                     if (a.assign) *q = acc[i][j][r];
                     else atomicAdd(q, acc[i][j][r]);
                 }
@@ -719,7 +720,7 @@ extern "C" int gs_upconv2x2_fwd(const void* x, const void* w, const float* bias,
 
 // plan only (x == nullptr): returns the K split of this geometry through *ksplit_out
 static int conv_wgrad_launch(const GsConvGeom* g, const void* x, const void* dy, float* dw, int dtype, void* stream,
-                             int assign, int* ksplit_out) {
+                             int assign, int* ksplit_out, int64_t slab_stride = 0) {
     int rc = check_geom(g, "gs_conv_wgrad");
     if (rc) return rc;
     const bool plan = ksplit_out != nullptr;
@@ -748,8 +749,10 @@ static int conv_wgrad_launch(const GsConvGeom* g, const void* x, const void* dy,
     a.kper = cdiv(ksteps, ksplit) * WG_KP;
     a.ksplit = cdiv(a.M, a.kper);
     if (plan) { *ksplit_out = a.ksplit; return GS_OK; }
-    GS_CHECK_ARG(!assign || a.ksplit == 1, "gs_conv_wgrad_assign: this geometry splits K (%d parts): zero dw and use gs_conv_wgrad", a.ksplit);
+    GS_CHECK_ARG(!assign || slab_stride > 0 || a.ksplit == 1,
+                 "gs_conv_wgrad_assign: this geometry splits K (%d parts): zero dw and use gs_conv_wgrad", a.ksplit);
     a.assign = assign;
+    a.slab_stride = slab_stride;
     const int ohw = g->OHg * g->OWg;
     a.d_n = WG_KP / ohw;
     const int rem = WG_KP - a.d_n * ohw;
@@ -776,6 +779,30 @@ extern "C" int gs_conv_wgrad_single_pass(const GsConvGeom* g) {
     int ks = 0;
     if (conv_wgrad_launch(g, nullptr, nullptr, nullptr, 0, nullptr, 0, &ks) != GS_OK) return 0;
     return ks == 1 ? 1 : 0;
+}
+
+// Deterministic form: the K parts of the launch store their partial gradients in slabs ws[part][tap][Cout][Cin] (no
+// zero fill, no atomics); gs_wgrad_reduce_unpack sums them in part order into the reference layout.
+static int64_t wgrad_slab_floats(const GsConvGeom* g) {
+    int tw = 0;
+    for (int t = 0; t < g->ntaps; ++t) tw = g->tap_w[t] > tw ? g->tap_w[t] : tw;
+    return (int64_t)(tw + 1) * g->Cout * g->Cin;
+}
+
+extern "C" int gs_conv_wgrad_parts(const GsConvGeom* g) {
+    int ks = 0;
+    if (conv_wgrad_launch(g, nullptr, nullptr, nullptr, 0, nullptr, 0, &ks) != GS_OK) return 0;
+    return ks;
+}
+
+extern "C" int64_t gs_conv_wgrad_ws_floats(const GsConvGeom* g) {
+    const int parts = gs_conv_wgrad_parts(g);
+    return parts > 0 ? (int64_t)parts * wgrad_slab_floats(g) : 0;
+}
+
+extern "C" int gs_conv_wgrad_slabs(const GsConvGeom* g, const void* x, const void* dy, float* ws, int dtype, void* stream) {
+    GS_CHECK_ARG(g != nullptr, "gs_conv_wgrad_slabs: null geometry");
+    return conv_wgrad_launch(g, x, dy, ws, dtype, stream, 1, nullptr, wgrad_slab_floats(g));
 }
 
 extern "C" int gs_conv_wgrad_assign(const GsConvGeom* g, const void* x, const void* dy, float* dw, int dtype, void* stream) {

@@ -395,6 +395,27 @@ def conv_wgrad(g: GsConvGeom, x, dy, dw, assign: bool = False):
         TIMER.stop("igemm_wgrad", ev, _geom_flops(g))
 
 
+def conv_wgrad_ws_floats(g: GsConvGeom) -> int:
+    return int(_lib.load().gs_conv_wgrad_ws_floats(g))
+
+
+def conv_wgrad_det(g: GsConvGeom, x, dy, ws, grad, A, B, taps, gscale, transposed=False):
+    """Deterministic generic weight gradient straight into the reference layout grad[A][B][taps] (transposed: [B][A][taps]):
+    K parts in fp32 slabs (ws, no zero fill, no atomics) + the ordered reduction fused with scale and unpack."""
+    _dev(x)
+    _f32(ws, "ws"); _f32(grad, "grad")
+    if x.dtype != dy.dtype:
+        raise TypeError("conv_wgrad_det: x and dy must share one 16-bit dtype")
+    if A != g.Cout or B != g.Cin or grad.numel() != taps * A * B or ws.numel() < conv_wgrad_ws_floats(g):
+        raise ValueError("conv_wgrad_det: workspace / gradient size")
+    ev = TIMER.start() if TIMER is not None else None
+    _lib.call("gs_conv_wgrad_slabs", g, _p(x), _p(dy), _p(ws), dt_code(x), _stream())
+    if ev is not None:
+        TIMER.stop("igemm_wgrad", ev, _geom_flops(g))
+    parts = int(_lib.load().gs_conv_wgrad_parts(g))
+    _lib.call("gs_wgrad_reduce_unpack", _p(ws), parts, _p(grad), A, B, taps, 1 if transposed else 0, float(gscale), _stream())
+
+
 def bn_partials_numel(ntiles: int, C: int) -> int:
     return int(_lib.load().gs_bn_partials_floats(ntiles, C))
 

@@ -354,7 +354,9 @@ class UNetEngine:
                 wg_need = max(wg_need, ops.conv3x3_wgrad_ws_floats(N, r.h, r.w, r.cin, r.cout))
             elif not r.inp_is_image:
                 tot_w += wnum
-        tot_w += sum(p.numel() for k, p in params.items() if k.endswith(".up.weight"))
+        for u in ctx["ups"]:
+            if u.geom_bwd is not None:                   # ConvTranspose2d weight gradient: slabs too (deterministic)
+                wg_need = max(wg_need, ops.conv_wgrad_ws_floats(u.geom_bwd))
         dw_arena = torch.zeros(max(tot_w, 1), dtype=torch.float32, device=dev)
         wg_ws = empty(wg_need, dtype=torch.float32)
         arena_off = [0]
@@ -447,10 +449,8 @@ class UNetEngine:
             wparam = params[wkey]
             db = galloc(prefix + ".up.bias", params[prefix + ".up.bias"])
             ops.colsum(dcat, 2 * cout_t, cout_t, N, u.H2, u.W2, u.pt, u.pl, 2 * u.h, 2 * u.w, cout_t, inv_s, col_ws, db)
-            dwp = dw_take(wparam.numel())
-            ops.conv_wgrad(u.geom_bwd, dcat, u.zin, dwp)
             dw = galloc(wkey, wparam)
-            ops.unpack_wgrad(dwp, dw, u.cin, u.cout, 4, False, inv_s)
+            ops.conv_wgrad_det(u.geom_bwd, dcat, u.zin, wg_ws, dw, u.cin, u.cout, 4, inv_s)
             dz = empty(N, u.h, u.w, u.cin)
             ops.conv_igemm(u.geom_bwd, dcat, u.wd, dz)
             emit(wkey, dw)

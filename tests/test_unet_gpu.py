@@ -143,8 +143,27 @@ def test_unet_forward_is_deterministic_and_retain_graph():
     net.zero_grad()
     loss.backward()
     for k, p in net.named_parameters():
-        r = (p.grad - g1[k]).norm() / (g1[k].norm() + 1e-20)
-        assert r < 1e-3, k          # wgrad uses fp32 atomics: equal up to summation order
+        # every weight gradient of the U-Net is summed in a fixed order (split-K slabs + ordered reduction for the 3x3
+        # convs and the transposed convs, two-stage block reductions elsewhere): bit-reproducible
+        assert torch.equal(p.grad, g1[k]), k
+
+
+@pytest.mark.parametrize("n_classes,B,S", [(2, 4, 128), (1, 3, 80)])
+def test_unet_backward_is_bit_reproducible(n_classes, B, S):
+    """Two independent forward+backward passes on the same inputs give identical gradients (no fp32 atomics anywhere on
+    the U-Net path), at sizes where the weight-gradient launches split K into many parts."""
+    from semantic_segmentation_amd.losses import seg_loss
+    net, _ = build_net(n_classes, seed=4)
+    net.train()
+    x, mask = oracle.synthetic_batch(B, S, seed=15)
+    x, mask = x.cuda(), mask.cuda()
+    runs = []
+    for _ in range(2):
+        net.zero_grad(set_to_none=True)
+        seg_loss(net(x), mask).backward()
+        runs.append({k: p.grad.clone() for k, p in net.named_parameters()})
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]), k
 
 
 def test_unet_input_gradient():
