@@ -147,11 +147,10 @@ def generator_backward(engine, ctx, arch, dout, need_dx):
                 ops.conv_smallcin_dgrad(dy, conv.weight.detach().contiguous(), dx, 4, 2, 1, inv_s)
         else:
             cin, cout = c[k - 1], c[k]
-            single = ops.conv_wgrad_single_pass(lv["geom"])
-            dwp = (torch.empty if single else torch.zeros)((16, cout, cin), dtype=torch.float32, device=dev)
-            ops.conv_wgrad(lv["geom"], lv["inp"], dy, dwp, assign=single)
+            # K parts in slabs + ordered reduction fused with scale / unpack (one part: a plain store): deterministic
             dw = torch.empty_like(conv.weight, memory_format=torch.contiguous_format)
-            ops.unpack_wgrad(dwp, dw, cout, cin, 16, False, inv_s)
+            wsl = empty(ops.conv_wgrad_ws_floats(lv["geom"]), dtype=torch.float32)
+            ops.conv_wgrad_det(lv["geom"], lv["inp"], dy, wsl, dw, cout, cin, 16, inv_s)
             emit(conv.weight, dw)
             dL = empty(N, hs[k - 1], ws[k - 1], cin)
             for cls in range(4):

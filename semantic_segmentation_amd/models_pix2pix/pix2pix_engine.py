@@ -422,11 +422,10 @@ class DiscriminatorEngine:
             ops.bn_act_bwd_apply(y, dz, cout, 0, None, coef[0], coef[1], coef[2], coef[3], c12[0], c12[1],
                                  ACT_LEAKY02, True, dy)
             k, s, p, cin = rec["k"], rec["s"], rec["p"], rec["cin"]
-            single = ops.conv_wgrad_single_pass(rec["geom"])
-            dwp = (torch.empty if single else torch.zeros)((k * k, cout, cin), dtype=torch.float32, device=dev)
-            ops.conv_wgrad(rec["geom"], rec["inp"], dy, dwp, assign=single)
+            # K parts in slabs + ordered reduction fused with scale / unpack (one part: a plain store): deterministic
             dw = torch.empty_like(conv.weight, memory_format=torch.contiguous_format)
-            ops.unpack_wgrad(dwp, dw, cout, cin, k * k, False, inv_s)
+            wsl = empty(ops.conv_wgrad_ws_floats(rec["geom"]), dtype=torch.float32)
+            ops.conv_wgrad_det(rec["geom"], rec["inp"], dy, wsl, dw, cout, cin, k * k, inv_s)
             grads[rec["name"] + ".weight"] = dw
             grads[rec["bnname"] + ".weight"] = dgamma
             grads[rec["bnname"] + ".bias"] = dbeta

@@ -250,9 +250,8 @@ class UNet3DEngine:
                     ops.conv3d3_wgrad_det(st.inp, dy, wsl, dw, NB, D, H, W, cin, cout, inv_s, in_stride=st.in_stride,
                                           in_coff=st.in_coff)
                 else:
-                    dwp = torch.zeros((27, cout, cin), dtype=torch.float32, device=dev)
-                    ops.conv_wgrad(st.geom, st.inp, dy, dwp)
-                    ops.unpack_wgrad(dwp, dw, cout, cin, 27, False, inv_s)
+                    wsl = empty(ops.conv_wgrad_ws_floats(st.geom), dtype=torch.float32)
+                    ops.conv_wgrad_det(st.geom, st.inp, dy, wsl, dw, cout, cin, 27, inv_s)
                 emit(wparam, dw.view(wparam.shape))
                 if need_dinp:
                     dinp = empty(n2, H, W, cin)
@@ -289,10 +288,9 @@ class UNet3DEngine:
             db = empty(cu, dtype=torch.float32)
             ops.colsum(dcat, ctot, 0, NB * D, H, W, 0, 0, H, W, cu, inv_s, col_ws, db)
             emit(sb.upconv1.bias, db)
-            dwp = torch.zeros((8, ccur, cu), dtype=torch.float32, device=dev)
-            ops.conv_wgrad(u["geom"], dcat, u["zin"], dwp)
             dw = torch.empty((ccur, cu, 8), dtype=torch.float32, device=dev)
-            ops.unpack_wgrad(dwp, dw, ccur, cu, 8, False, inv_s)
+            wsl = empty(ops.conv_wgrad_ws_floats(u["geom"]), dtype=torch.float32)
+            ops.conv_wgrad_det(u["geom"], dcat, u["zin"], wsl, dw, ccur, cu, 8, inv_s)
             emit(sb.upconv1.weight, dw.view(sb.upconv1.weight.shape))
             dz = empty(NB * d, h, w, ccur)
             ops.conv_igemm(u["geom"], dcat, u["wd"], dz)

@@ -286,3 +286,21 @@ def test_create_model_surface_and_stage1_steps(tmp_path):
     model.eval()
     model.test()
     assert model.fake_image.shape == (2, 1, 256, 256) and torch.isfinite(model.fake_image).all()
+
+
+def test_discriminator_backward_is_bit_reproducible():
+    """NLayerDiscriminator (networks.py:620-665): every weight gradient is summed in a fixed order (split-K slabs +
+    ordered reduction, block reductions for the 2-channel first and 1-channel last conv)."""
+    from semantic_segmentation_amd.models_pix2pix import networks
+    D = networks.NLayerDiscriminator(2, 64, 3, networks.get_norm_layer("batch"))
+    D.load_state_dict(seeded_discriminator_state_dict(seed=6), strict=True)
+    D = D.cuda().train()
+    x = torch.rand(4, 2, 256, 256, generator=torch.Generator().manual_seed(1)).cuda()
+    crit = networks.GANLoss("vanilla")
+    runs = []
+    for _ in range(2):
+        D.zero_grad(set_to_none=True)
+        crit(D(x), True).backward()
+        runs.append({k: p.grad.clone() for k, p in D.named_parameters()})
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]), k

@@ -120,3 +120,23 @@ def test_maxpool3d_kernels():
     ops.maxpool3d_bwd(zd, dp, dr, dz, NB, D, H, W, C, C + 8, 8, C, 0)
     gotd = dz.float().cpu().view(NB, D, H, W, C).permute(0, 4, 1, 2, 3)
     assert (gotd - want).abs().max() < 2e-2
+
+
+def test_unet3d_backward_is_bit_reproducible():
+    """No fp32 atomics on the UNet3D path: the 3x3x3 weight gradients, the 32-channel stem and the transposed convs sum
+    their split-K parts in a fixed order -- two forward+backward passes give identical gradients."""
+    from semantic_segmentation_amd.unet3d import UNet3D
+    sd = oracle.unet3d_state_dict(1, 2, seed=62)
+    net = UNet3D(1, 2)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1, 1, 32, 32, 32, generator=g).cuda()
+    mask = (torch.rand(1, 32, 32, 32, generator=g) > 0.5).long().cuda()
+    runs = []
+    for _ in range(2):
+        net.zero_grad(set_to_none=True)
+        vol_loss(net(x), mask).backward()
+        runs.append({k: p.grad.clone() for k, p in net.named_parameters()})
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]), k
