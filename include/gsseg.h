@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 16
+#define GS_ABI_VERSION 17
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -235,6 +235,12 @@ int gs_upconv_merge_pack(const float* w4, const float* w6, const float* w8, cons
 int gs_upconv_split_wgrad(const float* dwm, const float* w4, const float* w6, const float* w8, const float* softmax3,
                           float gscale, float* dw4, float* dw6, float* dw8, float* dots3, int Cin, int Cout,
                           void* stream);
+/* Same split with the three architecture dot products summed in a fixed order: every block stores its partial sums in ws
+ * (gs_upconv_split_wgrad_ws_floats(Cin, Cout) floats) and one small kernel adds them to dots3 in block order. */
+int64_t gs_upconv_split_wgrad_ws_floats(int Cin, int Cout);
+int gs_upconv_split_wgrad_det(const float* dwm, const float* w4, const float* w6, const float* w8, const float* softmax3,
+                              float gscale, float* dw4, float* dw6, float* dw8, float* dots3, float* ws, int Cin, int Cout,
+                              void* stream);
 
 /* layout helpers: fp32 NCHW <-> 16-bit NHWC */
 int gs_nchw_to_nhwc(const float* src, void* dst, int N, int C, int H, int W, int dst_pix_stride, int dst_coff,

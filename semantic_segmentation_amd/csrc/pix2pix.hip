@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void upconv_merge_pack_kernel(const float* __r
 __global__ __launch_bounds__(256) void upconv_split_wgrad_kernel(const float* __restrict__ dWm, const float* __restrict__ W4,
                                                                  const float* __restrict__ W6, const float* __restrict__ W8,
                                                                  const float* __restrict__ sm, float gscale, float* dW4,
-                                                                 float* dW6, float* dW8, float* dots, int Cin, int Cout) {
+                                                                 float* dW6, float* dW8, float* dots, int Cin, int Cout, float* dots_ws) {
     __shared__ float red[3][4];
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float d0 = 0.f, d1 = 0.f, d2 = 0.f;
@@ -88,8 +88,12 @@ __global__ __launch_bounds__(256) void upconv_split_wgrad_kernel(const float* __
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[0][w] = d0; red[1][w] = d1; red[2][w] = d2; }
     __syncthreads();
-    if (threadIdx.x < 3)
-        atomicAdd(dots + threadIdx.x, (red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]) * gscale);
+    if (threadIdx.x < 3) {
+        const float v = (red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]) * gscale;
+        // deterministic form: one slot per block, summed in block order by dots_reduce_kernel
+        if (dots_ws) dots_ws[(int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x] = v;
+        else atomicAdd(dots + threadIdx.x, v);
+    }
 }
 
 // ---- tiled versions ------------------------------------------------------------------------------------
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256) void upconv_merge_pack_dgrad_tiled(const float
 __global__ __launch_bounds__(256) void upconv_split_wgrad_tiled(const float* __restrict__ dWm, const float* __restrict__ W4,
                                                                 const float* __restrict__ W6, const float* __restrict__ W8,
                                                                 const float* __restrict__ sm, float gscale, float* dW4,
-                                                                float* dW6, float* dW8, float* dots, int Cin, int Cout) {
+                                                                float* dW6, float* dW8, float* dots, int Cin, int Cout, float* dots_ws) {
     __shared__ float lds[64 * 8 * 32];
     __shared__ float red[3][4];
     const int co0 = blockIdx.x * 8, ci0 = blockIdx.y * 32;
@@ -241,8 +245,27 @@ __global__ __launch_bounds__(256) void upconv_split_wgrad_tiled(const float* __r
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[0][w] = d0; red[1][w] = d1; red[2][w] = d2; }
     __syncthreads();
-    if (threadIdx.x < 3)
-        atomicAdd(dots + threadIdx.x, (red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]) * gscale);
+    if (threadIdx.x < 3) {
+        const float v = (red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]) * gscale;
+        // deterministic form: one slot per block, summed in block order by dots_reduce_kernel
+        if (dots_ws) dots_ws[(int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x] = v;
+        else atomicAdd(dots + threadIdx.x, v);
+    }
+}
+
+// dots[j] += sum over blocks of ws[b][j], in block order (fp64 running sum): 3 lanes, latency irrelevant (<= 8192 blocks)
+__global__ void dots_reduce_kernel(const float* __restrict__ ws, int nblocks, float* dots) {
+    __shared__ double red[3][64];
+    const int j = threadIdx.x / 64, l = threadIdx.x % 64;
+    double s = 0.0;
+    for (int b = l; b < nblocks; b += 64) s += (double)ws[(int64_t)b * 3 + j];
+    red[j][l] = s;
+    __syncthreads();
+    if (l == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 64; ++i) t += red[j][i];
+        dots[j] += (float)t;
+    }
 }
 
 }  // namespace
@@ -281,21 +304,46 @@ extern "C" int gs_upconv_merge_pack(const float* w4, const float* w6, const floa
     return GS_OK;
 }
 
+static int split_wgrad_blocks(int Cin, int Cout) {
+    if (Cin % 32 == 0 && Cout % 8 == 0) return (Cout / 8) * (Cin / 32);
+    return (int)cdiv64((int64_t)Cin * Cout, 256);
+}
+
+static int upconv_split_wgrad_launch(const float* dwm, const float* w4, const float* w6, const float* w8,
+                                     const float* softmax3, float gscale, float* dw4, float* dw6, float* dw8,
+                                     float* dots3, int Cin, int Cout, float* dots_ws, void* stream) {
+    GS_CHECK_ARG(dwm && w4 && w6 && w8 && softmax3 && dw4 && dw6 && dw8 && dots3 && Cin > 0 && Cout > 0,
+                 "gs_upconv_split_wgrad: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (Cin % 32 == 0 && Cout % 8 == 0) {
+        dim3 grid(Cout / 8, Cin / 32);
+        upconv_split_wgrad_tiled<<<grid, 256, 0, st>>>(dwm, w4, w6, w8, softmax3, gscale, dw4, dw6, dw8, dots3, Cin, Cout,
+                                                       dots_ws);
+    } else {
+        upconv_split_wgrad_kernel<<<split_wgrad_blocks(Cin, Cout), 256, 0, st>>>(dwm, w4, w6, w8, softmax3, gscale, dw4, dw6,
+                                                                                 dw8, dots3, Cin, Cout, dots_ws);
+    }
+    GS_CHECK_LAUNCH("gs_upconv_split_wgrad");
+    if (dots_ws) {
+        dots_reduce_kernel<<<1, 192, 0, st>>>(dots_ws, split_wgrad_blocks(Cin, Cout), dots3);
+        GS_CHECK_LAUNCH("gs_upconv_split_wgrad");
+    }
+    return GS_OK;
+}
+
 extern "C" int gs_upconv_split_wgrad(const float* dwm, const float* w4, const float* w6, const float* w8,
                                      const float* softmax3, float gscale, float* dw4, float* dw6, float* dw8,
                                      float* dots3, int Cin, int Cout, void* stream) {
-    GS_CHECK_ARG(dwm && w4 && w6 && w8 && softmax3 && dw4 && dw6 && dw8 && dots3 && Cin > 0 && Cout > 0,
-                 "gs_upconv_split_wgrad: bad arguments");
-    if (Cin % 32 == 0 && Cout % 8 == 0) {
-        dim3 grid(Cout / 8, Cin / 32);
-        upconv_split_wgrad_tiled<<<grid, 256, 0, (hipStream_t)stream>>>(dwm, w4, w6, w8, softmax3, gscale, dw4, dw6, dw8,
-                                                                       dots3, Cin, Cout);
-        GS_CHECK_LAUNCH("gs_upconv_split_wgrad");
-        return GS_OK;
-    }
-    const int nb = (int)cdiv64((int64_t)Cin * Cout, 256);
-    upconv_split_wgrad_kernel<<<nb, 256, 0, (hipStream_t)stream>>>(dwm, w4, w6, w8, softmax3, gscale, dw4, dw6, dw8, dots3,
-                                                                   Cin, Cout);
-    GS_CHECK_LAUNCH("gs_upconv_split_wgrad");
-    return GS_OK;
+    return upconv_split_wgrad_launch(dwm, w4, w6, w8, softmax3, gscale, dw4, dw6, dw8, dots3, Cin, Cout, nullptr, stream);
+}
+
+extern "C" int64_t gs_upconv_split_wgrad_ws_floats(int Cin, int Cout) {
+    return (Cin > 0 && Cout > 0) ? (int64_t)3 * split_wgrad_blocks(Cin, Cout) : 0;
+}
+
+extern "C" int gs_upconv_split_wgrad_det(const float* dwm, const float* w4, const float* w6, const float* w8,
+                                         const float* softmax3, float gscale, float* dw4, float* dw6, float* dw8,
+                                         float* dots3, float* ws, int Cin, int Cout, void* stream) {
+    GS_CHECK_ARG(ws != nullptr, "gs_upconv_split_wgrad_det: null workspace");
+    return upconv_split_wgrad_launch(dwm, w4, w6, w8, softmax3, gscale, dw4, dw6, dw8, dots3, Cin, Cout, ws, stream);
 }

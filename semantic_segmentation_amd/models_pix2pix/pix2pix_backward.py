@@ -75,10 +75,16 @@ def generator_backward(engine, ctx, arch, dout, need_dx):
             g_tapw_identity(g)
             geoms.append(g)
         # few-pixel layers: no K split, so every element is written exactly once -- no zero fill, no atomic adds
+        # otherwise: K parts in slabs + an ordered sum (deterministic; no same-address atomics)
         single = all(ops.conv_wgrad_single_pass(g) for g in geoms)
-        dwm = (torch.empty if single else torch.zeros)((4, 16, cpad, cin_t), dtype=torch.float32, device=dev)
-        for cls in range(4):
-            ops.conv_wgrad(geoms[cls], R[d + 1], du, dwm[cls], assign=single)
+        dwm = torch.empty((4, 16, cpad, cin_t), dtype=torch.float32, device=dev)
+        if single:
+            for cls in range(4):
+                ops.conv_wgrad(geoms[cls], R[d + 1], du, dwm[cls], assign=True)
+        else:
+            wsl = empty(max(ops.conv_wgrad_ws_floats(g) for g in geoms), dtype=torch.float32)
+            for cls in range(4):
+                ops.conv_wgrad_det(geoms[cls], R[d + 1], du, wsl, dwm[cls], cpad, cin_t, 16, 1.0, packed=True)
         if cpad != cout_t:
             dwm = dwm[:, :, :cout_t, :].contiguous()
         dw4 = torch.empty_like(w4, memory_format=torch.contiguous_format)

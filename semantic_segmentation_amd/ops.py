@@ -399,15 +399,18 @@ def conv_wgrad_ws_floats(g: GsConvGeom) -> int:
     return int(_lib.load().gs_conv_wgrad_ws_floats(g))
 
 
-def conv_wgrad_det(g: GsConvGeom, x, dy, ws, grad, A, B, taps, gscale, transposed=False):
-    """Deterministic generic weight gradient straight into the reference layout grad[A][B][taps] (transposed: [B][A][taps]):
-    K parts in fp32 slabs (ws, no zero fill, no atomics) + the ordered reduction fused with scale and unpack."""
+def conv_wgrad_det(g: GsConvGeom, x, dy, ws, grad, A, B, taps, gscale, transposed=False, packed=False):
+    """Deterministic generic weight gradient straight into the reference layout grad[A][B][taps] (transposed: [B][A][taps];
+    packed: the kernel layout [taps][A][B] is kept): K parts in fp32 slabs (ws, no zero fill, no atomics) + the ordered
+    reduction fused with scale and unpack."""
     _dev(x)
     _f32(ws, "ws"); _f32(grad, "grad")
     if x.dtype != dy.dtype:
         raise TypeError("conv_wgrad_det: x and dy must share one 16-bit dtype")
     if A != g.Cout or B != g.Cin or grad.numel() != taps * A * B or ws.numel() < conv_wgrad_ws_floats(g):
         raise ValueError("conv_wgrad_det: workspace / gradient size")
+    if packed:
+        A, taps = taps * A, 1              # [taps*A][B][1] is the slab layout itself: a plain ordered sum
     ev = TIMER.start() if TIMER is not None else None
     _lib.call("gs_conv_wgrad_slabs", g, _p(x), _p(dy), _p(ws), dt_code(x), _stream())
     if ev is not None:
@@ -607,8 +610,10 @@ def upconv_split_wgrad(dwm, w4, w6, w8, softmax3, gscale, dw4, dw6, dw8, dots3):
     for n, t in (("dwm", dwm), ("dw4", dw4), ("dw6", dw6), ("dw8", dw8), ("dots3", dots3)):
         _f32(t, n)
     Cin, Cout = w8.shape[0], w8.shape[1]
-    _lib.call("gs_upconv_split_wgrad", _p(dwm), _p(w4), _p(w6), _p(w8), _p(softmax3), float(gscale), _p(dw4), _p(dw6),
-              _p(dw8), _p(dots3), Cin, Cout, _stream())
+    # deterministic form: per-block partial dot products in a scratch tensor, summed in block order
+    ws = torch.empty(int(_lib.load().gs_upconv_split_wgrad_ws_floats(Cin, Cout)), dtype=torch.float32, device=dwm.device)
+    _lib.call("gs_upconv_split_wgrad_det", _p(dwm), _p(w4), _p(w6), _p(w8), _p(softmax3), float(gscale), _p(dw4), _p(dw6),
+              _p(dw8), _p(dots3), _p(ws), Cin, Cout, _stream())
 
 
 # ---------------------------------------------------------------------------- losses
