@@ -107,7 +107,7 @@ def generator_backward(engine, ctx, arch, dout, need_dx):
         # softmax backward for the architecture row (3 values)
         darch[li] = sm * (dots - (sm * dots).sum())
         # data gradient: stride-2 / pad-3 conv of du with the un-flipped merged kernel
-        pd = engine._merge_pack(d, w4, w6, w8, sm, cin_t, cout_t, cpad, dgrad=True)
+        pd = engine._merge_pack(d, w4, w6, w8, sm, cin_t, cout_t, cpad, dgrad=True, arch=arch)
         dr = empty(N, h, w, cin_t)
         g = ops.make_geom(N, 2 * h, 2 * w, cpad, h, w, cin_t, h, w, TAPS64, isy=2, isx=2)
         ops.conv_igemm(g, du, pd, dr)

@@ -74,7 +74,14 @@ class _PackCache:
         self._d.clear()
 
 
+_NOCACHE = [0]
+
+
 def _ver(*ts):
+    from ..unet import unet_engine
+    if not unet_engine.PACK_CACHE:                   # GSSEG_PACK_CACHE=0 (loops that write parameters through `.data`)
+        _NOCACHE[0] += 1
+        return (_NOCACHE[0],)
     return tuple((t.data_ptr(), t._version) for t in ts)
 
 
@@ -201,7 +208,7 @@ class GeneratorEngine:
             w4, w6, w8 = (cell._ops._ops[j].op.weight for j in range(3))
             sm = torch.softmax(arch[li].detach().float(), dim=-1).contiguous()
             cpad = cout_t if cout_t % 8 == 0 else ((cout_t + 7) // 8) * 8
-            pf = self._merge_pack(d, w4, w6, w8, sm, cin_t, cout_t, cpad, dgrad=False)
+            pf = self._merge_pack(d, w4, w6, w8, sm, cin_t, cout_t, cpad, dgrad=False, arch=arch)
             h, w = hs[d + 1], ws[d + 1]
             H2, W2 = 2 * h, 2 * w
             bias = None
@@ -255,8 +262,14 @@ class GeneratorEngine:
         ops.pack_weight(w.detach().contiguous(), wf, wd, False)
         return wf, wd
 
-    def _merge_pack(self, d, w4, w6, w8, sm, cin_t, cout_t, cpad, dgrad):
-        """class-major forward pack [4][16][cpad][cin] (or dgrad pack [64][cin][cpad]) of the merged kernel."""
+    def _merge_pack(self, d, w4, w6, w8, sm, cin_t, cout_t, cpad, dgrad, arch=None):
+        """class-major forward pack [4][16][cpad][cin] (or dgrad pack [64][cin][cpad]) of the merged kernel.  Cached per
+        (weights, architecture parameters) version: in the end-to-end loop the generator runs three times per iteration
+        (Generator, Discriminator and Unet steps) between two updates of its weights, and re-merging reads all 1.09 GB
+        of fp32 kernels each time."""
+        if arch is not None:
+            return self.packs.get(("merged", d, dgrad, cpad), _ver(w4, w6, w8, arch),
+                                  lambda: self._merge_pack(d, w4, w6, w8, sm, cin_t, cout_t, cpad, dgrad))
         dev = w8.device
         if cpad == cout_t:
             w4p, w6p, w8p = w4.detach().contiguous(), w6.detach().contiguous(), w8.detach().contiguous()

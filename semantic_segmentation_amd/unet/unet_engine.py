@@ -41,7 +41,18 @@ class _UpRec:
     __slots__ = ("name", "zin", "cat", "geom_bwd", "wd", "cin", "cout", "h", "w", "H2", "W2", "pt", "pl")
 
 
+# GSSEG_PACK_CACHE=0: never reuse a 16-bit weight pack.  The caches key on torch's version counters, which every torch
+# in-place op, every optimiser (torch's and the fused ones of optim.py) and load_state_dict bump -- but a write through
+# `p.data` (Betty's finite-difference perturbation does that) is invisible to them: such loops must switch the cache off or
+# call `invalidate_packs()` after the write.
+PACK_CACHE = os.environ.get("GSSEG_PACK_CACHE", "1") != "0"
+_NOCACHE = [0]
+
+
 def _pack_key(p: torch.Tensor):
+    if not PACK_CACHE:
+        _NOCACHE[0] += 1
+        return (_NOCACHE[0],)
     return (p.data_ptr(), p._version, p.dtype, tuple(p.shape))
 
 

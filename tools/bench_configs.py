@@ -50,8 +50,14 @@ def main():
 
         def g_step():
             zero(G, D); steps.generator_step_loss(G, D, crit, maskf, real).backward()
+            # stand-in for optimizer_G.step(): the generator's weights count as modified once per iteration, so the merged
+            # 16-bit packs are rebuilt once per trio (they are cached between the three steps of one iteration)
+            torch.autograd.graph.increment_version(list(G.parameters()))
 
         def d_step():
+            # first generator forward after optimizer_G.step(): pays the re-merge of the forward packs (conservative: the
+            # Generator step above is charged a forward re-merge too, which the real loop does not pay)
+            torch.autograd.graph.increment_version(list(G.parameters()))
             zero(G, D); steps.discriminator_step_loss(G, D, crit, maskf, real).backward()
 
         def u_step():
