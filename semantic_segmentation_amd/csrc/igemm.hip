@@ -50,7 +50,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 constexpr int FW_BM = 128, FW_BK = 64, FW_LDR = 72;   // LDS row = 64 + 8 pad elements (144 B)
 
-template <int DT, int BN>
+template <int DT, int BN, bool PACKED>
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
     typedef typename Elem<DT>::V8 V8;
     constexpr int NT = BN / 64;            // 32-wide N tiles per wave
@@ -113,17 +113,27 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
         }
         __syncthreads();
     }
-    const int nk_all = act_taps[0] * a.kchunks;
+    // PACKED (Cin == 8: the 1-channel image end of the Pix2Pix generator, padded to one 16-byte chunk): a K step carries
+    // EIGHT taps -- chunk c of the 64-wide K slice = (tap 8*step + c, channels 0..7) -- instead of one tap with 8 of its 64
+    // channels in use.  A separate instantiation: the per-chunk tap makes the tap offsets vector values.
+    const int nk_all = PACKED ? (act_taps[0] + 7) / 8 : act_taps[0] * a.kchunks;
     const int ks_begin = ksplit > 1 ? (int)((int64_t)nk_all * kpart / ksplit) : 0;
     const int ks_end = ksplit > 1 ? (int)((int64_t)nk_all * (kpart + 1) / ksplit) : nk_all;
     const int nk = ks_end - ks_begin;
 
     auto load_tile = [&](int ks) {
-        const int ti = (ks + ks_begin) / a.kchunks, cc = (ks + ks_begin) - ti * a.kchunks;
+        int ti = (ks + ks_begin) / a.kchunks;
+        const int cc = (ks + ks_begin) - ti * a.kchunks;
+        int ci = cc * FW_BK + chunk * 8;
+        bool cok = ci < g.Cin;
+        if constexpr (PACKED) {
+            ti = (ks + ks_begin) * 8 + chunk;
+            cok = ti < act_taps[0];
+            if (!cok) ti = 0;
+            ci = 0;
+        }
         const int tap = act_taps[1 + ti];
-        const int ci = cc * FW_BK + chunk * 8;
         const int dy = g.tap_dy[tap], dx = g.tap_dx[tap], dz = g.tap_dz[tap];
-        const bool cok = ci < g.Cin;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
@@ -613,10 +623,11 @@ static int launch_igemm(IgemmArgs& a, int dtype, hipStream_t s, const char* who,
     const int mt = cdiv(a.M, FW_BM);
     a.nblocks = mt * a.ntn;
     a.ksplit = 1; a.ws_acc = nullptr; a.ws_cnt = nullptr;
+    const bool packed = a.g.Cin == 8 && a.g.ntaps >= 8;
     if (ws != nullptr) {
         // layout of the caller's (zero-initialised, self-cleaning) workspace: [4096 tile counters][tile accumulators]
         const int64_t cnt_slots = 4096;
-        const int k = choose_ksplit(a.nblocks, a.g.ntaps * a.kchunks, ws_floats - cnt_slots, cnt_slots);
+        const int k = choose_ksplit(a.nblocks, packed ? cdiv(a.g.ntaps, 8) : a.g.ntaps * a.kchunks, ws_floats - cnt_slots, cnt_slots);
         if (k > 1) {
             a.ksplit = k;
             a.ws_cnt = reinterpret_cast<unsigned int*>(ws);
@@ -624,12 +635,20 @@ static int launch_igemm(IgemmArgs& a, int dtype, hipStream_t s, const char* who,
         }
     }
     dim3 grid(a.nblocks * a.ksplit), block(256);
-    if (dtype == GS_F16) {
-        if (bn == 64) igemm_fwd_kernel<GS_F16, 64><<<grid, block, 0, s>>>(a);
-        else igemm_fwd_kernel<GS_F16, 128><<<grid, block, 0, s>>>(a);
+    if (packed) {
+        if (dtype == GS_F16) {
+            if (bn == 64) igemm_fwd_kernel<GS_F16, 64, true><<<grid, block, 0, s>>>(a);
+            else igemm_fwd_kernel<GS_F16, 128, true><<<grid, block, 0, s>>>(a);
+        } else {
+            if (bn == 64) igemm_fwd_kernel<GS_BF16, 64, true><<<grid, block, 0, s>>>(a);
+            else igemm_fwd_kernel<GS_BF16, 128, true><<<grid, block, 0, s>>>(a);
+        }
+    } else if (dtype == GS_F16) {
+        if (bn == 64) igemm_fwd_kernel<GS_F16, 64, false><<<grid, block, 0, s>>>(a);
+        else igemm_fwd_kernel<GS_F16, 128, false><<<grid, block, 0, s>>>(a);
     } else {
-        if (bn == 64) igemm_fwd_kernel<GS_BF16, 64><<<grid, block, 0, s>>>(a);
-        else igemm_fwd_kernel<GS_BF16, 128><<<grid, block, 0, s>>>(a);
+        if (bn == 64) igemm_fwd_kernel<GS_BF16, 64, false><<<grid, block, 0, s>>>(a);
+        else igemm_fwd_kernel<GS_BF16, 128, false><<<grid, block, 0, s>>>(a);
     }
     GS_CHECK_LAUNCH(who);
     return GS_OK;

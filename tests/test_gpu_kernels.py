@@ -42,7 +42,7 @@ def tol(dt):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtn,dt", DTS)
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 13, 9, 64, 64), (1, 16, 16, 128, 192), (3, 7, 20, 72, 40),
-                                            (1, 32, 32, 256, 128)])
+                                            (1, 32, 32, 256, 128), (2, 21, 17, 8, 128), (1, 5, 6, 8, 72)])
 def test_conv3x3_fwd_bn_partials(dtn, dt, N, H, W, Cin, Cout):
     from semantic_segmentation_amd import ops
     g = torch.Generator().manual_seed(1)
