@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 17
+#define GS_ABI_VERSION 18
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -219,6 +219,14 @@ int gs_colsum(const void* t, int pix_stride, int coff, int N, int H, int W, int 
 int gs_pack_weight(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int taps, int transposed,
                    int dtype, void* stream);
 int gs_unpack_wgrad(const float* dw, float* grad, int A, int B, int taps, int transposed, float gscale, void* stream);
+
+/* Outermost generator layer (models_pix2pix/networks.py:588-593, merged 8x8 kernel): ConvTranspose2d(Cin -> Cout <= 4,
+ * k 8, stride 2, pad 3) + bias + activation written as the fp32 NCHW image out [N,Cout,2h,2w]; u (may be NULL) receives
+ * the pre-activation as 16-bit NHWC [N,2h,2w,cpad] for the backward pass.  x: 16-bit NHWC [N,h,w,*] (strided);
+ * pack_fwd: the class-major pack [4][16][cpad][Cin] of gs_upconv_merge_pack (cpad == 8).  Direct VALU kernel: on the MFMA
+ * engine this layer uses 1 of 64 N columns.  Needs (12*12*(Cin+8) + 64*Cout*Cin)*2 bytes <= 64 KB of LDS. */
+int gs_upconv8_image_fwd(const void* x, int in_pix_stride, int in_coff, const void* pack_fwd, int cpad, const float* bias,
+                         float* out, void* u, int N, int h, int w, int Cin, int Cout, int act, int dtype, void* stream);
 
 /* ---- Pix2Pix mixed transposed convolution (networks.py:486-511, operations.py:14-39) ------------------
  * The softmax-weighted sum of ConvTranspose2d k4p1 / k6p2 / k8p3 (stride 2) equals ONE k8/s2/p3 transposed

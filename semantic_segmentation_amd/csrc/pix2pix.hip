@@ -270,6 +270,131 @@ __global__ void dots_reduce_kernel(const float* __restrict__ ws, int nblocks, fl
 
 }  // namespace
 
+namespace {
+// ---------------------------------------------------------------------------------------------------------------------
+// Outermost generator layer (networks.py:588-593 with the merged 8x8 kernel): ConvTranspose2d(Cin -> 1..4 channels,
+// k 8, stride 2, pad 3) + bias + tanh, straight to the fp32 NCHW image.  On the MFMA engine this layer fills 1 of 64
+// N columns; here it is a direct VALU kernel: a block stages the (8+4)^2 input pixels of an 8x8 patch of input positions
+// and the four sub-pixel classes' weights (the cached class-major pack [4][16][cpad][Cin]) in LDS; wave = class (weights
+// are wave-uniform LDS broadcasts), lane = input position; 16 taps x Cin/8 chunks of packed dot products.
+//   class (py,px), tap (iy,ix): input (y + py + 1 - iy, x + px + 1 - ix) -> output (2y+py, 2x+px)   [geom_convT_class]
+// ---------------------------------------------------------------------------------------------------------------------
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+template <int DT>
+__device__ __forceinline__ float dot8(const uint4& a, const uint4& b, float acc) {
+    if constexpr (DT == GS_F16) {
+        const unsigned int av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, av[i]), __builtin_bit_cast(half2_t, bv[i]), acc, false);
+        return acc;
+    } else {
+        float fa[8], fb[8];
+        unpack8<DT>(a, fa); unpack8<DT>(b, fb);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc += fa[i] * fb[i];
+        return acc;
+    }
+}
+
+constexpr int UO_T = 8, UO_HW = UO_T + 4, UO_MAXC = 4;
+
+template <int DT, int NCO>
+__global__ __launch_bounds__(256) void upconv8_image_fwd_kernel(const unsigned short* __restrict__ x, int in_stride, int in_coff,
+                                                                const unsigned short* __restrict__ pf, int cpad,
+                                                                const float* __restrict__ bias, float* __restrict__ out,
+                                                                unsigned short* __restrict__ u, int N, int h, int w, int Cin,
+                                                                int act) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+    const int nch = Cin >> 3;
+    const int xstride = Cin + 8;                          // +16 bytes per pixel: conflict-free 16-byte reads across lanes
+    unsigned short* xs = lds;                             // [12*12][xstride]
+    unsigned short* ws = lds + UO_HW * UO_HW * xstride;   // [4 classes][16 taps][NCO][Cin]
+    const int tiles_x = (w + UO_T - 1) / UO_T, tiles_y = (h + UO_T - 1) / UO_T;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int n = b / tiles_y;
+    const int y0 = ty * UO_T, x0 = tx * UO_T;
+    const int t = threadIdx.x;
+    for (int i = t; i < UO_HW * UO_HW * nch; i += 256) {
+        const int c = i % nch, p = i / nch;
+        const int py_ = p / UO_HW, px_ = p - py_ * UO_HW;
+        const int gy = y0 + py_ - 2, gx = x0 + px_ - 2;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if ((unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w)
+            v = *reinterpret_cast<const uint4*>(x + ((int64_t)(n * h + gy) * w + gx) * in_stride + in_coff + c * 8);
+        *reinterpret_cast<uint4*>(xs + p * xstride + c * 8) = v;
+    }
+    for (int i = t; i < 64 * NCO * nch; i += 256) {
+        const int c = i % nch;
+        int r = i / nch;
+        const int co = r % NCO; r /= NCO;                 // r = cls*16 + tap
+        *reinterpret_cast<uint4*>(ws + ((int64_t)r * NCO + co) * Cin + c * 8) =
+            *reinterpret_cast<const uint4*>(pf + ((int64_t)r * cpad + co) * Cin + c * 8);
+    }
+    __syncthreads();
+    const int cls = t >> 6, lane = t & 63;
+    const int py = cls >> 1, px = cls & 1;
+    const int qy = lane >> 3, qx = lane & 7;
+    float acc[NCO];
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) acc[co] = 0.f;
+    for (int iy = 0; iy < 4; ++iy)
+        for (int ix = 0; ix < 4; ++ix) {
+            const unsigned short* xp = xs + ((qy + py + 1 - iy + 2) * UO_HW + (qx + px + 1 - ix + 2)) * xstride;
+            const unsigned short* wp = ws + (int64_t)((cls * 16 + iy * 4 + ix) * NCO) * Cin;
+            for (int c = 0; c < nch; ++c) {
+                const uint4 a = *reinterpret_cast<const uint4*>(xp + c * 8);
+#pragma unroll
+                for (int co = 0; co < NCO; ++co)
+                    acc[co] = dot8<DT>(a, *reinterpret_cast<const uint4*>(wp + co * Cin + c * 8), acc[co]);
+            }
+        }
+    const int iy_ = y0 + qy, ix_ = x0 + qx;
+    if (iy_ < h && ix_ < w) {
+        const int oy = 2 * iy_ + py, ox = 2 * ix_ + px, OH = 2 * h, OW = 2 * w;
+        float pre[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int co = 0; co < NCO; ++co) {
+            const float v = acc[co] + (bias ? bias[co] : 0.f);
+            pre[co] = v;
+            out[((int64_t)(n * NCO + co) * OH + oy) * OW + ox] = act_fwd(v, act);
+        }
+        if (u) *reinterpret_cast<uint4*>(u + ((int64_t)(n * OH + oy) * OW + ox) * cpad) = pack8<DT>(pre);
+    }
+}
+}  // namespace
+
+extern "C" int gs_upconv8_image_fwd(const void* x, int in_pix_stride, int in_coff, const void* pack_fwd, int cpad,
+                                    const float* bias, float* out, void* u, int N, int h, int w, int Cin, int Cout, int act,
+                                    int dtype, void* stream) {
+    GS_CHECK_ARG(x && pack_fwd && out && N > 0 && h > 0 && w > 0, "gs_upconv8_image_fwd: bad arguments");
+    GS_CHECK_ARG(Cin > 0 && Cin % 8 == 0 && Cout >= 1 && Cout <= UO_MAXC && cpad == 8, "gs_upconv8_image_fwd: Cin %% 8, 1 <= Cout <= 4, cpad == 8");
+    GS_CHECK_ARG(in_pix_stride >= in_coff + Cin && in_pix_stride % 8 == 0 && in_coff % 8 == 0, "gs_upconv8_image_fwd: bad input stride");
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_upconv8_image_fwd: bad dtype");
+    const size_t lds = ((size_t)UO_HW * UO_HW * (Cin + 8) + (size_t)64 * Cout * Cin) * 2;
+    GS_CHECK_ARG(lds <= 64 * 1024, "gs_upconv8_image_fwd: Cin %d x Cout %d does not fit the 64 KB LDS tile", Cin, Cout);
+    const int64_t blocks = (int64_t)N * cdiv(h, UO_T) * cdiv(w, UO_T);
+    GS_CHECK_ARG(blocks < 2147483000LL, "gs_upconv8_image_fwd: too many tiles");
+    hipStream_t st = (hipStream_t)stream;
+#define UO_LAUNCH(DT, NCO)                                                                                           \
+    upconv8_image_fwd_kernel<DT, NCO><<<(int)blocks, 256, lds, st>>>((const unsigned short*)x, in_pix_stride, in_coff,   \
+                                                                     (const unsigned short*)pack_fwd, cpad, bias, out,   \
+                                                                     (unsigned short*)u, N, h, w, Cin, act)
+    if (dtype == GS_F16) {
+        if (Cout == 1) UO_LAUNCH(GS_F16, 1); else if (Cout == 2) UO_LAUNCH(GS_F16, 2);
+        else if (Cout == 3) UO_LAUNCH(GS_F16, 3); else UO_LAUNCH(GS_F16, 4);
+    } else {
+        if (Cout == 1) UO_LAUNCH(GS_BF16, 1); else if (Cout == 2) UO_LAUNCH(GS_BF16, 2);
+        else if (Cout == 3) UO_LAUNCH(GS_BF16, 3); else UO_LAUNCH(GS_BF16, 4);
+    }
+#undef UO_LAUNCH
+    GS_CHECK_LAUNCH("gs_upconv8_image_fwd");
+    return GS_OK;
+}
+
 extern "C" int gs_upconv_merge_pack(const float* w4, const float* w6, const float* w8, const float* softmax3,
                                     void* pack_fwd, void* pack_dgrad, float* merged_f32, int Cin, int Cout, int dtype,
                                     void* stream) {

@@ -15,6 +15,7 @@ Gradients are carried multiplied by a power-of-two scale (see unet_engine.py).""
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -56,6 +57,10 @@ def _bn_coeffs(bn, partials, ntiles, C, count, training, dev):
         ops.bn_eval_coeffs(C, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps,
                            coef[0], coef[1], coef[2], coef[3])
     return coef, batch_stats
+
+
+# GSSEG_PIX2PIX_DIRECT_IMAGE=0: run the outermost generator layer on the MFMA engine (4 class launches + tanh + layout pass)
+DIRECT_IMAGE_LAYER = os.environ.get("GSSEG_PIX2PIX_DIRECT_IMAGE", "1") != "0"
 
 
 class _PackCache:
@@ -243,14 +248,18 @@ class GeneratorEngine:
                 if bias is not None:
                     bpad = torch.zeros(cpad, dtype=torch.float32, device=dev)
                     bpad[:cout_t] = bias
-                for cls in range(4):
-                    g = ops.geom_convT_class(N, h, w, cin_t, cpad, 8, 3, cls >> 1, cls & 1)
-                    g_tapw_identity(g)
-                    ops.conv_igemm(g, R[1], pf[cls], u, bpad, None)
                 out = torch.empty((N, cout_t, H2, W2), dtype=torch.float32, device=dev)
-                t = empty(N, H2, W2, cpad)
-                ops.bn_act_apply(u, None, None, ACT_TANH, t, cpad, 0)
-                ops.nhwc_to_nchw(t, out, cpad, 0)
+                if DIRECT_IMAGE_LAYER and cpad == 8 and ops.upconv8_image_fits(cin_t, cout_t):
+                    # direct kernel: bias + tanh + fp32 NCHW in one pass (the MFMA engine would use 1 of 64 N columns)
+                    ops.upconv8_image_fwd(R[1], pf, bpad, out, u if need_grad else None, N, h, w, cin_t, cout_t, ACT_TANH)
+                else:
+                    for cls in range(4):
+                        g = ops.geom_convT_class(N, h, w, cin_t, cpad, 8, 3, cls >> 1, cls & 1)
+                        g_tapw_identity(g)
+                        ops.conv_igemm(g, R[1], pf[cls], u, bpad, None)
+                    t = empty(N, H2, W2, cpad)
+                    ops.bn_act_apply(u, None, None, ACT_TANH, t, cpad, 0)
+                    ops.nhwc_to_nchw(t, out, cpad, 0)
                 ctx["ups"][0] = dict(u=u, sm=sm, cin=cin_t, cout=cout_t, cpad=cpad, li=li)
         ctx["R"], ctx["L"] = R, L
         return out, (ctx if need_grad else None)

@@ -606,6 +606,24 @@ def upconv_merge_pack(w4, w6, w8, softmax3, pack_fwd=None, pack_dgrad=None, merg
               _p(merged_f32), Cin, Cout, code, _stream())
 
 
+def upconv8_image_fits(Cin: int, Cout: int) -> bool:
+    """LDS budget of the direct outermost-layer kernel (gs_upconv8_image_fwd)."""
+    return Cin % 8 == 0 and 1 <= Cout <= 4 and (144 * (Cin + 8) + 64 * Cout * Cin) * 2 <= 64 * 1024
+
+
+def upconv8_image_fwd(x, pack_fwd, bias, out, u, N, h, w, Cin, Cout, act, in_stride=None, in_coff=0):
+    """Merged 8x8/s2/p3 transposed conv to a 1..4-channel fp32 NCHW image (+bias, activation); u: optional 16-bit NHWC
+    pre-activation [N,2h,2w,8]."""
+    _dev(x)
+    _f32(bias, "bias"); _f32(out, "out")
+    if x.dtype != pack_fwd.dtype or (u is not None and u.dtype != x.dtype):
+        raise TypeError("upconv8_image_fwd: x, pack and u must share one 16-bit dtype")
+    if pack_fwd.numel() != 4 * 16 * 8 * Cin or out.numel() != N * Cout * 4 * h * w:
+        raise ValueError("upconv8_image_fwd: pack / output size")
+    _lib.call("gs_upconv8_image_fwd", _p(x), Cin if in_stride is None else in_stride, in_coff, _p(pack_fwd), 8, _p(bias),
+              _p(out), _p(u), N, h, w, Cin, Cout, act, dt_code(x), _stream())
+
+
 def upconv_split_wgrad(dwm, w4, w6, w8, softmax3, gscale, dw4, dw6, dw8, dots3):
     for n, t in (("dwm", dwm), ("dw4", dw4), ("dw6", dw6), ("dw8", dw8), ("dots3", dots3)):
         _f32(t, n)

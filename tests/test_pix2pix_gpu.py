@@ -324,3 +324,30 @@ def test_generator_backward_is_bit_reproducible_batch8():
         runs.append(r)
     for k in runs[0]:
         assert torch.equal(runs[0][k], runs[1][k]), k
+
+
+def test_direct_image_layer_matches_mfma_path():
+    """gs_upconv8_image_fwd (outermost generator layer as a direct kernel: merged 8x8 transposed conv + bias + tanh ->
+    fp32 NCHW) against the same layer on the MFMA engine (4 class launches + tanh + layout pass): image and gradients."""
+    from semantic_segmentation_amd.models_pix2pix import networks, pix2pix_engine
+    torch.manual_seed(21)
+    G = networks.define_G(1, 1, 64, "unet_256", "batch", False).cuda().train()
+    networks.upconv_arch = (0.3 * torch.randn(8, 3)).cuda().requires_grad_(True)
+    x = (torch.rand(2, 1, 256, 256, generator=torch.Generator().manual_seed(4)) > 0.5).float().cuda()
+    res = {}
+    for direct in (True, False):
+        pix2pix_engine.DIRECT_IMAGE_LAYER = direct
+        try:
+            G.zero_grad(set_to_none=True)
+            networks.upconv_arch.grad = None
+            out = G(x)
+            (out * torch.linspace(-1, 1, out.numel(), device=out.device).view_as(out)).mean().backward()   # mean-type loss: the
+            # backward carries gradients times S ~ N*H*W in 16 bits
+            res[direct] = (out.detach().clone(), {k: p.grad.clone() for k, p in G.named_parameters()})
+        finally:
+            pix2pix_engine.DIRECT_IMAGE_LAYER = True
+    a, b = res[True], res[False]
+    assert float((a[0] - b[0]).abs().max()) < 4e-3            # 16-bit rounding of the pre-activation on the MFMA path
+    num = sum(float(((a[1][k] - b[1][k]).double() ** 2).sum()) for k in a[1])
+    den = sum(float((b[1][k].double() ** 2).sum()) for k in a[1])
+    assert (num / den) ** 0.5 < 2e-2
