@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 18
+#define GS_ABI_VERSION 19
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -219,6 +219,14 @@ int gs_colsum(const void* t, int pix_stride, int coff, int N, int H, int W, int 
 int gs_pack_weight(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int taps, int transposed,
                    int dtype, void* stream);
 int gs_unpack_wgrad(const float* dw, float* grad, int A, int B, int taps, int transposed, float gscale, void* stream);
+
+/* Fake-image post-processing of the Unet step (running_files/train_end2end_jsrt.py:197-200): global min-max scaling to
+ * [0,1] -> uint8 -> per-image histogram equalisation (torchvision F.equalize) -> gamma (F.adjust_gamma) -> float/255.
+ * x, out: fp32 [N][hw] (one channel); gamma_lut[256]: the float the pipeline maps equalised level e to
+ * (uint8(255*(e/255)^gamma)/255, computed once by the host); ws: gs_fake_postprocess_ws_floats(N) floats of scratch.
+ * Bit-identical to the torch expression it replaces. */
+int64_t gs_fake_postprocess_ws_floats(int N);
+int gs_fake_postprocess(const float* x, float* out, float* ws, const float* gamma_lut, int N, int64_t hw, void* stream);
 
 /* Outermost generator layer (models_pix2pix/networks.py:588-593, merged 8x8 kernel): ConvTranspose2d(Cin -> Cout <= 4,
  * k 8, stride 2, pad 3) + bias + activation written as the fp32 NCHW image out [N,Cout,2h,2w]; u (may be NULL) receives

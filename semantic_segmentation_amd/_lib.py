@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 GS_F16, GS_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH = 0, 1, 2, 3
 GS_MAX_TAPS = 64
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 class GsConvGeom(ctypes.Structure):
@@ -90,6 +90,8 @@ PROTOTYPES = {
     "gs_pack_weight": (c_int, [_F, _P, _P, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "gs_unpack_wgrad": (c_int, [_F, _F, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "gs_upconv_merge_pack": (c_int, [_F, _F, _F, _F, _P, _P, _F, c_int, c_int, c_int, c_void_p]),
+    "gs_fake_postprocess_ws_floats": (c_int64, [c_int]),
+    "gs_fake_postprocess": (c_int, [_F, _F, _F, _F, c_int, c_int64, c_void_p]),
     "gs_upconv8_image_fwd": (c_int, [_P, c_int, c_int, _P, c_int, _F, _F, _P] + [c_int] * 7 + [c_void_p]),
     "gs_upconv_split_wgrad": (c_int, [_F, _F, _F, _F, _F, c_float, _F, _F, _F, _F, c_int, c_int, c_void_p]),
     "gs_upconv_split_wgrad_det": (c_int, [_F, _F, _F, _F, _F, c_float, _F, _F, _F, _F, _F, c_int, c_int, c_void_p]),

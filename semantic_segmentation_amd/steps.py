@@ -17,6 +17,7 @@ from typing import Callable, Optional
 
 import torch
 
+from . import ops
 from .losses import l1_loss, seg_loss
 
 
@@ -55,8 +56,26 @@ def equalize_gamma_u8(img_u8: torch.Tensor, gamma: float = 0.5) -> torch.Tensor:
     return out
 
 
-def fake_image_postprocess(fake_image: torch.Tensor) -> torch.Tensor:
-    """train_end2end_jsrt.py:197-200."""
+_GAMMA_LUT = {}
+
+
+def _gamma_lut(device, gamma: float) -> torch.Tensor:
+    """float value the pipeline maps an equalised uint8 level to (same torch expression as equalize_gamma_u8, on the device)."""
+    key = (str(device), gamma)
+    if key not in _GAMMA_LUT:
+        e = torch.arange(256, device=device, dtype=torch.float32)
+        _GAMMA_LUT[key] = ((255.0 * (e / 255.0) ** gamma).clamp(0, 255).to(torch.uint8).float() / 255.0).contiguous()
+    return _GAMMA_LUT[key]
+
+
+def fake_image_postprocess(fake_image: torch.Tensor, fused: bool = True) -> torch.Tensor:
+    """train_end2end_jsrt.py:197-200.  One-channel batches run as three fused HIP launches (gs_fake_postprocess), bit-identical
+    to the torch expression below (`fused=False`)."""
+    if fused and fake_image.is_cuda and fake_image.dim() == 4 and fake_image.shape[1] == 1:
+        x = fake_image.detach().float().contiguous()
+        out = torch.empty_like(x)
+        ops.fake_postprocess(x, out, _gamma_lut(x.device, 0.5))
+        return out
     f = ((fake_image - fake_image.min()) / (fake_image.max() - fake_image.min())).detach()
     u8 = f.mul(255).add_(0.5).clamp_(0, 255).to(torch.uint8)
     return equalize_gamma_u8(u8, 0.5).float() / 255.0

@@ -30,6 +30,28 @@ def test_equalize_gamma_matches_definition():
         assert np.array_equal(out[n].flatten().numpy(), want)
 
 
+@pytest.mark.parametrize("N,H,W,kind", [(2, 256, 256, "tanh"), (5, 64, 96, "wide"), (3, 33, 47, "few_levels"), (1, 16, 16, "tanh")])
+def test_fused_fake_postprocess_is_bit_identical(N, H, W, kind):
+    """gs_fake_postprocess (three HIP launches) against the torch expression of train_end2end_jsrt.py:197-200
+    (global min-max -> uint8 -> per-image equalise -> gamma 0.5): every pixel identical."""
+    from semantic_segmentation_amd import steps
+    g = torch.Generator().manual_seed(7 + N)
+    x = torch.randn(N, 1, H, W, generator=g)
+    if kind == "tanh":
+        x = torch.tanh(2 * x)
+    elif kind == "wide":
+        x = x * 37.5 - 11.0
+    else:                                              # a handful of grey levels; one image nearly constant (tiny step)
+        x = torch.round(x * 2) / 7
+        x[0] = x[0, 0, 0, 0]
+        x[0, 0, 0, 1] += 0.3
+    x = x.cuda()
+    fused = steps.fake_image_postprocess(x, fused=True)
+    ref = steps.fake_image_postprocess(x, fused=False)
+    assert fused.dtype == ref.dtype and fused.shape == ref.shape
+    assert torch.equal(fused, ref), int((fused != ref).sum())
+
+
 def test_gan_and_unet_steps_vs_oracle():
     from semantic_segmentation_amd import steps
     from semantic_segmentation_amd.models_pix2pix import networks
