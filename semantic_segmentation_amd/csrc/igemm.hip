@@ -618,9 +618,11 @@ static int choose_ksplit(int tiles, int ksteps, int64_t ws_floats, int64_t cnt_s
 
 static int launch_igemm(IgemmArgs& a, int dtype, hipStream_t s, const char* who, float* ws = nullptr,
                         int64_t ws_floats = 0) {
-    const int bn = (a.g.Cout <= 64) ? 64 : 128;
-    a.ntn = cdiv(a.g.Cout, bn);
     const int mt = cdiv(a.M, FW_BM);
+    // few-tile (weight-streaming) launches take the 64-wide N tile: twice the blocks for the same 16-part split-K limit
+    static const int skinny_tiles = getenv("GSSEG_IGEMM_SKINNY") ? atoi(getenv("GSSEG_IGEMM_SKINNY")) : 16;
+    const int bn = (a.g.Cout <= 64 || mt * cdiv(a.g.Cout, 128) <= skinny_tiles) ? 64 : 128;
+    a.ntn = cdiv(a.g.Cout, bn);
     a.nblocks = mt * a.ntn;
     a.ksplit = 1; a.ws_acc = nullptr; a.ws_cnt = nullptr;
     const bool packed = a.g.Cin == 8 && a.g.ntaps >= 8;
