@@ -69,7 +69,9 @@ class EndToEndTrainer:
         for p in module.parameters():
             p.requires_grad = flag
 
-    def train_iteration(self) -> Dict[str, float]:
+    def train_iteration(self) -> Dict[str, "float | torch.Tensor"]:
+        """One lower-level iteration.  Losses come back as 0-dim device tensors (convert with float() when they are needed:
+        a conversion per step would make the host wait for the GPU four times per iteration)."""
         image, mask = self._batch(next(self._train_iter))
         real_mask, real_image = mask.float(), image
         out: Dict[str, float] = {}
@@ -86,13 +88,13 @@ class EndToEndTrainer:
             loss_d = steps.discriminator_step_loss(self.netG, self.netD, self.criterionGAN, real_mask, real_image)
             loss_d.backward()
             self.optimizer_D.step()
-            out.update(loss_G=float(loss_g.detach()), loss_D=float(loss_d.detach()))
+            out.update(loss_G=loss_g.detach(), loss_D=loss_d.detach())      # 0-dim device tensors: no host sync per step
         # Unet problem (:176-226): real pair + generated pair from the (augmented) masks
         self.optimizer_unet.zero_grad(set_to_none=True)
         loss_u = steps.unet_step_loss(self.net, self.netG, image, mask, self.loss_lambda, self.mask_augment)
         loss_u.backward()
         self.optimizer_unet.step()
-        out["loss_unet"] = float(loss_u.detach())
+        out["loss_unet"] = loss_u.detach()
         self.global_step += 1
         # Arch problem (:229-236) on validation data, every unroll_steps lower iterations
         if self.global_step % self.unroll_steps == 0:
@@ -110,7 +112,7 @@ class EndToEndTrainer:
                 self.optimizer_arch.step()
             for p in list(self.net.parameters()) + list(self.netG.parameters()):
                 p.grad = None
-            out["loss_arch"] = float(loss_a.detach())
+            out["loss_arch"] = loss_a.detach()
         if self.valid_every and self.global_step % self.valid_every == 0:
             out["val_score"] = self.validation()
         self.history.append(out)
@@ -148,14 +150,22 @@ class SyntheticLungDataset(torch.utils.data.Dataset):
 
     def __init__(self, n: int, size: int = 256, seed: int = 0):
         self.n, self.size, self.seed = n, size, seed
+        self._grid = torch.meshgrid(torch.arange(size, dtype=torch.float32), torch.arange(size, dtype=torch.float32),
+                                    indexing="ij")
+        self._items = {}                 # samples are deterministic in (seed, i): generated once (32 ms each on the host)
 
     def __len__(self):
         return self.n
 
     def __getitem__(self, i):
+        if i not in self._items:
+            self._items[i] = self._make(i)
+        return self._items[i]
+
+    def _make(self, i):
         g = torch.Generator().manual_seed(self.seed * 100003 + i)
         s = self.size
-        yy, xx = torch.meshgrid(torch.arange(s, dtype=torch.float32), torch.arange(s, dtype=torch.float32), indexing="ij")
+        yy, xx = self._grid
         mask = torch.zeros(s, s, dtype=torch.bool)
         for _ in range(int(torch.randint(1, 4, (1,), generator=g))):
             cy, cx = (torch.rand(2, generator=g) * 0.6 + 0.2) * s
