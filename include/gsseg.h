@@ -221,10 +221,10 @@ int gs_pack_weight(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin
 int gs_unpack_wgrad(const float* dw, float* grad, int A, int B, int taps, int transposed, float gscale, void* stream);
 
 /* Fake-image post-processing of the Unet step (running_files/train_end2end_jsrt.py:197-200): global min-max scaling to
- * [0,1] -> uint8 -> per-image histogram equalisation (torchvision F.equalize) -> gamma (F.adjust_gamma) -> float/255.
- * x, out: fp32 [N][hw] (one channel); gamma_lut[256]: the float the pipeline maps equalised level e to
- * (uint8(255*(e/255)^gamma)/255, computed once by the host); ws: gs_fake_postprocess_ws_floats(N) floats of scratch.
- * Bit-identical to the torch expression it replaces. */
+ * [0,1] -> uint8 -> per-plane histogram equalisation (torchvision 0.14.1 F.equalize) -> gamma (F.adjust_gamma) -> float/255.
+ * x, out: fp32 [N][hw], N = images x channels (one histogram per plane, min/max over everything); gamma_lut[256]: the
+ * float the pipeline maps equalised level e to (uint8(255.999f * clamp((e/255)^gamma, 0, 1)) / 255, computed once by the
+ * host); ws: gs_fake_postprocess_ws_floats(N) floats of scratch.  Bit-exact against oracle/postproc.py. */
 int64_t gs_fake_postprocess_ws_floats(int N);
 int gs_fake_postprocess(const float* x, float* out, float* ws, const float* gamma_lut, int N, int64_t hw, void* stream);
 

@@ -1,8 +1,9 @@
 // Fake-image post-processing of the Unet step (running_files/train_end2end_jsrt.py:197-200): global min-max scaling of
-// the generator output to [0,1], conversion to uint8, per-image histogram equalisation (torchvision F.equalize) and gamma
-// 0.5 (F.adjust_gamma), back to float.  Non-differentiable byte work: three launches instead of ~25 element-wise torch
-// launches.  Integer histogram / LUT arithmetic follows torchvision exactly; the float steps use non-contracted IEEE
-// operations in torch's order, so the result is bit-identical to the torch expression it replaces (tested).
+// the generator output to [0,1], conversion to uint8, per-plane histogram equalisation (torchvision 0.14.1 F.equalize) and
+// gamma 0.5 (F.adjust_gamma; its uint8 table is built by the host, steps.py), back to float.  Non-differentiable byte
+// work: three launches instead of ~25 element-wise torch launches.  Integer histogram / LUT arithmetic follows
+// torchvision's published algorithm; the float steps use non-contracted IEEE operations in torch's order.  Bit-exact
+// against oracle/postproc.py (tests/test_steps_gpu.py).
 //   pass 1: per-block min/max partials of the whole batch
 //   pass 2: u8 = trunc(clamp((x-min)/(max-min) * 255 + 0.5)); per-image 256-bin histogram (LDS, then integer atomics)
 //   pass 3: per-image LUT  lut[v] = (exclusive_cumsum[v] + step/2) / step,  step = (npix - hist[last non-zero bin]) / 255

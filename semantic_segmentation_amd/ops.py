@@ -635,12 +635,13 @@ def upconv_split_wgrad(dwm, w4, w6, w8, softmax3, gscale, dw4, dw6, dw8, dots3):
 
 
 def fake_postprocess(x, out, gamma_lut):
-    """gs_fake_postprocess: min-max -> uint8 -> equalise -> gamma -> float of a one-channel fp32 batch [N,1,H,W]."""
+    """gs_fake_postprocess: min-max -> uint8 -> equalise -> gamma -> float of an fp32 batch [N,C,H,W]; every
+    (image, channel) plane has its own histogram (torchvision equalises channel by channel), min/max are global."""
     _dev(x)
     _f32(x, "x"); _f32(out, "out"); _f32(gamma_lut, "gamma_lut")
     if not x.is_contiguous() or out.shape != x.shape or gamma_lut.numel() != 256:
         raise ValueError("fake_postprocess: contiguous x, out of the same shape and a 256-entry gamma table")
-    N = x.shape[0]
+    N = x.shape[0] * (x.shape[1] if x.dim() == 4 else 1)
     hw = x.numel() // N
     ws = torch.empty(int(_lib.load().gs_fake_postprocess_ws_floats(N)), dtype=torch.float32, device=x.device)
     _lib.call("gs_fake_postprocess", _p(x), _p(out), _p(ws), _p(gamma_lut), N, hw, _stream())

@@ -8,13 +8,13 @@ over this package's modules -- the per-step math Betty's ImplicitProblems run, w
 
 Everything heavy runs on the HIP kernels (U-Net / generator / discriminator engines, fused seg loss, GAN / L1
 reductions).  The fake-image post-processing of :197-200 (global min-max -> uint8 -> histogram equalise ->
-gamma 0.5) is non-differentiable, operates on a detached tensor and is done with a few device-side torch ops
-here; SURVEY section 8(f) ranks a fused kernel for it (with the on-device mask augmentation) as the next
-component.  `mask_augment` stands in for the reference's host-side imgaug pipeline (:100-112, :186-190)."""
+gamma 0.5) is non-differentiable byte work on a detached tensor: three fused HIP launches (csrc/postproc.hip),
+bit-exact against oracle/postproc.py's restatement of torchvision 0.14.1.  `mask_augment` stands in for the reference's host-side imgaug pipeline (:100-112, :186-190)."""
 from __future__ import annotations
 
 from typing import Callable, Optional
 
+import numpy as np
 import torch
 
 from . import ops
@@ -35,50 +35,33 @@ def discriminator_step_loss(netG, netD, criterionGAN, real_mask, real_image):
     return (criterionGAN(pred_fake, False) + criterionGAN(pred_real, True)) * 0.5
 
 
-def equalize_gamma_u8(img_u8: torch.Tensor, gamma: float = 0.5) -> torch.Tensor:
-    """torchvision.transforms.functional.equalize + adjust_gamma on uint8 [N,1,H,W] (per image), device side.
-    equalize: lut = (cumsum(hist) - hist + step//2) // step with step = (sum(hist) - last nonzero hist) // 255;
-    identity when step == 0.  adjust_gamma on uint8: (255 * (v/255)^gamma) truncated to uint8."""
-    n = img_u8.shape[0]
-    flat = img_u8.reshape(n, -1).long()
-    hist = torch.zeros((n, 256), dtype=torch.long, device=img_u8.device)
-    hist.scatter_add_(1, flat, torch.ones_like(flat))
-    idx = torch.arange(256, device=img_u8.device).expand(n, 256)
-    last_nz = torch.where(hist > 0, idx, torch.full_like(idx, -1)).max(dim=1).values
-    last_val = hist.gather(1, last_nz.clamp_min(0).unsqueeze(1)).squeeze(1)
-    step = torch.div(hist.sum(1) - last_val, 255, rounding_mode="floor")
-    csum = torch.cumsum(hist, 1) - hist                       # exclusive prefix sum
-    safe = step.clamp_min(1).unsqueeze(1)
-    lut = torch.div(csum + torch.div(safe, 2, rounding_mode="floor"), safe, rounding_mode="floor").clamp(0, 255)
-    lut = torch.where((step == 0).unsqueeze(1), idx, lut)
-    eq = lut.gather(1, flat).reshape(img_u8.shape)
-    out = (255.0 * (eq.float() / 255.0) ** gamma).clamp(0, 255).to(torch.uint8)
-    return out
-
-
 _GAMMA_LUT = {}
 
 
 def _gamma_lut(device, gamma: float) -> torch.Tensor:
-    """float value the pipeline maps an equalised uint8 level to (same torch expression as equalize_gamma_u8, on the device)."""
+    """The float an equalised uint8 level e ends up as: torchvision 0.14.1 `adjust_gamma` on a uint8 tensor
+    (functional_tensor.py: convert_image_dtype to float32 = e/255, `** gamma` (sqrt for 0.5), clamp(0,1),
+    convert_image_dtype back = mul(255 + 1 - 1e-3) truncated to uint8), followed by the script's `/ 255.0`
+    (train_end2end_jsrt.py:200).  Built on the host in IEEE float32, one rounding per operation, then uploaded."""
     key = (str(device), gamma)
     if key not in _GAMMA_LUT:
-        e = torch.arange(256, device=device, dtype=torch.float32)
-        _GAMMA_LUT[key] = ((255.0 * (e / 255.0) ** gamma).clamp(0, 255).to(torch.uint8).float() / 255.0).contiguous()
+        e = np.arange(256, dtype=np.float32) / np.float32(255.0)
+        r = np.sqrt(e) if gamma == 0.5 else np.power(e, np.float32(gamma))
+        r = np.clip(r.astype(np.float32), np.float32(0.0), np.float32(1.0))
+        u8 = (r * np.float32(255.0 + 1.0 - 1e-3)).astype(np.uint8)
+        _GAMMA_LUT[key] = torch.from_numpy(u8.astype(np.float32) / np.float32(255.0)).to(device).contiguous()
     return _GAMMA_LUT[key]
 
 
-def fake_image_postprocess(fake_image: torch.Tensor, fused: bool = True) -> torch.Tensor:
-    """train_end2end_jsrt.py:197-200.  One-channel batches run as three fused HIP launches (gs_fake_postprocess), bit-identical
-    to the torch expression below (`fused=False`)."""
-    if fused and fake_image.is_cuda and fake_image.dim() == 4 and fake_image.shape[1] == 1:
-        x = fake_image.detach().float().contiguous()
-        out = torch.empty_like(x)
-        ops.fake_postprocess(x, out, _gamma_lut(x.device, 0.5))
-        return out
-    f = ((fake_image - fake_image.min()) / (fake_image.max() - fake_image.min())).detach()
-    u8 = f.mul(255).add_(0.5).clamp_(0, 255).to(torch.uint8)
-    return equalize_gamma_u8(u8, 0.5).float() / 255.0
+def fake_image_postprocess(fake_image: torch.Tensor, gamma: float = 0.5) -> torch.Tensor:
+    """train_end2end_jsrt.py:197-200: global min-max -> uint8 -> per-(image, channel) histogram equalisation -> gamma
+    -> float, as three HIP launches (gs_fake_postprocess).  Device tensors only: there is no host path."""
+    if not fake_image.is_cuda or fake_image.dim() != 4:
+        raise RuntimeError("fake_image_postprocess: needs a device tensor [N,C,H,W] (no CPU path)")
+    x = fake_image.detach().float().contiguous()
+    out = torch.empty_like(x)
+    ops.fake_postprocess(x, out, _gamma_lut(x.device, gamma))
+    return out
 
 
 def unet_step_loss(net, netG, images, true_masks, loss_lambda: float = 1.0,

@@ -177,3 +177,50 @@ def test_unet3d_step_matches_reference(golden_dir, name):
     sd2 = dict(sd); sd2.update(updates)
     le = oracle.unet3d_forward(sd2, x, train=False)
     assert np.abs(le.numpy() - z["logits_eval"]).max() < 1e-3 * max(1.0, np.abs(z["logits_eval"]).max())
+
+
+# ---------------------------------------------------------------- fake-image post-processing (oracle/postproc.py)
+def test_postproc_gamma_table_known_answers():
+    """torchvision 0.14.1 adjust_gamma(uint8, 0.5): trunc(sqrt(v/255) * 255.999).  Hand-computed anchors
+    (128 -> 181, not the 180 of trunc(255 * sqrt(v/255))), monotone, end points fixed; the CUDA path's
+    multiply-by-reciprocal division gives the same 256 entries; the same float32 steps in torch-CPU agree."""
+    from oracle import postproc
+    t = postproc.gamma_table_u8(0.5)
+    assert t.dtype == np.uint8 and t.shape == (256,)
+    assert (t[0], t[1], t[64], t[128], t[254], t[255]) == (0, 16, 128, 181, 255, 255)
+    assert np.all(np.diff(t.astype(np.int64)) >= 0)
+    assert np.array_equal(t, postproc.gamma_table_u8(0.5, reciprocal_division=True))
+    naive = np.clip(255.0 * (np.arange(256) / 255.0) ** 0.5, 0, 255).astype(np.uint8)
+    assert int((naive != t).sum()) == 186                    # the count the round-1 review computed
+    v = torch.arange(256, dtype=torch.uint8)
+    r = (1 * (v.to(torch.float32) / 255.0) ** 0.5).clamp(0, 1)
+    assert np.array_equal(r.mul(255 + 1.0 - 1e-3).to(torch.uint8).numpy(), t)
+
+
+def test_postproc_equalize_small_cases():
+    from oracle import postproc
+    # constant plane and two-level plane with a tiny first bin: step == 0 -> unchanged
+    c = np.full((1, 1, 4, 4), 7, np.uint8)
+    assert np.array_equal(postproc.equalize(c), c)
+    # hand case: 510 pixels of level 10, 255 of level 20, 255 of level 200: step = (510+255)//255 = 3
+    p = np.concatenate([np.full(510, 10), np.full(255, 20), np.full(255, 200)]).astype(np.uint8).reshape(1, 1, 30, 34)
+    e = postproc.equalize(p)
+    # lut[v] = (pixels below v + 1) // 3: level 10 -> 0, level 20 -> 511//3 = 170, level 200 -> 766//3 = 255
+    assert sorted(np.unique(e).tolist()) == [0, 170, 255]
+    assert e.reshape(-1)[0] == 0 and e.reshape(-1)[510] == 170 and e.reshape(-1)[-1] == 255
+    # channels are equalised independently
+    q = np.concatenate([p, np.full_like(p, 3)], axis=1)
+    eq = postproc.equalize(q)
+    assert np.array_equal(eq[:, :1], e) and np.array_equal(eq[:, 1:], q[:, 1:])
+
+
+def test_postproc_pipeline_matches_torch_cpu_float_steps():
+    """The min-max / uint8 conversion in numpy float32 equals the script's torch-CPU expression (:197,199)."""
+    from oracle import postproc
+    g = torch.Generator().manual_seed(3)
+    x = torch.tanh(2 * torch.randn(3, 1, 48, 40, generator=g))
+    f = ((x - x.min()) / (x.max() - x.min()))
+    u8 = f.mul(255).add_(0.5).clamp_(0, 255).to(torch.uint8).numpy()
+    assert np.array_equal(postproc.minmax_to_u8(x.numpy()), u8)
+    out = postproc.fake_image_postprocess(x.numpy())
+    assert out.dtype == np.float32 and out.min() >= 0 and out.max() <= 1
