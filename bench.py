@@ -5,6 +5,8 @@ step and data loading excluded) on N MI355X, one process per GPU.
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        # no launcher: this process (which never touches a GPU) starts the N ranks itself
+    python bench.py --gpus 2 --backend gloo --dry    # CPU rehearsal of the launcher / rendezvous / reducer plumbing only
 
 Workload (BASELINE.json configs[1]): unet.UNet(n_channels=1, n_classes=2), 256x256, batch 32 PER GPU
 (weak scaling), synthetic images/masks resident in HBM, random-init weights, loss = CrossEntropy +
@@ -19,6 +21,9 @@ cores of this box on a bounded sample (batch 4), N=1 only.
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -73,6 +78,11 @@ def parse():
                     help="PCIe-inclusive variant: copy the batch from pinned host memory inside every timed step")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only with --dry")
+    ap.add_argument("--dry", action="store_true",
+                    help="plumbing rehearsal without kernels: launcher, rendezvous, barrier/max-over-ranks timing and the "
+                         "bucketed GradReducer on a small CPU stand-in model; the JSON line says \"dry\": true and is NOT a "
+                         "measurement")
     return ap.parse_args()
 
 
@@ -107,14 +117,115 @@ def cpu_baseline(args):
             "gflops": round(ips * GF_PER_IMG_FWDBWD.get(args.classes, 288.5) * (args.size / 256.0) ** 2, 1)}
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this script (one per GPU) with the
+    torch.distributed environment, relay rank 0's JSON line, fail if any rank fails.  This parent never initialises a
+    GPU (no HIP call, no torch.cuda.is_available()), and nothing is exec'ed: children are ordinary subprocesses."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    import tempfile
+    procs = []
+    with tempfile.TemporaryFile("w+") as out0:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                       LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        # a rank that dies leaves the others waiting in the rendezvous / a collective: stop exactly those PIDs
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                break
+            time.sleep(0.2)
+        codes = []
+        for p in procs:
+            try:
+                codes.append(p.wait(timeout=30))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                codes.append(p.wait())
+        out0.seek(0)
+        text = out0.read()
+    line = next((ln for ln in reversed(text.splitlines()) if ln.startswith("{")), None)
+    if any(codes) or line is None:
+        sys.stderr.write(f"bench.py: rank exit codes {codes}; rank-0 output:\n{text}\n")
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+def dry_main(args, world, rank):
+    """--dry: everything of the multi-rank bench except the kernels (CPU, gloo): rendezvous, replica broadcast, the bucketed
+    GradReducer driven in backward order by a stand-in model, barrier + max-over-ranks timing, one JSON line on rank 0."""
+    import torch.distributed as dist
+    from semantic_segmentation_amd.parallel import GradReducer, broadcast_module_state
+    if world > 1:
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    torch.manual_seed(1234 + rank)
+    net = torch.nn.Sequential(torch.nn.Conv2d(1, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.ReLU(),
+                              torch.nn.Conv2d(8, 2, 1))
+    broadcast_module_state(net)
+    reducer = GradReducer(net.named_parameters(), bucket_bytes=256) if world > 1 else None
+    x = torch.randn(args.batch, 1, 16, 16)
+    names = [n for n, _ in net.named_parameters()][::-1]
+    params = dict(net.named_parameters())
+
+    def step():
+        net.zero_grad(set_to_none=True)
+        loss = net(x).square().mean()
+        loss.backward()
+        if reducer is not None:
+            reducer.begin()
+            for n in names:
+                reducer.ready(n, params[n].grad)
+            reducer.finish()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        g = [torch.zeros_like(reducer.flat) for _ in range(world)]
+        dist.all_gather(g, reducer.flat)
+        assert all(torch.equal(g[0], q) for q in g), "averaged gradients differ across ranks"
+    if rank == 0:
+        print(json.dumps({"metric": "images/sec (fwd+bwd) U-Net 256x256 bs=32 per GPU", "dry": True,
+                          "value": round(world * args.batch * args.steps / elapsed, 2), "unit": "images/sec",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 3), "scaling": "weak",
+                          "ranks": dist.get_world_size() if world > 1 else 1, "backend": args.backend,
+                          "data": "stand-in model on CPU: plumbing rehearsal, not a measurement"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry:
+        return dry_main(args, world, rank)
+    if args.backend != "nccl":
+        raise SystemExit("--backend gloo is only for --dry (the product path has no CPU fallback)")
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)")
@@ -160,14 +271,33 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]    # on the launch (= current) stream
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
+        marks[i + 1].record()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    # the gradient exchange on its own (not overlapped with anything), for the scaling discussion: all buckets back to back
+    allreduce_ms = None
+    if reducer is not None:
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        dist.barrier()
+        e0.record()
+        for _ in range(reps):
+            for b in reducer.buckets:
+                lo, hi = b["range"]
+                dist.all_reduce(reducer.flat[lo:hi], op=reducer.op)
+        e1.record()
+        torch.cuda.synchronize()
+        allreduce_ms = e0.elapsed_time(e1) / reps
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -209,6 +339,12 @@ def main():
                    "global_batch": world * args.batch, "parallelism": f"dp{world}", "loss": float(loss.item()),
                    "dice": "global-batch (3-scalar all-reduce)" if (args.global_dice and world > 1) else "per-rank"},
         "input": "pinned host memory, copied every step (PCIe-inclusive)" if args.host_input else "resident in HBM",
+        "ms_per_step_median": round(statistics.median(step_ms), 3),
+        "ms_per_step_min_max": [round(min(step_ms), 3), round(max(step_ms), 3)],
+        "value_at_median_step": round(world * args.batch / statistics.median(step_ms) * 1e3, 2),
+        "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+        "allreduce_ms_per_step_unoverlapped": None if allreduce_ms is None else round(allreduce_ms, 3),
+        "grad_buckets": None if reducer is None else len(reducer.buckets),
         "whole_step_tflops": round(value * gf / 1e3, 1),
         "whole_step_frac_of_mfma_peak": round(value * gf / 1e3 / (MFMA_PEAK_TFLOPS * world), 4),
         "roofline": roof, "kernels": kern,

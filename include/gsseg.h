@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 19
+#define GS_ABI_VERSION 20
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -67,15 +67,15 @@ int gs_abi_version(void);
  * when given, per-M-tile sums of y and y*y (fp32 accumulators, before rounding, before bias) are
  * written there for train-mode BatchNorm (unet_parts.py:17,20).  Requires Cin % 8 == 0. */
 int gs_conv_igemm_mtiles(const GsConvGeom* g);
-int gs_conv_igemm(const GsConvGeom* g, const void* x, const void* w, void* y, const float* bias,
-                  float* bn_partials, int act, int dtype, void* stream);
-/* Optional split-K workspace of gs_conv_igemm: skinny GEMMs (few output tiles, long K: the 1x1 .. 16x16 levels of
- * the Pix2Pix generator at batch 2) are split over K, the parts store fp32 partial tiles in per-part slabs and the
- * last part of a tile sums them (in part order: deterministic) and runs the epilogue.  Caller-owned device memory, fp32,
- * gs_conv_igemm_workspace_floats() elements, zero-initialised ONCE (ticket counters return to zero); NULL = off.  Per process (= per GPU); launches
- * sharing it must be ordered on one stream. */
+/* splitk_ws: optional split-K workspace.  Skinny GEMMs (few output tiles, long K: the 1x1 .. 16x16 levels of the Pix2Pix
+ * generator at batch 2) are split over K, the parts store fp32 partial tiles in per-part slabs and the last part of a
+ * tile sums them (in part order: deterministic) and runs the epilogue.  Caller-owned device memory, fp32,
+ * gs_conv_igemm_workspace_floats() elements, zero-initialised ONCE (ticket counters return to zero); NULL = no split.
+ * The library holds no state: launches sharing a workspace must be ordered on one stream (one workspace per
+ * (device, stream) on the host side). */
 int64_t gs_conv_igemm_workspace_floats(void);
-int gs_conv_igemm_set_workspace(float* ws, int64_t ws_floats);
+int gs_conv_igemm(const GsConvGeom* g, const void* x, const void* w, void* y, const float* bias,
+                  float* bn_partials, int act, int dtype, float* splitk_ws, int64_t splitk_ws_floats, void* stream);
 
 /* ---- stride-2 / kernel-2 transposed convolution as ONE pointwise GEMM + sub-pixel scatter ------
  * replaces nn.ConvTranspose2d(C, C/2, kernel_size=2, stride=2) at unet/unet_parts.py:51 (Up.up) and

@@ -590,8 +590,6 @@ int check_geom(const GsConvGeom* g, const char* who) {
 
 }  // namespace
 
-float* g_splitk_ws = nullptr;                             // set by gs_conv_igemm_set_workspace (caller-owned memory)
-int64_t g_splitk_ws_floats = 0;
 constexpr int64_t SPLITK_TILE_FLOATS = 256 * 64;          // 256 threads x (2 x 2 x 16) accumulators of a 128x128 tile
 
 constexpr int SPLITK_MAX_PARTS = 16, SPLITK_MAX_SLABS = 512;
@@ -662,7 +660,8 @@ extern "C" int gs_conv_igemm_mtiles(const GsConvGeom* g) {
 }
 
 extern "C" int gs_conv_igemm(const GsConvGeom* g, const void* x, const void* w, void* y, const float* bias,
-                             float* bn_partials, int act, int dtype, void* stream) {
+                             float* bn_partials, int act, int dtype, float* splitk_ws, int64_t splitk_ws_floats,
+                             void* stream) {
     int rc = check_geom(g, "gs_conv_igemm");
     if (rc) return rc;
     GS_CHECK_ARG(x && w && y, "gs_conv_igemm: null pointer");
@@ -675,20 +674,16 @@ extern "C" int gs_conv_igemm(const GsConvGeom* g, const void* x, const void* w, 
     a.kchunks = cdiv(g->Cin, FW_BK);
     a.vec_store = (g->Cout % 8 == 0 && g->out_pix_stride % 8 == 0 && g->out_coff % 8 == 0) ? 1 : 0;
     a.shuffle_cout = 0; a.shuffle_cls = 0;
-    return launch_igemm(a, dtype, (hipStream_t)stream, "gs_conv_igemm", g_splitk_ws, g_splitk_ws_floats);
+    GS_CHECK_ARG(splitk_ws == nullptr || splitk_ws_floats >= 4096 + SPLITK_TILE_FLOATS,
+                 "gs_conv_igemm: split-K workspace too small (gs_conv_igemm_workspace_floats())");
+    return launch_igemm(a, dtype, (hipStream_t)stream, "gs_conv_igemm", splitk_ws, splitk_ws ? splitk_ws_floats : 0);
 }
 
-// Optional split-K workspace for gs_conv_igemm (skinny GEMMs: the 1x1 .. 16x16 levels of the Pix2Pix generator at
-// the script's batch size 2 run 4-8 blocks over multi-megabyte weight packs otherwise).  The caller owns the memory
-// (fp32, zero-initialised once; the kernels leave it zeroed); pass NULL / 0 to switch split-K off.  One workspace per
-// process: launches that share it must be ordered on one stream.
-extern "C" int gs_conv_igemm_set_workspace(float* ws, int64_t ws_floats) {
-    GS_CHECK_ARG(ws == nullptr || ws_floats >= 4096 + SPLITK_TILE_FLOATS, "gs_conv_igemm_set_workspace: workspace too small");
-    g_splitk_ws = ws;
-    g_splitk_ws_floats = ws ? ws_floats : 0;
-    return GS_OK;
-}
-
+// Split-K workspace of gs_conv_igemm (skinny GEMMs: the 1x1 .. 16x16 levels of the Pix2Pix generator at the script's
+// batch size 2 run 4-8 blocks over multi-megabyte weight packs otherwise): an explicit argument of every call, owned by
+// the caller (fp32, zero-initialised once; the kernels leave the ticket counters zeroed), NULL = no split.  The library
+// keeps no pointer: launches that share one workspace must be ordered on one stream, so the host keeps one per
+// (device, stream).
 extern "C" int64_t gs_conv_igemm_workspace_floats(void) {
     return 4096 + (int64_t)SPLITK_MAX_SLABS * SPLITK_TILE_FLOATS;
 }

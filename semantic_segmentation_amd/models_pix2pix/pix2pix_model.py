@@ -55,6 +55,7 @@ class Pix2PixModel:
             raise RuntimeError("Pix2PixModel (semantic_segmentation_amd) runs on the MI355X only (no CPU fallback)")
         index = getattr(opt, "cuda_index", self.gpu_ids[0] if self.gpu_ids else 0)
         self.device = torch.device("cuda", index)
+        torch.cuda.set_device(self.device)        # one process per GPU: kernels launch on the CURRENT device's stream
         self.save_dir = os.path.join(getattr(opt, "checkpoints_dir", "./checkpoints"), getattr(opt, "name", "pix2pix"))
         self.loss_names = ["G_GAN", "G_L1", "D_real", "D_fake"]
         self.visual_names = ["real_mask", "fake_image", "real_image"]

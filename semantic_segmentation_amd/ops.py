@@ -43,6 +43,11 @@ def _dev(t: torch.Tensor):
     if not t.is_cuda:
         raise RuntimeError("semantic_segmentation_amd ops need tensors on the MI355X (cuda) device; "
                            "there is no CPU path")
+    # launches go to the CURRENT device's current stream: a tensor of another device would be dereferenced there
+    cur = _RAW_DEVICE() if _RAW_DEVICE is not None else torch.cuda.current_device()
+    if t.device.index != cur:
+        raise RuntimeError(f"tensor on cuda:{t.device.index} but the current device is cuda:{cur}: one process per GPU "
+                           "-- call torch.cuda.set_device (or run under torch.cuda.device(t.device))")
 
 
 def _f32(t: Optional[torch.Tensor], name: str):
@@ -157,17 +162,22 @@ def geom_conv_s2_dgrad_class(N, IH, IW, Cin, Cout, k, pad, py, px, **kw) -> GsCo
 
 
 # ---------------------------------------------------------------------------- MFMA engine
-_SPLITK_WS = {}      # device index -> zeroed fp32 workspace handed to the library (kept alive here)
+_SPLITK_WS = {}      # (device index, stream handle) -> zeroed fp32 workspace (the library itself holds no state)
 
 
-def _ensure_splitk_workspace(device: torch.device) -> None:
-    """gs_conv_igemm's split-K workspace: allocated (zeroed) once per process; the kernels leave it zeroed."""
-    if os.environ.get("GSSEG_SPLITK", "1") == "0" or device.index in _SPLITK_WS:
-        return
-    n = int(_lib.load().gs_conv_igemm_workspace_floats())
-    ws = torch.zeros(n, dtype=torch.float32, device=device)
-    _lib.call("gs_conv_igemm_set_workspace", _p(ws), n)
-    _SPLITK_WS[device.index] = ws
+def _splitk_workspace(device: torch.device, stream) -> Optional[torch.Tensor]:
+    """gs_conv_igemm's split-K workspace, passed with every call: one per (device, stream), because launches that
+    share one must be ordered on one stream (ticket counters and slabs are reused); allocated zeroed once, the kernels
+    leave the counters zeroed.  Streams of a process are few (compute + side streams), so nothing is ever evicted."""
+    if os.environ.get("GSSEG_SPLITK", "1") == "0":
+        return None
+    key = (device.index, int(stream or 0))
+    ws = _SPLITK_WS.get(key)
+    if ws is None:
+        n = int(_lib.load().gs_conv_igemm_workspace_floats())
+        ws = torch.zeros(n, dtype=torch.float32, device=device)     # zero fill runs on this same (current) stream
+        _SPLITK_WS[key] = ws
+    return ws
 
 
 def conv_igemm(g: GsConvGeom, x, w, y, bias=None, bn_partials=None, act=ACT_NONE):
@@ -179,9 +189,11 @@ def conv_igemm(g: GsConvGeom, x, w, y, bias=None, bn_partials=None, act=ACT_NONE
         need = _lib.load().gs_bn_partials_floats(conv_igemm_mtiles(g), g.Cout)
         if bn_partials.numel() < need:
             raise ValueError(f"bn_partials too small: {bn_partials.numel()} < {need}")
-    _ensure_splitk_workspace(x.device)
+    stream = _stream()
+    ws = _splitk_workspace(x.device, stream)
     ev = TIMER.start() if TIMER is not None else None
-    _lib.call("gs_conv_igemm", g, _p(x), _p(w), _p(y), _p(bias), _p(bn_partials), act, dt_code(x), _stream())
+    _lib.call("gs_conv_igemm", g, _p(x), _p(w), _p(y), _p(bias), _p(bn_partials), act, dt_code(x), _p(ws),
+              ws.numel() if ws is not None else 0, stream)
     if ev is not None:
         TIMER.stop("igemm_fwd", ev, _geom_flops(g))
 

@@ -135,8 +135,12 @@ def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None):
     """Replicas start identical: parameters and buffers of rank `src` (DDP broadcast_buffers semantics)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    for t in list(module.parameters()) + list(module.buffers()):
+    tensors = list(module.parameters()) + list(module.buffers())
+    for t in tensors:
         dist.broadcast(t.data, src=src, group=group)
+    # the engines key their 16-bit weight packs / folded-BN caches on (data_ptr, _version): a write through `.data`
+    # does not bump the version, so do it here -- a broadcast AFTER a forward must not leave stale packs behind
+    torch.autograd.graph.increment_version(tensors)
 
 
 def shard_batch(n_global: int, rank: int, world: int):

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(lib):
 def test_argument_validation_is_synchronous(lib):
     from semantic_segmentation_amd import _lib
     g = _lib.GsConvGeom()
-    assert lib.gs_conv_igemm(g, None, None, None, None, None, 0, 0, None) != 0
+    assert lib.gs_conv_igemm(g, None, None, None, None, None, 0, 0, None, 0, None) != 0
     assert b"gs_conv_igemm" in lib.gs_last_error()
     assert lib.gs_bn_finalize(None, 0, 0, 0.0, None, None, None, None, 0.1, 1e-5, None, None, None, None, None) != 0
     assert lib.gs_bn_partials_floats(10, 64) >= 10 * 2 * 64

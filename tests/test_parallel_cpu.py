@@ -92,3 +92,23 @@ def test_shard_batch_rejects_uneven():
     from semantic_segmentation_amd.parallel import shard_batch
     with pytest.raises(ValueError):
         shard_batch(10, 0, 4)
+
+
+def test_bench_self_launcher_two_gloo_ranks():
+    """`python bench.py --gpus 2` with no launcher in front (how the driver may start it): the parent spawns the two ranks,
+    relays rank 0's JSON line and propagates failure.  --backend gloo --dry skips the kernels (no GPU here)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry",
+                        "--steps", "3", "--warmup", "1", "--batch", "4"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["dry"] is True and line["n_gpus"] == 2 and line["ranks"] == 2 and line["steps"] == 3
+    # a failing rank (no GPU here, real mode) must give a non-zero exit, not a hang
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0
