@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 20
+#define GS_ABI_VERSION 21
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -287,6 +287,33 @@ int gs_mean_loss_fwd(const float* x, const float* t, float cval, int mode, int64
                      void* stream);
 int gs_mean_loss_bwd(const float* x, const float* t, float cval, int mode, int64_t n, const float* gout,
                      float gscale, float* dx, void* stream);
+
+/* ---- precise mode of the U-Net forward (opt-in) ---------------------------------------------
+ * The 16-bit engine's logits differ from the fp32 reference (unet/unet_model.py:26-37) by up to ~4e-3 (23 stacked 16-bit
+ * roundings); in precise mode activations and weights travel as PAIRS of 16-bit values v = hi + lo (hi = 16-bit(v),
+ * lo = 16-bit(v - hi)) and the MFMA contractions run over the K concatenation [x_hi | x_lo | x_hi] . [w_hi | w_hi | w_lo]
+ * (exact products, one fp32 accumulator), which brings the logits to ~1e-5 of the reference.
+ * gs_pack_weight_split: w fp32 [Cout][Cin][taps] (transposed: [Cin][Cout][taps]) -> pack [taps][Cout][3*Cin] 16-bit.
+ * gs_conv3x3_precise: as gs_conv3x3 with x = [hi | lo] planes (in_wrap channels per pixel; K chunk c reads input chunk
+ *   c mod in_wrap), w = split pack with K = 3*Cin, result as the pair y_hi / y_lo (same stride / offset).
+ * gs_upconv2x2_fwd_precise: the same for Up.up (unet_parts.py:51).
+ * gs_conv_smallcin_fwd_split: first conv (fp32 image, fp32 weights) -> y pair; bn_partials as gs_conv_smallcin_fwd.
+ * gs_bn_act_apply_split: z = act(scale * (y_hi + y_lo) + shift) -> z pair (both with z_pix_stride / z_coff), optional 2x2
+ *   max-pooled pair (pixel stride zp_pix_stride).   gs_head1x1_fwd_split: OutConv on a dense pair, Cin == 64. */
+int gs_pack_weight_split(const float* w, void* pack, int Cout, int Cin, int taps, int transposed, int dtype, void* stream);
+int gs_conv3x3_precise(const void* x, const void* w, void* y_hi, void* y_lo, const float* bias, float* bn_partials, int N,
+                       int H, int W, int K, int in_pix_stride, int in_coff, int in_wrap, int Cout, int out_pix_stride,
+                       int out_coff, const int32_t* tap_dy, const int32_t* tap_dx, int act, int dtype, void* stream);
+int gs_upconv2x2_fwd_precise(const void* x, const void* w, const float* bias, void* y_hi, void* y_lo, int N, int IH, int IW,
+                             int K, int in_pix_stride, int in_coff, int in_wrap, int Cout, int OH, int OW,
+                             int out_pix_stride, int out_coff, int ooy, int oox, int dtype, void* stream);
+int gs_conv_smallcin_fwd_split(const float* x, const float* w, void* y_hi, void* y_lo, float* bn_partials, int N, int Cin,
+                               int H, int W, int Cout, int k, int pad, int dtype, void* stream);
+int gs_bn_act_apply_split(const void* y_hi, const void* y_lo, const float* scale, const float* shift, int act, void* z_hi,
+                          void* z_lo, int z_pix_stride, int z_coff, void* zp_hi, void* zp_lo, int zp_pix_stride, int N,
+                          int H, int W, int C, int dtype, void* stream);
+int gs_head1x1_fwd_split(const void* x_hi, const void* x_lo, const float* w, const float* bias, float* y, int N, int H,
+                         int W, int Cin, int Cout, int dtype, void* stream);
 
 /* Deterministic weight gradient of the 3x3 conv without atomics: gs_conv3x3_wgrad_slabs stores every split-K part's
  * tile into its own slab ws[part][9][Cout][Cin] (fp32, gs_conv3x3_wgrad_ws_floats() elements, no zero fill needed,

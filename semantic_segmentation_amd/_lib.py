@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 GS_F16, GS_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH = 0, 1, 2, 3
 GS_MAX_TAPS = 64
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 
 class GsConvGeom(ctypes.Structure):
@@ -102,6 +102,12 @@ PROTOTYPES = {
     "gs_dice_loss_fwd": (c_int, [_F, _F, c_int64, _F, _F, c_void_p]),
     "gs_dice_loss_bwd": (c_int, [_F, _F, _F, _F, c_int64, c_void_p]),
     "gs_mean_loss_fwd": (c_int, [_F, _F, c_float, c_int, c_int64, _F, _F, c_void_p]),
+    "gs_pack_weight_split": (c_int, [_F, _P, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "gs_conv3x3_precise": (c_int, [_P, _P, _P, _P, _F, _F] + [c_int] * 10 + [POINTER(c_int32), POINTER(c_int32), c_int, c_int, c_void_p]),
+    "gs_upconv2x2_fwd_precise": (c_int, [_P, _P, _F, _P, _P] + [c_int] * 15 + [c_void_p]),
+    "gs_conv_smallcin_fwd_split": (c_int, [_F, _F, _P, _P, _F] + [c_int] * 8 + [c_void_p]),
+    "gs_bn_act_apply_split": (c_int, [_P, _P, _F, _F, c_int, _P, _P, c_int, c_int, _P, _P] + [c_int] * 6 + [c_void_p]),
+    "gs_head1x1_fwd_split": (c_int, [_P, _P, _F, _F, _F] + [c_int] * 6 + [c_void_p]),
     "gs_mean_loss_bwd": (c_int, [_F, _F, c_float, c_int, c_int64, _F, c_float, _F, c_void_p]),
 }
 

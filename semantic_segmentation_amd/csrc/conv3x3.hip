@@ -33,6 +33,11 @@ struct C3Args {
     // 3-D (3x3x3) convolution: images are the N = volumes*D depth slices; stage (dz index, channel chunk) reads slice
     // n + tap_dz and the weight slots [dzi*9 .. dzi*9+8].  2-D: D = 1, ndz = 1, tap_dz = {0}.
     int D, ndz, tap_dz[3];
+    // precise mode (conv3x3_big_kernel<.., PREC>): the K extent Cin is a concatenation of segments over the same input
+    // channels -- K chunk c reads input chunk (c >= in_wrap ? c - in_wrap : c) -- and the result is stored as a 16-bit
+    // hi/lo pair: hi at y, lo = 16-bit(value - hi) at y_lo (same stride / offset).
+    unsigned short* y_lo;
+    int in_wrap;                  // in 64-channel chunks; 0 = no wrap
 };
 
 __device__ __forceinline__ int xcd_remap3(int bid, int nwg) {
@@ -539,8 +544,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_persist_kernel(const C3Args a)
 // the wave while the NEXT (patch, chunk) is prefetched into registers (29 x 16 B per lane).  N tile = 64 couts.
 // Modelled on wgrad3x3_kernel, which reaches ~1 PFLOP/s with 72 MFMAs per barrier pair.
 // ---------------------------------------------------------------------------------------------------
-template <int DT, int TW, bool WRES>
+template <int DT, int TW, bool WRES, bool PREC = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
+    static_assert(!(WRES && PREC), "the precise mode has at least two K segments: weights cannot stay resident");
     typedef typename Elem<DT>::V8 V8;
     constexpr int BN = 64, BM = 256;
     constexpr int TH = BM / TW;
@@ -625,8 +631,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
         const int d = a.D > 1 ? n % a.D : 0;
         r.n = n + dz;
         r.kill = ((unsigned)(d + dz) < (unsigned)a.D) ? 0u : VOOB;
-        r.sc = (unsigned)c * 128u;                                // 64 channels x 2 bytes per chunk
-        r.wsc = r.sc + (unsigned)(dzi * 9) * tap_stride_c;
+        int cx = c;                                               // input chunk of K chunk c
+        if (PREC && a.in_wrap > 0 && c >= a.in_wrap) cx = c - a.in_wrap;
+        r.sc = (unsigned)cx * 128u;                               // 64 channels x 2 bytes per chunk
+        r.wsc = (unsigned)c * 128u + (unsigned)(dzi * 9) * tap_stride_c;
         r.ckill = (c * 64 + chunk * 8 < a.Cin) ? 0u : VOOB;       // Cin % 64 != 0: the tail chunk is zero padded
         return r;
     };
@@ -677,9 +685,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
     };
 
     // ---- epilogue (same scheme as conv3x3_persist_kernel, N tile = 64) ----
-    static_assert(4 * STG_EL + 4 * 2 * BN * 2 <= HALO_EL, "epilogue staging must fit in the halo region");
+    static_assert((PREC ? 8 : 4) * STG_EL + 4 * 2 * BN * 2 <= HALO_EL, "epilogue staging must fit in the halo region");
     unsigned short* stg = halo + wave * STG_EL;                   // staging overlays the consumed halo (the weights
     float* red = reinterpret_cast<float*>(halo + 4 * STG_EL);     // may be resident); red = [4 waves][2][64]
+    unsigned short* stg_lo = halo + 4 * STG_EL + 4 * 2 * BN * 2 + wave * STG_EL;      // PREC: the lo halves
     const bool odd = lane & 1;
     const unsigned int psel = odd ? 0x03020706u : 0x05040100u;
     const float neg_slope = act == GS_ACT_RELU ? 0.f : (act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
@@ -693,6 +702,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
         asm volatile("" : "+s"(e_y0), "+s"(e_x0), "+s"(e_n), "+s"(e_n0));
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(a.y + (int64_t)e_n * a.H * a.W * a.out_stride), 0, (unsigned)a.H * a.W * a.out_stride * 2u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ry_lo = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((PREC ? a.y_lo : a.y) + (int64_t)e_n * a.H * a.W * a.out_stride), 0,
+            (unsigned)a.H * a.W * a.out_stride * 2u, 0x00020000);
         float bv[2] = {0.f, 0.f};
         if (!PLAIN) {
 #pragma unroll
@@ -742,6 +754,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
                     const unsigned int pk = __builtin_amdgcn_perm(oth, own, psel);
                     const int row = rowa + (odd ? 1 : 0);
                     *reinterpret_cast<unsigned int*>(stg + row * C3_LDR + j * 32 + (l31 & ~1)) = pk;
+                    if (PREC) {                               // lo = 16-bit(value - hi): the pair carries ~22 bits
+                        const float l0 = v0 - Elem<DT>::to_f((unsigned short)(own & 0xffffu));
+                        const float l1 = v1 - Elem<DT>::to_f((unsigned short)(own >> 16));
+                        const unsigned int own_l = Elem<DT>::pack2(l0, l1);
+                        const unsigned int oth_l = dpp_xor1(own_l);
+                        const unsigned int pk_l = __builtin_amdgcn_perm(oth_l, own_l, psel);
+                        *reinterpret_cast<unsigned int*>(stg_lo + row * C3_LDR + j * 32 + (l31 & ~1)) = pk_l;
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -762,6 +782,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
                 u32x4 d;
                 d[0] = sv[q].x; d[1] = sv[q].y; d[2] = sv[q].z; d[3] = sv[q].w;
                 __builtin_amdgcn_raw_buffer_store_b128(d, ry, off, 0, 0);
+                if (PREC) {
+                    const uint4 lv = *reinterpret_cast<const uint4*>(stg_lo + (q * 8 + (lane >> 3)) * C3_LDR + (lane & 7) * 8);
+                    u32x4 dl;
+                    dl[0] = lv.x; dl[1] = lv.y; dl[2] = lv.z; dl[3] = lv.w;
+                    __builtin_amdgcn_raw_buffer_store_b128(dl, ry_lo, off, 0, 0);
+                }
             }
             __builtin_amdgcn_wave_barrier();
             PH(9 + 2 * i);
@@ -988,10 +1014,14 @@ extern "C" int gs_conv3x3_mtiles(int N, int H, int W, int Cout) {
 static int conv3x3_launch(const void* x, const void* w, void* y, const float* bias, float* bn_partials, int N, int H,
                           int W, int Cin, int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff,
                           const int32_t* tap_dy, const int32_t* tap_dx, int act, int dtype, void* stream, int D, int ndz,
-                          const int32_t* tap_dz) {
+                          const int32_t* tap_dz, void* y_lo = nullptr, int in_wrap = 0) {
     GS_CHECK_ARG(x && w && y && tap_dy && tap_dx, "gs_conv3x3: null pointer");
     GS_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0 && Cout > 0, "gs_conv3x3: bad dims");
-    GS_CHECK_ARG(in_pix_stride >= in_coff + Cin && in_pix_stride % 8 == 0 && in_coff % 8 == 0, "gs_conv3x3: bad input stride");
+    const bool prec = y_lo != nullptr;
+    // precise mode: Cin is the K extent (segments x channels); the input holds in_wrap channels
+    GS_CHECK_ARG(!prec || (in_wrap > 0 && in_wrap % 64 == 0 && Cin % 64 == 0 && Cin > in_wrap && Cin <= 2 * in_wrap && ndz == 1),
+                 "gs_conv3x3_precise: K extent %d / wrap %d must be multiples of 64 with wrap < K <= 2*wrap", Cin, in_wrap);
+    GS_CHECK_ARG(in_pix_stride >= in_coff + (prec ? in_wrap : Cin) && in_pix_stride % 8 == 0 && in_coff % 8 == 0, "gs_conv3x3: bad input stride");
     GS_CHECK_ARG(out_pix_stride >= out_coff + Cout, "gs_conv3x3: bad output stride");
     GS_CHECK_ARG((int64_t)N * H * W < 2147483000LL, "gs_conv3x3: pixel count exceeds int32");
     GS_CHECK_ARG((int64_t)H * W * in_pix_stride * 2 < 4294967000LL && (int64_t)9 * Cout * Cin * 2 < 4294967000LL,
@@ -1011,6 +1041,7 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
         a.tap_dy[i] = tap_dy[i]; a.tap_dx[i] = tap_dx[i];
     }
     a.D = D; a.ndz = ndz;
+    a.y_lo = (unsigned short*)y_lo; a.in_wrap = in_wrap / 64;
     for (int i = 0; i < 3; ++i) a.tap_dz[i] = (tap_dz && i < ndz) ? tap_dz[i] : 0;
     const C3Plan p = c3_plan(H, W, Cout);
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y;
@@ -1031,6 +1062,17 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
         dim3 bgrid(a.nblocks < big_blocks ? a.nblocks : big_blocks);
         hipStream_t bs = (hipStream_t)stream;
         const bool wres = (Cin <= 64 && a.ntn == 1 && ndz == 1);   // one stage, one N tile: weights stay resident in LDS
+        if (prec) {
+            if (dtype == GS_F16) {
+                if (tw == 32) conv3x3_big_kernel<GS_F16, 32, false, true><<<bgrid, 256, 0, bs>>>(a);
+                else conv3x3_big_kernel<GS_F16, 16, false, true><<<bgrid, 256, 0, bs>>>(a);
+            } else {
+                if (tw == 32) conv3x3_big_kernel<GS_BF16, 32, false, true><<<bgrid, 256, 0, bs>>>(a);
+                else conv3x3_big_kernel<GS_BF16, 16, false, true><<<bgrid, 256, 0, bs>>>(a);
+            }
+            GS_CHECK_LAUNCH("gs_conv3x3_precise");
+            return GS_OK;
+        }
         if (dtype == GS_F16) {
             if (wres) {
                 if (tw == 32) conv3x3_big_kernel<GS_F16, 32, true><<<bgrid, 256, 0, bs>>>(a);
@@ -1051,6 +1093,7 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
         GS_CHECK_LAUNCH("gs_conv3x3");
         return GS_OK;
     }
+    GS_CHECK_ARG(!prec, "gs_conv3x3_precise: needs the big-K-step kernel (GSSEG_C3=2, Cout %% 8 == 0, 16-byte aligned output channels)");
     static const bool force_v1 = c3_variant() == 0;
     // the persistent kernel stores whole 16-byte channel groups; odd shapes go to the one-patch-per-block kernel
     const bool use_v1 = force_v1 || (Cout % 8) != 0 || (out_pix_stride % 8) != 0 || (out_coff % 8) != 0;
@@ -1096,6 +1139,20 @@ extern "C" int gs_conv3x3(const void* x, const void* w, void* y, const float* bi
                           const int32_t* tap_dy, const int32_t* tap_dx, int act, int dtype, void* stream) {
     return conv3x3_launch(x, w, y, bias, bn_partials, N, H, W, Cin, in_pix_stride, in_coff, Cout, out_pix_stride, out_coff,
                           tap_dy, tap_dx, act, dtype, stream, 1, 1, nullptr);
+}
+
+// Precise-mode 3x3 convolution (U-Net forward with hi/lo 16-bit pairs): x holds `in_wrap` channels per
+// pixel -- the [hi | lo] planes of the activation, or one plane -- and the weight pack [9][Cout][K] is the matching
+// concatenation of segments ([w_hi | w_hi | w_lo] against [x_hi | x_lo | x_hi]): K chunk c reads input chunk c mod in_wrap.
+// All products are accumulated in the same fp32 MFMA accumulators; the result leaves as a pair y_hi = 16-bit(v),
+// y_lo = 16-bit(v - y_hi) (same stride / offset for both).  BatchNorm partials as gs_conv3x3.
+extern "C" int gs_conv3x3_precise(const void* x, const void* w, void* y_hi, void* y_lo, const float* bias, float* bn_partials,
+                                  int N, int H, int W, int K, int in_pix_stride, int in_coff, int in_wrap, int Cout,
+                                  int out_pix_stride, int out_coff, const int32_t* tap_dy, const int32_t* tap_dx, int act,
+                                  int dtype, void* stream) {
+    GS_CHECK_ARG(y_lo != nullptr, "gs_conv3x3_precise: y_lo is NULL");
+    return conv3x3_launch(x, w, y_hi, bias, bn_partials, N, H, W, K, in_pix_stride, in_coff, Cout, out_pix_stride, out_coff,
+                          tap_dy, tap_dx, act, dtype, stream, 1, 1, nullptr, y_lo, in_wrap);
 }
 
 // 3x3x3 / stride 1 / pad 1 Conv3d (GenSeg-3D/UNet3D/unet3d.py:28-31,69-71) and its data gradient on the same halo-reuse

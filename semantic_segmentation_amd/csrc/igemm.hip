@@ -39,6 +39,11 @@ struct IgemmArgs {
     int ksplit;
     float* ws_acc;
     unsigned int* ws_cnt;
+    // precise mode (igemm_fwd_kernel<.., PREC>): K = g.Cin is a concatenation of segments over `in_wrap` input channels
+    // (K channel ci reads input channel ci >= in_wrap ? ci - in_wrap : ci); the result is stored as a 16-bit hi/lo pair
+    // (hi at y, lo = 16-bit(value - hi) at y_lo, same stride / offset).
+    unsigned short* y_lo = nullptr;
+    int in_wrap = 0;
 };
 
 // bijective XCD-aware remap: blocks that share an XCD (bid % 8) get a contiguous range of logical ids
@@ -50,8 +55,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 constexpr int FW_BM = 128, FW_BK = 64, FW_LDR = 72;   // LDS row = 64 + 8 pad elements (144 B)
 
-template <int DT, int BN, bool PACKED>
+template <int DT, int BN, bool PACKED, bool PREC = false>
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
+    static_assert(!(PACKED && PREC), "no precise form of the packed-tap kernel");
     typedef typename Elem<DT>::V8 V8;
     constexpr int NT = BN / 64;            // 32-wide N tiles per wave
     constexpr int BROWS = BN / 32;         // B rows staged per thread
@@ -134,6 +140,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
         }
         const int tap = act_taps[1 + ti];
         const int dy = g.tap_dy[tap], dx = g.tap_dx[tap], dz = g.tap_dz[tap];
+        const int cix = (PREC && a.in_wrap > 0 && ci >= a.in_wrap) ? ci - a.in_wrap : ci;     // input channel of K channel ci
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
             uint4 v = make_uint4(0, 0, 0, 0);
             if (ok) {
                 const int64_t pix = ((int64_t)(a_n[j] + dz) * g.IH + iy) * g.IW + ix;
-                v = *reinterpret_cast<const uint4*>(a.x + pix * g.in_pix_stride + g.in_coff + ci);
+                v = *reinterpret_cast<const uint4*>(a.x + pix * g.in_pix_stride + g.in_coff + cix);
             }
             ra[j] = v;
         }
@@ -321,13 +328,18 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
         unsigned short* stg = smem + 2048 + wave * (32 * STG_LD);     // behind rowpix / red
         const int ohw_out = g.OH * g.OW;
 #pragma unroll
+        for (int pass = 0; pass < (PREC ? 2 : 1); ++pass) {           // PREC pass 1: the lo halves, acc -= hi first
+        unsigned short* ydst = (PREC && pass == 1) ? a.y_lo : a.y;
+#pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    stg[row * STG_LD + j * 32 + l31] = Elem<DT>::from_f(acc[i][j][r]);
+                    const unsigned short q16 = Elem<DT>::from_f(acc[i][j][r]);
+                    stg[row * STG_LD + j * 32 + l31] = q16;
+                    if (PREC && pass == 0) acc[i][j][r] -= Elem<DT>::to_f(q16);
                 }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -343,10 +355,11 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
                         co -= cls * a.shuffle_cout;
                         p += (cls & 1) + ((cls >> 1) & 1) * g.OW + (a.shuffle_cls == 8 ? (cls >> 2) * ohw_out : 0);
                     }
-                    *reinterpret_cast<uint4*>(a.y + (int64_t)p * g.out_pix_stride + g.out_coff + co) = v;
+                    *reinterpret_cast<uint4*>(ydst + (int64_t)p * g.out_pix_stride + g.out_coff + co) = v;
                 }
             }
             __builtin_amdgcn_wave_barrier();
+        }
         }
     } else {
 #pragma unroll
@@ -635,6 +648,18 @@ static int launch_igemm(IgemmArgs& a, int dtype, hipStream_t s, const char* who,
         }
     }
     dim3 grid(a.nblocks * a.ksplit), block(256);
+    if (a.y_lo != nullptr) {                      // precise mode: hi/lo output pair, K segments over wrapped input channels
+        GS_CHECK_ARG(!packed && a.ksplit == 1 && a.vec_store && a.bnp == nullptr, "%s: precise mode needs 16-byte stores, no split-K", who);
+        if (dtype == GS_F16) {
+            if (bn == 64) igemm_fwd_kernel<GS_F16, 64, false, true><<<grid, block, 0, s>>>(a);
+            else igemm_fwd_kernel<GS_F16, 128, false, true><<<grid, block, 0, s>>>(a);
+        } else {
+            if (bn == 64) igemm_fwd_kernel<GS_BF16, 64, false, true><<<grid, block, 0, s>>>(a);
+            else igemm_fwd_kernel<GS_BF16, 128, false, true><<<grid, block, 0, s>>>(a);
+        }
+        GS_CHECK_LAUNCH(who);
+        return GS_OK;
+    }
     if (packed) {
         if (dtype == GS_F16) {
             if (bn == 64) igemm_fwd_kernel<GS_F16, 64, true><<<grid, block, 0, s>>>(a);
@@ -694,10 +719,35 @@ extern "C" int64_t gs_conv_igemm_workspace_floats(void) {
 // the input is read once instead of once per sub-pixel class.
 //   x  [N*D, IH, IW, Cin] 16-bit NHWC (strided);  w = gs_pack_weight slots [ncls][Cout][Cin], slot = (kz*2+ky)*2+kx
 //   y  [N*Dout, OH, OW, *] : voxel (2z+kz+ooz, 2y+ky+ooy, 2x+kx+oox), channels out_coff..out_coff+Cout
+static int upconv2x2_impl(const void* x, const void* w, const float* bias, void* y, void* y_lo, int in_wrap, int N, int D,
+                          int IH, int IW, int Cin, int in_pix_stride, int in_coff, int Cout, int Dout, int OH, int OW,
+                          int out_pix_stride, int out_coff, int ooz, int ooy, int oox, int act, int dtype, void* stream);
+
 extern "C" int gs_upconv2x2_fwd(const void* x, const void* w, const float* bias, void* y, int N, int D, int IH, int IW,
                                 int Cin, int in_pix_stride, int in_coff, int Cout, int Dout, int OH, int OW,
                                 int out_pix_stride, int out_coff, int ooz, int ooy, int oox, int act, int dtype,
                                 void* stream) {
+    return upconv2x2_impl(x, w, bias, y, nullptr, 0, N, D, IH, IW, Cin, in_pix_stride, in_coff, Cout, Dout, OH, OW,
+                          out_pix_stride, out_coff, ooz, ooy, oox, act, dtype, stream);
+}
+
+// Precise-mode form: x holds `in_wrap` channels per pixel (the [hi | lo] planes of the activation), w is
+// the [ncls][Cout][K] pack of matching segments ([w_hi | w_hi | w_lo]), K channel ci reads input channel ci mod in_wrap;
+// the up-sampled tensor leaves as the pair y_hi / y_lo (same stride and offset).
+extern "C" int gs_upconv2x2_fwd_precise(const void* x, const void* w, const float* bias, void* y_hi, void* y_lo, int N,
+                                        int IH, int IW, int K, int in_pix_stride, int in_coff, int in_wrap, int Cout,
+                                        int OH, int OW, int out_pix_stride, int out_coff, int ooy, int oox, int dtype,
+                                        void* stream) {
+    GS_CHECK_ARG(y_lo != nullptr && in_wrap > 0 && in_wrap % 8 == 0 && K > in_wrap && K <= 2 * in_wrap,
+                 "gs_upconv2x2_fwd_precise: need y_lo and in_wrap < K <= 2*in_wrap");
+    GS_CHECK_ARG(in_pix_stride >= in_coff + in_wrap, "gs_upconv2x2_fwd_precise: input stride smaller than the wrapped planes");
+    return upconv2x2_impl(x, w, bias, y_hi, y_lo, in_wrap, N, 1, IH, IW, K, in_pix_stride, in_coff, Cout, 1, OH, OW,
+                          out_pix_stride, out_coff, 0, ooy, oox, GS_ACT_NONE, dtype, stream);
+}
+
+static int upconv2x2_impl(const void* x, const void* w, const float* bias, void* y, void* y_lo, int in_wrap, int N, int D,
+                          int IH, int IW, int Cin, int in_pix_stride, int in_coff, int Cout, int Dout, int OH, int OW,
+                          int out_pix_stride, int out_coff, int ooz, int ooy, int oox, int act, int dtype, void* stream) {
     GS_CHECK_ARG(x && w && y, "gs_upconv2x2_fwd: null pointer");
     GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_upconv2x2_fwd: bad dtype %d", dtype);
     GS_CHECK_ARG(D >= 1 && Dout >= 1, "gs_upconv2x2_fwd: bad depth");
@@ -720,6 +770,7 @@ extern "C" int gs_upconv2x2_fwd(const void* x, const void* w, const float* bias,
     {
         GsConvGeom c = g;
         c.OH = OH + 1; c.OW = OW + 1; c.Dout = Dout + 1;      // the +1 sub-pixel is checked explicitly above
+        if (in_wrap > 0) c.Cin = in_wrap;                     // precise mode: the input holds in_wrap channels, K = Cin wraps
         int rc = check_geom(&c, "gs_upconv2x2_fwd");
         if (rc) return rc;
     }
@@ -731,6 +782,7 @@ extern "C" int gs_upconv2x2_fwd(const void* x, const void* w, const float* bias,
     a.M = N * D * IH * IW;
     a.kchunks = cdiv(Cin, FW_BK);
     a.vec_store = 1; a.shuffle_cout = Cout; a.shuffle_cls = ncls;
+    a.y_lo = (unsigned short*)y_lo; a.in_wrap = in_wrap;
     return launch_igemm(a, dtype, (hipStream_t)stream, "gs_upconv2x2_fwd");
 }
 

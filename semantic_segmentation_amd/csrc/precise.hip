@@ -1,0 +1,314 @@
+// Precise mode of the U-Net forward: activations and weights travel as PAIRS of 16-bit values
+// v = hi + lo (hi = 16-bit(v), lo = 16-bit(v - hi): ~22 significand bits for fp16), the MFMA contractions run over the K
+// concatenation [x_hi | x_lo | x_hi] . [w_hi | w_hi | w_lo] (every product exact, one fp32 accumulator) -- conv3x3.hip /
+// igemm.hip carry those; this file holds the memory-bound kernels around them:
+//   gs_pack_weight_split      fp32 conv / transposed-conv weight -> [taps][Cout][3*Cin] segment pack
+//   gs_conv_smallcin_fwd_split  the 1..4-channel first conv (unet_parts.py:16), fp32 image and weights -> y pair
+//   gs_bn_act_apply_split     z = act(bn(y_hi + y_lo)) -> z pair (+ 2x2 max-pooled pair), unet_parts.py:17-18,20-21,34
+//   gs_head1x1_fwd_split      OutConv (unet_parts.py:74) reading the z pair
+// Opt-in (UNet(..., precise=True)); the default engine stores single 16-bit values.
+#include "common.hpp"
+
+namespace {
+
+template <int DT>
+__device__ __forceinline__ void split8(const float (&v)[8], uint4& hi, uint4& lo) {
+    hi = pack8<DT>(v);
+    float h[8], l[8];
+    unpack8<DT>(hi, h);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) l[i] = v[i] - h[i];
+    lo = pack8<DT>(l);
+}
+
+template <int DT>
+__device__ __forceinline__ void join8(const uint4& hi, const uint4& lo, float (&v)[8]) {
+    float l[8];
+    unpack8<DT>(hi, v);
+    unpack8<DT>(lo, l);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += l[i];
+}
+
+// ---- weight pack ------------------------------------------------------------------------------------------------
+// conv (transposed == 0): w fp32 [Cout][Cin][taps]  -> out[t][co][s*Cin + ci]
+// convT (transposed == 1): w fp32 [Cin][Cout][taps] -> out[t][co][s*Cin + ci]
+// segment s: 0, 1 -> hi(w), 2 -> lo(w)
+template <int DT>
+__global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
+                                                         int Cout, int Cin, int taps, int transposed) {
+    const int64_t total = (int64_t)taps * Cout * Cin;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ci = (int)(i % Cin);
+        const int64_t r = i / Cin;
+        const int co = (int)(r % Cout), t = (int)(r / Cout);
+        const float v = transposed ? w[((int64_t)ci * Cout + co) * taps + t] : w[((int64_t)co * Cin + ci) * taps + t];
+        const unsigned short hi = Elem<DT>::from_f(v);
+        const unsigned short lo = Elem<DT>::from_f(v - Elem<DT>::to_f(hi));
+        unsigned short* o = out + ((int64_t)t * Cout + co) * 3 * Cin + ci;
+        o[0] = hi; o[Cin] = hi; o[2 * Cin] = lo;
+    }
+}
+
+// ---- first conv: fp32 NCHW image, fp32 weights, VALU; one thread per (pixel, 8-channel chunk) ----------------------
+constexpr int SCP_TILE = 1024;      // output pixels per block = per BatchNorm tile (== gs_conv_smallcin_mtiles)
+constexpr int SCP_MAX_W = 8192;
+
+struct SCPArgs {
+    const float* x; const float* w; unsigned short* y_hi; unsigned short* y_lo; float* bnp;
+    int N, Cin, H, W, Cout, k, pad;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void smallcin_split_kernel(const SCPArgs a) {
+    __shared__ float wl[SCP_MAX_W];            // [tap][Cout]
+    __shared__ float red[2][256][8];
+    const int T = a.Cin * a.k * a.k;
+    for (int i = threadIdx.x; i < T * a.Cout; i += 256) {
+        const int co = i % a.Cout, tap = i / a.Cout;
+        wl[i] = a.w[(int64_t)co * T + tap];
+    }
+    __syncthreads();
+    const int nch = a.Cout >> 3;
+    const int lanes = 256 / nch;
+    const int ch = threadIdx.x % nch, pl = threadIdx.x / nch;
+    const int64_t M = (int64_t)a.N * a.H * a.W;
+    const int64_t m0 = (int64_t)blockIdx.x * SCP_TILE;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+    if (pl < lanes) {
+        for (int p = pl; p < SCP_TILE; p += lanes) {
+            const int64_t m = m0 + p;
+            if (m >= M) break;
+            const int ox = (int)(m % a.W);
+            const int64_t r = m / a.W;
+            const int oy = (int)(r % a.H);
+            const int n = (int)(r / a.H);
+            float acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+            int tap = 0;
+            for (int ci = 0; ci < a.Cin; ++ci)
+                for (int ky = 0; ky < a.k; ++ky)
+                    for (int kx = 0; kx < a.k; ++kx, ++tap) {
+                        const int iy = oy - a.pad + ky, ix = ox - a.pad + kx;
+                        float xv = 0.f;
+                        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                            xv = a.x[(((int64_t)n * a.Cin + ci) * a.H + iy) * a.W + ix];
+                        const float* wp = wl + tap * a.Cout + ch * 8;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc[i] += xv * wp[i];
+                    }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s1[i] += acc[i]; s2[i] += acc[i] * acc[i]; }
+            uint4 hi, lo;
+            split8<DT>(acc, hi, lo);
+            *reinterpret_cast<uint4*>(a.y_hi + m * a.Cout + ch * 8) = hi;
+            *reinterpret_cast<uint4*>(a.y_lo + m * a.Cout + ch * 8) = lo;
+        }
+    }
+    if (a.bnp) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { red[0][threadIdx.x][i] = s1[i]; red[1][threadIdx.x][i] = s2[i]; }
+        __syncthreads();
+        if (pl == 0) {
+            float t1[8], t2[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { t1[i] = 0.f; t2[i] = 0.f; }
+            for (int q = 0; q < lanes; ++q)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { t1[i] += red[0][q * nch + ch][i]; t2[i] += red[1][q * nch + ch][i]; }
+            float* dst = a.bnp + (int64_t)blockIdx.x * 2 * a.Cout + ch * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { dst[i] = t1[i]; dst[a.Cout + i] = t2[i]; }
+        }
+    }
+}
+
+// ---- BatchNorm apply + activation (+ 2x2 max-pool) on pairs ---------------------------------------------------------
+struct ApplySArgs {
+    const unsigned short* y_hi; const unsigned short* y_lo;
+    const float* scale; const float* shift;
+    unsigned short* z_hi; unsigned short* z_lo;       // both with (zs, zc)
+    unsigned short* zp_hi; unsigned short* zp_lo;     // pooled pair, both with pixel stride zps (channel offset 0)
+    int act, N, H, W, C, zs, zc, zps;
+};
+
+template <int DT, bool POOL>
+__global__ __launch_bounds__(256) void bn_act_apply_split_kernel(const ApplySArgs a) {
+    const float slope = a.act == GS_ACT_RELU ? 0.f : (a.act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
+    const int nch = a.C >> 3;
+    const int PH = POOL ? (a.H + 1) / 2 : a.H, PW = POOL ? (a.W + 1) / 2 : a.W;
+    const int64_t total = (int64_t)a.N * PH * PW * nch;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % nch);
+        int64_t pidx = idx / nch;
+        const int px = (int)(pidx % PW); pidx /= PW;
+        const int py = (int)(pidx % PH);
+        const int n = (int)(pidx / PH);
+        const int c0 = ch * 8;
+        float sc[8], sh[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { sc[i] = a.scale ? a.scale[c0 + i] : 1.f; sh[i] = a.shift ? a.shift[c0 + i] : 0.f; }
+        float mx[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mx[i] = -INFINITY;
+#pragma unroll
+        for (int dy = 0; dy < (POOL ? 2 : 1); ++dy)
+#pragma unroll
+            for (int dx = 0; dx < (POOL ? 2 : 1); ++dx) {
+                const int yy = POOL ? 2 * py + dy : py, xx = POOL ? 2 * px + dx : px;
+                if (yy < a.H && xx < a.W) {
+                    const int64_t pix = ((int64_t)n * a.H + yy) * a.W + xx;
+                    float v[8];
+                    join8<DT>(*reinterpret_cast<const uint4*>(a.y_hi + pix * a.C + c0),
+                              *reinterpret_cast<const uint4*>(a.y_lo + pix * a.C + c0), v);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float u = v[i] * sc[i] + sh[i];
+                        v[i] = u > 0.f ? u : u * slope;
+                    }
+                    uint4 hi, lo;
+                    split8<DT>(v, hi, lo);
+                    *reinterpret_cast<uint4*>(a.z_hi + pix * a.zs + a.zc + c0) = hi;
+                    *reinterpret_cast<uint4*>(a.z_lo + pix * a.zs + a.zc + c0) = lo;
+                    if (POOL) {
+                        float r[8];                          // pool the STORED pair values
+                        join8<DT>(hi, lo, r);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) mx[i] = fmaxf(mx[i], r[i]);
+                    }
+                }
+            }
+        if (POOL && py < a.H / 2 && px < a.W / 2) {
+            const int64_t pp = ((int64_t)n * (a.H / 2) + py) * (a.W / 2) + px;
+            uint4 hi, lo;
+            split8<DT>(mx, hi, lo);
+            *reinterpret_cast<uint4*>(a.zp_hi + pp * a.zps + c0) = hi;
+            *reinterpret_cast<uint4*>(a.zp_lo + pp * a.zps + c0) = lo;
+        }
+    }
+}
+
+// ---- pointwise head, Cin == 64, on a pair of dense inputs: 8 lanes per pixel ---------------------------------------
+struct HeadSArgs {
+    const unsigned short* x_hi; const unsigned short* x_lo; const float* w; const float* bias; float* y;
+    int N, HW, Cout;
+};
+
+__device__ __forceinline__ float sum8_dpp_p(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    return v;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void head1x1_split_kernel(const HeadSArgs a) {
+    const int ch = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    float w[4][8], bv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        bv[c] = (c < a.Cout && a.bias) ? a.bias[c] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[c][i] = c < a.Cout ? a.w[c * 64 + ch * 8 + i] : 0.f;
+    }
+    const int M = a.N * a.HW;
+    for (int m = blockIdx.x * 32 + pl; m < M; m += gridDim.x * 32) {
+        float v[8], s[4];
+        join8<DT>(*reinterpret_cast<const uint4*>(a.x_hi + (int64_t)m * 64 + ch * 8),
+                  *reinterpret_cast<const uint4*>(a.x_lo + (int64_t)m * 64 + ch * 8), v);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t += v[i] * w[c][i];
+            s[c] = sum8_dpp_p(t);
+        }
+        if (ch == 0) {
+            const int n = m / a.HW, hw = m - n * a.HW;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < a.Cout) a.y[((int64_t)n * a.Cout + c) * a.HW + hw] = s[c] + bv[c];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int gs_pack_weight_split(const float* w, void* pack, int Cout, int Cin, int taps, int transposed, int dtype,
+                                    void* stream) {
+    GS_CHECK_ARG(w && pack && Cout > 0 && Cin > 0 && taps > 0, "gs_pack_weight_split: bad arguments");
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_pack_weight_split: bad dtype");
+    const int64_t total = (int64_t)taps * Cout * Cin;
+    int64_t nb = cdiv64(total, 256);
+    if (nb > 4096) nb = 4096;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GS_F16) pack_split_kernel<GS_F16><<<(int)nb, 256, 0, s>>>(w, (unsigned short*)pack, Cout, Cin, taps, transposed);
+    else pack_split_kernel<GS_BF16><<<(int)nb, 256, 0, s>>>(w, (unsigned short*)pack, Cout, Cin, taps, transposed);
+    GS_CHECK_LAUNCH("gs_pack_weight_split");
+    return GS_OK;
+}
+
+extern "C" int gs_conv_smallcin_fwd_split(const float* x, const float* w, void* y_hi, void* y_lo, float* bn_partials, int N,
+                                          int Cin, int H, int W, int Cout, int k, int pad, int dtype, void* stream) {
+    GS_CHECK_ARG(x && w && y_hi && y_lo, "gs_conv_smallcin_fwd_split: null pointer");
+    GS_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin >= 1 && Cin <= 4 && k >= 1 && 2 * pad == k - 1,
+                 "gs_conv_smallcin_fwd_split: stride-1 'same' convolutions of 1..4 channels only");
+    GS_CHECK_ARG(Cout % 8 == 0 && Cout >= 8 && Cout <= 256 && (256 % (Cout / 8)) == 0 && Cin * k * k * Cout <= SCP_MAX_W,
+                 "gs_conv_smallcin_fwd_split: Cout=%d not supported", Cout);
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_conv_smallcin_fwd_split: bad dtype");
+    SCPArgs a{x, w, (unsigned short*)y_hi, (unsigned short*)y_lo, bn_partials, N, Cin, H, W, Cout, k, pad};
+    const int nb = (int)cdiv64((int64_t)N * H * W, SCP_TILE);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GS_F16) smallcin_split_kernel<GS_F16><<<nb, 256, 0, s>>>(a);
+    else smallcin_split_kernel<GS_BF16><<<nb, 256, 0, s>>>(a);
+    GS_CHECK_LAUNCH("gs_conv_smallcin_fwd_split");
+    return GS_OK;
+}
+
+extern "C" int gs_bn_act_apply_split(const void* y_hi, const void* y_lo, const float* scale, const float* shift, int act,
+                                     void* z_hi, void* z_lo, int z_pix_stride, int z_coff, void* zp_hi, void* zp_lo,
+                                     int zp_pix_stride, int N, int H, int W, int C, int dtype, void* stream) {
+    GS_CHECK_ARG(y_hi && y_lo && z_hi && z_lo && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "gs_bn_act_apply_split: bad arguments");
+    GS_CHECK_ARG(z_pix_stride >= z_coff + C && z_pix_stride % 8 == 0 && z_coff % 8 == 0, "gs_bn_act_apply_split: bad z stride");
+    GS_CHECK_ARG((scale == nullptr) == (shift == nullptr), "gs_bn_act_apply_split: scale/shift must both be given or NULL");
+    GS_CHECK_ARG((zp_hi == nullptr) == (zp_lo == nullptr) && (zp_hi == nullptr || (zp_pix_stride >= C && zp_pix_stride % 8 == 0)),
+                 "gs_bn_act_apply_split: bad pooled output");
+    GS_CHECK_ARG(act == GS_ACT_NONE || act == GS_ACT_RELU || act == GS_ACT_LEAKY02, "gs_bn_act_apply_split: activation %d", act);
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_bn_act_apply_split: bad dtype");
+    ApplySArgs a{(const unsigned short*)y_hi, (const unsigned short*)y_lo, scale, shift, (unsigned short*)z_hi,
+                 (unsigned short*)z_lo, (unsigned short*)zp_hi, (unsigned short*)zp_lo, act, N, H, W, C, z_pix_stride, z_coff,
+                 zp_pix_stride};
+    const bool pool = zp_hi != nullptr;
+    const int PH = pool ? (H + 1) / 2 : H, PW = pool ? (W + 1) / 2 : W;
+    int64_t blocks = cdiv64((int64_t)N * PH * PW * (C / 8), 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GS_F16) {
+        if (pool) bn_act_apply_split_kernel<GS_F16, true><<<(int)blocks, 256, 0, s>>>(a);
+        else bn_act_apply_split_kernel<GS_F16, false><<<(int)blocks, 256, 0, s>>>(a);
+    } else {
+        if (pool) bn_act_apply_split_kernel<GS_BF16, true><<<(int)blocks, 256, 0, s>>>(a);
+        else bn_act_apply_split_kernel<GS_BF16, false><<<(int)blocks, 256, 0, s>>>(a);
+    }
+    GS_CHECK_LAUNCH("gs_bn_act_apply_split");
+    return GS_OK;
+}
+
+extern "C" int gs_head1x1_fwd_split(const void* x_hi, const void* x_lo, const float* w, const float* bias, float* y, int N,
+                                    int H, int W, int Cin, int Cout, int dtype, void* stream) {
+    GS_CHECK_ARG(x_hi && x_lo && w && y && N > 0 && H > 0 && W > 0, "gs_head1x1_fwd_split: bad arguments");
+    GS_CHECK_ARG(Cin == 64 && Cout >= 1 && Cout <= 4, "gs_head1x1_fwd_split: Cin must be 64 and Cout 1..4");
+    GS_CHECK_ARG((int64_t)N * H * W + 256 < 2147483647LL, "gs_head1x1_fwd_split: too many pixels");
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_head1x1_fwd_split: bad dtype");
+    HeadSArgs a{(const unsigned short*)x_hi, (const unsigned short*)x_lo, w, bias, y, N, H * W, Cout};
+    int64_t hb = cdiv64((int64_t)N * H * W, 32);
+    if (hb > 8192) hb = 8192;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GS_F16) head1x1_split_kernel<GS_F16><<<(int)hb, 256, 0, s>>>(a);
+    else head1x1_split_kernel<GS_BF16><<<(int)hb, 256, 0, s>>>(a);
+    GS_CHECK_LAUNCH("gs_head1x1_fwd_split");
+    return GS_OK;
+}

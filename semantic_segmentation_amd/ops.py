@@ -699,3 +699,91 @@ def mean_loss_fwd(x, t, cval, mode, ws, out):
 
 def mean_loss_bwd(x, t, cval, mode, gout, gscale, dx):
     _lib.call("gs_mean_loss_bwd", _p(x), _p(t), float(cval), mode, x.numel(), _p(gout), float(gscale), _p(dx), _stream())
+
+
+# ---------------------------------------------------------------------------- precise mode (hi/lo 16-bit pairs)
+# Tensors named *_hi / *_lo are the two planes of a pair; they may be channel slices of one buffer (the conv kernels
+# want [hi | lo] side by side: in_wrap = channels of both planes) or two dense tensors.  Strides are in elements.
+def pack_weight_split(w, pack, transposed: bool):
+    """fp32 conv weight [Cout][Cin][kh][kw] (transposed: [Cin][Cout][kh][kw]) -> pack [taps][Cout][3*Cin] = [hi | hi | lo]."""
+    _dev(w)
+    _f32(w, "w")
+    taps = w.shape[2] * w.shape[3]
+    cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+    if pack.numel() != taps * cout * 3 * cin or not pack.is_contiguous():
+        raise ValueError("pack_weight_split: pack must be contiguous [taps][Cout][3*Cin]")
+    _lib.call("gs_pack_weight_split", _p(w), _p(pack), cout, cin, taps, 1 if transposed else 0, dt_code(pack), _stream())
+
+
+def conv3x3_precise(x, w, y_hi, y_lo, N, H, W, Cin, Cout, in_stride, in_coff=0, out_stride=None, out_coff=0,
+                    bias=None, bn_partials=None, act=ACT_NONE, taps=TAPS3_FWD):
+    """3x3/s1/p1 convolution on pairs: x holds the [hi | lo] planes of Cin channels each (2*Cin consecutive channels at
+    in_coff), w = pack_weight_split pack [9][Cout][3*Cin]; the result leaves as y_hi / y_lo (same out_stride / out_coff)."""
+    _dev(x)
+    _f32(bias, "bias"); _f32(bn_partials, "bn_partials")
+    if not (x.dtype == w.dtype == y_hi.dtype == y_lo.dtype):
+        raise TypeError("conv3x3_precise: x, w, y must share one 16-bit dtype")
+    if Cin % 64 != 0 or w.numel() != 9 * Cout * 3 * Cin:
+        raise ValueError("conv3x3_precise: Cin must be a multiple of 64 and w the [9][Cout][3*Cin] split pack")
+    if bn_partials is not None and bn_partials.numel() < bn_partials_numel(conv3x3_mtiles(N, H, W, Cout), Cout):
+        raise ValueError("conv3x3_precise: bn_partials too small")
+    dy = (ctypes.c_int32 * 9)(*[t[0] for t in taps])
+    dx = (ctypes.c_int32 * 9)(*[t[1] for t in taps])
+    ev = TIMER.start() if TIMER is not None else None
+    _lib.call("gs_conv3x3_precise", _p(x), _p(w), _p(y_hi), _p(y_lo), _p(bias), _p(bn_partials), N, H, W, 3 * Cin,
+              in_stride, in_coff, 2 * Cin, Cout, Cout if out_stride is None else out_stride, out_coff, dy, dx, act,
+              dt_code(x), _stream())
+    if ev is not None:                       # algorithmic work of the convolution (the kernel executes 3x the MFMAs)
+        TIMER.stop("conv3x3_halo_precise", ev, 2.0 * N * H * W * Cout * 9 * Cin,
+                   2.0 * (N * H * W * 2 * (Cin + Cout) + 9 * 3 * Cin * Cout))
+
+
+def upconv2x2_fwd_precise(x, w, bias, y_hi, y_lo, N, IH, IW, Cin, Cout, OH, OW, in_stride, in_coff=0, out_stride=None,
+                          out_coff=0, ooy=0, oox=0):
+    """ConvTranspose2d(k 2, s 2) on pairs: x = [hi | lo] planes (2*Cin channels at in_coff), w = pack_weight_split(transposed)
+    [4][Cout][3*Cin]; output pair y_hi / y_lo (same stride / offset), e.g. the up half of both planes of a concat buffer."""
+    _dev(x)
+    _f32(bias, "bias")
+    if not (x.dtype == w.dtype == y_hi.dtype == y_lo.dtype):
+        raise TypeError("upconv2x2_fwd_precise: x, w, y must share one 16-bit dtype")
+    if w.numel() != 4 * Cout * 3 * Cin:
+        raise ValueError("upconv2x2_fwd_precise: w must be the [4][Cout][3*Cin] split pack")
+    ev = TIMER.start() if TIMER is not None else None
+    _lib.call("gs_upconv2x2_fwd_precise", _p(x), _p(w), _p(bias), _p(y_hi), _p(y_lo), N, IH, IW, 3 * Cin, in_stride,
+              in_coff, 2 * Cin, Cout, OH, OW, Cout if out_stride is None else out_stride, out_coff, ooy, oox,
+              dt_code(x), _stream())
+    if ev is not None:
+        TIMER.stop("igemm_fwd_precise", ev, 2.0 * N * IH * IW * Cin * 4 * Cout)
+
+
+def conv_smallcin_fwd_split(x, w, y_hi, y_lo, bn_partials, k, pad):
+    """First conv (fp32 NCHW image, fp32 weights, stride 1) -> dense pair y_hi / y_lo [N,H,W,Cout]."""
+    _dev(x)
+    _f32(x, "x"); _f32(w, "w"); _f32(bn_partials, "bn_partials")
+    N, Cin, H, W = x.shape
+    Cout = y_hi.shape[3]
+    if tuple(y_hi.shape) != (N, H, W, Cout) or y_lo.shape != y_hi.shape or not (y_hi.is_contiguous() and y_lo.is_contiguous()):
+        raise ValueError("conv_smallcin_fwd_split: y_hi / y_lo must be dense [N,H,W,Cout]")
+    _lib.call("gs_conv_smallcin_fwd_split", _p(x), _p(w), _p(y_hi), _p(y_lo), _p(bn_partials), N, Cin, H, W, Cout, k, pad,
+              dt_code(y_hi), _stream())
+
+
+def bn_act_apply_split(y_hi, y_lo, scale, shift, act, z_hi, z_lo, z_stride, z_coff, zp_hi=None, zp_lo=None, zp_stride=0):
+    """z pair = act(scale * (y_hi + y_lo) + shift); y_hi / y_lo dense [N,H,W,C]; optional 2x2 max-pooled pair."""
+    N, H, W, C = y_hi.shape
+    if not (y_hi.is_contiguous() and y_lo.is_contiguous()) or y_lo.shape != y_hi.shape:
+        raise ValueError("bn_act_apply_split: y_hi / y_lo must be dense NHWC of one shape")
+    _f32(scale, "scale"); _f32(shift, "shift")
+    _lib.call("gs_bn_act_apply_split", _p(y_hi), _p(y_lo), _p(scale), _p(shift), act, _p(z_hi), _p(z_lo), z_stride, z_coff,
+              _p(zp_hi), _p(zp_lo), zp_stride, N, H, W, C, dt_code(y_hi), _stream())
+
+
+def head1x1_fwd_split(x_hi, x_lo, w, bias, y):
+    """OutConv 1x1 on a dense pair [N,H,W,64] -> fp32 NCHW logits."""
+    _dev(x_hi)
+    _f32(w, "w"); _f32(bias, "bias"); _f32(y, "y")
+    N, H, W, Cin = x_hi.shape
+    if not (x_hi.is_contiguous() and x_lo.is_contiguous()) or x_lo.shape != x_hi.shape:
+        raise ValueError("head1x1_fwd_split: x_hi / x_lo must be dense NHWC of one shape")
+    _lib.call("gs_head1x1_fwd_split", _p(x_hi), _p(x_lo), _p(w), _p(bias), _p(y), N, H, W, Cin, y.shape[1], dt_code(x_hi),
+              _stream())

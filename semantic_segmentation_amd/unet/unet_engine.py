@@ -34,11 +34,11 @@ FOLD_BN_INFERENCE = os.environ.get("GSSEG_FOLD_BN", "1") != "0"
 class _ConvRec:
     """Saved state of one conv -> BN -> ReLU stage."""
     __slots__ = ("name", "wkey", "bnkey", "inp", "inp_is_image", "y", "coef", "geom", "cin", "cout", "h", "w",
-                 "wd", "train_stats")
+                 "wd", "train_stats", "inp_stride")
 
 
 class _UpRec:
-    __slots__ = ("name", "zin", "cat", "geom_bwd", "wd", "cin", "cout", "h", "w", "H2", "W2", "pt", "pl")
+    __slots__ = ("name", "zin", "cat", "geom_bwd", "geom_wg", "wd", "cin", "cout", "h", "w", "H2", "W2", "pt", "pl")
 
 
 # GSSEG_PACK_CACHE=0: never reuse a 16-bit weight pack.  The caches key on torch's version counters, which every torch
@@ -59,11 +59,14 @@ def _pack_key(p: torch.Tensor):
 class UNetEngine:
     """Executes UNet.forward / backward for a `UNet` module tree on the HIP kernels."""
 
-    def __init__(self, net, dtype: str = "f16"):
+    def __init__(self, net, dtype: str = "f16", precise: bool = False):
         if dtype not in _TORCH_DT:
             raise ValueError("dtype must be 'f16' or 'bf16'")
         self.net = net
         self.dtype = dtype
+        # precise forward (module docstring of forward_precise): activations / weights as hi+lo pairs of 16-bit values,
+        # logits within ~1e-5 of the fp32 reference instead of ~4e-3; the backward pass is unchanged (it reads the hi halves)
+        self.precise = bool(precise)
         self.tdt = _TORCH_DT[dtype]
         self._packs: Dict[str, tuple] = {}
         # data-parallel hooks (parallel.GradReducer): grads are allocated inside the reducer's flat buckets,
@@ -154,6 +157,8 @@ class UNetEngine:
             raise ValueError("input must be at least 16x16 (four 2x2 poolings)")
         if net.n_channels > 4 or net.n_classes > 4:
             raise NotImplementedError("n_channels / n_classes above 4 are not supported by the direct end kernels")
+        if self.precise:
+            return self.forward_precise(x, params, training, need_grad)
         dev, tdt = x.device, self.tdt
         x = x.contiguous().float()
         bufs = self.buffer_dict()
@@ -221,6 +226,7 @@ class UNetEngine:
             rec = _ConvRec()
             rec.name, rec.wkey, rec.bnkey = f"{prefix}.{idx}", wkey, bnkey
             rec.cin, rec.cout, rec.h, rec.w, rec.inp_is_image = cin, cout, h, w, image
+            rec.inp_stride = None
             nonlocal partials
             g = None if image else ops.geom_conv(N, h, w, cin, cout, 3, 1, 1)
             if image:
@@ -296,7 +302,7 @@ class UNetEngine:
                 u = _UpRec()
                 u.name, u.zin, u.cat, u.wd = prefix, inp, cat, wd
                 u.cin, u.cout, u.h, u.w, u.H2, u.W2, u.pt, u.pl = cin_t, cout_t, h, w, H2, W2, pt, pl
-                u.geom_bwd = None
+                u.geom_bwd = u.geom_wg = None
                 if not bilinear:
                     taps = [(py + pt, px + pl) for py in range(2) for px in range(2)]
                     # the ConvTranspose2d seen from its output side: a stride-2, 4-tap conv dU -> x
@@ -319,6 +325,168 @@ class UNetEngine:
         ctx = None
         if need_grad:
             ctx = dict(recs=recs, ups=ups, x=x, z_last=inp, N=N, H=H, W=W, hs=hs, ws=ws_, C=C, training=training)
+        return logits, ctx
+
+    # ------------------------------------------------------------------ precise forward
+    def _packed_split(self, name: str, w: torch.Tensor, transposed: bool):
+        """[taps][Cout][3*Cin] = [w_hi | w_hi | w_lo] pack of a conv weight, cached until the Parameter is modified."""
+        key = _pack_key(w)
+        ent = self._packs.get(name + "|split")
+        if ent is not None and ent[0] == key:
+            return ent[1]
+        cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+        pack = torch.empty((w.shape[2] * w.shape[3], cout, 3 * cin), dtype=self.tdt, device=w.device)
+        ops.pack_weight_split(w.detach().contiguous(), pack, transposed)
+        self._packs[name + "|split"] = (key, pack)
+        return pack
+
+    def forward_precise(self, x: torch.Tensor, params: Dict[str, torch.Tensor], training: bool, need_grad: bool):
+        """The same network with every activation and weight carried as a PAIR of 16-bit values v = hi + lo
+        (hi = 16-bit(v), lo = 16-bit(v - hi): ~22 significand bits in fp16).  The MFMA contractions run over the K
+        concatenation [x_hi | x_lo | x_hi] . [w_hi | w_hi | w_lo] -- exact products, one fp32 accumulator, 3x the MFMA work
+        of the forward convolutions -- and BatchNorm / ReLU / max-pool / the head read and write pairs.  Measured against
+        the fp32 reference (unet/unet_model.py:26-37): max |dlogit| ~1e-5 instead of ~4e-3 (tools/parity_attribution.py
+        shows that the 16-bit error comes from the full-resolution stages, so a precise *tail* alone buys nothing).
+
+        HBM layout: a pair buffer is [N,h,w,2*Ct] = [hi plane (Ct) | lo plane (Ct)]; for the concat levels Ct = 2C with
+        skip in channels [0,C) and the up-sampled tensor in [C,2C) of EACH plane.  Raw conv outputs are two dense tensors.
+        The backward pass is the default one: it reads the hi halves (exactly what the default mode stores) through
+        strides, so gradients have the default mode's accuracy."""
+        net = self.net
+        if net.bilinear:
+            raise NotImplementedError("precise mode is implemented for the transposed-convolution U-Net (bilinear=False)")
+        if not ops.USE_HALO_CONV:
+            raise RuntimeError("precise mode needs the halo-reuse conv kernel (GSSEG_CONV3X3=halo)")
+        N, _, H, W = x.shape
+        dev, tdt = x.device, self.tdt
+        x = x.contiguous().float()
+        bufs = self.buffer_dict()
+        nbt_pending = []
+        hs = [H >> i for i in range(5)]
+        ws_ = [W >> i for i in range(5)]
+        C = [64, 128, 256, 512, 1024]
+
+        def empty(*shape, dtype=tdt):
+            return torch.empty(shape, dtype=dtype, device=dev)
+
+        recs: List[_ConvRec] = []
+        ups: List[_UpRec] = []
+
+        def stage(prefix, idx, inp, cin, cout, h, w, z_hi, z_lo, z_stride, zp_hi=None, zp_lo=None, zp_stride=0,
+                  image=False):
+            """prefix.double_conv.{idx} conv + BN + ReLU on pairs; inp: fp32 image or a pair buffer [N,h,w,2*cin]."""
+            wkey, bnkey = f"{prefix}.double_conv.{idx}.weight", f"{prefix}.double_conv.{idx + 1}"
+            wparam = params[wkey]
+            y_hi, y_lo = empty(N, h, w, cout), empty(N, h, w, cout)
+            rm = bufs.get(bnkey + ".running_mean")
+            batch_stats = training or rm is None
+            ntiles = ops.conv_smallcin_mtiles(N, h, w) if image else ops.conv3x3_mtiles(N, h, w, cout)
+            partials = empty(ops.bn_partials_numel(ntiles, cout), dtype=torch.float32) if batch_stats else None
+            if image:
+                ops.conv_smallcin_fwd_split(inp, wparam.detach().contiguous(), y_hi, y_lo, partials, 3, 1)
+            else:
+                ops.conv3x3_precise(inp, self._packed_split(wkey, wparam, False), y_hi, y_lo, N, h, w, cin, cout,
+                                    in_stride=2 * cin, bn_partials=partials)
+            coef = empty(4, cout, dtype=torch.float32)
+            gamma, beta = params[bnkey + ".weight"], params[bnkey + ".bias"]
+            bn_mod = self.submodule(bnkey)
+            if batch_stats:
+                nbt = bufs.get(bnkey + ".num_batches_tracked")
+                mom = bn_mod.momentum
+                if training and nbt is not None:
+                    if mom is None:
+                        nbt.add_(1)
+                    else:
+                        nbt_pending.append(nbt)
+                if mom is None:
+                    mom = 1.0 / float(nbt.item()) if nbt is not None else 0.0
+                upd = training and rm is not None
+                ops.bn_finalize(partials, ntiles, cout, N * h * w, gamma.detach(), beta.detach(), rm if upd else None,
+                                bufs.get(bnkey + ".running_var") if upd else None, mom, bn_mod.eps,
+                                coef[0], coef[1], coef[2], coef[3])
+            else:
+                ops.bn_eval_coeffs(cout, gamma.detach(), beta.detach(), rm, bufs[bnkey + ".running_var"], bn_mod.eps,
+                                   coef[0], coef[1], coef[2], coef[3])
+            ops.bn_act_apply_split(y_hi, y_lo, coef[0], coef[1], ACT_RELU, z_hi, z_lo, z_stride, 0, zp_hi, zp_lo, zp_stride)
+            if need_grad:
+                rec = _ConvRec()
+                rec.name, rec.wkey, rec.bnkey = f"{prefix}.{idx}", wkey, bnkey
+                rec.cin, rec.cout, rec.h, rec.w, rec.inp_is_image = cin, cout, h, w, image
+                rec.inp, rec.y, rec.coef, rec.train_stats = inp, y_hi, coef, batch_stats
+                rec.inp_stride = None if image else 2 * cin
+                rec.geom = None
+                rec.wd = None if image else self._packed(wkey, wparam, False, True)[1]
+                recs.append(rec)
+
+        # ---- encoder ----
+        cats = [None] * 4
+        for i in range(4):
+            zero_needed = (hs[i] - 2 * hs[i + 1]) or (ws_[i] - 2 * ws_[i + 1])
+            alloc = torch.zeros if zero_needed else torch.empty
+            cats[i] = alloc((N, hs[i], ws_[i], 4 * C[i]), dtype=tdt, device=dev)      # [skip_h up_h | skip_l up_l]
+        inp, cin = x, net.n_channels
+        for i in range(5):
+            prefix = "inc" if i == 0 else f"down{i}.maxpool_conv.1"
+            h, w = hs[i], ws_[i]
+            zmid = empty(N, h, w, 2 * C[i])
+            stage(prefix, 0, inp, cin, C[i], h, w, zmid, zmid[..., C[i]:], 2 * C[i], image=(i == 0))
+            if i < 4:
+                pooled = empty(N, hs[i + 1], ws_[i + 1], 2 * C[i])
+                cat = cats[i]
+                stage(prefix, 3, zmid, C[i], C[i], h, w, cat, cat[..., 2 * C[i]:], 4 * C[i],
+                      pooled, pooled[..., C[i]:], 2 * C[i])
+                inp, cin = pooled, C[i]
+            else:
+                x5 = empty(N, h, w, 2 * C[i])
+                stage(prefix, 3, zmid, C[i], C[i], h, w, x5, x5[..., C[i]:], 2 * C[i])
+                inp = x5
+
+        # ---- decoder ----
+        z_last = None
+        for j in range(1, 5):
+            lvl = 4 - j
+            prefix = f"up{j}"
+            cout_t, cin_t = C[lvl], 2 * C[lvl]
+            h, w = hs[lvl + 1], ws_[lvl + 1]
+            H2, W2 = hs[lvl], ws_[lvl]
+            pt, pl = (H2 - 2 * h) // 2, (W2 - 2 * w) // 2
+            cat = cats[lvl]
+            wkey = prefix + ".up.weight"
+            ops.upconv2x2_fwd_precise(inp, self._packed_split(wkey, params[wkey], True), params[prefix + ".up.bias"].detach(),
+                                      cat[..., cout_t:], cat[..., 3 * cout_t:], N, h, w, cin_t, cout_t, H2, W2,
+                                      in_stride=2 * cin_t, out_stride=4 * cout_t, ooy=pt, oox=pl)
+            if need_grad:
+                u = _UpRec()
+                u.name, u.zin, u.cat = prefix, inp, cat
+                u.wd = self._packed(wkey, params[wkey], True, True)[1]
+                u.cin, u.cout, u.h, u.w, u.H2, u.W2, u.pt, u.pl = cin_t, cout_t, h, w, H2, W2, pt, pl
+                taps = [(py + pt, px + pl) for py in range(2) for px in range(2)]
+                # the transposed conv seen from its output side (dU -> dx); dU is the up half of the DENSE gradient of the
+                # concat input, x the hi plane of the pair buffer (pixel stride 2*cin_t) for the weight gradient
+                u.geom_bwd = ops.make_geom(N, H2, W2, cout_t, h, w, cin_t, h, w, taps, isy=2, isx=2,
+                                           in_stride=2 * cout_t, in_coff=cout_t)
+                u.geom_wg = ops.make_geom(N, H2, W2, cout_t, h, w, cin_t, h, w, taps, isy=2, isx=2,
+                                          in_stride=2 * cout_t, in_coff=cout_t, out_stride=2 * cin_t)
+                ups.append(u)
+            zmid = empty(N, H2, W2, 2 * cout_t)
+            stage(prefix + ".conv", 0, cat, 2 * cout_t, cout_t, H2, W2, zmid, zmid[..., cout_t:], 2 * cout_t)
+            if j < 4:
+                zout = empty(N, H2, W2, 2 * cout_t)
+                stage(prefix + ".conv", 3, zmid, cout_t, cout_t, H2, W2, zout, zout[..., cout_t:], 2 * cout_t)
+                inp = zout
+            else:                                  # last stage: two dense planes (the head and its backward read dense tensors)
+                zl_hi, zl_lo = empty(N, H2, W2, cout_t), empty(N, H2, W2, cout_t)
+                stage(prefix + ".conv", 3, zmid, cout_t, cout_t, H2, W2, zl_hi, zl_lo, cout_t)
+                z_last = zl_hi
+
+        logits = empty(N, net.n_classes, H, W, dtype=torch.float32)
+        ops.head1x1_fwd_split(zl_hi, zl_lo, params["outc.conv.weight"].detach().contiguous(),
+                              params["outc.conv.bias"].detach(), logits)
+        if nbt_pending:
+            torch._foreach_add_(nbt_pending, 1)
+        ctx = None
+        if need_grad:
+            ctx = dict(recs=recs, ups=ups, x=x, z_last=z_last, N=N, H=H, W=W, hs=hs, ws=ws_, C=C, training=training)
         return logits, ctx
 
     # ------------------------------------------------------------------ backward
@@ -367,7 +535,7 @@ class UNetEngine:
                 tot_w += wnum
         for u in ctx["ups"]:
             if u.geom_bwd is not None:                   # ConvTranspose2d weight gradient: slabs too (deterministic)
-                wg_need = max(wg_need, ops.conv_wgrad_ws_floats(u.geom_bwd))
+                wg_need = max(wg_need, ops.conv_wgrad_ws_floats(u.geom_wg if u.geom_wg is not None else u.geom_bwd))
         dw_arena = torch.zeros(max(tot_w, 1), dtype=torch.float32, device=dev)
         wg_ws = empty(wg_need, dtype=torch.float32)
         arena_off = [0]
@@ -421,11 +589,11 @@ class UNetEngine:
                 dw = galloc(rec.wkey, wparam)
                 if rec.name in det_recs:
                     # split-K parts in slabs + ordered reduction fused with scale / unpack: deterministic, no atomics
-                    ops.conv3x3_wgrad_det(rec.inp, dy, wg_ws, dw, N, h, w, cin, cout, inv_s)
+                    ops.conv3x3_wgrad_det(rec.inp, dy, wg_ws, dw, N, h, w, cin, cout, inv_s, in_stride=rec.inp_stride)
                 else:
                     dwp = dw_take(wparam.numel())
                     if ops.USE_HALO_CONV and cin % 8 == 0 and cout % 8 == 0:
-                        ops.conv3x3_wgrad(rec.inp, dy, dwp, N, h, w, cin, cout)
+                        ops.conv3x3_wgrad(rec.inp, dy, dwp, N, h, w, cin, cout, in_stride=rec.inp_stride)
                     else:
                         ops.conv_wgrad(rec.geom, rec.inp, dy, dwp)
                     ops.unpack_wgrad(dwp, dw, cout, cin, 9, False, inv_s)
@@ -461,7 +629,8 @@ class UNetEngine:
             db = galloc(prefix + ".up.bias", params[prefix + ".up.bias"])
             ops.colsum(dcat, 2 * cout_t, cout_t, N, u.H2, u.W2, u.pt, u.pl, 2 * u.h, 2 * u.w, cout_t, inv_s, col_ws, db)
             dw = galloc(wkey, wparam)
-            ops.conv_wgrad_det(u.geom_bwd, dcat, u.zin, wg_ws, dw, u.cin, u.cout, 4, inv_s)
+            ops.conv_wgrad_det(u.geom_wg if u.geom_wg is not None else u.geom_bwd, dcat, u.zin, wg_ws, dw, u.cin, u.cout,
+                               4, inv_s)
             dz = empty(N, u.h, u.w, u.cin)
             ops.conv_igemm(u.geom_bwd, dcat, u.wd, dz)
             emit(wkey, dw)

@@ -13,7 +13,7 @@ from .unet_parts import DoubleConv, Down, OutConv, Up
 
 
 class UNet(nn.Module):
-    def __init__(self, n_channels, n_classes, bilinear=False, compute_dtype=None):
+    def __init__(self, n_channels, n_classes, bilinear=False, compute_dtype=None, precise=None):
         super(UNet, self).__init__()
         self.n_channels = n_channels
         self.n_classes = n_classes
@@ -33,7 +33,11 @@ class UNet(nn.Module):
         # 16-bit storage/MFMA dtype of the engine: fp16 (default: 8x finer mantissa than bf16 at the same
         # MFMA rate; gradients are loss-scaled internally) or bf16.  Not part of the state dict.
         dt = compute_dtype or os.environ.get("GSSEG_DTYPE", "f16")
-        object.__setattr__(self, "_engine", UNetEngine(self, dt))
+        # precise=True (or GSSEG_PRECISE=1): hi/lo pair forward, logits ~1e-5 from the fp32 reference at ~3x the forward MFMA
+        # work (unet_engine.forward_precise); default: single 16-bit storage, logits within ~4e-3.
+        if precise is None:
+            precise = os.environ.get("GSSEG_PRECISE", "0") == "1"
+        object.__setattr__(self, "_engine", UNetEngine(self, dt, precise=precise))
 
     @property
     def engine(self) -> UNetEngine:

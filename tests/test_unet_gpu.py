@@ -365,3 +365,107 @@ def test_inference_forward_is_hipgraph_capturable():
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(sy, net(x2))
+
+
+# ------------------------------------------------------------------------------------------------ precise mode
+def build_precise(n_classes, seed, dtype="f16"):
+    from semantic_segmentation_amd.unet import UNet
+    sd = oracle.unet_state_dict(1, n_classes, seed=seed)
+    net = UNet(1, n_classes, compute_dtype=dtype, precise=True)
+    net.load_state_dict(sd, strict=True)
+    return net.cuda(), sd
+
+
+@pytest.mark.parametrize("name", ["unet_c2_128_b4", "unet_c1_64", "unet_c2_64", "unet_c1_odd", "unet_c1_zeros"])
+def test_precise_mode_meets_the_north_star_bound_vs_golden(golden_dir, name):
+    """UNet(precise=True) -- hi/lo 16-bit pairs -- against the reference-generated fixtures: max |dlogit| below the north
+    star's 1e-3 (asserted at 3e-5 = 3x the measured 6.4e-6 .. 8.9e-6), loss / Dice / running statistics tight, eval mode too."""
+    from semantic_segmentation_amd.losses import seg_loss
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    n_classes, seed = int(z["n_classes"]), int(z["seed"])
+    net, sd = build_precise(n_classes, seed)
+    net.train()
+    x = torch.from_numpy(z["x"]).cuda()
+    mask = torch.from_numpy(z["mask"].astype(np.int64)).cuda()
+    logits = net(x)
+    loss, parts = seg_loss(logits, mask, return_parts=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    d = np.abs(logits.detach().cpu().numpy() - z["logits"])
+    worst = 0.0
+    for k, p in net.named_parameters():
+        ref = z["gsum/" + k]
+        worst = max(worst, abs(grad_summary(p.grad.cpu())[1] - ref[1]) / max(ref[1], 1e-12))
+    bworst = 0.0
+    for k, b in net.named_buffers():
+        if "num_batches" not in k:
+            ref = z["buf/" + k]
+            bworst = max(bworst, float(np.abs(b.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-6)))
+    net.eval()
+    with torch.no_grad():
+        le = net(x)
+    de = np.abs(le.cpu().numpy() - z["logits_eval"])
+    REPORT["precise_" + name] = {"logit_max_abs": float(d.max()), "logit_mean_abs": float(d.mean()),
+                                 "loss_abs_err": abs(float(loss.item()) - float(z["loss"])),
+                                 "dice_abs_err": abs(float(parts[2].item()) - float(z["loss_dice"])),
+                                 "grad_norm_rel_err_worst": worst, "bn_buffer_rel_err_worst": bworst,
+                                 "eval_logit_max_abs": float(de.max())}
+    _dump()
+    assert d.max() < 3e-5 and d.mean() < 4e-6, REPORT["precise_" + name]
+    assert abs(float(loss.item()) - float(z["loss"])) < 2e-5
+    assert abs(float(parts[2].item()) - float(z["loss_dice"])) < 2e-5
+    assert bworst < 1e-4
+    assert worst < 8e-2                      # backward = the default 16-bit one
+    assert de.max() < 1e-4 * max(1.0, np.abs(z["logits_eval"]).max())
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_precise_mode_vs_oracle_256(dtype):
+    """256x256 (BASELINE config 2 shape) batch 2 against the oracle in precise mode."""
+    from semantic_segmentation_amd.losses import seg_loss
+    net, sd = build_precise(2, seed=11, dtype=dtype)
+    net.train()
+    x, mask = oracle.synthetic_batch(2, 256, seed=99)
+    ref_logits, ref_loss, ref_grads, _ = oracle.unet_step(sd, x, mask, train=True)
+    logits = net(x.cuda())
+    loss = seg_loss(logits, mask.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    d = (logits.detach().cpu() - ref_logits).abs()
+    rel = {}
+    for k, p in net.named_parameters():
+        g, r = p.grad.cpu().double(), ref_grads[k].double()
+        rel[k] = float((g - r).norm() / max(r.norm().item(), 1e-20))
+    REPORT["precise_oracle256_" + dtype] = {"logit_max_abs": float(d.max()), "logit_mean_abs": float(d.mean()),
+                                            "loss_abs_err": abs(float(loss.item()) - float(ref_loss.item())),
+                                            "grad_rel_l2_median": float(np.median(list(rel.values()))),
+                                            "grad_rel_l2_worst": max(rel.values())}
+    _dump()
+    # bf16 pairs carry 16 significand bits: ~2^-17 per rounding instead of 2^-23.  Measured: f16 max 9.5e-6 / mean 1.3e-6,
+    # bf16 max 5.2e-5 / mean 8.1e-6 -- both inside the north star's 1e-3; asserted at ~3x the measurement
+    lim_max, lim_mean = (3e-5, 4e-6) if dtype == "f16" else (1.5e-4, 2.5e-5)
+    assert d.max() < lim_max and d.mean() < lim_mean, REPORT["precise_oracle256_" + dtype]
+    assert abs(loss.item() - ref_loss.item()) < 2e-5
+    assert max(rel.values()) < (0.1 if dtype == "f16" else 0.25)      # measured 4.3 % / 11.5 % worst, 2.4 % / 7.0 % median
+
+
+def test_precise_mode_is_deterministic_and_matches_default_backward_path():
+    """Two precise passes are bit-identical (logits and every gradient); eval-mode precise logits agree with the default
+    engine within the default engine's own error."""
+    from semantic_segmentation_amd.losses import seg_loss
+    net, sd = build_precise(2, seed=5)
+    net.train()
+    x, mask = oracle.synthetic_batch(2, 64, seed=8)
+    x, mask = x.cuda(), mask.cuda()
+    outs = []
+    for _ in range(2):
+        net.load_state_dict(sd, strict=True)
+        net.zero_grad(set_to_none=True)
+        lg = net(x)
+        seg_loss(lg, mask).backward()
+        outs.append((lg.detach().clone(), [p.grad.clone() for p in net.parameters()]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
+    ref, _ = build_net(2, seed=5)
+    ref.train()
+    assert (ref(x) - outs[0][0]).abs().max() < 1e-2
