@@ -104,16 +104,26 @@ class KernelTimer:
     the stream handed to the C ABI) and accumulates algorithmic work per kernel class.  Used by bench.py
     for the roofline figures; off by default (TIMER is None)."""
 
-    def __init__(self):
+    def __init__(self, pool: int = 0):
         self.records = []          # (kind, flops, bytes, ev0, ev1)
+        # events created (and recorded once, which is what really creates the HIP event) up front, so that the timed
+        # region of a benchmark does not contain thousands of hipEventCreate calls
+        self._pool = [torch.cuda.Event(enable_timing=True) for _ in range(pool)]
+        for ev in self._pool:
+            ev.record()
+        if pool:
+            torch.cuda.synchronize()
+
+    def _event(self):
+        return self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
 
     def start(self):
-        ev = torch.cuda.Event(enable_timing=True)
+        ev = self._event()
         ev.record()
         return ev
 
     def stop(self, kind, ev0, flops=0.0, nbytes=0.0):
-        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1 = self._event()
         ev1.record()
         self.records.append((kind, float(flops), float(nbytes), ev0, ev1))
 

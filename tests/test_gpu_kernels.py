@@ -620,8 +620,9 @@ def test_igemm_split_k_skinny(dtn, dt, N, h, Cin, Cout, k, s, p):
     ps = part[: nt * 2 * Cout].view(nt, 2, Cout).double().sum(0).cpu()
     r1 = ref_raw.double().sum(dim=(0, 2, 3))
     assert float((ps[0] - r1).abs().max() / (r1.abs().max() + 1e-6)) < 3e-3
-    ws = ops._SPLITK_WS[0]
-    assert int(ws[:4096].view(torch.int32).abs().max()) == 0        # the tile ticket counters are back to zero
+    assert ops._SPLITK_WS                                            # one workspace per (device, stream), passed per call
+    for ws in ops._SPLITK_WS.values():
+        assert int(ws[:4096].view(torch.int32).abs().max()) == 0    # the tile ticket counters are back to zero
 
 
 @pytest.mark.parametrize("C", [1, 2])
