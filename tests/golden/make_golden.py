@@ -16,6 +16,8 @@ import argparse
 import os
 import sys
 
+sys.dont_write_bytecode = True          # the reference checkout is read-only: no __pycache__ there
+
 import numpy as np
 import torch
 
@@ -185,7 +187,10 @@ def make_ops_micro():
     print("ops_micro done")
 
 
-def make_pix2pix(size=256, batch=2):
+def make_pix2pix(size=256, batch=2, name=None, compact=False):
+    """compact=True (the batch-8 train-mode fixture): the real image is stored as uint8 levels (real = u8 / 255), the
+    generator output sub-sampled 4x4, and the eval-mode outputs are left out -- a well-conditioned BatchNorm case that pins
+    the generator's backward with the reference itself (batch 2 puts BN over 2..8 values at the deepest levels)."""
     from models_pix2pix import networks
     norm = networks.get_norm_layer("batch")
     G = networks.UnetGenerator(1, 1, 8, 64, norm_layer=norm, use_dropout=True)
@@ -203,11 +208,17 @@ def make_pix2pix(size=256, batch=2):
     for m in G.modules():                     # dropout p forced to 0
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
-    out = {"arch": arch.numpy(), "mask": mask.numpy().astype(np.uint8), "real_image": real_image.numpy()}
+    out = {"arch": arch.numpy(), "mask": mask.numpy().astype(np.uint8)}
+    if compact:
+        u8 = (real_image * 256.0).floor().clamp(0, 255).to(torch.uint8)
+        real_image = u8.float() / 255.0
+        out["real_image_u8"] = u8.numpy()
+    else:
+        out["real_image"] = real_image.numpy()
     # train-mode generator + discriminator, the two GAN step losses and grads
     G.train(); D.train()
     fake = G(real_mask)
-    out["fake_train"] = fake.detach().numpy()
+    out["fake_train"] = fake.detach().numpy()[:, :, ::4, ::4].copy() if compact else fake.detach().numpy()
     crit = networks.GANLoss("vanilla")
     pred_fake = D(torch.cat((real_mask, fake), 1))
     out["pred_fake_train"] = pred_fake.detach().numpy()
@@ -235,6 +246,13 @@ def make_pix2pix(size=256, batch=2):
     out["pred_real_train"] = pr.detach().numpy()
     for k, p in D2.named_parameters():
         out["gsumD/" + k] = grad_summary(p.grad)
+    if compact:
+        for k, b in D2.named_buffers():
+            if "num_batches" not in k:
+                out["bufD/" + k] = b.detach().numpy().copy()
+        np.savez_compressed(os.path.join(HERE, (name or f"pix2pix_{size}_b{batch}") + ".npz"), **out)
+        print("pix2pix", size, "batch", batch, "loss_G", loss_G.item(), "loss_D", loss_D.item())
+        return
     # eval-mode outputs from the seeded (un-stepped) state
     G3 = networks.UnetGenerator(1, 1, 8, 64, norm_layer=norm, use_dropout=True)
     G3.load_state_dict(sdG, strict=True)
@@ -309,6 +327,8 @@ if __name__ == "__main__":
         make_ops_micro()
     if a.only in ("", "pix2pix"):
         make_pix2pix(256, 2)
+    if a.only in ("", "pix2pix", "pix2pix_b8"):
+        make_pix2pix(256, 8, name="pix2pix_256_b8", compact=True)
     if a.only in ("", "unet3d"):
         make_unet3d("unet3d_c2_16", 2, 2, 16, seed=51)
         make_unet3d("unet3d_c1_16", 1, 2, 16, seed=52)

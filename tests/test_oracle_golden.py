@@ -149,6 +149,37 @@ def test_pix2pix_matches_reference(golden_dir):
     assert abs(loss_D.item() - float(z["loss_D"])) < 1e-5
 
 
+def test_pix2pix_train_batch8_matches_reference(golden_dir):
+    """Well-conditioned train-mode case (batch 8; reference-generated pix2pix_256_b8.npz): oracle generator / discriminator
+    forward, both GAN step losses, every generator gradient (norm + sampled elements) and the architecture gradient."""
+    z = load(golden_dir, "pix2pix_256_b8")
+    sdG = seeded_generator_state_dict(seed=21)
+    sdD = seeded_discriminator_state_dict(seed=22)
+    arch = torch.from_numpy(z["arch"])
+    mask = torch.from_numpy(z["mask"].astype(np.float32))
+    real_image = torch.from_numpy(z["real_image_u8"]).float() / 255.0
+    pG = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sdG.items()}
+    pD = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sdD.items()}
+    a = arch.clone().requires_grad_(True)
+    fake = oracle.unet_generator_forward(pG, a, mask, train=True)
+    assert np.abs(fake.detach().numpy()[:, :, ::4, ::4] - z["fake_train"]).max() < 2e-5
+    pred_fake = oracle.nlayer_discriminator_forward(pD, torch.cat((mask, fake), 1), train=True)
+    assert np.abs(pred_fake.detach().numpy() - z["pred_fake_train"]).max() < 1e-4
+    loss_G = oracle.gan_loss(pred_fake, True) + oracle.l1_loss(fake, real_image) * 100.0
+    assert abs(loss_G.item() - float(z["loss_G"])) < 1e-4
+    leaves = {k: v for k, v in pG.items() if v.requires_grad}
+    grads = torch.autograd.grad(loss_G, list(leaves.values()) + [a])
+    ag = z["arch_grad_G"]
+    assert np.abs(grads[-1].numpy() - ag).max() < 2e-3 * np.abs(ag).max()
+    for (k, _), g in zip(leaves.items(), grads[:-1]):
+        ref = z["gsumG/" + k]
+        got = grad_summary(g)
+        assert abs(got[1] - ref[1]) / max(ref[1], 1e-12) < 2e-3, k
+        assert np.abs(got[2:] - ref[2:]).max() < 5e-3 * max(np.abs(ref[2:]).max(), 1e-12) + 2e-3 * ref[1] / np.sqrt(g.numel()), k
+    loss_D = oracle.discriminator_step_loss(sdG, sdD, arch, mask, real_image)
+    assert abs(loss_D.item() - float(z["loss_D"])) < 1e-5
+
+
 @pytest.mark.parametrize("name", ["unet3d_c2_16", "unet3d_c1_16"])
 def test_unet3d_step_matches_reference(golden_dir, name):
     z = load(golden_dir, name)

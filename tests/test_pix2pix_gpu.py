@@ -108,14 +108,86 @@ def test_gan_steps_train_mode(golden_dir):
     rep["D_grad_norm_rel_err_worst"] = dworst
     REPORT["train"] = rep
     _dump()
-    assert abs(rep["loss_G"] - rep["loss_G_ref"]) < 5e-2 * abs(rep["loss_G_ref"]), rep
-    assert abs(rep["loss_D"] - rep["loss_D_ref"]) < 2e-2, rep
-    # batch 2 puts BatchNorm over 2x(2x2) = 8 values at the deepest levels: ill-conditioned (SURVEY 2b "legal but
-    # noisy"), so 16-bit rounding is amplified there; losses and the bulk of the gradients still agree
+    # batch 2 puts BatchNorm over 2x(1x1 .. 2x2) = 2..8 values at the deepest levels: ill-conditioned (SURVEY 2b "legal
+    # but noisy"), so 16-bit rounding is amplified there.  What IS stable at batch 2 is asserted at ~2x its measured value
+    # (r01: loss_G 8e-4 relative, loss_D 4e-4 absolute, D gradient norms 6.7 %, architecture gradient 1.7 %); the
+    # generator's weight gradients are pinned by the reference at batch 8 (test_gan_steps_train_mode_batch8_vs_golden).
+    assert abs(rep["loss_G"] - rep["loss_G_ref"]) < 2.5e-3 * abs(rep["loss_G_ref"]), rep
+    assert abs(rep["loss_D"] - rep["loss_D_ref"]) < 1.5e-3, rep
     assert rep["fake_train_mean_abs"] < 6e-2, rep
     assert dworst < 0.1, rep
-    # (generator weight gradients at batch 2 are reported, not asserted: see the batch-8 oracle test below)
-    assert rep["arch_grad_rel_err"] < 0.25, rep
+    assert rep["arch_grad_rel_err"] < 0.05, rep
+
+
+def test_gan_steps_train_mode_batch8_vs_golden(golden_dir):
+    """The same two steps at batch 8 against the REFERENCE-generated fixture pix2pix_256_b8.npz (well-conditioned
+    BatchNorm): fake image, both losses, every generator / discriminator gradient norm, sampled gradient elements, the
+    architecture gradient and the BatchNorm running statistics."""
+    from semantic_segmentation_amd.losses import l1_loss
+    from semantic_segmentation_amd.models_pix2pix import networks
+    z = np.load(os.path.join(golden_dir, "pix2pix_256_b8.npz"))
+    norm = networks.get_norm_layer("batch")
+    G = networks.UnetGenerator(1, 1, 8, 64, norm_layer=norm, use_dropout=True)
+    D = networks.NLayerDiscriminator(2, 64, 3, norm)
+    sdG, sdD = seeded_generator_state_dict(seed=21), seeded_discriminator_state_dict(seed=22)
+    G.load_state_dict(sdG, strict=True); D.load_state_dict(sdD, strict=True)
+    G, D = G.cuda().train(), D.cuda().train()
+    arch = torch.from_numpy(z["arch"]).cuda().requires_grad_(True)
+    networks.upconv_arch = arch
+    mask = torch.from_numpy(z["mask"].astype(np.float32)).cuda()
+    real = (torch.from_numpy(z["real_image_u8"]).float() / 255.0).cuda()
+    crit = networks.GANLoss("vanilla").cuda()
+    fake = G(mask, dropout_masks=ones_masks(8))
+    dfk = (fake.detach().cpu()[:, :, ::4, ::4] - torch.from_numpy(z["fake_train"])).abs()
+    pred_fake = D(torch.cat((mask, fake), 1))
+    loss_G = crit(pred_fake, True) + l1_loss(fake, real) * 100.0
+    loss_G.backward()
+    torch.cuda.synchronize()
+    nerr, serr = {}, {}
+    for k, p in G.named_parameters():
+        ref, got = z["gsumG/" + k], grad_summary(p.grad.cpu())
+        nerr[k] = abs(got[1] - ref[1]) / max(ref[1], 1e-12)
+        rms = ref[1] / math.sqrt(p.numel())                      # sampled elements against the gradient's RMS
+        serr[k] = float(np.abs(got[2:] - ref[2:]).max() / max(rms, 1e-20))
+    ag = z["arch_grad_G"]
+    arel = float(np.abs(arch.grad.cpu().numpy() - ag).max() / np.abs(ag).max())
+    bworst = 0.0
+    for k, b in G.named_buffers():
+        if "num_batches" not in k:
+            ref = z["bufG/" + k]
+            bworst = max(bworst, float(np.abs(b.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-6)))
+    D.load_state_dict(sdD, strict=True)
+    for p in D.parameters():
+        p.grad = None
+    pf = D(torch.cat((mask, fake), 1).detach())
+    pr = D(torch.cat((mask, real), 1))
+    loss_D = (crit(pf, False) + crit(pr, True)) * 0.5
+    loss_D.backward()
+    torch.cuda.synchronize()
+    dn = max(abs(grad_summary(p.grad.cpu())[1] - z["gsumD/" + k][1]) / max(z["gsumD/" + k][1], 1e-12)
+             for k, p in D.named_parameters())
+    dbw = 0.0
+    for k, b in D.named_buffers():
+        if "num_batches" not in k:
+            ref = z["bufD/" + k]
+            dbw = max(dbw, float(np.abs(b.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-6)))
+    rep = {"fake_mean_abs": float(dfk.mean()), "fake_max_abs": float(dfk.max()),
+           "loss_G": float(loss_G.item()), "loss_G_ref": float(z["loss_G"]),
+           "loss_D": float(loss_D.item()), "loss_D_ref": float(z["loss_D"]),
+           "G_grad_norm_rel_err_median": float(np.median(list(nerr.values()))),
+           "G_grad_norm_rel_err_worst": max(nerr.values()), "G_grad_norm_worst_key": max(nerr, key=nerr.get),
+           "G_grad_sample_err_over_rms_median": float(np.median(list(serr.values()))),
+           "G_grad_sample_err_over_rms_worst": max(serr.values()),
+           "arch_grad_rel_err": arel, "G_bn_buffer_rel_err_worst": bworst, "D_grad_norm_rel_err_worst": dn,
+           "D_bn_buffer_rel_err_worst": dbw}
+    REPORT["train_b8_golden"] = rep
+    _dump()
+    assert rep["fake_mean_abs"] < 1e-3 and rep["fake_max_abs"] < 2e-2, rep
+    assert abs(rep["loss_G"] - rep["loss_G_ref"]) < 1e-3 * abs(rep["loss_G_ref"]), rep
+    assert abs(rep["loss_D"] - rep["loss_D_ref"]) < 1e-3, rep
+    assert rep["G_grad_norm_rel_err_median"] < 0.03 and rep["G_grad_norm_rel_err_worst"] < 0.15, rep
+    assert rep["G_grad_sample_err_over_rms_median"] < 0.5, rep
+    assert arel < 0.02 and bworst < 5e-3 and dbw < 5e-3 and dn < 0.1, rep
 
 
 def test_discriminator_gradients_vs_oracle():
