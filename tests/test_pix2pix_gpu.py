@@ -32,11 +32,23 @@ def build(golden_dir):
     sdG, sdD = seeded_generator_state_dict(seed=21), seeded_discriminator_state_dict(seed=22)
     G.load_state_dict(sdG, strict=True)
     D.load_state_dict(sdD, strict=True)
+    no_dropout(G)
     arch = torch.from_numpy(z["arch"]).cuda().requires_grad_(True)
     networks.upconv_arch = arch                      # the reference re-binds the module global too (pix2pix_model.py:64)
     mask = torch.from_numpy(z["mask"].astype(np.float32)).cuda()
     real = torch.from_numpy(z["real_image"]).cuda()
     return networks, G.cuda(), D.cuda(), z, mask, real, sdG, sdD
+
+
+def no_dropout(G):
+    """The fixtures were generated with the dropout probability forced to 0 (make_golden.py): do the same here.  (All-ones
+    keep masks are NOT equivalent: kept values are scaled by 1/(1-p) = 2.)"""
+    n = 0
+    for m in G.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+            n += 1
+    assert n == 3, n
 
 
 def ones_masks(N):
@@ -67,7 +79,7 @@ def test_gan_steps_train_mode(golden_dir):
     networks, G, D, z, mask, real, sdG, sdD = build(golden_dir)
     G.train(); D.train()
     crit = networks.GANLoss("vanilla").cuda()
-    fake = G(mask, dropout_masks=ones_masks(2))
+    fake = G(mask)
     dfk = (fake.detach().cpu() - torch.from_numpy(z["fake_train"])).abs()
     pred_fake = D(torch.cat((mask, fake), 1))
     loss_G = crit(pred_fake, True) + l1_loss(fake, real) * 100.0
@@ -108,15 +120,16 @@ def test_gan_steps_train_mode(golden_dir):
     rep["D_grad_norm_rel_err_worst"] = dworst
     REPORT["train"] = rep
     _dump()
-    # batch 2 puts BatchNorm over 2x(1x1 .. 2x2) = 2..8 values at the deepest levels: ill-conditioned (SURVEY 2b "legal
-    # but noisy"), so 16-bit rounding is amplified there.  What IS stable at batch 2 is asserted at ~2x its measured value
-    # (r01: loss_G 8e-4 relative, loss_D 4e-4 absolute, D gradient norms 6.7 %, architecture gradient 1.7 %); the
-    # generator's weight gradients are pinned by the reference at batch 8 (test_gan_steps_train_mode_batch8_vs_golden).
-    assert abs(rep["loss_G"] - rep["loss_G_ref"]) < 2.5e-3 * abs(rep["loss_G_ref"]), rep
-    assert abs(rep["loss_D"] - rep["loss_D_ref"]) < 1.5e-3, rep
-    assert rep["fake_train_mean_abs"] < 6e-2, rep
-    assert dworst < 0.1, rep
-    assert rep["arch_grad_rel_err"] < 0.05, rep
+    # Measured on MI355X (fp16): loss_G 2.4e-6 relative, loss_D 4e-5, fake image mean |d| 1.5e-4 / max 1.4e-3, generator
+    # gradient norms median 5e-4 / worst 1.2e-2, architecture gradient 1.1e-3, discriminator gradient norms 1.0e-3 --
+    # asserted at ~3-4x those values.  (Round 1 reported 3e-2 / 118 % here and blamed BatchNorm over 2..8 values: the test
+    # had fed all-ones dropout masks at p = 0.5, i.e. scaled the kept activations by 2, while the fixture has p = 0.)
+    assert abs(rep["loss_G"] - rep["loss_G_ref"]) < 1e-4 * abs(rep["loss_G_ref"]), rep
+    assert abs(rep["loss_D"] - rep["loss_D_ref"]) < 2e-4, rep
+    assert rep["fake_train_mean_abs"] < 5e-4 and rep["fake_train_max_abs"] < 5e-3, rep
+    assert rep["G_grad_norm_rel_err_median"] < 3e-3 and rep["G_grad_norm_rel_err_worst"] < 5e-2, rep
+    assert dworst < 5e-3, rep
+    assert rep["arch_grad_rel_err"] < 5e-3, rep
 
 
 def test_gan_steps_train_mode_batch8_vs_golden(golden_dir):
@@ -131,13 +144,14 @@ def test_gan_steps_train_mode_batch8_vs_golden(golden_dir):
     D = networks.NLayerDiscriminator(2, 64, 3, norm)
     sdG, sdD = seeded_generator_state_dict(seed=21), seeded_discriminator_state_dict(seed=22)
     G.load_state_dict(sdG, strict=True); D.load_state_dict(sdD, strict=True)
+    no_dropout(G)
     G, D = G.cuda().train(), D.cuda().train()
     arch = torch.from_numpy(z["arch"]).cuda().requires_grad_(True)
     networks.upconv_arch = arch
     mask = torch.from_numpy(z["mask"].astype(np.float32)).cuda()
     real = (torch.from_numpy(z["real_image_u8"]).float() / 255.0).cuda()
     crit = networks.GANLoss("vanilla").cuda()
-    fake = G(mask, dropout_masks=ones_masks(8))
+    fake = G(mask)
     dfk = (fake.detach().cpu()[:, :, ::4, ::4] - torch.from_numpy(z["fake_train"])).abs()
     pred_fake = D(torch.cat((mask, fake), 1))
     loss_G = crit(pred_fake, True) + l1_loss(fake, real) * 100.0
@@ -182,12 +196,14 @@ def test_gan_steps_train_mode_batch8_vs_golden(golden_dir):
            "D_bn_buffer_rel_err_worst": dbw}
     REPORT["train_b8_golden"] = rep
     _dump()
-    assert rep["fake_mean_abs"] < 1e-3 and rep["fake_max_abs"] < 2e-2, rep
-    assert abs(rep["loss_G"] - rep["loss_G_ref"]) < 1e-3 * abs(rep["loss_G_ref"]), rep
-    assert abs(rep["loss_D"] - rep["loss_D_ref"]) < 1e-3, rep
-    assert rep["G_grad_norm_rel_err_median"] < 0.03 and rep["G_grad_norm_rel_err_worst"] < 0.15, rep
-    assert rep["G_grad_sample_err_over_rms_median"] < 0.5, rep
-    assert arel < 0.02 and bworst < 5e-3 and dbw < 5e-3 and dn < 0.1, rep
+    # measured: fake mean 1.3e-4 / max 1.2e-3, loss_G 4.4e-6 rel, loss_D 3e-5, G gradient norms median 3.9e-4 / worst
+    # 8.2e-3, sampled elements 5 % of the tensor RMS (median), arch 3.8e-4, BN buffers 5.9e-4 (G) / 2.5e-4 (D), D norms 1.3e-3
+    assert rep["fake_mean_abs"] < 5e-4 and rep["fake_max_abs"] < 5e-3, rep
+    assert abs(rep["loss_G"] - rep["loss_G_ref"]) < 1e-4 * abs(rep["loss_G_ref"]), rep
+    assert abs(rep["loss_D"] - rep["loss_D_ref"]) < 2e-4, rep
+    assert rep["G_grad_norm_rel_err_median"] < 2e-3 and rep["G_grad_norm_rel_err_worst"] < 3e-2, rep
+    assert rep["G_grad_sample_err_over_rms_median"] < 0.2, rep
+    assert arel < 2e-3 and bworst < 3e-3 and dbw < 1e-3 and dn < 5e-3, rep
 
 
 def test_discriminator_gradients_vs_oracle():
