@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 21
+#define GS_ABI_VERSION 22
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -278,6 +278,15 @@ int gs_seg_loss_bwd(const float* logits, const uint8_t* mask, const float* out, 
                     float* dlogits, int N, int C, int H, int W, void* stream);
 /* generic dice_loss(input, target) on fp32 tensors of n elements, one global sum (dice_score.py:25-28 with
  * reduce_batch_first=True): out[0]=loss, out[1..3]=inter,sum_p,sum_t.  bwd: dinput = dloss/dinput * gout[0]. */
+/* Per-item Dice coefficients in ONE launch pair (util/dice_score.py:5-17 with reduce_batch_first=False, the form
+ * unet/evaluate.py:29-43 averages): item b = n_per consecutive elements of p / t; out[0] = mean over the B items,
+ * out[1 + b] = dice_b.  ws: gs_dice_batched_ws_floats(B) floats.
+ * gs_eval_dice fuses the prediction of unet/evaluate.py:31,38-41 in front of it: sigmoid(logit) > 0.5 (C == 1) or the
+ * arg-max class (first maximum), one item per (sample, foreground class); logits fp32 NCHW, mask uint8 [N][HW];
+ * ws for B = N * max(1, C - 1) items, out[1 + N*max(1,C-1)]. */
+int64_t gs_dice_batched_ws_floats(int B);
+int gs_dice_coeff_batched(const float* p, const float* t, int B, int64_t n_per, float* ws, float* out, void* stream);
+int gs_eval_dice(const float* logits, const uint8_t* mask, int N, int C, int64_t HW, float* ws, float* out, void* stream);
 int gs_dice_loss_fwd(const float* p, const float* t, int64_t n, float* ws, float* out, void* stream);
 int gs_dice_loss_bwd(const float* t, const float* out, const float* gout, float* dp, int64_t n, void* stream);
 /* mean-reduced elementwise losses: mode 0 = BCEWithLogits vs constant label `cval` (GANLoss vanilla),

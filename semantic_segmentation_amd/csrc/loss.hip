@@ -250,6 +250,131 @@ extern "C" int gs_seg_loss_bwd(const float* logits, const uint8_t* mask, const f
     return GS_OK;
 }
 
+// ---- per-item Dice coefficients in one launch (dice_score.py:5-17 with reduce_batch_first=False; unet/evaluate.py:29-43) --
+// item b has n_per consecutive elements; grid (DB_BLOCKS, B); ws[b][blk][3] partial sums; the finalising block turns them
+// into dice_b = (2 sum(pt) + eps) / (sum p + sum t + eps) (sets == 0 -> inter, dice_score.py:14) and their mean.
+constexpr int DB_BLOCKS = 16;
+
+__global__ __launch_bounds__(256) void dice_batched_kernel(const float* __restrict__ p, const float* __restrict__ t,
+                                                           int64_t n_per, float* __restrict__ ws) {
+    __shared__ float red[3][4];
+    const float* pp = p + (int64_t)blockIdx.y * n_per;
+    const float* tt = t + (int64_t)blockIdx.y * n_per;
+    float s[3] = {0.f, 0.f, 0.f};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_per; i += (int64_t)gridDim.x * 256) {
+        const float a = pp[i], b = tt[i];
+        s[0] += a * b; s[1] += a; s[2] += b;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s[k] = wave_sum(s[k]);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s[0]; red[1][threadIdx.x >> 6] = s[1]; red[2][threadIdx.x >> 6] = s[2]; }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        ws[((int64_t)blockIdx.y * DB_BLOCKS + blockIdx.x) * 3 + threadIdx.x] =
+            red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+
+// fused evaluation head: prediction = sigmoid(logit) > 0.5 (C == 1) or arg-max over classes (first maximum), one item per
+// (sample, foreground class); sums are pixel counts (exact in fp32 per block)
+__global__ __launch_bounds__(256) void eval_dice_kernel(const float* __restrict__ x, const uint8_t* __restrict__ m, int C,
+                                                        int64_t HW, float* __restrict__ ws) {
+    __shared__ float red[9][4];
+    const int K = C == 1 ? 1 : C - 1;
+    const float* xp = x + (int64_t)blockIdx.y * C * HW;
+    const uint8_t* mp = m + (int64_t)blockIdx.y * HW;
+    float s[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // [k][inter, pred, true], K <= 3
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (int64_t)gridDim.x * 256) {
+        const int t = mp[i];
+        int pred;
+        if (C == 1) {
+            pred = sigmoidf_(xp[i]) > 0.5f ? 1 : 0;
+        } else {
+            float best = xp[i];
+            pred = 0;
+            for (int c = 1; c < C; ++c) {
+                const float v = xp[(int64_t)c * HW + i];
+                if (v > best) { best = v; pred = c; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (k < K) {
+                const float pk = pred == k + 1 ? 1.f : 0.f, tk = t == k + 1 ? 1.f : 0.f;
+                s[3 * k] += pk * tk; s[3 * k + 1] += pk; s[3 * k + 2] += tk;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s[k] = wave_sum(s[k]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) red[k][threadIdx.x >> 6] = s[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 * K) {
+        const int k = threadIdx.x / 3, q = threadIdx.x - 3 * k;
+        ws[(((int64_t)blockIdx.y * K + k) * DB_BLOCKS + blockIdx.x) * 3 + q] =
+            red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+    }
+}
+
+// out[0] = mean of the B coefficients, out[1 + b] = dice_b
+__global__ __launch_bounds__(256) void dice_batched_finalize_kernel(const float* __restrict__ ws, int B, int nblk,
+                                                                    float* __restrict__ out) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        double spt = 0.0, sp = 0.0, st = 0.0;
+        for (int j = 0; j < nblk; ++j) {
+            const float* q = ws + ((int64_t)b * DB_BLOCKS + j) * 3;
+            spt += (double)q[0]; sp += (double)q[1]; st += (double)q[2];
+        }
+        const float inter = 2.f * (float)spt;
+        float sets = (float)sp + (float)st;
+        if (sets == 0.f) sets = inter;
+        const float d = (inter + DICE_EPS) / (sets + DICE_EPS);
+        out[1 + b] = d;
+        acc += (double)d;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)(red[0] / (double)B);
+}
+
+static int dice_batched_blocks(int64_t n_per) {
+    int64_t nb = cdiv64(n_per, 256 * 8);
+    return (int)(nb < 1 ? 1 : (nb > DB_BLOCKS ? DB_BLOCKS : nb));
+}
+
+extern "C" int64_t gs_dice_batched_ws_floats(int B) { return B > 0 ? (int64_t)B * DB_BLOCKS * 3 : 0; }
+
+extern "C" int gs_dice_coeff_batched(const float* p, const float* t, int B, int64_t n_per, float* ws, float* out,
+                                     void* stream) {
+    GS_CHECK_ARG(p && t && ws && out && B > 0 && B <= 65535 && n_per > 0, "gs_dice_coeff_batched: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = dice_batched_blocks(n_per);
+    dice_batched_kernel<<<dim3(nb, B), 256, 0, s>>>(p, t, n_per, ws);
+    dice_batched_finalize_kernel<<<1, 256, 0, s>>>(ws, B, nb, out);
+    GS_CHECK_LAUNCH("gs_dice_coeff_batched");
+    return GS_OK;
+}
+
+extern "C" int gs_eval_dice(const float* logits, const uint8_t* mask, int N, int C, int64_t HW, float* ws, float* out,
+                            void* stream) {
+    GS_CHECK_ARG(logits && mask && ws && out && N > 0 && N <= 65535 && C >= 1 && C <= 4 && HW > 0, "gs_eval_dice: bad arguments (C <= 4)");
+    hipStream_t s = (hipStream_t)stream;
+    const int K = C == 1 ? 1 : C - 1;
+    const int nb = dice_batched_blocks(HW);
+    eval_dice_kernel<<<dim3(nb, N), 256, 0, s>>>(logits, mask, C, HW, ws);
+    dice_batched_finalize_kernel<<<1, 256, 0, s>>>(ws, N * K, nb, out);
+    GS_CHECK_LAUNCH("gs_eval_dice");
+    return GS_OK;
+}
+
 extern "C" int gs_dice_loss_fwd(const float* p, const float* t, int64_t n, float* ws, float* out, void* stream) {
     GS_CHECK_ARG(p && t && ws && out && n > 0, "gs_dice_loss_fwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;

@@ -100,6 +100,31 @@ class _DiceLoss(torch.autograd.Function):
         return d, None
 
 
+def dice_coeff_per_item(inp: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """Mean over items of the per-item Dice coefficient (dice_score.py:5-17, reduce_batch_first=False): inp / target
+    [B, ...] with every trailing dim summed per item.  One launch pair for the whole batch; no gradient (validation metric)."""
+    if inp.shape != target.shape or inp.dim() < 2:
+        raise ValueError("dice_coeff_per_item: inp / target must share a shape [B, ...]")
+    B = inp.shape[0]
+    p = inp.detach().reshape(B, -1).contiguous().float()
+    t = target.detach().reshape(B, -1).contiguous().float()
+    out = torch.empty(1 + B, dtype=torch.float32, device=p.device)
+    ops.dice_coeff_batched(p, t, out)
+    return out[0]
+
+
+def eval_dice(logits: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """Validation Dice of one batch as unet/evaluate.py:29-43 computes it -- (sigmoid > 0.5 | arg-max) prediction, per-sample
+    Dice of the foreground class(es), mean -- fused into one pass over the logits."""
+    if logits.dim() != 4:
+        raise ValueError("eval_dice: logits must be [N,C,H,W]")
+    N, C, H, W = logits.shape
+    m = _mask_u8(mask, N, H, W)
+    out = torch.empty(1 + N * max(1, C - 1), dtype=torch.float32, device=logits.device)
+    ops.eval_dice(logits.detach().contiguous().float(), m, out)
+    return out[0]
+
+
 def dice_loss_op(inp: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     """1 - dice with ONE global sum over every element (dice_score.py:25-28, reduce_batch_first=True)."""
     return _DiceLoss.apply(inp, target)

@@ -701,6 +701,31 @@ def dice_loss_bwd(t, out, gout, dp):
     _lib.call("gs_dice_loss_bwd", _p(t), _p(out), _p(gout), _p(dp), t.numel(), _stream())
 
 
+def dice_coeff_batched(p, t, out):
+    """Per-item Dice coefficients of p, t [B, n_per] fp32 in one launch pair: out[0] = mean, out[1 + b] = dice_b."""
+    _dev(p)
+    _f32(p, "p"); _f32(t, "t"); _f32(out, "out")
+    B, n_per = p.shape
+    if t.shape != p.shape or out.numel() < 1 + B:
+        raise ValueError("dice_coeff_batched: p, t must be [B, n] of one shape and out hold 1 + B floats")
+    ws = torch.empty(int(_lib.load().gs_dice_batched_ws_floats(B)), dtype=torch.float32, device=p.device)
+    _lib.call("gs_dice_coeff_batched", _p(p), _p(t), B, n_per, _p(ws), _p(out), _stream())
+
+
+def eval_dice(logits, mask_u8, out):
+    """Fused evaluation head (unet/evaluate.py:29-43): threshold / arg-max + per-(sample, foreground class) Dice, mean in out[0]."""
+    _dev(logits)
+    _f32(logits, "logits"); _f32(out, "out")
+    N, C, H, W = logits.shape
+    if mask_u8.dtype != torch.uint8 or not mask_u8.is_contiguous() or mask_u8.numel() != N * H * W:
+        raise TypeError("eval_dice: mask must be contiguous uint8 [N,H,W]")
+    B = N * max(1, C - 1)
+    if out.numel() < 1 + B:
+        raise ValueError("eval_dice: out must hold 1 + N*max(1,C-1) floats")
+    ws = torch.empty(int(_lib.load().gs_dice_batched_ws_floats(B)), dtype=torch.float32, device=logits.device)
+    _lib.call("gs_eval_dice", _p(logits), _p(mask_u8), N, C, H * W, _p(ws), _p(out), _stream())
+
+
 def mean_loss_fwd(x, t, cval, mode, ws, out):
     _dev(x)
     _f32(x, "x"); _f32(t, "target")

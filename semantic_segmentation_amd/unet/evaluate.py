@@ -1,31 +1,28 @@
-"""Validation Dice (reference: unet/evaluate.py:10-43): eval-mode forward on the HIP engine (BatchNorm from
-running statistics), threshold / arg-max, per-sample Dice (`reduce_batch_first=False`) averaged over batches.
-`amp` is accepted for signature parity; the engine already computes in 16-bit with fp32 accumulation."""
-import torch
-import torch.nn.functional as F
+"""Validation Dice on the HIP engine (what unet/evaluate.py:10-43 of the reference returns).
 
-from ..util.dice_score import dice_coeff, multiclass_dice_coeff
+Per batch: eval-mode forward (BatchNorm from the running statistics, folded into the convolutions), then ONE fused pass
+over the logits -- prediction (sigmoid > 0.5 for one class, arg-max otherwise), per-sample Dice of the foreground
+class(es) (`reduce_batch_first=False`), mean -- instead of the reference's one-hot / permute / per-sample reductions.  The
+batch scores are accumulated on the device; the result is their mean over the loader, as a 0-d tensor like the reference.
+`amp` is accepted for signature parity: the engine already computes in 16 bits with fp32 accumulation."""
+import torch
+
+from ..losses import eval_dice
 
 
 @torch.no_grad()
 def evaluate(net, dataloader, device, amp=False):
     net.eval()
-    num_val_batches = len(dataloader)
-    dice_score = 0
-    for i, batch in enumerate(dataloader):
-        image, mask_true = batch['image'], batch['mask']
-        image = image.to(device=device, dtype=torch.float32)
-        mask_true = mask_true.to(device=device, dtype=torch.long)
-        mask_pred = net(image)
-        if net.n_classes == 1:
-            assert mask_true.min() >= 0 and mask_true.max() <= 1, 'True mask indices should be in [0, 1]'
-            mask_pred = (torch.sigmoid(mask_pred) > 0.5).float()
-            dice_score += dice_coeff(mask_pred.squeeze(), mask_true.float().squeeze(), reduce_batch_first=False)
-        else:
-            assert mask_true.min() >= 0 and mask_true.max() < net.n_classes, \
-                'True mask indices should be in [0, n_classes['
-            mask_true = F.one_hot(mask_true.squeeze(1), net.n_classes).permute(0, 3, 1, 2).float()
-            mask_pred = F.one_hot(mask_pred.argmax(dim=1), net.n_classes).permute(0, 3, 1, 2).float()
-            dice_score += multiclass_dice_coeff(mask_pred[:, 1:], mask_true[:, 1:], reduce_batch_first=False)
-    net.train()
-    return dice_score / max(num_val_batches, 1)
+    total, batches = None, 0
+    for batch in dataloader:
+        logits = net(batch["image"].to(device=device, dtype=torch.float32))
+        mask = batch["mask"].to(device=device)
+        if mask.dim() == 4 and mask.shape[1] != 1:
+            raise ValueError("evaluate: mask must hold class indices [N,1,H,W] or [N,H,W]")
+        score = eval_dice(logits, mask)
+        total = score if total is None else total + score
+        batches += 1
+    net.train()                       # the reference always leaves the network in train mode (evaluate.py:42)
+    if total is None:
+        return 0
+    return total / max(len(dataloader), 1)

@@ -4,7 +4,7 @@ sets = sum p + sum t with the exact-zero replacement (:13-14), eps 1e-6 (:16), m
 import torch
 from torch import Tensor
 
-from ..losses import dice_loss_op
+from ..losses import dice_coeff_per_item, dice_loss_op
 
 
 def dice_coeff(input: Tensor, target: Tensor, reduce_batch_first: bool = False, epsilon: float = 1e-6):
@@ -14,12 +14,9 @@ def dice_coeff(input: Tensor, target: Tensor, reduce_batch_first: bool = False, 
         raise NotImplementedError("the HIP dice kernels are built for the reference's epsilon = 1e-6")
     if input.dim() == 2 or reduce_batch_first:
         return 1 - dice_loss_op(input, target)          # one global reduction
-    # per-sample sums over the last two dims, then the mean over the leading ones (dice_score.py:10,17)
-    lead = input.shape[:-2]
-    flat_i = input.reshape(-1, *input.shape[-2:])
-    flat_t = target.reshape(-1, *target.shape[-2:])
-    vals = [1 - dice_loss_op(flat_i[k], flat_t[k]) for k in range(flat_i.shape[0])]
-    return torch.stack(vals).reshape(lead).mean()
+    # per-item sums over the last two dims, then the mean over the leading ones (dice_score.py:10,17): one launch pair for
+    # the whole batch (a validation metric: no gradient through this branch)
+    return dice_coeff_per_item(input.reshape(-1, *input.shape[-2:]), target.reshape(-1, *target.shape[-2:]))
 
 
 def multiclass_dice_coeff(input: Tensor, target: Tensor, reduce_batch_first: bool = False, epsilon: float = 1e-6):

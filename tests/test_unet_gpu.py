@@ -469,3 +469,72 @@ def test_precise_mode_is_deterministic_and_matches_default_backward_path():
     ref, _ = build_net(2, seed=5)
     ref.train()
     assert (ref(x) - outs[0][0]).abs().max() < 1e-2
+
+
+# ------------------------------------------------------------------------------------------------ RGB input, fused eval
+@pytest.mark.parametrize("precise", [False, True])
+def test_unet_rgb_input_vs_oracle(precise):
+    """UNet(n_channels=3, n_classes=1) -- the ISIC / RGB configuration (train_end2end_isic.py) -- forward + backward against
+    the oracle at 96x80 (the direct first-layer kernels read 1..4 input channels)."""
+    from semantic_segmentation_amd.losses import seg_loss
+    from semantic_segmentation_amd.unet import UNet
+    sd = oracle.unet_state_dict(3, 1, seed=17)
+    net = UNet(3, 1, precise=precise)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(2, 3, 96, 80, generator=g)
+    mask = (torch.rand(2, 1, 96, 80, generator=g) > 0.6).long()
+    ref_logits, ref_loss, ref_grads, _ = oracle.unet_step(sd, x, mask, train=True)
+    logits = net(x.cuda())
+    loss = seg_loss(logits, mask.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    d = (logits.detach().cpu() - ref_logits).abs()
+    rel = {k: float((p.grad.cpu().double() - ref_grads[k].double()).norm() / max(ref_grads[k].double().norm().item(), 1e-20))
+           for k, p in net.named_parameters()}
+    REPORT["rgb_c1" + ("_precise" if precise else "")] = {"logit_max_abs": float(d.max()), "logit_mean_abs": float(d.mean()),
+                                                         "loss_abs_err": abs(loss.item() - ref_loss.item()),
+                                                         "grad_rel_l2_worst": max(rel.values()),
+                                                         "grad_rel_l2_first_conv": rel["inc.double_conv.0.weight"]}
+    _dump()
+    assert abs(loss.item() - ref_loss.item()) < (2e-5 if precise else 1e-3)
+    assert d.max() < (3e-5 if precise else 1e-2) and d.mean() < (4e-6 if precise else 1.5e-3)
+    assert max(rel.values()) < 0.3
+
+
+@pytest.mark.parametrize("C", [1, 2, 3])
+def test_fused_eval_dice_matches_oracle(C):
+    """gs_eval_dice (threshold / arg-max + per-sample Dice + mean in one pass) against the oracle's restatement of
+    unet/evaluate.py:29-43, incl. a sample with an empty mask and empty prediction (Dice = 1 through the sets == 0 rule)."""
+    from semantic_segmentation_amd.losses import eval_dice
+    g = torch.Generator().manual_seed(30 + C)
+    N, H, W = 5, 70, 52
+    logits = torch.randn(N, C, H, W, generator=g) * 3
+    mask = torch.randint(0, max(2, C), (N, 1, H, W), generator=g)
+    mask[1] = 0
+    if C == 1:
+        logits[1] = -5.0                                  # nothing predicted, nothing true: dice == 1
+    else:
+        logits[1, 0] = 9.0
+    mask[2] = 1
+    want = oracle.evaluate_dice(logits, mask)
+    got = eval_dice(logits.cuda(), mask.cuda())
+    assert abs(got.item() - want.item()) < 2e-7, (got.item(), want.item())
+    got3 = eval_dice(logits.cuda(), mask[:, 0].cuda())    # [N,H,W] masks too
+    assert got3.item() == got.item()
+
+
+def test_dice_coeff_per_item_is_one_launch_pair_and_exact():
+    from semantic_segmentation_amd.util.dice_score import dice_coeff, multiclass_dice_coeff
+    g = torch.Generator().manual_seed(2)
+    p = torch.rand(6, 40, 56, generator=g)
+    t = (torch.rand(6, 40, 56, generator=g) > 0.5).float()
+    t[3] = 0
+    p[3] = 0
+    want = oracle.dice_coeff(p, t, reduce_batch_first=False)
+    got = dice_coeff(p.cuda(), t.cuda(), reduce_batch_first=False)
+    assert abs(got.item() - want.item()) < 2e-7
+    pm, tm = p.reshape(2, 3, 40, 56), t.reshape(2, 3, 40, 56)
+    assert abs(multiclass_dice_coeff(pm.cuda(), tm.cuda(), False).item()
+               - oracle.multiclass_dice_coeff(pm, tm, False).item()) < 2e-7
