@@ -350,6 +350,103 @@ static int dice_batched_blocks(int64_t n_per) {
     return (int)(nb < 1 ? 1 : (nb > DB_BLOCKS ? DB_BLOCKS : nb));
 }
 
+// ---- BCE + Jaccard loss of the ISIC variant (train_end2end_isic.py:40-56,247-249; one class) -----------------------------
+// per sample i: I_i = sum p t, S_i = sum (p + t), jac_i = (I_i + 1) / (S_i - I_i + 1); loss = mean BCE + 1 - mean_i jac_i.
+// fwd: grid (DB_BLOCKS, N) partial sums [bce, I, S]; finalize: out[0] = loss, out[1] = bce, out[2] = 1 - mean jac,
+// out[4 + 2 i] = I_i, out[5 + 2 i] = S_i (kept for the backward pass).
+__global__ __launch_bounds__(256) void jaccard_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ m,
+                                                          int64_t HW, float* __restrict__ ws) {
+    __shared__ float red[3][4];
+    const float* xp = x + (int64_t)blockIdx.y * HW;
+    const uint8_t* mp = m + (int64_t)blockIdx.y * HW;
+    float s[3] = {0.f, 0.f, 0.f};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (int64_t)gridDim.x * 256) {
+        const float v = xp[i], tf = (float)mp[i];
+        s[0] += fmaxf(v, 0.f) - v * tf + softplus_neg_abs(v);
+        const float p = sigmoidf_(v);
+        s[1] += p * tf; s[2] += p + tf;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s[k] = wave_sum(s[k]);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s[0]; red[1][threadIdx.x >> 6] = s[1]; red[2][threadIdx.x >> 6] = s[2]; }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        ws[((int64_t)blockIdx.y * DB_BLOCKS + blockIdx.x) * 3 + threadIdx.x] =
+            red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+
+__global__ __launch_bounds__(256) void jaccard_finalize_kernel(const float* __restrict__ ws, int N, int nblk, int64_t HW,
+                                                               float* __restrict__ out) {
+    __shared__ double red[2][256];
+    double bce = 0.0, jac = 0.0;
+    for (int b = threadIdx.x; b < N; b += 256) {
+        double sb = 0.0, si = 0.0, ss = 0.0;
+        for (int j = 0; j < nblk; ++j) {
+            const float* q = ws + ((int64_t)b * DB_BLOCKS + j) * 3;
+            sb += (double)q[0]; si += (double)q[1]; ss += (double)q[2];
+        }
+        const float I = (float)si, S = (float)ss;
+        out[4 + 2 * b] = I; out[5 + 2 * b] = S;
+        bce += sb;
+        jac += (double)((I + 1.f) / (S - I + 1.f));
+    }
+    red[0][threadIdx.x] = bce; red[1][threadIdx.x] = jac;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float l_bce = (float)(red[0][0] / ((double)N * (double)HW));
+        const float l_jac = 1.f - (float)(red[1][0] / (double)N);
+        out[0] = l_bce + l_jac; out[1] = l_bce; out[2] = l_jac; out[3] = 0.f;
+    }
+}
+
+// dx = g * [ (p - t) / (N HW)  -  p (1 - p) / N * ( t (D) - (I + 1)(1 - t) ) / D^2 ],  D = S - I + 1
+__global__ __launch_bounds__(256) void jaccard_bwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ m,
+                                                          const float* __restrict__ out, const float* gout, float gscale,
+                                                          float* __restrict__ dx, int N, int64_t HW) {
+    const float g = (gout ? gout[0] : 1.f) * gscale;
+    const float inv_m = 1.f / ((float)N * (float)HW), inv_n = 1.f / (float)N;
+    const int n = blockIdx.y;
+    const float I = out[4 + 2 * n], S = out[5 + 2 * n];
+    const float D = S - I + 1.f, inv_d2 = 1.f / (D * D);
+    const float* xp = x + (int64_t)n * HW;
+    const uint8_t* mp = m + (int64_t)n * HW;
+    float* dp = dx + (int64_t)n * HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (int64_t)gridDim.x * 256) {
+        const float tf = (float)mp[i];
+        const float p = sigmoidf_(xp[i]);
+        const float djac = (tf * D - (I + 1.f) * (1.f - tf)) * inv_d2;        // d jac_n / d p
+        dp[i] = g * ((p - tf) * inv_m - p * (1.f - p) * inv_n * djac);
+    }
+}
+
+extern "C" int64_t gs_jaccard_loss_out_floats(int N) { return N > 0 ? 4 + 2 * (int64_t)N : 0; }
+
+extern "C" int gs_jaccard_seg_loss_fwd(const float* logits, const uint8_t* mask, int N, int64_t HW, float* ws, float* out,
+                                       void* stream) {
+    GS_CHECK_ARG(logits && mask && ws && out && N > 0 && N <= 65535 && HW > 0, "gs_jaccard_seg_loss_fwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = dice_batched_blocks(HW);
+    jaccard_fwd_kernel<<<dim3(nb, N), 256, 0, s>>>(logits, mask, HW, ws);
+    jaccard_finalize_kernel<<<1, 256, 0, s>>>(ws, N, nb, HW, out);
+    GS_CHECK_LAUNCH("gs_jaccard_seg_loss_fwd");
+    return GS_OK;
+}
+
+extern "C" int gs_jaccard_seg_loss_bwd(const float* logits, const uint8_t* mask, const float* out, const float* gout,
+                                       float gscale, float* dlogits, int N, int64_t HW, void* stream) {
+    GS_CHECK_ARG(logits && mask && out && dlogits && N > 0 && N <= 65535 && HW > 0, "gs_jaccard_seg_loss_bwd: bad arguments");
+    int64_t nb = cdiv64(HW, 256 * 4);
+    if (nb > 256) nb = 256;
+    if (nb < 1) nb = 1;
+    jaccard_bwd_kernel<<<dim3((int)nb, N), 256, 0, (hipStream_t)stream>>>(logits, mask, out, gout, gscale, dlogits, N, HW);
+    GS_CHECK_LAUNCH("gs_jaccard_seg_loss_bwd");
+    return GS_OK;
+}
+
 extern "C" int64_t gs_dice_batched_ws_floats(int B) { return B > 0 ? (int64_t)B * DB_BLOCKS * 3 : 0; }
 
 extern "C" int gs_dice_coeff_batched(const float* p, const float* t, int B, int64_t n_per, float* ws, float* out,

@@ -2,6 +2,7 @@
 
 seg_loss            fused single-pass  BCEWithLogits + Dice (n_classes == 1)  or  CrossEntropy + multiclass
                     Dice (n_classes > 1): the per-step loss of running_files/train_end2end_jsrt.py:181-183.
+seg_loss_jaccard    BCEWithLogits + per-sample Jaccard loss of the ISIC variant (train_end2end_isic.py:40-56,247-249).
 dice_loss_op        util/dice_score.py:25-28 (one global sum over the batch).
 mean_loss           GANLoss (networks.py:263-281), L1Loss and BCEWithLogits (train_end2end_jsrt.py:136-138).
 """
@@ -78,6 +79,34 @@ def seg_loss(logits: torch.Tensor, mask: torch.Tensor, return_parts: bool = Fals
     (SURVEY 8e); the CE/BCE mean needs no exchange (mean of equal-sized rank means)."""
     n, c, h, w = logits.shape
     loss, parts = _SegLoss.apply(logits, _mask_u8(mask, n, h, w), global_dice)
+    return (loss, parts) if return_parts else loss
+
+
+class _JaccardSegLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, mask_u8):
+        logits = logits.contiguous().float()
+        out = torch.empty(4 + 2 * logits.shape[0], dtype=torch.float32, device=logits.device)
+        ops.jaccard_seg_loss_fwd(logits, mask_u8, out)
+        ctx.save_for_backward(logits, mask_u8, out)
+        return out[0].clone(), out.detach()
+
+    @staticmethod
+    def backward(ctx, gout, _gparts):
+        logits, mask_u8, out = ctx.saved_tensors
+        d = torch.empty_like(logits)
+        ops.jaccard_seg_loss_bwd(logits, mask_u8, out, gout.contiguous().float().reshape(1), 1.0, d)
+        return d, None
+
+
+def seg_loss_jaccard(logits: torch.Tensor, mask: torch.Tensor, return_parts: bool = False):
+    """The per-step loss of the ISIC / RGB variant (running_files/train_end2end_isic.py:247-249, one class):
+    BCEWithLogits(logits, mask) + jaccard_index_loss(sigmoid(logits), mask) (:40-56: per-sample Jaccard, mean over the
+    batch, smooth = 1), one fused pass over the logits.  parts = [loss, bce, 1 - mean jaccard, 0, (I_i, S_i)...]."""
+    n, c, h, w = logits.shape
+    if c != 1:
+        raise ValueError("seg_loss_jaccard: the ISIC loss is defined for n_classes == 1")
+    loss, parts = _JaccardSegLoss.apply(logits, _mask_u8(mask, n, h, w))
     return (loss, parts) if return_parts else loss
 
 

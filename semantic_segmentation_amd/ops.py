@@ -726,6 +726,27 @@ def eval_dice(logits, mask_u8, out):
     _lib.call("gs_eval_dice", _p(logits), _p(mask_u8), N, C, H * W, _p(ws), _p(out), _stream())
 
 
+def jaccard_seg_loss_fwd(logits, mask_u8, out):
+    _dev(logits)
+    _f32(logits, "logits"); _f32(out, "out")
+    N, C, H, W = logits.shape
+    if C != 1:
+        raise ValueError("the Jaccard loss of train_end2end_isic.py is the one-class form")
+    if mask_u8.dtype != torch.uint8 or not mask_u8.is_contiguous() or mask_u8.numel() != N * H * W:
+        raise TypeError("mask must be contiguous uint8 [N,H,W]")
+    if out.numel() < int(_lib.load().gs_jaccard_loss_out_floats(N)):
+        raise ValueError("jaccard_seg_loss_fwd: out too small")
+    ws = torch.empty(int(_lib.load().gs_dice_batched_ws_floats(N)), dtype=torch.float32, device=logits.device)
+    _lib.call("gs_jaccard_seg_loss_fwd", _p(logits), _p(mask_u8), N, H * W, _p(ws), _p(out), _stream())
+
+
+def jaccard_seg_loss_bwd(logits, mask_u8, out, gout, gscale, dlogits):
+    _f32(gout, "gout"); _f32(dlogits, "dlogits")
+    N, C, H, W = logits.shape
+    _lib.call("gs_jaccard_seg_loss_bwd", _p(logits), _p(mask_u8), _p(out), _p(gout), float(gscale), _p(dlogits), N, H * W,
+              _stream())
+
+
 def mean_loss_fwd(x, t, cval, mode, ws, out):
     _dev(x)
     _f32(x, "x"); _f32(t, "target")

@@ -128,6 +128,39 @@ def make_dice_cases():
     print("dice_cases done")
 
 
+def make_jaccard_cases():
+    """jaccard_index / jaccard_index_loss of running_files/train_end2end_isic.py:40-56.  The script itself cannot be
+    imported (betty, wandb, imgaug, torchvision, CUDA at import time), so the two pure functions are compiled from its
+    syntax tree here, in the build container, and only their inputs / outputs are stored."""
+    import ast
+    path = os.path.join(REF, "running_files", "train_end2end_isic.py")
+    tree = ast.parse(open(path).read())
+    fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("jaccard_index", "jaccard_index_loss")]
+    assert len(fns) == 2
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), path, "exec"), ns)
+    jaccard_index, jaccard_index_loss = ns["jaccard_index"], ns["jaccard_index_loss"]
+    g = torch.Generator().manual_seed(11)
+    out = {}
+    x = torch.randn(3, 1, 19, 14, generator=g) * 2
+    t = (torch.rand(3, 1, 19, 14, generator=g) > 0.55).float()
+    t[1] = 0                                                   # an empty mask
+    out["logits"], out["mask"] = x.numpy(), t.numpy().astype(np.uint8)
+    xg = x.clone().requires_grad_(True)
+    bce = torch.nn.BCEWithLogitsLoss()(xg, t)                  # train_end2end_isic.py:248-249
+    loss = bce + jaccard_index_loss(torch.sigmoid(xg.squeeze()), t.float().squeeze())
+    loss.backward()
+    out["loss"], out["bce"], out["grad"] = loss.item(), bce.item(), xg.grad.numpy()
+    p = torch.sigmoid(x.squeeze())
+    out["jaccard"] = jaccard_index(t.squeeze(), p).item()
+    out["jaccard_2d"] = jaccard_index(t[0, 0], p[0]).item()   # the dim() == 2 branch (batch of one after squeeze)
+    x1, t1 = x[:1], t[:1]
+    out["loss_b1"] = (torch.nn.BCEWithLogitsLoss()(x1, t1) +
+                      jaccard_index_loss(torch.sigmoid(x1.squeeze()), t1.float().squeeze())).item()
+    np.savez_compressed(os.path.join(HERE, "jaccard_cases.npz"), **out)
+    print("jaccard_cases done", out["loss"], out["jaccard"])
+
+
 def make_ops_micro():
     """Per-op micro fixtures at tiny shapes from the reference's own modules."""
     from unet.unet_parts import DoubleConv, Down, Up, OutConv
@@ -325,6 +358,8 @@ if __name__ == "__main__":
     if a.only in ("", "ops"):
         make_dice_cases()
         make_ops_micro()
+    if a.only in ("", "ops", "jaccard"):
+        make_jaccard_cases()
     if a.only in ("", "pix2pix"):
         make_pix2pix(256, 2)
     if a.only in ("", "pix2pix", "pix2pix_b8"):
