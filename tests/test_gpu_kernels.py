@@ -725,3 +725,32 @@ def test_conv_wgrad_assign_mode(dtn, dt, N, h, Cin, Cout, k, s, p):
     xb = torch.zeros(8, 64, 64, 64, dtype=dt, device=dev())
     with pytest.raises(RuntimeError):
         ops.conv_wgrad(big, xb, xb, torch.zeros(9, 64, 64, device=dev()), assign=True)
+
+
+def test_jaccard_seg_loss_matches_golden_and_oracle(golden_dir):
+    """BCE + Jaccard loss of the ISIC variant (train_end2end_isic.py:40-56,247-249): HIP kernel vs the reference-generated
+    vectors (value + gradient) and vs the oracle on a larger random case with an empty mask."""
+    import os
+    from oracle import oracle
+    from semantic_segmentation_amd.losses import seg_loss_jaccard
+    z = np.load(os.path.join(golden_dir, "jaccard_cases.npz"))
+    x = torch.from_numpy(z["logits"]).to(dev()).requires_grad_(True)
+    m = torch.from_numpy(z["mask"].astype(np.int64)).to(dev())
+    loss, parts = seg_loss_jaccard(x, m, return_parts=True)
+    loss.backward()
+    assert abs(loss.item() - float(z["loss"])) < 2e-6
+    assert abs(parts[1].item() - float(z["bce"])) < 2e-6
+    assert np.abs(x.grad.cpu().numpy() - z["grad"]).max() < 2e-7
+    assert abs(seg_loss_jaccard(x.detach()[:1], m[:1]).item() - float(z["loss_b1"])) < 2e-6
+    g = torch.Generator().manual_seed(3)
+    xl = (torch.randn(4, 1, 96, 128, generator=g) * 3)
+    ml = (torch.rand(4, 1, 96, 128, generator=g) > 0.7).long()
+    ml[2] = 0
+    xr = xl.clone().requires_grad_(True)
+    ref = oracle.seg_loss_jaccard(xr, ml)
+    ref.backward()
+    xd = xl.to(dev()).requires_grad_(True)
+    got = seg_loss_jaccard(xd, ml.to(dev()))
+    (got * 3.0).backward()
+    assert abs(got.item() - ref.item()) < 2e-6
+    assert (xd.grad.cpu() - 3.0 * xr.grad).abs().max() < 1e-8 + 2e-6 * xr.grad.abs().max()

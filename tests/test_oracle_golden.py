@@ -255,3 +255,19 @@ def test_postproc_pipeline_matches_torch_cpu_float_steps():
     assert np.array_equal(postproc.minmax_to_u8(x.numpy()), u8)
     out = postproc.fake_image_postprocess(x.numpy())
     assert out.dtype == np.float32 and out.min() >= 0 and out.max() <= 1
+
+
+def test_jaccard_loss_matches_reference(golden_dir):
+    """oracle.seg_loss_jaccard / jaccard_index against vectors produced by the reference's own functions
+    (train_end2end_isic.py:40-56,247-249; tests/golden/make_golden.py::make_jaccard_cases)."""
+    z = load(golden_dir, "jaccard_cases")
+    x = torch.from_numpy(z["logits"]).requires_grad_(True)
+    m = torch.from_numpy(z["mask"].astype(np.int64))
+    loss = oracle.seg_loss_jaccard(x, m)
+    loss.backward()
+    assert abs(loss.item() - float(z["loss"])) < 1e-6
+    assert np.abs(x.grad.numpy() - z["grad"]).max() < 1e-7
+    p = torch.sigmoid(x.detach()[:, 0])
+    assert abs(oracle.jaccard_index(m[:, 0].float(), p).item() - float(z["jaccard"])) < 1e-6
+    assert abs(oracle.jaccard_index(m[0, 0].float(), p[0]).item() - float(z["jaccard_2d"])) < 1e-6
+    assert abs(oracle.seg_loss_jaccard(x.detach()[:1], m[:1]).item() - float(z["loss_b1"])) < 1e-6
