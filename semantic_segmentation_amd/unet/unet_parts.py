@@ -4,7 +4,9 @@
 The leaf modules (nn.Conv2d / nn.BatchNorm2d / nn.ConvTranspose2d) are PARAMETER CONTAINERS only: they
 give identical parameter names, shapes, default initialisation and checkpoint compatibility.  Their ATen
 forward is never used on the hot path -- `UNet.forward` runs the whole network through the hand-written
-HIP kernels (unet_engine.py).  Calling a block on its own is routed through the same kernels."""
+HIP kernels (unet_engine.py), which fuse across block boundaries (pool into the producer's BN pass, the
+transposed conv straight into the concat buffer).  Calling a block on its own is therefore NOT provided:
+`forward` raises (there is no ATen fallback to fall back to)."""
 import torch
 import torch.nn as nn
 

@@ -439,3 +439,49 @@ def test_direct_image_layer_matches_mfma_path():
     num = sum(float(((a[1][k] - b[1][k]).double() ** 2).sum()) for k in a[1])
     den = sum(float((b[1][k].double() ** 2).sum()) for k in a[1])
     assert (num / den) ** 0.5 < 2e-2
+
+
+def test_rgb_generator_and_discriminator_vs_oracle():
+    """The ISIC / RGB configuration of the GAN (scripts/train_end2end_isic.sh: --input_nc 1 --output_nc 3): UnetGenerator(1, 3)
+    and NLayerDiscriminator(1 + 3) forward, GAN-step losses and gradients against the oracle at batch 4, 256x256."""
+    from semantic_segmentation_amd import steps
+    from semantic_segmentation_amd.models_pix2pix import networks
+    N = 4
+    sdG = seeded_generator_state_dict(seed=61, input_nc=1, output_nc=3)
+    sdD = seeded_discriminator_state_dict(seed=62, input_nc=4)
+    norm = networks.get_norm_layer("batch")
+    G = networks.UnetGenerator(1, 3, 8, 64, norm_layer=norm, use_dropout=False)
+    D = networks.NLayerDiscriminator(4, 64, 3, norm)
+    G.load_state_dict(sdG, strict=True); D.load_state_dict(sdD, strict=True)
+    G, D = G.cuda().train(), D.cuda().train()
+    g = torch.Generator().manual_seed(6)
+    arch = 0.4 * torch.randn(8, 3, generator=g)
+    _, mask = oracle.synthetic_batch(N, 256, seed=13)
+    maskf = mask.float()
+    real = torch.rand(N, 3, 256, 256, generator=g)
+    crit = networks.GANLoss("vanilla").cuda()
+    ag = arch.cuda().requires_grad_(True)
+    networks.upconv_arch = ag
+    with torch.no_grad():
+        ref_fake = oracle.unet_generator_forward(sdG, arch, maskf, train=True)
+        fake = G(maskf.cuda())
+    d = (fake.cpu() - ref_fake).abs()
+    assert fake.shape == (N, 3, 256, 256)
+    assert d.mean() < 5e-4 and d.max() < 1e-2, (float(d.mean()), float(d.max()))
+    G.load_state_dict(sdG, strict=True)
+    lG = steps.generator_step_loss(G, D, crit, maskf.cuda(), real.cuda(), 100.0)
+    lG.backward()
+    pG = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sdG.items()}
+    a = arch.clone().requires_grad_(True)
+    rG = oracle.generator_step_loss(pG, sdD, a, maskf, real, 100.0)
+    rG.backward()
+    assert abs(lG.item() - rG.item()) < 2e-4 * abs(rG.item()), (lG.item(), rG.item())
+    nerr = [abs(float(q.grad.norm()) - float(pG[k].grad.norm())) / max(float(pG[k].grad.norm()), 1e-20)
+            for k, q in G.named_parameters()]
+    assert np.median(nerr) < 5e-3 and max(nerr) < 8e-2, (float(np.median(nerr)), max(nerr))
+    assert float((ag.grad.cpu() - a.grad).abs().max() / a.grad.abs().max()) < 1e-2
+    G.load_state_dict(sdG, strict=True); D.load_state_dict(sdD, strict=True)
+    lD = steps.discriminator_step_loss(G, D, crit, maskf.cuda(), real.cuda())
+    with torch.no_grad():
+        rD = oracle.discriminator_step_loss(sdG, sdD, arch, maskf, real)
+    assert abs(lD.item() - rD.item()) < 5e-4, (lD.item(), rD.item())
