@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 23
+#define GS_ABI_VERSION 24
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -76,6 +76,14 @@ int gs_conv_igemm_mtiles(const GsConvGeom* g);
 int64_t gs_conv_igemm_workspace_floats(void);
 int gs_conv_igemm(const GsConvGeom* g, const void* x, const void* w, void* y, const float* bias,
                   float* bn_partials, int act, int dtype, float* splitk_ws, int64_t splitk_ws_floats, void* stream);
+/* Up to four such GEMMs over the same x / y / bias in ONE grid: the four sub-pixel classes of a stride-2 transposed
+ * convolution (networks.py:486-511 merged kernel) or of the data gradient of a stride-2 convolution (networks.py:582,640-655).
+ * g[i] / w[i] / bn_partials[i] (array may be NULL) per GEMM; <= 16 taps each, Cin != 8, one tile shape for all (equal
+ * Cout and pixel counts).  GEMM i splits K through the i-th quarter of the workspace (a single gs_conv_igemm uses the
+ * first quarter). */
+int gs_conv_igemm_batch(int n, const GsConvGeom* const* g, const void* x, const void* const* w, void* y, const float* bias,
+                        float* const* bn_partials, int act, int dtype, float* splitk_ws, int64_t splitk_ws_floats,
+                        void* stream);
 
 /* ---- stride-2 / kernel-2 transposed convolution as ONE pointwise GEMM + sub-pixel scatter ------
  * replaces nn.ConvTranspose2d(C, C/2, kernel_size=2, stride=2) at unet/unet_parts.py:51 (Up.up) and

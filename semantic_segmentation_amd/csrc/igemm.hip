@@ -18,8 +18,24 @@
 
 namespace {
 
-struct IgemmArgs {
-    GsConvGeom g;
+// Compact geometry for batched launches (several GEMMs -- the four sub-pixel classes of a stride-2 transposed conv or of a
+// stride-2 conv's data gradient -- in ONE grid): same field names as GsConvGeom with 16-tap arrays, so that four of them fit
+// in the 4 KB kernel-argument segment.
+constexpr int GEOMC_MAX_TAPS = 16;
+struct GeomC {
+    int32_t N, IH, IW, Cin, in_pix_stride, in_coff;
+    int32_t OHg, OWg, Cout;
+    int32_t OH, OW, out_pix_stride, out_coff;
+    int32_t isy, isx, osy, osx, ooy, oox;
+    int32_t ntaps;
+    int32_t tap_dy[GEOMC_MAX_TAPS], tap_dx[GEOMC_MAX_TAPS], tap_w[GEOMC_MAX_TAPS];
+    int32_t Dg, Din, Dout, isz, osz, ooz;
+    int32_t tap_dz[GEOMC_MAX_TAPS];
+};
+
+template <typename GEOM>
+struct IgemmArgsT {
+    GEOM g;
     const unsigned short* x;
     const unsigned short* w;
     unsigned short* y;
@@ -45,6 +61,15 @@ struct IgemmArgs {
     unsigned short* y_lo = nullptr;
     int in_wrap = 0;
 };
+typedef IgemmArgsT<GsConvGeom> IgemmArgs;
+typedef IgemmArgsT<GeomC> IgemmArgsC;
+constexpr int IGEMM_BATCH_MAX = 4;
+struct IgemmBatchArgs {
+    IgemmArgsC c[IGEMM_BATCH_MAX];
+    int start[IGEMM_BATCH_MAX + 1];     // first block of every GEMM; start[n] = grid size
+    int n;
+};
+static_assert(sizeof(IgemmBatchArgs) <= 3800, "batched igemm arguments must fit the kernel-argument segment");
 
 // bijective XCD-aware remap: blocks that share an XCD (bid % 8) get a contiguous range of logical ids
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -55,8 +80,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 constexpr int FW_BM = 128, FW_BK = 64, FW_LDR = 72;   // LDS row = 64 + 8 pad elements (144 B)
 
-template <int DT, int BN, bool PACKED, bool PREC = false>
-__global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
+template <int DT, int BN, bool PACKED, bool PREC, typename ARGS>
+__device__ __forceinline__ void igemm_fwd_body(const ARGS& a, const int block_id) {
     static_assert(!(PACKED && PREC), "no precise form of the packed-tap kernel");
     typedef typename Elem<DT>::V8 V8;
     constexpr int NT = BN / 64;            // 32-wide N tiles per wave
@@ -65,12 +90,12 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
     constexpr int BUF_EL = A_EL + B_EL;
     __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BUF_EL];
 
-    const GsConvGeom& g = a.g;
+    const auto& g = a.g;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
     const int ksplit = a.ksplit;
-    const int kpart = ksplit > 1 ? (int)(blockIdx.x % ksplit) : 0;
-    const int lid = ksplit > 1 ? (int)(blockIdx.x / ksplit) : xcd_remap(blockIdx.x, a.nblocks);
+    const int kpart = ksplit > 1 ? (int)(block_id % ksplit) : 0;
+    const int lid = ksplit > 1 ? (int)(block_id / ksplit) : xcd_remap(block_id, a.nblocks);
     const int ntile = lid % a.ntn, mtile = lid / a.ntn;
     const int m0 = mtile * FW_BM, n0 = ntile * BN;
 
@@ -387,6 +412,23 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
     }
 }
 
+template <int DT, int BN, bool PACKED, bool PREC = false>
+__global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
+    igemm_fwd_body<DT, BN, PACKED, PREC>(a, (int)blockIdx.x);
+}
+
+// Several independent GEMMs (<= 4, <= 16 taps each) in one grid: block b belongs to GEMM c with start[c] <= b < start[c+1].
+// The sub-pixel classes of a layer are latency bound at the script's batch size (M = a few hundred pixels, one launch
+// fills a fraction of the chip and costs a launch gap): together they fill it and pay one gap.
+template <int DT, int BN>
+__global__ __launch_bounds__(256) void igemm_fwd_batch_kernel(const IgemmBatchArgs b) {
+    int c = 0;
+#pragma unroll
+    for (int i = 1; i < IGEMM_BATCH_MAX; ++i)
+        if (i < b.n && (int)blockIdx.x >= b.start[i]) c = i;
+    igemm_fwd_body<DT, BN, false, false>(b.c[c], (int)blockIdx.x - b.start[c]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight gradient
 // ------------------------------------------------------------------------------------------------
@@ -606,6 +648,7 @@ int check_geom(const GsConvGeom* g, const char* who) {
 constexpr int64_t SPLITK_TILE_FLOATS = 256 * 64;          // 256 threads x (2 x 2 x 16) accumulators of a 128x128 tile
 
 constexpr int SPLITK_MAX_PARTS = 16, SPLITK_MAX_SLABS = 512;
+constexpr int64_t SPLITK_CNT_SLOTS = 1024;                // tile ticket counters per GEMM (split launches have <= 128 tiles)
 
 // ksplit for a launch with `tiles` output tiles and up to `ksteps` K steps.  Skinny GEMMs (few M/N tiles, long K: the
 // batch-2 Pix2Pix layers) are latency bound -- one block walks 128 K steps of ~0.5 us with 64 blocks on 256 CUs --
@@ -627,8 +670,8 @@ static int choose_ksplit(int tiles, int ksteps, int64_t ws_floats, int64_t cnt_s
     return k < 2 ? 1 : k;
 }
 
-static int launch_igemm(IgemmArgs& a, int dtype, hipStream_t s, const char* who, float* ws = nullptr,
-                        int64_t ws_floats = 0) {
+// tile shape, N tiles, block count and K split of one GEMM; ws (may be NULL): [cnt_slots tile counters][slabs]
+static int plan_igemm(IgemmArgs& a, float* ws, int64_t ws_floats, int64_t cnt_slots) {
     const int mt = cdiv(a.M, FW_BM);
     // few-tile (weight-streaming) launches take the 64-wide N tile: twice the blocks for the same 16-part split-K limit
     static const int skinny_tiles = getenv("GSSEG_IGEMM_SKINNY") ? atoi(getenv("GSSEG_IGEMM_SKINNY")) : 16;
@@ -638,8 +681,7 @@ static int launch_igemm(IgemmArgs& a, int dtype, hipStream_t s, const char* who,
     a.ksplit = 1; a.ws_acc = nullptr; a.ws_cnt = nullptr;
     const bool packed = a.g.Cin == 8 && a.g.ntaps >= 8;
     if (ws != nullptr) {
-        // layout of the caller's (zero-initialised, self-cleaning) workspace: [4096 tile counters][tile accumulators]
-        const int64_t cnt_slots = 4096;
+        // layout of the caller's (zero-initialised, self-cleaning) workspace: [tile counters][tile accumulators]
         const int k = choose_ksplit(a.nblocks, packed ? cdiv(a.g.ntaps, 8) : a.g.ntaps * a.kchunks, ws_floats - cnt_slots, cnt_slots);
         if (k > 1) {
             a.ksplit = k;
@@ -647,6 +689,14 @@ static int launch_igemm(IgemmArgs& a, int dtype, hipStream_t s, const char* who,
             a.ws_acc = ws + cnt_slots;
         }
     }
+    return bn;
+}
+
+static int launch_igemm(IgemmArgs& a, int dtype, hipStream_t s, const char* who, float* ws = nullptr,
+                        int64_t ws_floats = 0) {
+    // a single launch uses the first quarter of the workspace (the batched form gives each of its <= 4 GEMMs a quarter)
+    const int bn = plan_igemm(a, ws, ws ? ws_floats / IGEMM_BATCH_MAX : 0, SPLITK_CNT_SLOTS);
+    const bool packed = a.g.Cin == 8 && a.g.ntaps >= 8;
     dim3 grid(a.nblocks * a.ksplit), block(256);
     if (a.y_lo != nullptr) {                      // precise mode: hi/lo output pair, K segments over wrapped input channels
         GS_CHECK_ARG(!packed && a.ksplit == 1 && a.vec_store && a.bnp == nullptr, "%s: precise mode needs 16-byte stores, no split-K", who);
@@ -699,7 +749,7 @@ extern "C" int gs_conv_igemm(const GsConvGeom* g, const void* x, const void* w, 
     a.kchunks = cdiv(g->Cin, FW_BK);
     a.vec_store = (g->Cout % 8 == 0 && g->out_pix_stride % 8 == 0 && g->out_coff % 8 == 0) ? 1 : 0;
     a.shuffle_cout = 0; a.shuffle_cls = 0;
-    GS_CHECK_ARG(splitk_ws == nullptr || splitk_ws_floats >= 4096 + SPLITK_TILE_FLOATS,
+    GS_CHECK_ARG(splitk_ws == nullptr || splitk_ws_floats >= IGEMM_BATCH_MAX * (SPLITK_CNT_SLOTS + SPLITK_TILE_FLOATS),
                  "gs_conv_igemm: split-K workspace too small (gs_conv_igemm_workspace_floats())");
     return launch_igemm(a, dtype, (hipStream_t)stream, "gs_conv_igemm", splitk_ws, splitk_ws ? splitk_ws_floats : 0);
 }
@@ -710,7 +760,68 @@ extern "C" int gs_conv_igemm(const GsConvGeom* g, const void* x, const void* w, 
 // keeps no pointer: launches that share one workspace must be ordered on one stream, so the host keeps one per
 // (device, stream).
 extern "C" int64_t gs_conv_igemm_workspace_floats(void) {
-    return 4096 + (int64_t)SPLITK_MAX_SLABS * SPLITK_TILE_FLOATS;
+    return IGEMM_BATCH_MAX * (SPLITK_CNT_SLOTS + (int64_t)SPLITK_MAX_SLABS * SPLITK_TILE_FLOATS);
+}
+
+// Up to four GEMMs over the same x / y / bias in ONE grid (the sub-pixel classes of a stride-2 transposed convolution, or
+// of the data gradient of a stride-2 convolution): g[i], w[i], bn_partials[i] per GEMM, <= 16 taps each, equal Cin / Cout /
+// logical pixel counts.  GEMM i splits K through the i-th quarter of the workspace.
+extern "C" int gs_conv_igemm_batch(int n, const GsConvGeom* const* g, const void* x, const void* const* w, void* y,
+                                   const float* bias, float* const* bn_partials, int act, int dtype, float* splitk_ws,
+                                   int64_t splitk_ws_floats, void* stream) {
+    GS_CHECK_ARG(n >= 1 && n <= IGEMM_BATCH_MAX && g && w && x && y, "gs_conv_igemm_batch: bad arguments (1..4 GEMMs)");
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_conv_igemm_batch: bad dtype %d", dtype);
+    GS_CHECK_ARG(splitk_ws == nullptr || splitk_ws_floats >= IGEMM_BATCH_MAX * (SPLITK_CNT_SLOTS + SPLITK_TILE_FLOATS),
+                 "gs_conv_igemm_batch: split-K workspace too small (gs_conv_igemm_workspace_floats())");
+    IgemmBatchArgs b;
+    b.n = n;
+    int bn0 = 0, total = 0;
+    const int64_t quarter = splitk_ws ? splitk_ws_floats / IGEMM_BATCH_MAX : 0;
+    for (int i = 0; i < n; ++i) {
+        int rc = check_geom(g[i], "gs_conv_igemm_batch");
+        if (rc) return rc;
+        GS_CHECK_ARG(w[i] != nullptr, "gs_conv_igemm_batch: null weight pointer");
+        GS_CHECK_ARG(g[i]->ntaps <= GEOMC_MAX_TAPS, "gs_conv_igemm_batch: at most %d taps per GEMM", GEOMC_MAX_TAPS);
+        GS_CHECK_ARG(!(g[i]->Cin == 8 && g[i]->ntaps >= 8), "gs_conv_igemm_batch: packed-tap (Cin == 8) layers are not batched");
+        IgemmArgs a;
+        a.g = *g[i];
+        a.x = (const unsigned short*)x; a.w = (const unsigned short*)w[i]; a.y = (unsigned short*)y;
+        a.bias = bias; a.bnp = bn_partials ? bn_partials[i] : nullptr; a.act = act;
+        a.M = g[i]->N * g[i]->Dg * g[i]->OHg * g[i]->OWg;
+        a.kchunks = cdiv(g[i]->Cin, FW_BK);
+        a.vec_store = (g[i]->Cout % 8 == 0 && g[i]->out_pix_stride % 8 == 0 && g[i]->out_coff % 8 == 0) ? 1 : 0;
+        a.shuffle_cout = 0; a.shuffle_cls = 0;
+        const int bn = plan_igemm(a, splitk_ws ? splitk_ws + i * quarter : nullptr, quarter, SPLITK_CNT_SLOTS);
+        if (i == 0) bn0 = bn;
+        GS_CHECK_ARG(bn == bn0, "gs_conv_igemm_batch: the GEMMs of a batch must share one tile shape");
+        IgemmArgsC& c = b.c[i];
+        const GsConvGeom& s0 = a.g;
+        c.g.N = s0.N; c.g.IH = s0.IH; c.g.IW = s0.IW; c.g.Cin = s0.Cin; c.g.in_pix_stride = s0.in_pix_stride; c.g.in_coff = s0.in_coff;
+        c.g.OHg = s0.OHg; c.g.OWg = s0.OWg; c.g.Cout = s0.Cout; c.g.OH = s0.OH; c.g.OW = s0.OW;
+        c.g.out_pix_stride = s0.out_pix_stride; c.g.out_coff = s0.out_coff;
+        c.g.isy = s0.isy; c.g.isx = s0.isx; c.g.osy = s0.osy; c.g.osx = s0.osx; c.g.ooy = s0.ooy; c.g.oox = s0.oox;
+        c.g.ntaps = s0.ntaps;
+        for (int t = 0; t < GEOMC_MAX_TAPS; ++t) {
+            c.g.tap_dy[t] = s0.tap_dy[t]; c.g.tap_dx[t] = s0.tap_dx[t]; c.g.tap_w[t] = s0.tap_w[t]; c.g.tap_dz[t] = s0.tap_dz[t];
+        }
+        c.g.Dg = s0.Dg; c.g.Din = s0.Din; c.g.Dout = s0.Dout; c.g.isz = s0.isz; c.g.osz = s0.osz; c.g.ooz = s0.ooz;
+        c.x = a.x; c.w = a.w; c.y = a.y; c.bias = a.bias; c.bnp = a.bnp; c.act = a.act; c.M = a.M; c.kchunks = a.kchunks;
+        c.ntn = a.ntn; c.nblocks = a.nblocks; c.vec_store = a.vec_store; c.shuffle_cout = 0; c.shuffle_cls = 0;
+        c.ksplit = a.ksplit; c.ws_acc = a.ws_acc; c.ws_cnt = a.ws_cnt; c.y_lo = nullptr; c.in_wrap = 0;
+        b.start[i] = total;
+        total += a.nblocks * a.ksplit;
+    }
+    for (int i = n; i <= IGEMM_BATCH_MAX; ++i) b.start[i] = total;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GS_F16) {
+        if (bn0 == 64) igemm_fwd_batch_kernel<GS_F16, 64><<<total, 256, 0, s>>>(b);
+        else igemm_fwd_batch_kernel<GS_F16, 128><<<total, 256, 0, s>>>(b);
+    } else {
+        if (bn0 == 64) igemm_fwd_batch_kernel<GS_BF16, 64><<<total, 256, 0, s>>>(b);
+        else igemm_fwd_batch_kernel<GS_BF16, 128><<<total, 256, 0, s>>>(b);
+    }
+    GS_CHECK_LAUNCH("gs_conv_igemm_batch");
+    return GS_OK;
 }
 
 // Merged stride-2 / kernel-2 transposed convolution (unet_parts.py:51 ConvTranspose2d(C, C/2, 2, 2);

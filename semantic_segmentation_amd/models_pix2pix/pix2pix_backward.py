@@ -159,7 +159,6 @@ def generator_backward(engine, ctx, arch, dout, need_dx):
             ops.conv_wgrad_det(lv["geom"], lv["inp"], dy, wsl, dw, cout, cin, 16, inv_s)
             emit(conv.weight, dw)
             dL = empty(N, hs[k - 1], ws[k - 1], cin)
-            for cls in range(4):
-                gd = ops.geom_conv_s2_dgrad_class(N, hs[k - 1], ws[k - 1], cin, cout, 4, 1, cls >> 1, cls & 1)
-                ops.conv_igemm(gd, dy, lv["wd"], dL)
+            gds = [ops.geom_conv_s2_dgrad_class(N, hs[k - 1], ws[k - 1], cin, cout, 4, 1, cls >> 1, cls & 1) for cls in range(4)]
+            ops.conv_igemm_batch(gds, dy, [lv["wd"]] * 4, dL)
     return grads, darch.to(arch.device), dx

@@ -224,11 +224,14 @@ class GeneratorEngine:
                 mt = ops.conv_igemm_mtiles(ops.geom_convT_class(N, h, w, cin_t, cout_t, 8, 3, 0, 0))
                 use_stats = training or upnorm.running_mean is None
                 part = empty(ops.bn_partials_numel(4 * mt, cout_t), dtype=torch.float32) if use_stats else None
+                geoms = []
                 for cls in range(4):
                     g = ops.geom_convT_class(N, h, w, cin_t, cout_t, 8, 3, cls >> 1, cls & 1)
                     g_tapw_identity(g)
-                    pslice = part[cls * mt * 2 * cout_t:] if part is not None else None
-                    ops.conv_igemm(g, R[d + 1], pf[cls], u, bias, pslice)
+                    geoms.append(g)
+                pslices = [part[cls * mt * 2 * cout_t:] for cls in range(4)] if part is not None else None
+                # the four sub-pixel classes in ONE launch (each is latency bound on its own at the script's batch size)
+                ops.conv_igemm_batch(geoms, R[d + 1], [pf[cls] for cls in range(4)], u, bias, pslices)
                 coef, stats = _bn_coeffs(upnorm, part, 4 * mt, cout_t, N * H2 * W2, training, dev)
                 keep, kscale = None, 1.0
                 if drop is not None and training and drop.p > 0:
@@ -253,10 +256,12 @@ class GeneratorEngine:
                     # direct kernel: bias + tanh + fp32 NCHW in one pass (the MFMA engine would use 1 of 64 N columns)
                     ops.upconv8_image_fwd(R[1], pf, bpad, out, u if need_grad else None, N, h, w, cin_t, cout_t, ACT_TANH)
                 else:
+                    geoms = []
                     for cls in range(4):
                         g = ops.geom_convT_class(N, h, w, cin_t, cpad, 8, 3, cls >> 1, cls & 1)
                         g_tapw_identity(g)
-                        ops.conv_igemm(g, R[1], pf[cls], u, bpad, None)
+                        geoms.append(g)
+                    ops.conv_igemm_batch(geoms, R[1], [pf[cls] for cls in range(4)], u, bpad, None)
                     t = empty(N, H2, W2, cpad)
                     ops.bn_act_apply(u, None, None, ACT_TANH, t, cpad, 0)
                     ops.nhwc_to_nchw(t, out, cpad, 0)
@@ -455,9 +460,9 @@ class DiscriminatorEngine:
             if s == 1:
                 ops.conv_igemm(ops.geom_conv_dgrad_s1(N, rec["ih"], rec["iw"], cin, cout, k, p), dy, rec["wd"], dz)
             else:
-                for cls in range(4):
-                    gd = ops.geom_conv_s2_dgrad_class(N, rec["ih"], rec["iw"], cin, cout, k, p, cls >> 1, cls & 1)
-                    ops.conv_igemm(gd, dy, rec["wd"], dz)
+                gds = [ops.geom_conv_s2_dgrad_class(N, rec["ih"], rec["iw"], cin, cout, k, p, cls >> 1, cls & 1)
+                       for cls in range(4)]
+                ops.conv_igemm_batch(gds, dy, [rec["wd"]] * 4, dz)
         first = recs[0]
         conv = first["conv"]
         z = first["z"]

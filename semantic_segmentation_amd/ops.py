@@ -209,6 +209,34 @@ def conv_igemm(g: GsConvGeom, x, w, y, bias=None, bn_partials=None, act=ACT_NONE
 
 
 # taps of a 3x3/pad-1 conv in weight order, and the flipped list that turns the same kernel into its dgrad
+def conv_igemm_batch(geoms, x, ws_list, y, bias=None, bn_partials=None, act=ACT_NONE):
+    """Up to four GEMMs (the sub-pixel classes of one layer) over the same x / y / bias in ONE launch: geoms[i] with weights
+    ws_list[i] and optional BatchNorm partials bn_partials[i].  At the script's batch size (2) a class launch fills a
+    fraction of the chip; together the classes fill it and pay one launch gap."""
+    _dev(x)
+    _f32(bias, "bias")
+    n = len(geoms)
+    if not 1 <= n <= 4 or len(ws_list) != n or (bn_partials is not None and len(bn_partials) != n):
+        raise ValueError("conv_igemm_batch: 1..4 GEMMs with one weight tensor (and optionally one partials tensor) each")
+    if any(w.dtype != x.dtype for w in ws_list) or y.dtype != x.dtype:
+        raise TypeError("conv_igemm_batch: x, w, y must share one 16-bit dtype")
+    if bn_partials is not None:
+        for g, p in zip(geoms, bn_partials):
+            _f32(p, "bn_partials")
+            if p.numel() < _lib.load().gs_bn_partials_floats(conv_igemm_mtiles(g), g.Cout):
+                raise ValueError("conv_igemm_batch: bn_partials too small")
+    garr = (ctypes.POINTER(GsConvGeom) * n)(*[ctypes.pointer(g) for g in geoms])
+    warr = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws_list])
+    parr = (ctypes.c_void_p * n)(*[p.data_ptr() for p in bn_partials]) if bn_partials is not None else None
+    stream = _stream()
+    ws = _splitk_workspace(x.device, stream)
+    ev = TIMER.start() if TIMER is not None else None
+    _lib.call("gs_conv_igemm_batch", n, garr, _p(x), warr, _p(y), _p(bias), parr, act, dt_code(x), _p(ws),
+              ws.numel() if ws is not None else 0, stream)
+    if ev is not None:
+        TIMER.stop("igemm_fwd", ev, sum(_geom_flops(g) for g in geoms))
+
+
 TAPS3_FWD = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
 TAPS3_DGRAD = [(1 - ky, 1 - kx) for ky in range(3) for kx in range(3)]
 USE_HALO_CONV = os.environ.get("GSSEG_CONV3X3", "halo") != "generic"

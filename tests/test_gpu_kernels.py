@@ -622,7 +622,9 @@ def test_igemm_split_k_skinny(dtn, dt, N, h, Cin, Cout, k, s, p):
     assert float((ps[0] - r1).abs().max() / (r1.abs().max() + 1e-6)) < 3e-3
     assert ops._SPLITK_WS                                            # one workspace per (device, stream), passed per call
     for ws in ops._SPLITK_WS.values():
-        assert int(ws[:4096].view(torch.int32).abs().max()) == 0    # the tile ticket counters are back to zero
+        q = ws.numel() // 4                                          # one quarter per GEMM of a batched launch
+        for i in range(4):
+            assert int(ws[i * q:i * q + 1024].view(torch.int32).abs().max()) == 0    # tile ticket counters back to zero
 
 
 @pytest.mark.parametrize("C", [1, 2])
@@ -754,3 +756,47 @@ def test_jaccard_seg_loss_matches_golden_and_oracle(golden_dir):
     (got * 3.0).backward()
     assert abs(got.item() - ref.item()) < 2e-6
     assert (xd.grad.cpu() - 3.0 * xr.grad).abs().max() < 1e-8 + 2e-6 * xr.grad.abs().max()
+
+
+@pytest.mark.parametrize("N,h,cin,cout", [(2, 4, 1024, 512), (2, 16, 512, 256), (8, 32, 256, 128)])
+def test_igemm_batch_equals_per_class_launches(N, h, cin, cout):
+    """gs_conv_igemm_batch (four sub-pixel classes of a merged k8/s2 transposed conv in one grid, incl. split-K through the
+    per-GEMM workspace quarters and BatchNorm partials) is bit-identical to four gs_conv_igemm launches."""
+    from semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(h)
+    dt = torch.float16
+    x = torch.randn(N, h, h, cin, generator=g).to(dev()).to(dt)
+    pf = (0.05 * torch.randn(4, 16, cout, cin, generator=g)).to(dev()).to(dt)
+    bias = torch.randn(cout, generator=g).to(dev())
+    geoms = []
+    for cls in range(4):
+        gm = ops.geom_convT_class(N, h, h, cin, cout, 8, 3, cls >> 1, cls & 1)
+        for t in range(gm.ntaps):
+            gm.tap_w[t] = t
+        geoms.append(gm)
+    mt = ops.conv_igemm_mtiles(geoms[0])
+    npart = ops.bn_partials_numel(4 * mt, cout)
+    y1 = torch.zeros(N, 2 * h, 2 * h, cout, dtype=dt, device=dev())
+    p1 = torch.zeros(npart, device=dev())
+    for cls in range(4):
+        ops.conv_igemm(geoms[cls], x, pf[cls], y1, bias, p1[cls * mt * 2 * cout:])
+    y2 = torch.zeros_like(y1)
+    p2 = torch.zeros(npart, device=dev())
+    ops.conv_igemm_batch(geoms, x, [pf[c] for c in range(4)], y2, bias, [p2[c * mt * 2 * cout:] for c in range(4)])
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2)
+    assert torch.equal(p1[:4 * mt * 2 * cout], p2[:4 * mt * 2 * cout])
+    ref = torch.nn.functional.conv_transpose2d(x.float().permute(0, 3, 1, 2).cpu(),
+                                               _unpack_merged(pf.float().cpu(), cin, cout), bias.cpu(), stride=2, padding=3)
+    assert rel_err(from_nhwc(y2), ref) < tol(dt)
+
+
+def _unpack_merged(pf, cin, cout):
+    """class-major pack [4][16][Cout][Cin] -> ConvTranspose2d weight [Cin][Cout][8][8] (csrc/pix2pix.hip layout)."""
+    w = torch.zeros(cin, cout, 8, 8)
+    for ky in range(8):
+        for kx in range(8):
+            c = (1 - (ky & 1)) * 2 + (1 - (kx & 1))
+            t = (ky >> 1) * 4 + (kx >> 1)
+            w[:, :, ky, kx] = pf[c, t].t()
+    return w

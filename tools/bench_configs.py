@@ -49,14 +49,17 @@ def main():
         real = torch.rand(B, 1, 256, 256, device=dev)
 
         def g_step():
+            # the Generator step of iteration k+1 runs on the weights the Discriminator / Unet steps of iteration k already
+            # packed for their forward passes: it re-uses that forward pack and builds the data-gradient pack (stale since
+            # optimizer_G.step()).  The version bump that stands for optimizer_G.step() sits in d_step, so per trio the
+            # merged packs are built exactly as often as in the real loop: one forward pack + one data-gradient pack.
+            for key in [k for k in G._engine.packs._d if k[0] == "merged" and k[2]]:
+                del G._engine.packs._d[key]                 # data-gradient packs: stale after optimizer_G.step()
             zero(G, D); steps.generator_step_loss(G, D, crit, maskf, real).backward()
-            # stand-in for optimizer_G.step(): the generator's weights count as modified once per iteration, so the merged
-            # 16-bit packs are rebuilt once per trio (they are cached between the three steps of one iteration)
-            torch.autograd.graph.increment_version(list(G.parameters()))
 
         def d_step():
-            # first generator forward after optimizer_G.step(): pays the re-merge of the forward packs (conservative: the
-            # Generator step above is charged a forward re-merge too, which the real loop does not pay)
+            # stand-in for optimizer_G.step() at the end of the Generator step: the first generator forward afterwards
+            # (this one) pays the re-merge of the forward packs
             torch.autograd.graph.increment_version(list(G.parameters()))
             zero(G, D); steps.discriminator_step_loss(G, D, crit, maskf, real).backward()
 
