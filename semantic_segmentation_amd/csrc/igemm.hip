@@ -55,6 +55,11 @@ struct IgemmArgsT {
     int ksplit;
     float* ws_acc;
     unsigned int* ws_cnt;
+    // split-K runs as TWO launches on the stream (no in-kernel hand-off): phase 1 = K parts store their fp32 tiles in slabs,
+    // phase 2 = one block per tile sums the slabs in part order and runs the epilogue.  (The former one-launch form -- every
+    // block a device-scope release fence, a ticket, the last arriver reducing -- made a launch of 512-1024 blocks cost
+    // 180-350 us: the fences write back the whole L2 and serialise.)  phase 0: no split.
+    int phase;
     // precise mode (igemm_fwd_kernel<.., PREC>): K = g.Cin is a concatenation of segments over `in_wrap` input channels
     // (K channel ci reads input channel ci >= in_wrap ? ci - in_wrap : ci); the result is stored as a 16-bit hi/lo pair
     // (hi at y, lo = 16-bit(value - hi) at y_lo, same stride / offset).
@@ -94,8 +99,9 @@ __device__ __forceinline__ void igemm_fwd_body(const ARGS& a, const int block_id
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
     const int ksplit = a.ksplit;
-    const int kpart = ksplit > 1 ? (int)(block_id % ksplit) : 0;
-    const int lid = ksplit > 1 ? (int)(block_id / ksplit) : xcd_remap(block_id, a.nblocks);
+    const bool reduce_phase = ksplit > 1 && a.phase == 2;       // one block per tile: slabs -> epilogue
+    const int kpart = (ksplit > 1 && !reduce_phase) ? (int)(block_id % ksplit) : 0;
+    const int lid = (ksplit > 1 && !reduce_phase) ? (int)(block_id / ksplit) : xcd_remap(block_id, a.nblocks);
     const int ntile = lid % a.ntn, mtile = lid / a.ntn;
     const int m0 = mtile * FW_BM, n0 = ntile * BN;
 
@@ -120,6 +126,7 @@ __device__ __forceinline__ void igemm_fwd_body(const ARGS& a, const int block_id
     // 1x1 .. 8x8 bottom of the Pix2Pix generator 75-94 % of the 4x4 / 8x8 taps fall outside the feature map, and with
     // M = a few pixels the kernel otherwise streams (and multiplies by zero) the whole multi-megabyte weight pack.
     __shared__ int act_taps[GS_MAX_TAPS + 1];
+    __shared__ int4 tap_info[GS_MAX_TAPS];          // (dy, dx, dz, weight slot) of the active taps, in list order
     {
         unsigned long long mask = 0ull;              // ntaps <= 64
         for (int tp = 0; tp < g.ntaps; ++tp) {
@@ -139,7 +146,12 @@ __device__ __forceinline__ void igemm_fwd_body(const ARGS& a, const int block_id
             const unsigned long long m4 = wmask[0] | wmask[1] | wmask[2] | wmask[3];
             int n = 0;
             for (int tp = 0; tp < g.ntaps; ++tp)
-                if ((m4 >> tp) & 1ull) act_taps[1 + n++] = tp;
+                if ((m4 >> tp) & 1ull) {
+                    // the tap descriptors move to LDS with the list: indexing the kernel-argument arrays with a run-time
+                    // tap number inside the K loop is a scalar memory load per K-step per wave
+                    tap_info[n] = make_int4(g.tap_dy[tp], g.tap_dx[tp], g.tap_dz[tp], g.tap_w[tp]);
+                    act_taps[1 + n++] = tp;
+                }
             act_taps[0] = n;
         }
         __syncthreads();
@@ -150,7 +162,7 @@ __device__ __forceinline__ void igemm_fwd_body(const ARGS& a, const int block_id
     const int nk_all = PACKED ? (act_taps[0] + 7) / 8 : act_taps[0] * a.kchunks;
     const int ks_begin = ksplit > 1 ? (int)((int64_t)nk_all * kpart / ksplit) : 0;
     const int ks_end = ksplit > 1 ? (int)((int64_t)nk_all * (kpart + 1) / ksplit) : nk_all;
-    const int nk = ks_end - ks_begin;
+    const int nk = reduce_phase ? 0 : ks_end - ks_begin;
 
     auto load_tile = [&](int ks) {
         int ti = (ks + ks_begin) / a.kchunks;
@@ -163,8 +175,8 @@ __device__ __forceinline__ void igemm_fwd_body(const ARGS& a, const int block_id
             if (!cok) ti = 0;
             ci = 0;
         }
-        const int tap = act_taps[1 + ti];
-        const int dy = g.tap_dy[tap], dx = g.tap_dx[tap], dz = g.tap_dz[tap];
+        const int4 ti4 = tap_info[ti];
+        const int dy = ti4.x, dx = ti4.y, dz = ti4.z, tapw = ti4.w;
         const int cix = (PREC && a.in_wrap > 0 && ci >= a.in_wrap) ? ci - a.in_wrap : ci;     // input channel of K channel ci
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -183,7 +195,7 @@ __device__ __forceinline__ void igemm_fwd_body(const ARGS& a, const int block_id
             const int co = n0 + rbase + 32 * j;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (cok && co < g.Cout)
-                v = *reinterpret_cast<const uint4*>(a.w + ((int64_t)g.tap_w[tap] * g.Cout + co) * g.Cin + ci);
+                v = *reinterpret_cast<const uint4*>(a.w + ((int64_t)tapw * g.Cout + co) * g.Cin + ci);
             rb[j] = v;
         }
     };
@@ -233,39 +245,29 @@ __device__ __forceinline__ void igemm_fwd_body(const ARGS& a, const int block_id
     }
 
     if (ksplit > 1) {
-        // every part stores its partial tile in its own slab (plain 16-byte stores: same-address atomics from dozens
-        // of blocks serialise in L2); the LAST part to take a ticket sums the slabs in part order (deterministic)
+        // phase 1: every part stores its partial tile in its own slab (plain 16-byte stores) and is done; phase 2 (the next
+        // launch on the stream) sums the slabs in part order -- deterministic, no atomics, no fences
         constexpr int REGS = 2 * NT * 16;
-        float* slab = a.ws_acc + (((int64_t)lid * ksplit + kpart) * 256 + t) * REGS;
         // a 32-row block of the tile that lies wholly beyond M (skinny GEMMs fill 8..32 of the 128 rows) is neither
         // stored nor summed: its accumulators are never written to y
         bool rows_ok[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) rows_ok[i] = m0 + wm * 64 + i * 32 < a.M;
+        if (!reduce_phase) {
+            float* slab = a.ws_acc + (((int64_t)lid * ksplit + kpart) * 256 + t) * REGS;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (!rows_ok[i]) continue;
+            for (int i = 0; i < 2; ++i) {
+                if (!rows_ok[i]) continue;
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
+                for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4)
-                    *reinterpret_cast<float4*>(slab + (i * NT + j) * 16 + r4 * 4) =
-                        make_float4(acc[i][j][r4 * 4], acc[i][j][r4 * 4 + 1], acc[i][j][r4 * 4 + 2], acc[i][j][r4 * 4 + 3]);
+                    for (int r4 = 0; r4 < 4; ++r4)
+                        *reinterpret_cast<float4*>(slab + (i * NT + j) * 16 + r4 * 4) =
+                            make_float4(acc[i][j][r4 * 4], acc[i][j][r4 * 4 + 1], acc[i][j][r4 * 4 + 2], acc[i][j][r4 * 4 + 3]);
+            }
+            return;
         }
-        __threadfence();                                           // release: the slab is visible device-wide
-        __syncthreads();
-        __shared__ unsigned int ticket;
-        if (t == 0) ticket = __hip_atomic_fetch_add(a.ws_cnt + lid, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (ticket != (unsigned)(ksplit - 1)) return;             // not the last part of this tile
-        __threadfence();                                           // acquire: see the other parts' slabs
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        for (int pp = 0; pp < ksplit; ++pp) {
+        for (int pp = 0; pp < ksplit; ++pp) {                     // acc is still zero: no K step ran in this phase
             const float* q = a.ws_acc + (((int64_t)lid * ksplit + pp) * 256 + t) * REGS;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -280,8 +282,6 @@ __device__ __forceinline__ void igemm_fwd_body(const ARGS& a, const int block_id
                     }
             }
         }
-        if (t == 0) __hip_atomic_store(a.ws_cnt + lid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ticket counter back to 0
-        __syncthreads();
     }
 
     // ---- epilogue: row table (output pixel index per tile row), stores, BN partial sums ----
@@ -670,6 +670,21 @@ static int choose_ksplit(int tiles, int ksteps, int64_t ws_floats, int64_t cnt_s
     return k < 2 ? 1 : k;
 }
 
+// taps some logical output pixel can see inside the input (the kernel drops the others from its K loop per tile: at the
+// 1x1 .. 4x4 bottom of the generator most of the 16 taps of a class fall outside the feature map)
+static int visible_taps(const GsConvGeom& g) {
+    auto axis_ok = [](int n_out, int step, int off, int n_in) {
+        if (n_out <= 0) return false;
+        int o = off < 0 ? (-off + step - 1) / step : 0;             // first output index whose input index is >= 0
+        return o < n_out && o * step + off < n_in;
+    };
+    int n = 0;
+    for (int t = 0; t < g.ntaps; ++t)
+        if (axis_ok(g.OHg, g.isy, g.tap_dy[t], g.IH) && axis_ok(g.OWg, g.isx, g.tap_dx[t], g.IW) &&
+            axis_ok(g.Dg, g.isz, g.tap_dz[t], g.Din)) ++n;
+    return n < 1 ? 1 : n;
+}
+
 // tile shape, N tiles, block count and K split of one GEMM; ws (may be NULL): [cnt_slots tile counters][slabs]
 static int plan_igemm(IgemmArgs& a, float* ws, int64_t ws_floats, int64_t cnt_slots) {
     const int mt = cdiv(a.M, FW_BM);
@@ -682,7 +697,8 @@ static int plan_igemm(IgemmArgs& a, float* ws, int64_t ws_floats, int64_t cnt_sl
     const bool packed = a.g.Cin == 8 && a.g.ntaps >= 8;
     if (ws != nullptr) {
         // layout of the caller's (zero-initialised, self-cleaning) workspace: [tile counters][tile accumulators]
-        const int k = choose_ksplit(a.nblocks, packed ? cdiv(a.g.ntaps, 8) : a.g.ntaps * a.kchunks, ws_floats - cnt_slots, cnt_slots);
+        const int vt = visible_taps(a.g);
+        const int k = choose_ksplit(a.nblocks, packed ? cdiv(vt, 8) : vt * a.kchunks, ws_floats - cnt_slots, cnt_slots);
         if (k > 1) {
             a.ksplit = k;
             a.ws_cnt = reinterpret_cast<unsigned int*>(ws);
@@ -697,6 +713,7 @@ static int launch_igemm(IgemmArgs& a, int dtype, hipStream_t s, const char* who,
     // a single launch uses the first quarter of the workspace (the batched form gives each of its <= 4 GEMMs a quarter)
     const int bn = plan_igemm(a, ws, ws ? ws_floats / IGEMM_BATCH_MAX : 0, SPLITK_CNT_SLOTS);
     const bool packed = a.g.Cin == 8 && a.g.ntaps >= 8;
+    a.phase = a.ksplit > 1 ? 1 : 0;
     dim3 grid(a.nblocks * a.ksplit), block(256);
     if (a.y_lo != nullptr) {                      // precise mode: hi/lo output pair, K segments over wrapped input channels
         GS_CHECK_ARG(!packed && a.ksplit == 1 && a.vec_store && a.bnp == nullptr, "%s: precise mode needs 16-byte stores, no split-K", who);
@@ -710,22 +727,30 @@ static int launch_igemm(IgemmArgs& a, int dtype, hipStream_t s, const char* who,
         GS_CHECK_LAUNCH(who);
         return GS_OK;
     }
-    if (packed) {
-        if (dtype == GS_F16) {
-            if (bn == 64) igemm_fwd_kernel<GS_F16, 64, true><<<grid, block, 0, s>>>(a);
-            else igemm_fwd_kernel<GS_F16, 128, true><<<grid, block, 0, s>>>(a);
+    auto run = [&](const IgemmArgs& aa, dim3 gr) {
+        if (packed) {
+            if (dtype == GS_F16) {
+                if (bn == 64) igemm_fwd_kernel<GS_F16, 64, true><<<gr, block, 0, s>>>(aa);
+                else igemm_fwd_kernel<GS_F16, 128, true><<<gr, block, 0, s>>>(aa);
+            } else {
+                if (bn == 64) igemm_fwd_kernel<GS_BF16, 64, true><<<gr, block, 0, s>>>(aa);
+                else igemm_fwd_kernel<GS_BF16, 128, true><<<gr, block, 0, s>>>(aa);
+            }
+        } else if (dtype == GS_F16) {
+            if (bn == 64) igemm_fwd_kernel<GS_F16, 64, false><<<gr, block, 0, s>>>(aa);
+            else igemm_fwd_kernel<GS_F16, 128, false><<<gr, block, 0, s>>>(aa);
         } else {
-            if (bn == 64) igemm_fwd_kernel<GS_BF16, 64, true><<<grid, block, 0, s>>>(a);
-            else igemm_fwd_kernel<GS_BF16, 128, true><<<grid, block, 0, s>>>(a);
+            if (bn == 64) igemm_fwd_kernel<GS_BF16, 64, false><<<gr, block, 0, s>>>(aa);
+            else igemm_fwd_kernel<GS_BF16, 128, false><<<gr, block, 0, s>>>(aa);
         }
-    } else if (dtype == GS_F16) {
-        if (bn == 64) igemm_fwd_kernel<GS_F16, 64, false><<<grid, block, 0, s>>>(a);
-        else igemm_fwd_kernel<GS_F16, 128, false><<<grid, block, 0, s>>>(a);
-    } else {
-        if (bn == 64) igemm_fwd_kernel<GS_BF16, 64, false><<<grid, block, 0, s>>>(a);
-        else igemm_fwd_kernel<GS_BF16, 128, false><<<grid, block, 0, s>>>(a);
-    }
+    };
+    run(a, grid);
     GS_CHECK_LAUNCH(who);
+    if (a.ksplit > 1) {                            // phase 2: one block per tile sums the parts and runs the epilogue
+        a.phase = 2;
+        run(a, dim3(a.nblocks));
+        GS_CHECK_LAUNCH(who);
+    }
     return GS_OK;
 }
 
@@ -808,19 +833,34 @@ extern "C" int gs_conv_igemm_batch(int n, const GsConvGeom* const* g, const void
         c.x = a.x; c.w = a.w; c.y = a.y; c.bias = a.bias; c.bnp = a.bnp; c.act = a.act; c.M = a.M; c.kchunks = a.kchunks;
         c.ntn = a.ntn; c.nblocks = a.nblocks; c.vec_store = a.vec_store; c.shuffle_cout = 0; c.shuffle_cls = 0;
         c.ksplit = a.ksplit; c.ws_acc = a.ws_acc; c.ws_cnt = a.ws_cnt; c.y_lo = nullptr; c.in_wrap = 0;
+        c.phase = a.ksplit > 1 ? 1 : 0;
         b.start[i] = total;
         total += a.nblocks * a.ksplit;
     }
     for (int i = n; i <= IGEMM_BATCH_MAX; ++i) b.start[i] = total;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GS_F16) {
-        if (bn0 == 64) igemm_fwd_batch_kernel<GS_F16, 64><<<total, 256, 0, s>>>(b);
-        else igemm_fwd_batch_kernel<GS_F16, 128><<<total, 256, 0, s>>>(b);
-    } else {
-        if (bn0 == 64) igemm_fwd_batch_kernel<GS_BF16, 64><<<total, 256, 0, s>>>(b);
-        else igemm_fwd_batch_kernel<GS_BF16, 128><<<total, 256, 0, s>>>(b);
-    }
+    auto run = [&](const IgemmBatchArgs& bb, int blocks) {
+        if (dtype == GS_F16) {
+            if (bn0 == 64) igemm_fwd_batch_kernel<GS_F16, 64><<<blocks, 256, 0, s>>>(bb);
+            else igemm_fwd_batch_kernel<GS_F16, 128><<<blocks, 256, 0, s>>>(bb);
+        } else {
+            if (bn0 == 64) igemm_fwd_batch_kernel<GS_BF16, 64><<<blocks, 256, 0, s>>>(bb);
+            else igemm_fwd_batch_kernel<GS_BF16, 128><<<blocks, 256, 0, s>>>(bb);
+        }
+    };
+    run(b, total);
     GS_CHECK_LAUNCH("gs_conv_igemm_batch");
+    // phase 2 for the GEMMs that split K: one block per tile sums the parts and runs the epilogue (the others are done)
+    int total2 = 0;
+    for (int i = 0; i < n; ++i) {
+        b.start[i] = total2;
+        if (b.c[i].ksplit > 1) { b.c[i].phase = 2; total2 += b.c[i].nblocks; }
+    }
+    for (int i = n; i <= IGEMM_BATCH_MAX; ++i) b.start[i] = total2;
+    if (total2 > 0) {
+        run(b, total2);
+        GS_CHECK_LAUNCH("gs_conv_igemm_batch");
+    }
     return GS_OK;
 }
 
