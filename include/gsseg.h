@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 24
+#define GS_ABI_VERSION 25
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -128,6 +128,13 @@ int gs_conv_wgrad_assign(const GsConvGeom* g, const void* x, const void* dy, flo
 int gs_conv_wgrad_parts(const GsConvGeom* g);
 int64_t gs_conv_wgrad_ws_floats(const GsConvGeom* g);
 int gs_conv_wgrad_slabs(const GsConvGeom* g, const void* x, const void* dy, float* ws, int dtype, void* stream);
+/* The same for up to four GEMMs over one x / dy in ONE grid (the sub-pixel classes of the merged transposed convolution,
+ * networks.py:486-511): equal gradient sizes, tile shapes and K splits; GEMM i writes part p to
+ * ws + p * (n * slab) + i * slab, slab = gs_conv_wgrad_ws_floats(g[i]) / gs_conv_wgrad_parts(g[i]) -- one slab of all n
+ * gradients per part, so ONE gs_wgrad_reduce_unpack over [n*taps*Cout][Cin] sums every class; with a single part ws may be
+ * the gradient tensor itself ([n][taps][Cout][Cin]). */
+int gs_conv_wgrad_slabs_batch(int n, const GsConvGeom* const* g, const void* x, const void* dy, float* ws, int dtype,
+                              void* stream);
 
 /* ---- direct (VALU) convolutions for 1..4-channel ends of the nets ----------------------------
  * gs_conv_smallcin_fwd: x fp32 NCHW [N,Cin,IH,IW] (the image / mask as the loader hands it,

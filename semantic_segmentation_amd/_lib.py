@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 GS_F16, GS_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH = 0, 1, 2, 3
 GS_MAX_TAPS = 64
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 
 class GsConvGeom(ctypes.Structure):
@@ -65,6 +65,7 @@ PROTOTYPES = {
     "gs_conv_wgrad_parts": (c_int, [POINTER(GsConvGeom)]),
     "gs_conv_wgrad_ws_floats": (c_int64, [POINTER(GsConvGeom)]),
     "gs_conv_wgrad_slabs": (c_int, [POINTER(GsConvGeom), _P, _P, _F, c_int, c_void_p]),
+    "gs_conv_wgrad_slabs_batch": (c_int, [c_int, POINTER(POINTER(GsConvGeom)), _P, _P, _F, c_int, c_void_p]),
     "gs_conv_smallcin_mtiles": (c_int, [c_int, c_int, c_int]),
     "gs_conv_smallcin_fwd": (c_int, [_F, _F, _F, _P, _F] + [c_int] * 12 + [c_void_p]),
     "gs_conv_direct_wgrad_ws_floats": (c_int64, [c_int] * 6),

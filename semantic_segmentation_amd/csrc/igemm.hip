@@ -432,8 +432,9 @@ __global__ __launch_bounds__(256) void igemm_fwd_batch_kernel(const IgemmBatchAr
 // ------------------------------------------------------------------------------------------------
 // weight gradient
 // ------------------------------------------------------------------------------------------------
-struct WgradArgs {
-    GsConvGeom g;
+template <typename GEOM>
+struct WgradArgsT {
+    GEOM g;
     const unsigned short* x;
     const unsigned short* dy;
     float* dw;
@@ -446,12 +447,20 @@ struct WgradArgs {
     int assign;            // plain stores instead of atomic adds: ksplit == 1 (dw need not be zeroed) or slab mode
     int64_t slab_stride;   // > 0: K part ks writes its own slab dw + ks*slab_stride (ordered reduction afterwards)
 };
+typedef WgradArgsT<GsConvGeom> WgradArgs;
+typedef WgradArgsT<GeomC> WgradArgsC;
+struct WgradBatchArgs {
+    WgradArgsC c[IGEMM_BATCH_MAX];
+    int start[IGEMM_BATCH_MAX + 1];
+    int n;
+};
+static_assert(sizeof(WgradBatchArgs) <= 3800, "batched wgrad arguments must fit the kernel-argument segment");
 
 constexpr int WG_KP = 64;   // pixels per K step
 
 // WR = wave rows: 2 -> block tile 128 co x 2 column blocks; 1 -> 64 co x 4 column blocks
-template <int DT, int WR>
-__global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs a) {
+template <int DT, int WR, typename ARGS>
+__device__ __forceinline__ void igemm_wgrad_body(const ARGS& a, const int block_id) {
     typedef typename Elem<DT>::V8 V8;
     constexpr int WC = 4 / WR;                 // column blocks per block (= wave columns)
     constexpr int BCO = 64 * WR;
@@ -463,11 +472,11 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs a) {
     constexpr int DY_ROWS_STEP = 256 / DY_CH;
     __shared__ __attribute__((aligned(16))) unsigned short smem[DY_EL + WC * X_EL];
 
-    const GsConvGeom& g = a.g;
+    const auto& g = a.g;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = (WR == 2) ? (wave >> 1) : 0;
     const int wn = (WR == 2) ? (wave & 1) : wave;
-    int bid = blockIdx.x;
+    int bid = block_id;
     const int cot = bid % a.n_cotiles; bid /= a.n_cotiles;
     const int cbg = bid % a.n_cbgroups; bid /= a.n_cbgroups;
     const int ks_id = bid;
@@ -614,6 +623,21 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs a) {
                 }
             }
         }
+}
+
+template <int DT, int WR>
+__global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs a) {
+    igemm_wgrad_body<DT, WR>(a, (int)blockIdx.x);
+}
+
+// the weight gradients of several GEMMs (the four sub-pixel classes of a merged transposed conv) in one grid
+template <int DT, int WR>
+__global__ __launch_bounds__(256) void igemm_wgrad_batch_kernel(const WgradBatchArgs b) {
+    int c = 0;
+#pragma unroll
+    for (int i = 1; i < IGEMM_BATCH_MAX; ++i)
+        if (i < b.n && (int)blockIdx.x >= b.start[i]) c = i;
+    igemm_wgrad_body<DT, WR>(b.c[c], (int)blockIdx.x - b.start[c]);
 }
 
 int check_geom(const GsConvGeom* g, const char* who) {
@@ -939,7 +963,7 @@ static int upconv2x2_impl(const void* x, const void* w, const float* bias, void*
 
 // plan only (x == nullptr): returns the K split of this geometry through *ksplit_out
 static int conv_wgrad_launch(const GsConvGeom* g, const void* x, const void* dy, float* dw, int dtype, void* stream,
-                             int assign, int* ksplit_out, int64_t slab_stride = 0) {
+                             int assign, int* ksplit_out, int64_t slab_stride = 0, WgradArgs* batch_out = nullptr) {
     int rc = check_geom(g, "gs_conv_wgrad");
     if (rc) return rc;
     const bool plan = ksplit_out != nullptr;
@@ -977,6 +1001,10 @@ static int conv_wgrad_launch(const GsConvGeom* g, const void* x, const void* dy,
     const int rem = WG_KP - a.d_n * ohw;
     a.d_oy = rem / g->OWg;
     a.d_ox = rem - a.d_oy * g->OWg;
+    if (batch_out != nullptr) {                 // batched launch: hand the planned arguments back
+        *batch_out = a;
+        return GS_OK;
+    }
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(base_blocks * a.ksplit), block(256);
     if (dtype == GS_F16) {
@@ -1026,4 +1054,57 @@ extern "C" int gs_conv_wgrad_slabs(const GsConvGeom* g, const void* x, const voi
 
 extern "C" int gs_conv_wgrad_assign(const GsConvGeom* g, const void* x, const void* dy, float* dw, int dtype, void* stream) {
     return conv_wgrad_launch(g, x, dy, dw, dtype, stream, 1, nullptr);
+}
+
+// The weight gradients of up to four GEMMs over the same x / dy in ONE grid (the sub-pixel classes of a merged transposed
+// convolution): GEMM i writes its K parts to ws + part * (n * slab) + i * slab, slab = gs_conv_wgrad_ws_floats(g[i]) /
+// gs_conv_wgrad_parts(g[i]) floats (equal for all i) -- i.e. one slab of all n gradients per part, so that ONE
+// gs_wgrad_reduce_unpack over [n * taps * Cout][Cin] sums every class; with one part the "workspace" is the gradient itself.
+extern "C" int gs_conv_wgrad_slabs_batch(int n, const GsConvGeom* const* g, const void* x, const void* dy, float* ws, int dtype,
+                                         void* stream) {
+    GS_CHECK_ARG(n >= 1 && n <= IGEMM_BATCH_MAX && g && x && dy && ws, "gs_conv_wgrad_slabs_batch: bad arguments (1..4 GEMMs)");
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_conv_wgrad_slabs_batch: bad dtype %d", dtype);
+    WgradBatchArgs b;
+    b.n = n;
+    int total = 0, wr0 = 0, parts0 = 0;
+    int64_t slab0 = 0;
+    for (int i = 0; i < n; ++i) {
+        GS_CHECK_ARG(g[i] != nullptr && g[i]->ntaps <= GEOMC_MAX_TAPS, "gs_conv_wgrad_slabs_batch: at most %d taps per GEMM", GEOMC_MAX_TAPS);
+        const int64_t slab = wgrad_slab_floats(g[i]);
+        if (i == 0) slab0 = slab;
+        GS_CHECK_ARG(slab == slab0, "gs_conv_wgrad_slabs_batch: the GEMMs of a batch must have equal gradient sizes");
+        WgradArgs a;
+        int rc = conv_wgrad_launch(g[i], x, dy, ws + (int64_t)i * slab0, dtype, stream, 1, nullptr, (int64_t)n * slab0, &a);
+        if (rc) return rc;
+        const int wr = (g[i]->Cout <= 64) ? 1 : 2;
+        if (i == 0) { wr0 = wr; parts0 = a.ksplit; }
+        GS_CHECK_ARG(wr == wr0 && a.ksplit == parts0, "gs_conv_wgrad_slabs_batch: the GEMMs of a batch must share tile shape and K split");
+        WgradArgsC& c = b.c[i];
+        const GsConvGeom& s0 = a.g;
+        c.g.N = s0.N; c.g.IH = s0.IH; c.g.IW = s0.IW; c.g.Cin = s0.Cin; c.g.in_pix_stride = s0.in_pix_stride; c.g.in_coff = s0.in_coff;
+        c.g.OHg = s0.OHg; c.g.OWg = s0.OWg; c.g.Cout = s0.Cout; c.g.OH = s0.OH; c.g.OW = s0.OW;
+        c.g.out_pix_stride = s0.out_pix_stride; c.g.out_coff = s0.out_coff;
+        c.g.isy = s0.isy; c.g.isx = s0.isx; c.g.osy = s0.osy; c.g.osx = s0.osx; c.g.ooy = s0.ooy; c.g.oox = s0.oox;
+        c.g.ntaps = s0.ntaps;
+        for (int t = 0; t < GEOMC_MAX_TAPS; ++t) {
+            c.g.tap_dy[t] = s0.tap_dy[t]; c.g.tap_dx[t] = s0.tap_dx[t]; c.g.tap_w[t] = s0.tap_w[t]; c.g.tap_dz[t] = s0.tap_dz[t];
+        }
+        c.g.Dg = s0.Dg; c.g.Din = s0.Din; c.g.Dout = s0.Dout; c.g.isz = s0.isz; c.g.osz = s0.osz; c.g.ooz = s0.ooz;
+        c.x = a.x; c.dy = a.dy; c.dw = a.dw; c.M = a.M; c.kchunks = a.kchunks; c.ncb = a.ncb;
+        c.n_cotiles = a.n_cotiles; c.n_cbgroups = a.n_cbgroups; c.ksplit = a.ksplit; c.kper = a.kper;
+        c.d_n = a.d_n; c.d_oy = a.d_oy; c.d_ox = a.d_ox; c.assign = 1; c.slab_stride = a.slab_stride;
+        b.start[i] = total;
+        total += a.n_cotiles * a.n_cbgroups * a.ksplit;
+    }
+    for (int i = n; i <= IGEMM_BATCH_MAX; ++i) b.start[i] = total;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GS_F16) {
+        if (wr0 == 1) igemm_wgrad_batch_kernel<GS_F16, 1><<<total, 256, 0, s>>>(b);
+        else igemm_wgrad_batch_kernel<GS_F16, 2><<<total, 256, 0, s>>>(b);
+    } else {
+        if (wr0 == 1) igemm_wgrad_batch_kernel<GS_BF16, 1><<<total, 256, 0, s>>>(b);
+        else igemm_wgrad_batch_kernel<GS_BF16, 2><<<total, 256, 0, s>>>(b);
+    }
+    GS_CHECK_LAUNCH("gs_conv_wgrad_slabs_batch");
+    return GS_OK;
 }

@@ -74,17 +74,12 @@ def generator_backward(engine, ctx, arch, dout, need_dx):
             g = ops.geom_convT_class(N, h, w, cin_t, cpad, 8, 3, cls >> 1, cls & 1)
             g_tapw_identity(g)
             geoms.append(g)
-        # few-pixel layers: no K split, so every element is written exactly once -- no zero fill, no atomic adds
-        # otherwise: K parts in slabs + an ordered sum (deterministic; no same-address atomics)
-        single = all(ops.conv_wgrad_single_pass(g) for g in geoms)
+        # the four classes in ONE launch.  Few-pixel layers do not split K: every element is written exactly once, straight
+        # into dwm; otherwise the K parts go to slabs and one ordered sum over all classes follows (deterministic, no atomics)
         dwm = torch.empty((4, 16, cpad, cin_t), dtype=torch.float32, device=dev)
-        if single:
-            for cls in range(4):
-                ops.conv_wgrad(geoms[cls], R[d + 1], du, dwm[cls], assign=True)
-        else:
-            wsl = empty(max(ops.conv_wgrad_ws_floats(g) for g in geoms), dtype=torch.float32)
-            for cls in range(4):
-                ops.conv_wgrad_det(geoms[cls], R[d + 1], du, wsl, dwm[cls], cpad, cin_t, 16, 1.0, packed=True)
+        parts = ops.conv_wgrad_parts(geoms[0])
+        wsl = empty(parts * dwm.numel(), dtype=torch.float32) if parts > 1 else None
+        ops.conv_wgrad_det_batch(geoms, R[d + 1], du, wsl, dwm)
         if cpad != cout_t:
             dwm = dwm[:, :, :cout_t, :].contiguous()
         dw4 = torch.empty_like(w4, memory_format=torch.contiguous_format)

@@ -445,6 +445,10 @@ def conv_wgrad(g: GsConvGeom, x, dy, dw, assign: bool = False):
         TIMER.stop("igemm_wgrad", ev, _geom_flops(g))
 
 
+def conv_wgrad_parts(g: GsConvGeom) -> int:
+    return int(_lib.load().gs_conv_wgrad_parts(g))
+
+
 def conv_wgrad_ws_floats(g: GsConvGeom) -> int:
     return int(_lib.load().gs_conv_wgrad_ws_floats(g))
 
@@ -467,6 +471,36 @@ def conv_wgrad_det(g: GsConvGeom, x, dy, ws, grad, A, B, taps, gscale, transpose
         TIMER.stop("igemm_wgrad", ev, _geom_flops(g))
     parts = int(_lib.load().gs_conv_wgrad_parts(g))
     _lib.call("gs_wgrad_reduce_unpack", _p(ws), parts, _p(grad), A, B, taps, 1 if transposed else 0, float(gscale), _stream())
+
+
+def conv_wgrad_det_batch(geoms, x, dy, ws, grad, gscale=1.0):
+    """Deterministic weight gradients of up to four GEMMs (the sub-pixel classes of one merged transposed conv) in ONE
+    launch, in the kernel layout grad[n][taps][Cout][Cin]: K parts in fp32 slabs (ws) + one ordered reduction over all
+    classes; a layer that does not split K writes grad directly (ws unused)."""
+    _dev(x)
+    _f32(grad, "grad")
+    if x.dtype != dy.dtype:
+        raise TypeError("conv_wgrad_det_batch: x and dy must share one 16-bit dtype")
+    n, g0 = len(geoms), geoms[0]
+    per = g0.ntaps * g0.Cout * g0.Cin
+    parts = int(_lib.load().gs_conv_wgrad_parts(g0))
+    if grad.numel() != n * per or not grad.is_contiguous():
+        raise ValueError("conv_wgrad_det_batch: grad must be contiguous [n][taps][Cout][Cin]")
+    garr = (ctypes.POINTER(GsConvGeom) * n)(*[ctypes.pointer(g) for g in geoms])
+    if parts > 1:
+        _f32(ws, "ws")
+        if ws.numel() < parts * n * per:
+            raise ValueError("conv_wgrad_det_batch: workspace too small")
+    target = grad if parts == 1 else ws
+    ev = TIMER.start() if TIMER is not None else None
+    _lib.call("gs_conv_wgrad_slabs_batch", n, garr, _p(x), _p(dy), _p(target), dt_code(x), _stream())
+    if ev is not None:
+        TIMER.stop("igemm_wgrad", ev, sum(_geom_flops(g) for g in geoms))
+    if parts > 1:
+        _lib.call("gs_wgrad_reduce_unpack", _p(ws), parts, _p(grad), n * g0.ntaps * g0.Cout, g0.Cin, 1, 0, float(gscale), _stream())
+    elif gscale != 1.0:
+        grad.mul_(gscale)
+    return parts
 
 
 def bn_partials_numel(ntiles: int, C: int) -> int:
