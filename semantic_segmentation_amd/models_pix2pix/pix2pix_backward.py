@@ -77,8 +77,8 @@ def generator_backward(engine, ctx, arch, dout, need_dx):
         # the four classes in ONE launch.  Few-pixel layers do not split K: every element is written exactly once, straight
         # into dwm; otherwise the K parts go to slabs and one ordered sum over all classes follows (deterministic, no atomics)
         dwm = torch.empty((4, 16, cpad, cin_t), dtype=torch.float32, device=dev)
-        parts = ops.conv_wgrad_parts(geoms[0])
-        wsl = empty(parts * dwm.numel(), dtype=torch.float32) if parts > 1 else None
+        nparts = ops.conv_wgrad_parts(geoms[0])
+        wsl = empty(nparts * dwm.numel(), dtype=torch.float32) if nparts > 1 else None
         ops.conv_wgrad_det_batch(geoms, R[d + 1], du, wsl, dwm)
         if cpad != cout_t:
             dwm = dwm[:, :, :cout_t, :].contiguous()
