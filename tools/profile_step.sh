@@ -3,7 +3,7 @@
 # Usage (on the GPU box): bash tools/profile_step.sh r01_final
 set -e
 TAG=${1:-prof}
-STEPS=5; WARM=2; N=$((STEPS + WARM))
+STEPS=5; WARM=2; N=$((STEPS + WARM + 1))   # + the untimed probe step of bench.py
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
