@@ -67,6 +67,7 @@ class UNetEngine:
         # precise forward (module docstring of forward_precise): activations / weights as hi+lo pairs of 16-bit values,
         # logits within ~1e-5 of the fp32 reference instead of ~4e-3; the backward pass is unchanged (it reads the hi halves)
         self.precise = bool(precise)
+        self.dynamic_loss_scale = os.environ.get("GSSEG_DYNAMIC_LOSS_SCALE", "0") == "1"
         self.tdt = _TORCH_DT[dtype]
         self._packs: Dict[str, tuple] = {}
         # data-parallel hooks (parallel.GradReducer): grads are allocated inside the reducer's flat buckets,
@@ -496,8 +497,22 @@ class UNetEngine:
         dev = dlogits.device
         recs: Dict[str, _ConvRec] = {r.name: r for r in ctx["recs"]}
         ups: Dict[str, _UpRec] = {u.name: u for u in ctx["ups"]}
+        # Gradients travel in 16 bits multiplied by a power-of-two scale S so that fp16 neither underflows nor overflows.
+        # The static choice S = 2^round(log2(N*H*W)) assumes |dlogits| ~ 1/(N*H*W): a MEAN-reduced loss with O(1)..O(100)
+        # weights (every loss of the reference's scripts).  A sum-reduced loss, a 1e4 loss weight or torch's GradScaler
+        # (x65536) breaks that assumption: set `dynamic_loss_scale` (UNet(..., dynamic_loss_scale=True) /
+        # GSSEG_DYNAMIC_LOSS_SCALE=1) and the incoming gradient is renormalised ON THE DEVICE (no host sync) by a power of
+        # two derived from its own amax; the parameter gradients are multiplied back at the end (exact).  bf16 does not need it.
         S = float(2 ** round(math.log2(N * H * W)))
         inv_s = 1.0 / S
+        renorm = None
+        if self.dynamic_loss_scale:
+            amax = dlogits.detach().abs().amax().float()
+            # r = 2^k with amax * S * r in [1, 2): the head's fp16 data gradient then has the magnitude the static scale
+            # is designed for (mean-reduced CE / BCE: amax * N*H*W ~ 1)
+            k = torch.floor(-torch.log2(torch.clamp(amax * S, min=1e-30)))
+            renorm = torch.exp2(torch.clamp(k, -60.0, 60.0))
+            dlogits = dlogits * renorm
         grads: Dict[str, torch.Tensor] = {}
 
         def empty(*shape, dtype=tdt):
@@ -651,6 +666,15 @@ class UNetEngine:
                 dpool = dinp
             else:
                 dx = dinp
+        if renorm is not None:
+            # data-parallel note: the bucket all-reduces were issued on the renormalised gradients of THIS rank; with the
+            # dynamic scale every rank must use the same factor, so it is only supported without a reducer
+            if self.grad_ready_hook is not None:
+                raise RuntimeError("dynamic_loss_scale is not supported together with the bucketed GradReducer")
+            inv_r = torch.reciprocal(renorm)
+            torch._foreach_mul_(list(grads.values()), inv_r)
+            if dx is not None:
+                dx = dx * inv_r
         if self.after_backward is not None:
             self.after_backward()
         return grads, dx

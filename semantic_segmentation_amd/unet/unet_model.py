@@ -13,7 +13,7 @@ from .unet_parts import DoubleConv, Down, OutConv, Up
 
 
 class UNet(nn.Module):
-    def __init__(self, n_channels, n_classes, bilinear=False, compute_dtype=None, precise=None):
+    def __init__(self, n_channels, n_classes, bilinear=False, compute_dtype=None, precise=None, dynamic_loss_scale=None):
         super(UNet, self).__init__()
         self.n_channels = n_channels
         self.n_classes = n_classes
@@ -38,6 +38,10 @@ class UNet(nn.Module):
         if precise is None:
             precise = os.environ.get("GSSEG_PRECISE", "0") == "1"
         object.__setattr__(self, "_engine", UNetEngine(self, dt, precise=precise))
+        # fp16 backward: gradients are carried times a static power-of-two scale that assumes a mean-reduced loss;
+        # dynamic_loss_scale=True renormalises the incoming gradient on the device (sum-reduced losses, GradScaler, ...)
+        if dynamic_loss_scale is not None:
+            self._engine.dynamic_loss_scale = bool(dynamic_loss_scale)
 
     @property
     def engine(self) -> UNetEngine:

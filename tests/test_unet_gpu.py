@@ -538,3 +538,33 @@ def test_dice_coeff_per_item_is_one_launch_pair_and_exact():
     pm, tm = p.reshape(2, 3, 40, 56), t.reshape(2, 3, 40, 56)
     assert abs(multiclass_dice_coeff(pm.cuda(), tm.cuda(), False).item()
                - oracle.multiclass_dice_coeff(pm, tm, False).item()) < 2e-7
+
+
+def test_dynamic_loss_scale_survives_a_1e4_loss_weight():
+    """fp16 backward with the loss multiplied by 1e4 (and by 1e-4): the static loss scale assumes a mean-reduced loss and
+    overflows / underflows fp16; dynamic_loss_scale renormalises on the device and gives the scaled baseline gradient."""
+    from semantic_segmentation_amd.losses import seg_loss
+    from semantic_segmentation_amd.unet import UNet
+    sd = oracle.unet_state_dict(1, 1, seed=9)
+    x, mask = oracle.synthetic_batch(2, 64, seed=6)
+    x, mask = x.cuda(), mask.cuda()
+
+    def grads(factor, dynamic):
+        net = UNet(1, 1, dynamic_loss_scale=dynamic)
+        net.load_state_dict(sd, strict=True)
+        net = net.cuda().train()
+        (seg_loss(net(x), mask) * factor).backward()
+        return {k: p.grad.clone() for k, p in net.named_parameters()}
+
+    base = grads(1.0, False)
+    for factor in (1e4, 1e-4):
+        got = grads(factor, True)
+        for k in base:
+            ref = base[k] * factor
+            assert torch.isfinite(got[k]).all(), k
+            err = float((got[k] - ref).norm() / ref.norm().clamp_min(1e-30))
+            assert err < 2e-2, (factor, k, err)      # same 16-bit roundings up to the power-of-two renormalisation
+    big = grads(1e4, False)                      # documents the limit of the static scale: not finite (or saturated)
+    bad = sum(int((~torch.isfinite(v)).sum()) for v in big.values())
+    REPORT["static_scale_x1e4_nonfinite_grad_elements"] = bad
+    _dump()
