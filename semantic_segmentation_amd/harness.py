@@ -42,7 +42,7 @@ class EndToEndTrainer:
     def __init__(self, net, netG, netD, criterionGAN, train_loader, val_loader, device, *, unet_lr=1e-5, gan_lr=2e-4,
                  beta1=0.5, arch_lr=3e-4, lambda_L1=100.0, loss_lambda=1.0, unroll_steps=1, valid_every=10,
                  mask_augment: Optional[Callable] = None, save_dir: Optional[str] = None,
-                 arch_through_generator: bool = False, train_gan: bool = True):
+                 arch_through_generator: bool = False, train_gan: bool = True, data_parallel: bool = False):
         self.net, self.netG, self.netD, self.criterionGAN = net, netG, netD, criterionGAN
         self.device, self.train_loader, self.val_loader = device, train_loader, val_loader
         self.lambda_L1, self.loss_lambda, self.unroll_steps, self.valid_every = lambda_L1, loss_lambda, unroll_steps, valid_every
@@ -56,6 +56,19 @@ class EndToEndTrainer:
         self.optimizer_arch = torch.optim.Adam(networks.arch_parameters(), lr=arch_lr, betas=(0.5, 0.999), weight_decay=1e-5)
         self.global_step, self.val_best_score, self.history = 0, -1.0, []
         self._train_iter, self._val_iter = _cycle(train_loader), _cycle(val_loader)
+        # data parallel (one process per GPU, torch.distributed initialised by the caller, every rank feeds its own shard
+        # of the loaders): replicas start from rank 0's parameters / buffers; after every backward the gradients of the
+        # problem that is about to step are averaged over the ranks in flat fp32 buckets (parallel.all_reduce_gradients: the
+        # packing of bucket k+1 overlaps the collective of bucket k).  BatchNorm statistics and the Dice sums stay per rank
+        # (SURVEY 8e).  The Unet problem accumulates two backward passes, so its exchange runs once, after both.
+        self.data_parallel = bool(data_parallel)
+        if self.data_parallel:
+            from . import parallel
+            for m in (net, netG, netD):
+                parallel.broadcast_module_state(m)
+            for a in networks.arch_parameters():
+                if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+                    torch.distributed.broadcast(a.data, src=0)
 
     # ---- one batch to the device in the layout the steps expect (JSRT_loader dict keys) ----
     def _batch(self, batch: Dict[str, torch.Tensor]):
@@ -64,6 +77,11 @@ class EndToEndTrainer:
         if mask.dim() == 3:
             mask = mask.unsqueeze(1)
         return image, mask
+
+    def _exchange(self, params):
+        if self.data_parallel:
+            from . import parallel
+            parallel.all_reduce_gradients(list(params))
 
     def _set_requires_grad(self, module, flag: bool):
         for p in module.parameters():
@@ -81,18 +99,21 @@ class EndToEndTrainer:
             self.optimizer_G.zero_grad(set_to_none=True)
             loss_g = steps.generator_step_loss(self.netG, self.netD, self.criterionGAN, real_mask, real_image, self.lambda_L1)
             loss_g.backward()
+            self._exchange(self.netG.parameters())
             self.optimizer_G.step()
             # Discriminator problem (:157-172)
             self._set_requires_grad(self.netD, True)
             self.optimizer_D.zero_grad(set_to_none=True)
             loss_d = steps.discriminator_step_loss(self.netG, self.netD, self.criterionGAN, real_mask, real_image)
             loss_d.backward()
+            self._exchange(self.netD.parameters())
             self.optimizer_D.step()
             out.update(loss_G=loss_g.detach(), loss_D=loss_d.detach())      # 0-dim device tensors: no host sync per step
         # Unet problem (:176-226): real pair + generated pair from the (augmented) masks
         self.optimizer_unet.zero_grad(set_to_none=True)
         loss_u = steps.unet_step_loss(self.net, self.netG, image, mask, self.loss_lambda, self.mask_augment)
         loss_u.backward()
+        self._exchange(self.net.parameters())
         self.optimizer_unet.step()
         out["loss_unet"] = loss_u.detach()
         self.global_step += 1
@@ -108,6 +129,7 @@ class EndToEndTrainer:
             for p in self.net.parameters():                    # the arch optimiser owns only the arch tensors
                 p.grad = None
             loss_a.backward()
+            self._exchange(networks.arch_parameters())
             if any(a.grad is not None for a in networks.arch_parameters()):
                 self.optimizer_arch.step()
             for p in list(self.net.parameters()) + list(self.netG.parameters()):

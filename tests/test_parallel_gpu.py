@@ -66,5 +66,17 @@ def test_grad_reducer_on_unet_engine_rccl_single_rank():
         # the generic post-backward exchange on HIP tensors (1-rank group: early return)
         net = UNet(1, 2).to(dev)
         assert all_reduce_gradients(net.parameters()) == 0
+        # the end-to-end harness in data-parallel mode inside the (1-rank) RCCL group: replica broadcast at start, one
+        # gradient exchange per problem step (the multi-rank arithmetic of that exchange is covered on CPU with gloo)
+        from semantic_segmentation_amd.harness import EndToEndTrainer, SyntheticLungDataset
+        from semantic_segmentation_amd.models_pix2pix import networks
+        netU = UNet(1, 1).to(dev)
+        netG = networks.define_G(1, 1, 64, "unet_256", "batch", True, "normal", 0.02, [0])
+        netD = networks.define_D(2, 64, "basic", 3, "batch", "normal", 0.02, [0])
+        mk = lambda n, seed: torch.utils.data.DataLoader(SyntheticLungDataset(n, 256, seed), batch_size=2, drop_last=True)
+        tr = EndToEndTrainer(netU, netG, netD, networks.GANLoss("vanilla").to(dev), mk(4, 1), mk(2, 2), dev, unroll_steps=1,
+                             valid_every=0, data_parallel=True)
+        tr.run(2, log_every=0)
+        assert tr.global_step == 2 and all(torch.isfinite(v).all() for rec in tr.history for v in rec.values())
     finally:
         dist.destroy_process_group()
