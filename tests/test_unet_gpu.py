@@ -2,17 +2,17 @@
 vs the CPU oracle on seeded inputs.  GPU only.
 
 Tolerances (north star: 1e-3 on logits / Dice vs the reference CPU path):
-  * loss and Dice: |delta| <= 1e-3 (asserted).
-  * logits: the engine stores activations in 16 bits (fp16: 11-bit significand).  Through 23 stacked
-    convolutions that gives mean |delta logit| ~7e-4 and max ~5e-3 in fp16 (3e-2 in bf16) -- measured by
-    simulating 16-bit storage in the oracle.  Asserted: mean <= 1.5e-3, max <= 1e-2 for fp16; the measured
-    numbers are written to gpurun_out/parity_unet.json so the gap to 1e-3 max is reported, not hidden.
-  * gradients: 16-bit activations flip the ReLU gate (and the max-pool arg-max) of the ~8e-4 of elements
-    whose pre-activation lies within the rounding error of zero.  Each flipped element changes its gradient
-    by 100 %, i.e. sqrt(8e-4) ~ 2.8 % relative L2 per ReLU layer, ~12 % through 18 layers (fp16; ~30 % bf16).
-    That is a property of 16-bit storage (every per-kernel backward test in test_gpu_kernels.py is tight at
-    1e-3), so whole-net gradients are checked (a) loosely against the oracle and (b) tightly as the
-    first-order descent direction of OUR forward (test_unet_gradient_is_descent_direction).
+  * loss and Dice: |delta| <= 1e-3 asserted in both modes (measured <= 7e-6).
+  * logits, DEFAULT mode: the engine stores activations in 16 bits (fp16: 11-bit significand); 23 stacked convolutions
+    give mean |delta logit| 5-6e-4 and max 2.3-4.3e-3 in fp16 (3.5e-2 in bf16) -- the same numbers come out of a CPU
+    simulation of 16-bit storage (tools/parity_attribution.py), which also shows that the error is made at the
+    full-resolution stages.  Asserted at 1.5x the measured values.
+  * logits, PRECISE mode (UNet(precise=True): hi/lo 16-bit pairs): max 6.4e-6 - 9.5e-6 (bf16 pairs: 5.2e-5): the north star's
+    1e-3 with two orders of magnitude to spare; asserted at 3e-5 (test_precise_mode_*).
+  * gradients: 16-bit activations flip the ReLU gate (and the max-pool arg-max) of the ~8e-4 of elements whose
+    pre-activation lies within the rounding error of zero; each flip changes its gradient by 100 %, i.e. ~2.8 % relative L2
+    per ReLU layer, ~11 % through 18 layers (fp16; ~30 % bf16; 2.4 % with the precise forward).  Whole-net gradients are
+    checked (a) against the oracle / fixtures at 1.5x measured and (b) as the first-order descent direction of OUR forward.
 """
 import json
 import os
@@ -83,9 +83,11 @@ def test_unet_step_vs_golden(golden_dir, name):
     assert np.isfinite(lg).all()
     assert abs(rep["loss"] - rep["loss_ref"]) < 1e-3, rep
     assert abs(rep["dice_loss"] - rep["dice_loss_ref"]) < 1e-3, rep
-    # bilinear: four more 16-bit roundings (the interpolated tensors) and half as many channels to average over
-    assert rep["logit_mean_abs"] < (2.5e-3 if bilinear else 1.5e-3) and rep["logit_max_abs"] < 1e-2, rep
-    assert worst < 8e-2, rep
+    # DEFAULT mode (single 16-bit storage): asserted at 1.5x the worst value measured on MI355X -- max 4.34e-3 / mean 6.0e-4
+    # (bilinear: four more 16-bit roundings and half as many channels to average over: 8.55e-3 / 1.59e-3).  The north star's
+    # 1e-3 on logits is met by precise mode (test_precise_mode_*), not by this mode; loss / Dice meet it in both.
+    assert rep["logit_max_abs"] < (1.3e-2 if bilinear else 6.5e-3) and rep["logit_mean_abs"] < (2.4e-3 if bilinear else 9e-4), rep
+    assert worst < 5e-2, rep                  # gradient norms: measured <= 3.4 %
     assert bworst < 5e-3, rep
     # eval mode with the updated running statistics + evaluate.py Dice
     net.eval()
@@ -123,9 +125,10 @@ def test_unet_vs_oracle_256(dtype):
                                     "grad_rel_l2_median": float(np.median(list(rel.values())))}
     _dump()
     assert abs(loss.item() - ref_loss.item()) < 1e-3
-    lim_mean, lim_max = (1.5e-3, 1e-2) if dtype == "f16" else (1.2e-2, 8e-2)
+    # 1.5x the measured values (f16: max 4.25e-3 / mean 5.7e-4, gradients worst 17 %; bf16: 3.5e-2 / 4.5e-3, 47 %)
+    lim_mean, lim_max = (9e-4, 6.5e-3) if dtype == "f16" else (6.8e-3, 5.3e-2)
     assert d.mean() < lim_mean and d.max() < lim_max, REPORT
-    assert rel[worst_k] < (0.3 if dtype == "f16" else 0.7), (worst_k, rel[worst_k])
+    assert rel[worst_k] < (0.26 if dtype == "f16" else 0.7), (worst_k, rel[worst_k])
 
 
 def test_unet_forward_is_deterministic_and_retain_graph():
@@ -499,7 +502,7 @@ def test_unet_rgb_input_vs_oracle(precise):
                                                          "grad_rel_l2_first_conv": rel["inc.double_conv.0.weight"]}
     _dump()
     assert abs(loss.item() - ref_loss.item()) < (2e-5 if precise else 1e-3)
-    assert d.max() < (3e-5 if precise else 1e-2) and d.mean() < (4e-6 if precise else 1.5e-3)
+    assert d.max() < (3e-5 if precise else 7.5e-3) and d.mean() < (4e-6 if precise else 1.05e-3)     # default: 4.97e-3 / 6.8e-4 measured
     assert max(rel.values()) < 0.3
 
 
