@@ -55,25 +55,25 @@ __global__ __launch_bounds__(64 * WAVES) void k_lds(const h8* in, float* out, in
 
 typedef __attribute__((ext_vector_type(4))) float f4v;
 // 16x16x32: a 64x64 wave tile = 4x4 tiles; per K=32 step 4 A + 4 B fragments (16 B each) feed 16 MFMAs
-template <int WAVES>
+template <int WAVES, int LDR = 72>
 __global__ __launch_bounds__(64 * WAVES) void k_lds16(const h8* in, float* out, int iters) {
-    __shared__ __attribute__((aligned(16))) unsigned short lds[128 * 72 * 2];
-    for (int i = threadIdx.x; i < 128 * 72 * 2 / 8; i += blockDim.x) ((h8*)lds)[i] = in[i % 1024];
+    __shared__ __attribute__((aligned(16))) unsigned short lds[128 * LDR * 2];
+    for (int i = threadIdx.x; i < 128 * LDR * 2 / 8; i += blockDim.x) ((h8*)lds)[i] = in[i % 1024];
     __syncthreads();
     const int lane = threadIdx.x & 63, l15 = lane & 15, q = lane >> 4, w = threadIdx.x >> 6;
-    const unsigned short* A = lds + (w % 2) * 64 * 72 + l15 * 72 + q * 8;
-    const unsigned short* B = lds + 128 * 72 + (w / 2 % 2) * 64 * 72 + l15 * 72 + q * 8;
+    const unsigned short* A = lds + (w % 2) * 64 * LDR + l15 * LDR + q * 8;
+    const unsigned short* B = lds + 128 * LDR + (w / 2 % 2) * 64 * LDR + l15 * LDR + q * 8;
     f4v c[4][4];
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) c[i][j] = f4v{0, 0, 0, 0};
     h8 a[4], b[4];
-    for (int i = 0; i < 4; ++i) { a[i] = *(const h8*)(A + i * 16 * 72); b[i] = *(const h8*)(B + i * 16 * 72); }
+    for (int i = 0; i < 4; ++i) { a[i] = *(const h8*)(A + i * 16 * LDR); b[i] = *(const h8*)(B + i * 16 * LDR); }
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int nk = ((kk + 1) & 1) * 32;
             h8 na[4], nb[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { na[i] = *(const h8*)(A + i * 16 * 72 + nk); nb[i] = *(const h8*)(B + i * 16 * 72 + nk); }
+            for (int i = 0; i < 4; ++i) { na[i] = *(const h8*)(A + i * 16 * LDR + nk); nb[i] = *(const h8*)(B + i * 16 * LDR + nk); }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -114,5 +114,9 @@ int main() {
     // 16x16x32: 32 MFMAs of 16384 FLOP per iteration = 16 "32x32x16-equivalents"
     printf("lds16x16x32 4 waves/CU: %.0f TFLOP/s\n", run(k_lds16<4>, 256, 256, in, out, 5000, 16));
     printf("lds16x16x32 8 waves/CU: %.0f TFLOP/s\n", run(k_lds16<4>, 512, 256, in, out, 5000, 16));
+    // 160-byte rows: conflict-free for the 16-row x 4 k-group fragments (144-byte rows are 2-way conflicted)
+    printf("lds16x16x32 4 waves/CU, 160-B rows: %.0f TFLOP/s\n", run(k_lds16<4, 80>, 256, 256, in, out, 5000, 16));
+    printf("lds16x16x32 8 waves/CU, 160-B rows: %.0f TFLOP/s\n", run(k_lds16<4, 80>, 512, 256, in, out, 5000, 16));
+    printf("lds  4 waves/CU (1/SIMD) again: %.0f TFLOP/s\n", run(k_lds<4>, 256, 256, in, out, 5000, 16));
     return 0;
 }
