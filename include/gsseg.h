@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 25
+#define GS_ABI_VERSION 26
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -302,6 +302,9 @@ int gs_seg_loss_bwd(const float* logits, const uint8_t* mask, const float* out, 
 int64_t gs_dice_batched_ws_floats(int B);
 int gs_dice_coeff_batched(const float* p, const float* t, int B, int64_t n_per, float* ws, float* out, void* stream);
 int gs_eval_dice(const float* logits, const uint8_t* mask, int N, int C, int64_t HW, float* ws, float* out, void* stream);
+/* the ISIC script's validation metric (running_files/train_end2end_isic.py:58-84): sigmoid(logit) > 0.5, per-sample Jaccard
+ * index (I + 1) / (P + T - I + 1), mean over the batch; one class; ws / out as gs_eval_dice with B = N. */
+int gs_eval_jaccard(const float* logits, const uint8_t* mask, int N, int64_t HW, float* ws, float* out, void* stream);
 /* BCE + Jaccard loss of the ISIC variant (running_files/train_end2end_isic.py:40-56,247-249; one class): per sample
  * jac_i = (sum p t + 1) / (sum (p + t) - sum p t + 1), loss = mean BCEWithLogits + 1 - mean_i jac_i.  logits fp32 [N][HW],
  * mask uint8 [N][HW]; out: gs_jaccard_loss_out_floats(N) floats = {loss, bce, 1 - mean jac, 0, (I_i, S_i) per sample} (the

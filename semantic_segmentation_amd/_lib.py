@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 GS_F16, GS_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH = 0, 1, 2, 3
 GS_MAX_TAPS = 64
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 
 class GsConvGeom(ctypes.Structure):
@@ -108,6 +108,7 @@ PROTOTYPES = {
     "gs_jaccard_loss_out_floats": (c_int64, [c_int]),
     "gs_jaccard_seg_loss_fwd": (c_int, [_F, _P, c_int, c_int64, _F, _F, c_void_p]),
     "gs_jaccard_seg_loss_bwd": (c_int, [_F, _P, _F, _F, c_float, _F, c_int, c_int64, c_void_p]),
+    "gs_eval_jaccard": (c_int, [_F, _P, c_int, c_int64, _F, _F, c_void_p]),
     "gs_dice_loss_fwd": (c_int, [_F, _F, c_int64, _F, _F, c_void_p]),
     "gs_dice_loss_bwd": (c_int, [_F, _F, _F, _F, c_int64, c_void_p]),
     "gs_mean_loss_fwd": (c_int, [_F, _F, c_float, c_int, c_int64, _F, _F, c_void_p]),

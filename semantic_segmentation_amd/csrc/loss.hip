@@ -319,8 +319,9 @@ __global__ __launch_bounds__(256) void eval_dice_kernel(const float* __restrict_
 }
 
 // out[0] = mean of the B coefficients, out[1 + b] = dice_b
+// metric 0: Dice (dice_score.py:12-16); 1: Jaccard index with smooth = 1 (train_end2end_isic.py:40-53)
 __global__ __launch_bounds__(256) void dice_batched_finalize_kernel(const float* __restrict__ ws, int B, int nblk,
-                                                                    float* __restrict__ out) {
+                                                                    float* __restrict__ out, int metric = 0) {
     __shared__ double red[256];
     double acc = 0.0;
     for (int b = threadIdx.x; b < B; b += 256) {
@@ -329,10 +330,16 @@ __global__ __launch_bounds__(256) void dice_batched_finalize_kernel(const float*
             const float* q = ws + ((int64_t)b * DB_BLOCKS + j) * 3;
             spt += (double)q[0]; sp += (double)q[1]; st += (double)q[2];
         }
-        const float inter = 2.f * (float)spt;
-        float sets = (float)sp + (float)st;
-        if (sets == 0.f) sets = inter;
-        const float d = (inter + DICE_EPS) / (sets + DICE_EPS);
+        float d;
+        if (metric == 1) {
+            const float I = (float)spt, S = (float)sp + (float)st;
+            d = (I + 1.f) / (S - I + 1.f);
+        } else {
+            const float inter = 2.f * (float)spt;
+            float sets = (float)sp + (float)st;
+            if (sets == 0.f) sets = inter;
+            d = (inter + DICE_EPS) / (sets + DICE_EPS);
+        }
         out[1 + b] = d;
         acc += (double)d;
     }
@@ -460,16 +467,26 @@ extern "C" int gs_dice_coeff_batched(const float* p, const float* t, int B, int6
     return GS_OK;
 }
 
-extern "C" int gs_eval_dice(const float* logits, const uint8_t* mask, int N, int C, int64_t HW, float* ws, float* out,
-                            void* stream) {
-    GS_CHECK_ARG(logits && mask && ws && out && N > 0 && N <= 65535 && C >= 1 && C <= 4 && HW > 0, "gs_eval_dice: bad arguments (C <= 4)");
+static int eval_metric(const float* logits, const uint8_t* mask, int N, int C, int64_t HW, int metric, float* ws, float* out,
+                       void* stream, const char* who) {
+    GS_CHECK_ARG(logits && mask && ws && out && N > 0 && N <= 65535 && C >= 1 && C <= 4 && HW > 0, "%s: bad arguments (C <= 4)", who);
     hipStream_t s = (hipStream_t)stream;
     const int K = C == 1 ? 1 : C - 1;
     const int nb = dice_batched_blocks(HW);
     eval_dice_kernel<<<dim3(nb, N), 256, 0, s>>>(logits, mask, C, HW, ws);
-    dice_batched_finalize_kernel<<<1, 256, 0, s>>>(ws, N * K, nb, out);
-    GS_CHECK_LAUNCH("gs_eval_dice");
+    dice_batched_finalize_kernel<<<1, 256, 0, s>>>(ws, N * K, nb, out, metric);
+    GS_CHECK_LAUNCH(who);
     return GS_OK;
+}
+
+extern "C" int gs_eval_dice(const float* logits, const uint8_t* mask, int N, int C, int64_t HW, float* ws, float* out,
+                            void* stream) {
+    return eval_metric(logits, mask, N, C, HW, 0, ws, out, stream, "gs_eval_dice");
+}
+
+// the ISIC script's validation metric (train_end2end_isic.py:58-84): thresholded prediction, per-sample Jaccard index, mean
+extern "C" int gs_eval_jaccard(const float* logits, const uint8_t* mask, int N, int64_t HW, float* ws, float* out, void* stream) {
+    return eval_metric(logits, mask, N, 1, HW, 1, ws, out, stream, "gs_eval_jaccard");
 }
 
 extern "C" int gs_dice_loss_fwd(const float* p, const float* t, int64_t n, float* ws, float* out, void* stream) {

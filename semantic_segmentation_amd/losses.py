@@ -154,6 +154,17 @@ def eval_dice(logits: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     return out[0]
 
 
+def eval_jaccard(logits: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """Validation Jaccard index of one batch as the ISIC script computes it (train_end2end_isic.py:58-84): sigmoid > 0.5
+    prediction, per-sample (I + 1) / (P + T - I + 1), mean -- one fused pass over the logits."""
+    if logits.dim() != 4 or logits.shape[1] != 1:
+        raise ValueError("eval_jaccard: logits must be [N,1,H,W]")
+    N, _, H, W = logits.shape
+    out = torch.empty(1 + N, dtype=torch.float32, device=logits.device)
+    ops.eval_jaccard(logits.detach().contiguous().float(), _mask_u8(mask, N, H, W), out)
+    return out[0]
+
+
 def dice_loss_op(inp: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     """1 - dice with ONE global sum over every element (dice_score.py:25-28, reduce_batch_first=True)."""
     return _DiceLoss.apply(inp, target)

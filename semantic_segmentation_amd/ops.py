@@ -809,6 +809,17 @@ def jaccard_seg_loss_bwd(logits, mask_u8, out, gout, gscale, dlogits):
               _stream())
 
 
+def eval_jaccard(logits, mask_u8, out):
+    """Fused ISIC validation metric (train_end2end_isic.py:58-84): threshold + per-sample Jaccard index, mean in out[0]."""
+    _dev(logits)
+    _f32(logits, "logits"); _f32(out, "out")
+    N, C, H, W = logits.shape
+    if C != 1 or mask_u8.dtype != torch.uint8 or not mask_u8.is_contiguous() or mask_u8.numel() != N * H * W or out.numel() < 1 + N:
+        raise ValueError("eval_jaccard: one-class logits, contiguous uint8 mask [N,H,W], out of 1 + N floats")
+    ws = torch.empty(int(_lib.load().gs_dice_batched_ws_floats(N)), dtype=torch.float32, device=logits.device)
+    _lib.call("gs_eval_jaccard", _p(logits), _p(mask_u8), N, H * W, _p(ws), _p(out), _stream())
+
+
 def mean_loss_fwd(x, t, cval, mode, ws, out):
     _dev(x)
     _f32(x, "x"); _f32(t, "target")

@@ -571,3 +571,19 @@ def test_dynamic_loss_scale_survives_a_1e4_loss_weight():
     bad = sum(int((~torch.isfinite(v)).sum()) for v in big.values())
     REPORT["static_scale_x1e4_nonfinite_grad_elements"] = bad
     _dump()
+
+
+def test_fused_eval_jaccard_matches_oracle():
+    """gs_eval_jaccard against the oracle's restatement of the ISIC evaluate (train_end2end_isic.py:58-84), incl. an empty
+    sample (Jaccard = 1 through smooth = 1)."""
+    from semantic_segmentation_amd.losses import eval_jaccard
+    g = torch.Generator().manual_seed(77)
+    N, H, W = 4, 70, 52
+    logits = torch.randn(N, 1, H, W, generator=g) * 3
+    mask = torch.randint(0, 2, (N, 1, H, W), generator=g)
+    mask[1] = 0
+    logits[1] = -5.0
+    pred = (torch.sigmoid(logits) > 0.5).float()
+    want = oracle.jaccard_index(pred.squeeze(), mask.float().squeeze())
+    got = eval_jaccard(logits.cuda(), mask.cuda())
+    assert abs(got.item() - want.item()) < 2e-7, (got.item(), want.item())
