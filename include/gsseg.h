@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 26
+#define GS_ABI_VERSION 27
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -242,6 +242,16 @@ int gs_unpack_wgrad(const float* dw, float* grad, int A, int B, int taps, int tr
  * host); ws: gs_fake_postprocess_ws_floats(N) floats of scratch.  Bit-exact against oracle/postproc.py. */
 int64_t gs_fake_postprocess_ws_floats(int N);
 int gs_fake_postprocess(const float* x, float* out, float* ws, const float* gamma_lut, int N, int64_t hw, void* stream);
+
+/* ISIC variant of the fake-image post-processing (running_files/train_end2end_isic.py:178-184,263-264): global min-max ->
+ * uint8 -> [RandomEqualize] -> posterize(bits) -> [adjust_sharpness] -> [autocontrast] -> [adjust_saturation] -> float/255
+ * (torchvision 0.14.1 algorithms).  The per-call random decisions are made by the host: *_on flags; blend ratios as the
+ * pair (float(ratio), float(1.0 - ratio)) the reference's float arithmetic uses.  x, out: fp32 [N][C][H][W], C <= 4
+ * (saturation needs C == 3); ws: gs_isic_fake_trans_ws_bytes(N*C, H*W) bytes.  Bit-exact against oracle/postproc.py. */
+int64_t gs_isic_fake_trans_ws_bytes(int planes, int64_t hw);
+int gs_isic_fake_trans(const float* x, float* out, void* ws, int N, int C, int H, int W, int equalize_on, int bits,
+                       int sharpness_on, float sharp_r1, float sharp_r2, int autocontrast_on, int saturation_on, float sat_r1,
+                       float sat_r2, void* stream);
 
 /* Outermost generator layer (models_pix2pix/networks.py:588-593, merged 8x8 kernel): ConvTranspose2d(Cin -> Cout <= 4,
  * k 8, stride 2, pad 3) + bias + activation written as the fp32 NCHW image out [N,Cout,2h,2w]; u (may be NULL) receives

@@ -731,6 +731,22 @@ def fake_postprocess(x, out, gamma_lut):
     _lib.call("gs_fake_postprocess", _p(x), _p(out), _p(ws), _p(gamma_lut), N, hw, _stream())
 
 
+def isic_fake_trans(x, out, equalize_on, bits, sharpness_on, sharpness_factor, autocontrast_on, saturation_factor):
+    """gs_isic_fake_trans on an fp32 batch [N,C,H,W]; saturation_factor None = no saturation step.  The blend ratios are
+    passed as (float32(r), float32(1.0 - r)) with the subtraction in double, as torchvision's `_blend` evaluates them."""
+    _dev(x)
+    _f32(x, "x"); _f32(out, "out")
+    if x.dim() != 4 or not x.is_contiguous() or out.shape != x.shape or not out.is_contiguous():
+        raise ValueError("isic_fake_trans: contiguous x, out [N,C,H,W] of one shape")
+    N, C, H, W = x.shape
+    ws = torch.empty(int(_lib.load().gs_isic_fake_trans_ws_bytes(N * C, H * W)), dtype=torch.uint8, device=x.device)
+    sat_on = saturation_factor is not None and C == 3
+    sr = float(saturation_factor) if sat_on else 1.0
+    _lib.call("gs_isic_fake_trans", _p(x), _p(out), _p(ws), N, C, H, W, int(bool(equalize_on)), int(bits),
+              int(bool(sharpness_on)), float(sharpness_factor), float(1.0 - float(sharpness_factor)), int(bool(autocontrast_on)),
+              int(sat_on), sr, float(1.0 - sr), _stream())
+
+
 # ---------------------------------------------------------------------------- losses
 LOSS_WS = 4 * 1024
 

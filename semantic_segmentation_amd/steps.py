@@ -64,6 +64,46 @@ def fake_image_postprocess(fake_image: torch.Tensor, gamma: float = 0.5) -> torc
     return out
 
 
+def isic_fake_trans(fake_image: torch.Tensor, generator: Optional[torch.Generator] = None, decisions=None) -> torch.Tensor:
+    """The fake-image post-processing of the ISIC / RGB script (running_files/train_end2end_isic.py:178-184,263-264):
+    global min-max -> uint8 -> fake_trans -> / 255, with fake_trans = Compose([RandomEqualize(p=0.5), RandomPosterize(4, p=1),
+    RandomAdjustSharpness(0.3, p=0.5), RandomAutocontrast(p=0.5), ColorJitter(saturation=0.5)]) of torchvision 0.14.1.  As in
+    torchvision every Random* transform draws ONE decision per call for the whole batch; they are drawn here on the host (in
+    torchvision's order: four `rand(1) < p`, then ColorJitter's `randperm(4)` and `uniform_(0.5, 1.5)`) and the image work runs
+    in six small HIP launches.  `decisions` = (equalize, sharpness, autocontrast, saturation_factor) overrides the draws."""
+    if not fake_image.is_cuda or fake_image.dim() != 4:
+        raise RuntimeError("isic_fake_trans: needs a device tensor [N,C,H,W] (no CPU path)")
+    if decisions is None:
+        r = lambda: float(torch.rand(1, generator=generator))
+        eq_on = r() < 0.5
+        r()                                           # RandomPosterize(p=1.0) draws too
+        sharp_on = r() < 0.5
+        ac_on = r() < 0.5
+        torch.randperm(4, generator=generator)        # ColorJitter.get_params: order of its (single active) adjustment
+        sat = float(torch.empty(1).uniform_(0.5, 1.5, generator=generator))
+    else:
+        eq_on, sharp_on, ac_on, sat = decisions
+    x = fake_image.detach().float().contiguous()
+    out = torch.empty_like(x)
+    ops.isic_fake_trans(x, out, eq_on, 4, sharp_on, 0.3, ac_on, sat)
+    return out
+
+
+def unet_step_loss_isic(net, netG, images, true_masks, loss_lambda: float = 1.0,
+                        mask_augment: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, generator=None):
+    """Unet.training_step of running_files/train_end2end_isic.py:241-270: BCE + Jaccard loss on the real pair plus
+    loss_lambda times the same loss on the generated RGB pair (G is cut by the detach)."""
+    from .losses import seg_loss_jaccard
+    loss = seg_loss_jaccard(net(images), true_masks)
+    fake_mask = true_masks.float()
+    if mask_augment is not None:
+        fake_mask = mask_augment(fake_mask)
+    fake_mask = torch.where(fake_mask > 0.1, torch.ones_like(fake_mask), torch.zeros_like(fake_mask))
+    with torch.no_grad():
+        fake_image = isic_fake_trans(netG(fake_mask), generator)
+    return loss + loss_lambda * seg_loss_jaccard(net(fake_image), fake_mask)
+
+
 def unet_step_loss(net, netG, images, true_masks, loss_lambda: float = 1.0,
                    mask_augment: Optional[Callable[[torch.Tensor], torch.Tensor]] = None):
     """loss(net(images), masks) + loss_lambda * loss(net(G(aug(masks))), aug(masks)); G is cut by the detach."""

@@ -271,3 +271,32 @@ def test_jaccard_loss_matches_reference(golden_dir):
     assert abs(oracle.jaccard_index(m[:, 0].float(), p).item() - float(z["jaccard"])) < 1e-6
     assert abs(oracle.jaccard_index(m[0, 0].float(), p[0]).item() - float(z["jaccard_2d"])) < 1e-6
     assert abs(oracle.seg_loss_jaccard(x.detach()[:1], m[:1]).item() - float(z["loss_b1"])) < 1e-6
+
+
+def test_postproc_isic_chain_matches_torch_cpu_formulas():
+    """oracle/postproc.py's ISIC fake_trans steps (posterize, sharpness, autocontrast, saturation) against torch-CPU
+    evaluating torchvision 0.14.1's published formulas (conv2d blur + round, amin/amax scale, grey blend): same bytes.
+    (torchvision itself is absent: parity unpinned, see the oracle header.)"""
+    from oracle import postproc
+    g = torch.Generator().manual_seed(12)
+    x = torch.tanh(torch.randn(2, 3, 24, 28, generator=g))
+    u8 = postproc.minmax_to_u8(x.numpy())
+    t = torch.from_numpy(u8)
+    assert np.array_equal((t & -int(2 ** (8 - 4))).numpy(), postproc.posterize(u8, 4))
+    k = torch.ones(3, 3); k[1, 1] = 5.0; k /= k.sum(); k = k.expand(3, 1, 3, 3)
+    blur = torch.round(torch.nn.functional.conv2d(t.float(), k, groups=3)).to(torch.uint8)
+    res = t.clone(); res[..., 1:-1, 1:-1] = blur
+    sharp = (0.3 * t + (1.0 - 0.3) * res).clamp(0, 255).to(torch.uint8)
+    assert np.array_equal(sharp.numpy(), postproc.adjust_sharpness(u8, 0.3))
+    mn, mx = t.amin(dim=(-2, -1), keepdim=True).float(), t.amax(dim=(-2, -1), keepdim=True).float()
+    ac = ((t - mn) * (255.0 / (mx - mn))).clamp(0, 255).to(torch.uint8)
+    assert np.array_equal(ac.numpy(), postproc.autocontrast(u8))
+    const = np.full((1, 3, 4, 4), 9, np.uint8)                     # max == min: unchanged
+    assert np.array_equal(postproc.autocontrast(const), const)
+    r, gg, b = t.unbind(dim=-3)
+    grey = (0.2989 * r + 0.587 * gg + 0.114 * b).to(torch.uint8).unsqueeze(-3)
+    for f in (0.5, 0.77, 1.3, 1.5):
+        sat = (f * t + (1.0 - f) * grey).clamp(0, 255).to(torch.uint8)
+        assert np.array_equal(sat.numpy(), postproc.adjust_saturation(u8, f)), f
+    out = postproc.isic_fake_trans(x.numpy(), True, True, True, 1.2)
+    assert out.dtype == np.float32 and out.shape == x.shape and 0.0 <= out.min() and out.max() <= 1.0

@@ -82,3 +82,42 @@ def test_gan_and_unet_steps_vs_oracle():
     lU.backward()
     assert all(p.grad is not None for p in U.parameters())
     assert all(p.grad is None for p in G.parameters())            # G is cut by the detach (:197)
+
+
+@pytest.mark.parametrize("C,H,W", [(3, 64, 80), (3, 33, 47), (1, 40, 24)])
+def test_isic_fake_trans_bit_exact_vs_oracle(C, H, W):
+    """gs_isic_fake_trans (train_end2end_isic.py:178-184,263-264: min-max -> uint8 -> equalize? -> posterize(4) -> sharpness? ->
+    autocontrast? -> saturation -> /255) against oracle/postproc.py for every combination of the random decisions."""
+    from oracle import postproc
+    from semantic_segmentation_amd import steps
+    g = torch.Generator().manual_seed(C * 100 + H)
+    x = torch.tanh(1.5 * torch.randn(3, C, H, W, generator=g))
+    x[1, 0] = 0.25                                         # a constant plane: equalize / autocontrast edge paths
+    for eq in (False, True):
+        for sh in (False, True):
+            for ac in (False, True):
+                for sat in (0.5, 1.37):
+                    got = steps.isic_fake_trans(x.cuda(), decisions=(eq, sh, ac, sat)).cpu().numpy()
+                    want = postproc.isic_fake_trans(x.numpy(), eq, sh, ac, sat)
+                    assert np.array_equal(got, want), (eq, sh, ac, sat, int((got != want).sum()))
+    # drawn decisions: reproducible from the generator, output in [0, 1]
+    a = steps.isic_fake_trans(x.cuda(), generator=torch.Generator().manual_seed(5))
+    b = steps.isic_fake_trans(x.cuda(), generator=torch.Generator().manual_seed(5))
+    assert torch.equal(a, b) and float(a.min()) >= 0.0 and float(a.max()) <= 1.0
+
+
+def test_isic_unet_step_runs_and_cuts_the_generator():
+    from semantic_segmentation_amd import steps
+    from semantic_segmentation_amd.models_pix2pix import networks
+    from semantic_segmentation_amd.unet import UNet
+    norm = networks.get_norm_layer("batch")
+    G = networks.UnetGenerator(1, 3, 8, 64, norm_layer=norm, use_dropout=False).cuda().train()
+    U = UNet(3, 1).cuda().train()
+    networks.upconv_arch = (0.1 * torch.randn(8, 3)).cuda()
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(2, 3, 256, 256, generator=g).cuda()
+    _, mask = oracle.synthetic_batch(2, 256, seed=21)
+    loss = steps.unet_step_loss_isic(U, G, x, mask.cuda(), 1.0, generator=torch.Generator().manual_seed(1))
+    loss.backward()
+    assert torch.isfinite(loss) and all(p.grad is not None for p in U.parameters())
+    assert all(p.grad is None for p in G.parameters())
