@@ -14,6 +14,15 @@ namespace {
 
 constexpr int PP_BLOCKS = 512;      // min/max partials
 
+// a product that stays a product: the file is built with -ffp-contract=fast and __fmul_rn / __fadd_rn are plain operators to
+// the compiler, so mul + add pairs would otherwise be fused into one FMA (one rounding instead of torch's two)
+__device__ __forceinline__ float mul_keep(float a, float b) {
+    float r = a * b;
+    asm volatile("" : "+v"(r));
+    return r;
+}
+
+
 __device__ __forceinline__ void block_minmax(float& mn, float& mx, float* red) {
     for (int o = 32; o > 0; o >>= 1) {
         mn = fminf(mn, __shfl_xor(mn, o, 64));
@@ -48,7 +57,7 @@ __device__ __forceinline__ void global_minmax(const float* part, int nparts, flo
 __device__ __forceinline__ int to_u8(float v, float mn, float d) {
     // torch: ((x - min) / (max - min)).mul(255).add_(0.5).clamp_(0, 255).to(uint8)   -- separate roundings, truncation
     float f = __fdiv_rn(__fsub_rn(v, mn), d);
-    f = __fadd_rn(__fmul_rn(f, 255.f), 0.5f);
+    f = mul_keep(f, 255.f) + 0.5f;
     f = fminf(fmaxf(f, 0.f), 255.f);
     return (int)f;
 }
@@ -171,7 +180,7 @@ __global__ __launch_bounds__(256) void it_lut_kernel(uint8_t* __restrict__ A, in
 }
 
 __device__ __forceinline__ int blend_u8(int a, int b, float r1, float r2) {
-    float v = __fadd_rn(__fmul_rn(r1, (float)a), __fmul_rn(r2, (float)b));
+    float v = mul_keep(r1, (float)a) + mul_keep(r2, (float)b);
     v = fminf(fmaxf(v, 0.f), 255.f);
     return (int)v;
 }
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(256) void it_sharp_kernel(const uint8_t* __restrict
             for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
                 for (int dx = -1; dx <= 1; ++dx)
-                    acc = __fadd_rn(acc, __fmul_rn((dy == 0 && dx == 0) ? k5 : k1, (float)a[i + (int64_t)dy * W + dx]));
+                    acc = acc + mul_keep((dy == 0 && dx == 0) ? k5 : k1, (float)a[i + (int64_t)dy * W + dx]);
             blur = (int)rintf(acc);
         }
         b[i] = (uint8_t)blend_u8(v, blur, r1, r2);
@@ -237,8 +246,7 @@ __global__ __launch_bounds__(256) void it_final_kernel(const uint8_t* __restrict
             v[c] = u;
         }
         if (sat_on && C == 3) {
-            const float g = __fadd_rn(__fadd_rn(__fmul_rn(0.2989f, (float)v[0]), __fmul_rn(0.587f, (float)v[1])),
-                                      __fmul_rn(0.114f, (float)v[2]));
+            const float g = (mul_keep(0.2989f, (float)v[0]) + mul_keep(0.587f, (float)v[1])) + mul_keep(0.114f, (float)v[2]);
             const int grey = (int)g;
             for (int c = 0; c < 3; ++c) v[c] = blend_u8(v[c], grey, s1, s2);
         }
