@@ -149,7 +149,9 @@ class MixedOp_upconv(nn.Module):
             self._ops.append(OPS[primitive](C_in, C_out, bias))
 
     def forward(self, x, weights):
-        raise RuntimeError("MixedOp_upconv runs merged inside UnetGenerator.forward (HIP engine)")
+        """sum(w * op(x)) (networks.py:495-496) as ONE merged transposed conv on the HIP kernels (cell_engine.py)."""
+        from .cell_engine import mixed_upconv
+        return mixed_upconv(x, weights, list(self._ops))
 
 
 class Cell_upconv(nn.Module):
@@ -161,7 +163,9 @@ class Cell_upconv(nn.Module):
         self._ops = MixedOp_upconv(C_in, C_out, bias)
 
     def forward(self, input):
-        raise RuntimeError("Cell_upconv runs merged inside UnetGenerator.forward (HIP engine)")
+        """networks.py:507-511: softmax of this cell's row of the architecture tensor, then the mixed op."""
+        weights = torch.softmax(upconv_arch[self._layer_index].to(input.device), dim=-1)
+        return self._ops(input, weights)
 
 
 class UnetSkipConnectionBlock(nn.Module):

@@ -98,3 +98,49 @@ def test_standalone_block_updates_bn_buffers_and_eval_mode():
     sd = {"blk." + k: v.detach().cpu() for k, v in m.state_dict().items()}
     ref = oracle.double_conv(x.cpu(), sd, "blk", False)
     assert _rel(y.cpu(), ref) < 3e-3
+
+
+def test_cell_upconv_and_primitives_standalone():
+    """Cell_upconv(x) (networks.py:499-511), MixedOp_upconv(x, w) and a single re_conv primitive called on their own: forward,
+    weight / bias / input gradients and the gradient of the architecture row against the oracle's three-way sum."""
+    import torch.nn.functional as F
+    from semantic_segmentation_amd.architecture_pix2pix.operations import re_conv_622
+    from semantic_segmentation_amd.models_pix2pix import networks
+    torch.manual_seed(7)
+    cell = networks.Cell_upconv(64, 40, bias=True, layer_index=2).cuda()
+    for o in cell._ops._ops:
+        torch.nn.init.normal_(o.op.weight, 0.0, 0.05)
+        torch.nn.init.normal_(o.op.bias, 0.0, 0.1)
+    arch = (0.5 * torch.randn(8, 3)).cuda().requires_grad_(True)
+    networks.upconv_arch = arch
+    x = torch.randn(2, 64, 9, 7)
+    xg = x.clone().cuda().requires_grad_(True)
+    y = cell(xg)
+    g = torch.Generator().manual_seed(1)
+    dout = torch.randn(y.shape, generator=g) / y.numel()
+    y.backward(dout.cuda())
+    # oracle: sum_j softmax(arch[2])_j * ConvTranspose2d_j(x)
+    xr = x.clone().requires_grad_(True)
+    ar = arch.detach().cpu().clone().requires_grad_(True)
+    ws = [o.op.weight.detach().cpu().clone().requires_grad_(True) for o in cell._ops._ops]
+    bs = [o.op.bias.detach().cpu().clone().requires_grad_(True) for o in cell._ops._ops]
+    sm = torch.softmax(ar[2], -1)
+    ref = sum(sm[j] * F.conv_transpose2d(xr, ws[j], bs[j], stride=2, padding=p) for j, p in enumerate((1, 2, 3)))
+    ref.backward(dout)
+    assert y.shape == ref.shape == (2, 40, 18, 14)
+    assert _rel(y.detach().cpu(), ref.detach()) < 3e-3
+    assert _rel(xg.grad.cpu(), xr.grad) < 1e-2
+    for j, o in enumerate(cell._ops._ops):
+        assert _rel(o.op.weight.grad.cpu(), ws[j].grad) < 1e-2, j
+        assert _rel(o.op.bias.grad.cpu(), bs[j].grad) < 1e-2, j
+    assert _rel(arch.grad[2].cpu(), ar.grad[2]) < 1e-2 and float(arch.grad[[0, 1, 3]].abs().sum()) == 0.0
+    # one primitive on its own
+    prim = re_conv_622(64, 24, True).cuda()
+    xp = torch.randn(2, 64, 5, 6)
+    yp = prim(xp.cuda())
+    refp = F.conv_transpose2d(xp, prim.op.weight.detach().cpu(), prim.op.bias.detach().cpu(), stride=2, padding=2)
+    assert _rel(yp.detach().cpu(), refp) < 3e-3
+    yp.sum().backward()
+    assert prim.op.weight.grad is not None and torch.isfinite(prim.op.weight.grad).all()
+    with pytest.raises(RuntimeError):
+        prim(xp)
