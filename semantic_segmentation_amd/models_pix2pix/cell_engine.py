@@ -66,8 +66,8 @@ class _MixedUpconvFunction(torch.autograd.Function):
         dev, tdt = dy.device, _tdt()
         r = _grad_scale(dy)
         inv_r = torch.reciprocal(r)
-        du = torch.zeros((N, 2 * H, 2 * W, cpad), dtype=tdt, device=dev) if cpad != Cout else \\
-            torch.empty((N, 2 * H, 2 * W, cpad), dtype=tdt, device=dev)
+        alloc = torch.zeros if cpad != Cout else torch.empty
+        du = alloc((N, 2 * H, 2 * W, cpad), dtype=tdt, device=dev)
         ops.nchw_to_nhwc((dy.contiguous().float() * r).contiguous(), du, cpad, 0)
         dwm = torch.empty((4, 16, cpad, Cin), dtype=torch.float32, device=dev)
         nparts = ops.conv_wgrad_parts(ctx.geoms[0])
