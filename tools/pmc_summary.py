@@ -73,8 +73,48 @@ def pmc(dfetch, dwrite, nsteps, out):
         json.dump(res, f, indent=1)
 
 
+def mfma(d, nsteps, out):
+    """Matrix-pipe occupancy per kernel from one PMC pass (GRBM_GUI_ACTIVE, SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES) joined
+    with the kernel durations of the same pass.  MI355X_MICROARCH.md: GRBM_GUI_ACTIVE is summed over the 8 XCDs, so the
+    clock a dispatch held is GRBM_GUI_ACTIVE / 8 / duration (reads high on dispatches under ~0.3 ms);
+    SQ_VALU_MFMA_BUSY_CYCLES counts matrix-pipe busy cycles summed over the chip's 1024 SIMDs (256 CUs x 4), so
+    busy / (1024 * GRBM_GUI_ACTIVE / 8) is the fraction of SIMD-cycles with an MFMA in flight."""
+    vals = defaultdict(lambda: defaultdict(float))
+    cnt = defaultdict(int)
+    dur = defaultdict(float)
+    seen = set()
+    with open(find(d, "*counter_collection.csv")) as f:
+        for r in csv.DictReader(f):
+            k = short(r["Kernel_Name"])
+            vals[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            key = (r.get("Dispatch_Id"), k)
+            if key not in seen:
+                seen.add(key)
+                cnt[k] += 1
+                if r.get("End_Timestamp") and r.get("Start_Timestamp"):
+                    dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    res = {"_note": "rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES over bench.py; "
+                    "per kernel: launches/step, clock_GHz = GRBM_GUI_ACTIVE/8/duration, mfma_busy_frac = "
+                    "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE/8)"}
+    for k in sorted(vals, key=lambda k: -vals[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)):
+        v = vals[k]
+        gui = v.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        if gui <= 0:
+            continue
+        ent = {"launches_per_step": round(cnt[k] / nsteps, 2),
+               "mfma_busy_frac": round(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * gui), 4)}
+        if dur[k] > 0:
+            ent["clock_GHz"] = round(gui / dur[k] / 1e3, 3)
+            ent["avg_us"] = round(dur[k] / cnt[k], 2)
+        res[k] = ent
+    with open(out, "w") as f:
+        json.dump(res, f, indent=1)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], int(sys.argv[3]), sys.argv[4])
+    elif sys.argv[1] == "mfma":
+        mfma(sys.argv[2], int(sys.argv[3]), sys.argv[4])
     else:
         pmc(sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5])
