@@ -1014,6 +1014,352 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
 #undef PH
 }
 
+// ---------------------------------------------------------------------------------------------------
+// v4 "LDS-DMA": the same (patch x 64 couts) items as the big K-step kernel, but the operands never pass through
+// registers: every K stage (32 input channels: the halo + the nine 64x32 weight slabs) is written into LDS by
+// `buffer_load_dwordx4 ... lds` (1 KiB = 16 rows x 64 B per wave-instruction) into the buffer the previous stage has just
+// left, while the current stage's 72 MFMAs per wave run -- no staging registers, no ds_write phase, one barrier per stage.
+//   LDS image : rows of 64 B (32 channels), no padding (the DMA destination is lane-linear); the 16-byte slot s of row r
+//               lives at slot s ^ ((r >> 2) & 3): any 16 rows {b..b+3, b+12..b+15, b+20..b+27} (one ds_read_b128 lane
+//               group of a 32-row fragment) hit 16 distinct 16-byte bank groups for every base b.  The swizzle is
+//               applied on the SOURCE side: lane l of a piece fetches logical slot (l & 3) ^ ((l >> 4) & 3).
+//   zero pad  : out-of-image halo pixels / couts >= Cout carry an out-of-range buffer offset: the DMA writes zeros.
+//   stage s   : wait vmcnt(0) + barrier (stage s landed everywhere, stage s-1 fully read) -> issue the pieces of stage
+//               s+1 interleaved with the first MFMA steps -> 18 steps of 4 MFMAs (fragment reads one step ahead).
+//   NWV       : 4 waves = 8x32 pixels (one wave per SIMD) or 8 waves = 16x32 pixels (two per SIMD, weights fetched
+//               once per 512 pixels); BatchNorm partials are always written per 8x32 half (gs_conv3x3_mtiles()).
+// Requires Cin % 64 == 0 (an even number of stages keeps the buffer parity fixed per item), W >= 24, the forward or the
+// data-gradient (flipped) tap table, 2-D; everything else stays on conv3x3_big_kernel.
+// ---------------------------------------------------------------------------------------------------
+// (a "v" constraint inside the kernel body itself would make the host-side instantiation of the launch stub invalid)
+__device__ __forceinline__ void opaque_vgpr(unsigned& x) { asm volatile("" : "+v"(x)); }
+// one LDS-DMA piece: lane l's 16 bytes at buffer offset voff + soff land at dst + 16 l (dst wave-uniform).  A device
+// function of its own: the address-space cast inside the kernel body invalidates the host-side launch stub.
+__device__ __forceinline__ void dma_piece16(const __amdgpu_buffer_rsrc_t& rs, unsigned char* dst, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)dst, 16, voff, soff, 0, 0);
+}
+
+template <int DT, int NWV>
+__global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a) {
+    typedef typename Elem<DT>::V8 V8;
+    constexpr int BN = 64, TW = 32, TH = 2 * NWV, TWS = 5;
+    constexpr int HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;
+    constexpr int HI = (HP + 15) / 16;                     // halo pieces that hold real rows
+    constexpr int HJ = (HI + NWV - 1) / NWV;               // halo pieces per wave (the tail ones are spare)
+    constexpr int NWP = (NWV == 4) ? 9 : 5;                // weight pieces per wave
+    constexpr int HALO_B = HJ * NWV * 1024, W_B = 9 * BN * 64, STAGE_B = HALO_B + W_B;
+    constexpr int STG_EL = 32 * C3_LDR;
+    constexpr unsigned VOOB = 0x80000000u;
+    static_assert(2 * STAGE_B <= 160 * 1024, "two stages must fit in LDS");
+    static_assert(NWV * STG_EL * 2 + NWV * 2 * BN * 4 <= HALO_B, "epilogue staging overlays the second halo buffer");
+    static_assert(NWP + HJ <= 18, "one DMA piece per MFMA step");
+    static_assert(NWV == 4 || HI < HJ * NWV, "the 8-wave variant parks its odd weight piece in the spare halo piece");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE_B];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nitems = a.nblocks;
+    const int act = a.act & 0xff;
+    const int nstage = a.Cin >> 5;
+    const unsigned img_bytes = (unsigned)a.H * a.W * a.in_stride * 2u;
+    const unsigned tap_stride = (unsigned)a.Cout * a.Cin * 2u;
+    const bool flip = a.tap_dy[0] > 0;                     // data-gradient table: geometric tap g uses weight slot 8 - g
+    const int tiles_y8 = (a.H + 7) >> 3;                   // BatchNorm partial rows are numbered in 8x32 patches
+
+    struct Item { int n, y0, x0, n0, mt; };
+    const __amdgpu_buffer_rsrc_t w_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)(9u * a.Cout * a.Cin * 2u), 0x00020000);
+
+    // ---- DMA side: lane l of a piece fills physical slot l & 3 of row l >> 2 ----
+    const int drow = lane >> 2;
+    const int dls = (lane & 3) ^ ((lane >> 4) & 3);
+    unsigned hv[HJ], wv;
+    auto setup_item = [&](const Item& itn) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < HJ; ++j) {
+            const int r = (wave + j * NWV) * 16 + drow;
+            const int hy = r / HWD, hx = r - hy * HWD;
+            const int gy = itn.y0 + hy - 1, gx = itn.x0 + hx - 1;
+            const bool ok = r < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            hv[j] = ok ? (unsigned)(((gy * a.W + gx) * a.in_stride + a.in_coff + dls * 8) * 2) : VOOB;
+        }
+        const int co = itn.n0 + (wave & 3) * 16 + drow;
+        wv = co < a.Cout ? (unsigned)((co * a.Cin + dls * 8) * 2) : VOOB;
+    };
+    // LDS: [halo 0 | halo 1 | weights 0 | weights 1] -- every fragment read is (per-lane base register) + (16-bit immediate)
+    // piece k (compile-time) of stage (image rx, channel byte offset sc) into buffer bb
+    auto issue_piece = [&](int k, const __amdgpu_buffer_rsrc_t& rx, unsigned sc, unsigned bb, unsigned kill) __attribute__((always_inline)) {
+        if (k < NWP) {
+            const int tap = (NWV == 8) ? 2 * k + (wave >> 2) : k;
+            const bool real = tap < 9;                     // 8 waves: waves 4..7 have four weight pieces only
+            const int slot = flip ? 8 - tap : tap;
+            const unsigned dst = real ? (unsigned)(2 * HALO_B + tap * 4096 + (wave & 3) * 1024) + bb * W_B
+                                      : (unsigned)(HALO_B - 1024) + bb * HALO_B;
+            dma_piece16(w_rsrc, smem + dst, real ? (wv | kill) : VOOB, (unsigned)slot * tap_stride + sc);
+        } else if (k - NWP < HJ) {
+            const int j = k - NWP < HJ ? k - NWP : 0;
+            const unsigned dst = bb * HALO_B + (unsigned)(wave + j * NWV) * 1024u;
+            dma_piece16(rx, smem + dst, hv[j] | kill, sc);
+        }
+    };
+
+    // ---- MFMA side: fragment byte addresses inside a stage buffer (item independent) ----
+    // (kept opaque: hipcc otherwise materialises every base + constant combination of both buffers in its own register)
+    unsigned aaddr[2][4][3];                               // [k half][halo row 2*wave + e, e = i + dy + 1][column l31 + dx + 1]
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int r = (2 * wave + e) * HWD + l31 + d;
+            aaddr[0][e][d] = (unsigned)(r * 64 + ((h ^ ((r >> 2) & 3)) << 4));
+            aaddr[1][e][d] = aaddr[0][e][d] ^ 32u;
+            opaque_vgpr(aaddr[0][e][d]); opaque_vgpr(aaddr[1][e][d]);
+        }
+    unsigned baddr[2][2];                                  // [buffer][k half]
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        baddr[b][0] = (unsigned)(2 * HALO_B + b * W_B + l31 * 64 + ((h ^ ((l31 >> 2) & 3)) << 4));
+        baddr[b][1] = baddr[b][0] ^ 32u;
+        opaque_vgpr(baddr[b][0]); opaque_vgpr(baddr[b][1]);
+    }
+
+    f32x16 acc[2][2];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+
+    // one stage: 18 steps (tap, k half) of 4 MFMAs out of buffer BUF; the pieces of the next stage (image rx_n, channel
+    // offset sc_n) go into the other buffer, one per step
+    auto run_stage = [&](auto buf_tag, const __amdgpu_buffer_rsrc_t& rx_n, unsigned sc_n, unsigned kill) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        constexpr unsigned NB = 1 - BUF;
+        V8 af[2][2], bf[2][2];
+        auto frag_load = [&](int step, V8 (&fa)[2], V8 (&fb)[2]) __attribute__((always_inline)) {
+            const int tap = step >> 1, kh = step & 1;
+            const int dyi = tap / 3, dxi = tap - 3 * dyi;
+            fa[0] = *reinterpret_cast<const V8*>(smem + aaddr[kh][dyi][dxi] + BUF * HALO_B);
+            fb[0] = *reinterpret_cast<const V8*>(smem + baddr[BUF][kh] + tap * 4096);
+            fa[1] = *reinterpret_cast<const V8*>(smem + aaddr[kh][dyi + 1][dxi] + BUF * HALO_B);
+            fb[1] = *reinterpret_cast<const V8*>(smem + baddr[BUF][kh] + tap * 4096 + 2048);
+        };
+        frag_load(0, af[0], bf[0]);
+#pragma unroll
+        for (int step = 0; step < 18; ++step) {
+            const int cur = step & 1;
+            if (step + 1 < 18) frag_load(step + 1, af[cur ^ 1], bf[cur ^ 1]);
+            issue_piece(step, rx_n, sc_n, NB, kill);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i][j] = Elem<DT>::mfma32(af[cur][i], bf[cur][j], acc[i][j]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // one LDS fragment read in its shadow
+            }
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);           // the DMA piece of this step
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // stage hand-over: this wave's pieces have landed; after the barrier everybody's have, and nobody reads the other
+    // buffer any more.  (Stores count in vmcnt too: the epilogue's are drained here as well.)
+    auto stage_sync = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    // ---- epilogue: as conv3x3_big_kernel (staging overlays the second halo buffer, which the last stage has just left) ----
+    unsigned short* stg = reinterpret_cast<unsigned short*>(smem + HALO_B) + wave * STG_EL;
+    float* red = reinterpret_cast<float*>(smem + HALO_B + NWV * STG_EL * 2);           // [NWV][2][64]
+    const bool odd = lane & 1;
+    const unsigned int psel = odd ? 0x03020706u : 0x05040100u;
+    const float neg_slope = act == GS_ACT_RELU ? 0.f : (act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
+    auto epilogue_t = [&](const Item& itc, auto plain_tag, auto full_tag) __attribute__((always_inline)) {
+        constexpr bool PLAIN = decltype(plain_tag)::value;
+        constexpr bool FULL = decltype(full_tag)::value;
+        int e_y0 = itc.y0, e_x0 = itc.x0, e_n = itc.n, e_n0 = itc.n0;
+        asm volatile("" : "+s"(e_y0), "+s"(e_x0), "+s"(e_n), "+s"(e_n0));
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.y + (int64_t)e_n * a.H * a.W * a.out_stride), 0, (unsigned)a.H * a.W * a.out_stride * 2u, 0x00020000);
+        float bv[2] = {0.f, 0.f};
+        if (!PLAIN) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int co = e_n0 + j * 32 + l31;
+                bv[j] = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
+            }
+        }
+        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+        const bool want_stats = a.bnp != nullptr;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int prow0 = (wave * 2 + i) * 32;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int r0 = 2 * m;
+                const int rowa = (r0 & 3) + 8 * (r0 >> 2) + 4 * h;
+                float w0 = 1.f, w1 = 1.f;
+                if (!FULL && want_stats) {
+                    const int p0 = prow0 + rowa;
+                    const int gy0 = e_y0 + (p0 >> TWS), gx0 = e_x0 + (p0 & (TW - 1));
+                    const int gy1 = e_y0 + ((p0 + 1) >> TWS), gx1 = e_x0 + ((p0 + 1) & (TW - 1));
+                    w0 = (float)((unsigned)((gy0 - a.H) & (gx0 - a.W)) >> 31);
+                    w1 = (float)((unsigned)((gy1 - a.H) & (gx1 - a.W)) >> 31);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v0 = acc[i][j][r0], v1 = acc[i][j][r0 + 1];
+                    if (want_stats) {
+                        if (FULL) {
+                            s1[j] += v0 + v1;
+                            s2[j] += v0 * v0 + v1 * v1;
+                        } else {
+                            const float u0 = v0 * w0, u1 = v1 * w1;
+                            s1[j] += u0 + u1;
+                            s2[j] += u0 * u0 + u1 * u1;
+                        }
+                    }
+                    if (!PLAIN) {
+                        v0 += bv[j];
+                        v1 += bv[j];
+                        v0 = v0 > 0.f ? v0 : v0 * neg_slope;
+                        v1 = v1 > 0.f ? v1 : v1 * neg_slope;
+                    }
+                    const unsigned int own = Elem<DT>::pack2(v0, v1);
+                    const unsigned int oth = dpp_xor1(own);
+                    const unsigned int pk = __builtin_amdgcn_perm(oth, own, psel);
+                    const int row = rowa + (odd ? 1 : 0);
+                    *reinterpret_cast<unsigned int*>(stg + row * C3_LDR + j * 32 + (l31 & ~1)) = pk;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint4 sv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                sv[q] = *reinterpret_cast<const uint4*>(stg + (q * 8 + (lane >> 3)) * C3_LDR + (lane & 7) * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int p = prow0 + q * 8 + (lane >> 3);
+                const int gy = e_y0 + (p >> TWS), gx = e_x0 + (p & (TW - 1));
+                const int co = e_n0 + (lane & 7) * 8;
+                const bool ok = (FULL || (gy < a.H && gx < a.W)) && co < a.Cout;
+                const unsigned off = ok ? (unsigned)(((gy * a.W + gx) * a.out_stride + a.out_coff + co) * 2) : VOOB;
+                u32x4 d;
+                d[0] = sv[q].x; d[1] = sv[q].y; d[2] = sv[q].z; d[3] = sv[q].w;
+                __builtin_amdgcn_raw_buffer_store_b128(d, ry, off, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (want_stats) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                s1[j] += __shfl_xor(s1[j], 32, 64);
+                s2[j] += __shfl_xor(s2[j], 32, 64);
+                if (h == 0) {
+                    red[(wave * 2 + 0) * BN + j * 32 + l31] = s1[j];
+                    red[(wave * 2 + 1) * BN + j * 32 + l31] = s2[j];
+                }
+            }
+        }
+    };
+    const bool plain = (a.bias == nullptr && act == GS_ACT_NONE);
+    auto epilogue = [&](const Item& itc) __attribute__((always_inline)) {
+        const bool full = (itc.y0 + TH <= a.H) && (itc.x0 + TW <= a.W);
+        if (plain && full) epilogue_t(itc, std::true_type{}, std::true_type{});
+        else epilogue_t(itc, std::false_type{}, std::false_type{});
+    };
+    // partial sums of the 8x32 halves: waves 4*half .. 4*half+3
+    auto finish_stats = [&](const Item& itc) __attribute__((always_inline)) {
+        constexpr int NH = NWV / 4;
+        if (a.bnp != nullptr && t < NH * BN) {
+            const int half = t >> 6, c = t & 63;
+            if (itc.n0 + c < a.Cout && (itc.y0 >> 3) + half < tiles_y8) {
+                float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    v1 += red[((half * 4 + m) * 2 + 0) * BN + c];
+                    v2 += red[((half * 4 + m) * 2 + 1) * BN + c];
+                }
+                float* dst = a.bnp + (int64_t)(itc.mt + half * a.tiles_x) * 2 * a.Cout + itc.n0 + c;
+                dst[0] = v1;
+                dst[a.Cout] = v2;
+            }
+        }
+    };
+
+    // ---- items: same numbering and XCD-aware start as conv3x3_big_kernel ----
+    int it = a.xcd_order ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+    if (it >= nitems) return;
+    int dg0 = it % a.ntn, dg1, dg2, dg3;
+    {
+        int r = it / a.ntn;
+        dg1 = r % a.tiles_x; r /= a.tiles_x;
+        dg2 = r % a.tiles_y; dg3 = r / a.tiles_y;
+    }
+    int st0, st1, st2, st3;
+    {
+        int r = gridDim.x;
+        st0 = r % a.ntn; r /= a.ntn;
+        st1 = r % a.tiles_x; r /= a.tiles_x;
+        st2 = r % a.tiles_y; st3 = r / a.tiles_y;
+    }
+    auto make_item = [&]() __attribute__((always_inline)) {
+        Item r;
+        r.n = dg3; r.y0 = dg2 * TH; r.x0 = dg1 * TW; r.n0 = dg0 * BN;
+        r.mt = (dg3 * tiles_y8 + (r.y0 >> 3)) * a.tiles_x + dg1;
+        return r;
+    };
+    auto advance_item = [&]() __attribute__((always_inline)) {
+        dg0 += st0; int c = dg0 >= a.ntn ? 1 : 0; dg0 -= c * a.ntn;
+        dg1 += st1 + c; c = dg1 >= a.tiles_x ? 1 : 0; dg1 -= c * a.tiles_x;
+        dg2 += st2 + c; c = dg2 >= a.tiles_y ? 1 : 0; dg2 -= c * a.tiles_y;
+        dg3 += st3 + c;
+        return make_item();
+    };
+    auto image_rsrc = [&](int n) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)n * a.H * a.W * a.in_stride), 0, img_bytes, 0x00020000);
+    };
+    Item cur = make_item();
+    setup_item(cur);
+    {
+        const __amdgpu_buffer_rsrc_t rx0 = image_rsrc(cur.n);
+#pragma unroll
+        for (int k = 0; k < NWP + HJ; ++k) issue_piece(k, rx0, 0u, 0u, 0u);       // stage 0 -> buffer 0
+    }
+    zero_acc();
+    for (;;) {
+        const int nit = it + gridDim.x;
+        const bool more_items = nit < nitems;
+        Item nxt = cur;
+        if (more_items) nxt = advance_item();
+        for (int sp = 0; sp < nstage; sp += 2) {
+            const bool last = sp + 2 >= nstage;
+            stage_sync();
+            run_stage(std::integral_constant<int, 0>{}, image_rsrc(cur.n), (unsigned)(sp + 1) * 64u, 0u);
+            stage_sync();
+            if (last && more_items) setup_item(nxt);
+            run_stage(std::integral_constant<int, 1>{}, image_rsrc(last ? nxt.n : cur.n), last ? 0u : (unsigned)(sp + 2) * 64u,
+                      (last && !more_items) ? VOOB : 0u);
+        }
+        __builtin_amdgcn_s_barrier();              // every wave has left the second buffer: staging may overlay it
+        asm volatile("" ::: "memory");
+        epilogue(cur);
+        zero_acc();
+        __syncthreads();
+        finish_stats(cur);
+        if (!more_items) break;
+        it = nit;
+        cur = nxt;
+    }
+}
+
 struct C3Plan { int bn, tw, th, tiles_x, tiles_y; };
 
 int c3_variant_get();
@@ -1118,6 +1464,30 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
                 else conv3x3_big_kernel<GS_BF16, 16, false, true><<<bgrid, 256, 0, bs>>>(a);
             }
             GS_CHECK_LAUNCH("gs_conv3x3_precise");
+            return GS_OK;
+        }
+        // LDS-DMA variant (GSSEG_C3_DMA = 4 or 8 waves per block, 0 = off)
+        static const int dma_env = getenv("GSSEG_C3_DMA") ? atoi(getenv("GSSEG_C3_DMA")) : 0;
+        bool std_taps = true, flip_taps = true;
+        for (int i = 0; i < 9; ++i) {
+            std_taps = std_taps && tap_dy[i] == i / 3 - 1 && tap_dx[i] == i % 3 - 1;
+            flip_taps = flip_taps && tap_dy[i] == 1 - i / 3 && tap_dx[i] == 1 - i % 3;
+        }
+        if ((dma_env == 4 || dma_env == 8) && ndz == 1 && D == 1 && tw == 32 && Cin % 64 == 0 && (std_taps || flip_taps)) {
+            if (dma_env == 8) {
+                a.tiles_y = cdiv(H, 16);
+                a.nblocks = N * a.tiles_x * a.tiles_y * a.ntn;
+            }
+            dim3 dgrid(a.nblocks < big_blocks ? a.nblocks : big_blocks);
+            a.xcd_order = (xcd_env && (dgrid.x % 8) == 0 && a.ntn > 1 && (int64_t)N * H * W > (int64_t)18 * Cout) ? 1 : 0;
+            if (dtype == GS_F16) {
+                if (dma_env == 8) conv3x3_dma_kernel<GS_F16, 8><<<dgrid, 512, 0, bs>>>(a);
+                else conv3x3_dma_kernel<GS_F16, 4><<<dgrid, 256, 0, bs>>>(a);
+            } else {
+                if (dma_env == 8) conv3x3_dma_kernel<GS_BF16, 8><<<dgrid, 512, 0, bs>>>(a);
+                else conv3x3_dma_kernel<GS_BF16, 4><<<dgrid, 256, 0, bs>>>(a);
+            }
+            GS_CHECK_LAUNCH("gs_conv3x3");
             return GS_OK;
         }
         if (dtype == GS_F16) {
