@@ -1061,6 +1061,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
     const int l31 = lane & 31, h = lane >> 5;
     const int nitems = a.nblocks;
     const int act = a.act & 0xff;
+    const int dbg = a.act >> 8;                            // ablation bits (GSSEG_C3_DEBUG=1): 1 no stores, 2 no MFMAs, 4 no epilogue
     const int nstage = a.Cin >> 5;
     const unsigned img_bytes = (unsigned)a.H * a.W * a.in_stride * 2u;
     const unsigned tap_stride = (unsigned)a.Cout * a.Cin * 2u;
@@ -1139,6 +1140,11 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
     auto run_stage = [&](auto buf_tag, const __amdgpu_buffer_rsrc_t& rx_n, unsigned sc_n, unsigned kill) __attribute__((always_inline)) {
         constexpr int BUF = decltype(buf_tag)::value;
         constexpr unsigned NB = 1 - BUF;
+        if (dbg & 2) {                                     // ablation: DMA traffic only
+#pragma unroll
+            for (int k = 0; k < NWP + HJ; ++k) issue_piece(k, rx_n, sc_n, NB, kill);
+            return;
+        }
         V8 af[2][2], bf[2][2];
         auto frag_load = [&](int step, V8 (&fa)[2], V8 (&fb)[2]) __attribute__((always_inline)) {
             const int tap = step >> 1, kh = step & 1;
@@ -1174,6 +1180,8 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
+    // (A counted wait at the item boundary -- vmcnt(8) = "all but the eight output stores issued behind the last piece" --
+    // instead of draining the stores measured the same: 4.36 / 4.32 vs 4.35 / 4.31 ms over the 13 layer shapes.)
 
     // ---- epilogue: as conv3x3_big_kernel (staging overlays the second halo buffer, which the last stage has just left) ----
     unsigned short* stg = reinterpret_cast<unsigned short*>(smem + HALO_B) + wave * STG_EL;
@@ -1249,7 +1257,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
                 const int p = prow0 + q * 8 + (lane >> 3);
                 const int gy = e_y0 + (p >> TWS), gx = e_x0 + (p & (TW - 1));
                 const int co = e_n0 + (lane & 7) * 8;
-                const bool ok = (FULL || (gy < a.H && gx < a.W)) && co < a.Cout;
+                const bool ok = (FULL || (gy < a.H && gx < a.W)) && co < a.Cout && !(dbg & 1);
                 const unsigned off = ok ? (unsigned)(((gy * a.W + gx) * a.out_stride + a.out_coff + co) * 2) : VOOB;
                 u32x4 d;
                 d[0] = sv[q].x; d[1] = sv[q].y; d[2] = sv[q].z; d[3] = sv[q].w;
@@ -1350,7 +1358,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
         }
         __builtin_amdgcn_s_barrier();              // every wave has left the second buffer: staging may overlay it
         asm volatile("" ::: "memory");
-        epilogue(cur);
+        if (!(dbg & 4)) epilogue(cur);
         zero_acc();
         __syncthreads();
         finish_stats(cur);
@@ -1466,25 +1474,34 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
             GS_CHECK_LAUNCH("gs_conv3x3_precise");
             return GS_OK;
         }
-        // LDS-DMA variant (GSSEG_C3_DMA = 4 or 8 waves per block, 0 = off)
-        static const int dma_env = getenv("GSSEG_C3_DMA") ? atoi(getenv("GSSEG_C3_DMA")) : 0;
+        // LDS-DMA kernel (conv3x3_dma_kernel) for the 2-D layers it covers; GSSEG_C3_DMA = 0 (off) / 4 / 8 forces a form.
+        // Default: the 8-wave form (16x32-pixel items, -11..13 % against the big K-step kernel over the U-Net layer shapes)
+        // unless its items -- twice the work each -- fill the 256 CUs worse than the 4-wave form's (-2 %) do.
+        static const int dma_env = getenv("GSSEG_C3_DMA") ? atoi(getenv("GSSEG_C3_DMA")) : -1;
         bool std_taps = true, flip_taps = true;
         for (int i = 0; i < 9; ++i) {
             std_taps = std_taps && tap_dy[i] == i / 3 - 1 && tap_dx[i] == i % 3 - 1;
             flip_taps = flip_taps && tap_dy[i] == 1 - i / 3 && tap_dx[i] == 1 - i % 3;
         }
-        if ((dma_env == 4 || dma_env == 8) && ndz == 1 && D == 1 && tw == 32 && Cin % 64 == 0 && (std_taps || flip_taps)) {
-            if (dma_env == 8) {
+        int dma_waves = 0;
+        if (dma_env != 0 && ndz == 1 && D == 1 && tw == 32 && Cin % 64 == 0 && (std_taps || flip_taps)) {
+            const int64_t items4 = (int64_t)N * a.tiles_x * cdiv(H, 8) * a.ntn, items8 = (int64_t)N * a.tiles_x * cdiv(H, 16) * a.ntn;
+            const double cost4 = 0.98 * (double)((items4 + big_blocks - 1) / big_blocks);
+            const double cost8 = 0.87 * 2.0 * (double)((items8 + big_blocks - 1) / big_blocks);
+            dma_waves = (dma_env == 4 || dma_env == 8) ? dma_env : (cost8 <= cost4 ? 8 : 4);
+        }
+        if (dma_waves != 0) {
+            if (dma_waves == 8) {
                 a.tiles_y = cdiv(H, 16);
                 a.nblocks = N * a.tiles_x * a.tiles_y * a.ntn;
             }
             dim3 dgrid(a.nblocks < big_blocks ? a.nblocks : big_blocks);
             a.xcd_order = (xcd_env && (dgrid.x % 8) == 0 && a.ntn > 1 && (int64_t)N * H * W > (int64_t)18 * Cout) ? 1 : 0;
             if (dtype == GS_F16) {
-                if (dma_env == 8) conv3x3_dma_kernel<GS_F16, 8><<<dgrid, 512, 0, bs>>>(a);
+                if (dma_waves == 8) conv3x3_dma_kernel<GS_F16, 8><<<dgrid, 512, 0, bs>>>(a);
                 else conv3x3_dma_kernel<GS_F16, 4><<<dgrid, 256, 0, bs>>>(a);
             } else {
-                if (dma_env == 8) conv3x3_dma_kernel<GS_BF16, 8><<<dgrid, 512, 0, bs>>>(a);
+                if (dma_waves == 8) conv3x3_dma_kernel<GS_BF16, 8><<<dgrid, 512, 0, bs>>>(a);
                 else conv3x3_dma_kernel<GS_BF16, 4><<<dgrid, 256, 0, bs>>>(a);
             }
             GS_CHECK_LAUNCH("gs_conv3x3");
