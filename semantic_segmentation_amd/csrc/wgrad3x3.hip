@@ -170,16 +170,215 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const W3Args a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// LDS-DMA form (W >= 24, 2-D): one 8-wave block per CU, 256-pixel patches (8 x 32).  The dY tile [256 px][64 co] and the X
+// halo [10 x 34 px][64 ci] of the NEXT patch are written into the other LDS buffer by `buffer_load_dwordx4 ... lds` (8 rows
+// x 128 B per wave-instruction) while the current patch is multiplied: no staging registers, no ds_write pass, one barrier
+// per patch.  Waves 0-3 / 4-7 (split as co-half x ci-half like the 4-wave kernel) take the left / right 16 pixels of every
+// patch row -- a split of K inside the block; the two partial tiles are added in LDS in a fixed order at the end.
+//   LDS image: 128-byte rows without padding (the DMA destination is lane-linear); the two 64-byte halves of row r are
+//   swapped when (r >> 1) & 1: the four rows of a transposing read's 32-lane group then cover four distinct 64-byte bank
+//   windows for every base row.  The swap is applied on the source side (lane l of a piece fetches slot (l&7) ^ ((l>>4&1)<<2)).
+// ---------------------------------------------------------------------------------------------------
+// One piece: lane l's 16 bytes at buffer offset voff land at dst + 16 l (dst wave-uniform).  Issued as inline assembly: with
+// the builtin hipcc (ROCm 7.2) puts an `s_waitcnt vmcnt(0)` in front of every transposing LDS read that follows a piece (it
+// cannot tell the read from the DMA's destination), which serialises the K loop.  The pieces are therefore invisible to the
+// compiler's counters: the kernel waits for them itself (`s_waitcnt vmcnt(0)` + barrier before a buffer is read).  Extra
+// outstanding operations only ever make a compiler-computed vmcnt(N) wait longer (completion is counted in issue order).
+__device__ __forceinline__ void w3_dma_piece16(const __amdgpu_buffer_rsrc_t& rs, unsigned char* dst, unsigned voff) {
+    const unsigned lds_addr = (unsigned)(size_t)(LDS_AS void*)dst;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rs) : "memory");
+}
+__device__ __forceinline__ void w3_opaque(unsigned& x) { asm volatile("" : "+v"(x)); }
+
+template <int DT>
+__global__ __launch_bounds__(512, 1) void wgrad3x3_dma_kernel(const W3Args a) {
+    typedef typename Elem<DT>::V8 V8;
+    constexpr int TW = 32, TH = 8, TWS = 5, BM = 256;
+    constexpr int HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;       // 340 halo pixels
+    static_assert(BM / 8 == 4 * 8, "32 dY pieces: four per wave");
+    constexpr int HJ = 6;                                            // halo piece slots per wave: 48 slots, 43 real + spare
+    constexpr int HPC = (HP + 7) / 8;                                // 43
+    constexpr int DY_B = BM * 128, HALO_B = (HPC + 1) * 1024;        // one spare piece takes the surplus slots
+    constexpr int HALO_OFF = 2 * DY_B;
+    constexpr unsigned VOOB = 0x80000000u;
+    static_assert(HPC + 1 <= HJ * 8 && 2 * (DY_B + HALO_B) <= 160 * 1024, "LDS budget");
+    static_assert(4 * 9 * 16 * 64 * 4 <= 2 * (DY_B + HALO_B), "final in-block reduction overlays the stage buffers");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (DY_B + HALO_B)];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int grp = wave >> 2;                 // K group: pixel columns 16*grp .. 16*grp+15 of every patch row
+    const int wm = (wave >> 1) & 1, wn = wave & 1;
+    int bid;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int cob = bid % a.ncob; bid /= a.ncob;
+    const int cib = bid % a.ncib; bid /= a.ncib;
+    const int ks = bid;
+    const int co0 = cob * 64, ci0 = cib * 64;
+    const int p_begin = ks * a.pps;
+    const int p_end = min(a.npatches, p_begin + a.pps);
+    if (p_begin >= p_end) return;
+
+    const unsigned x_img_bytes = (unsigned)a.H * a.W * a.in_stride * 2u;
+    const unsigned dy_img_bytes = (unsigned)a.H * a.W * a.out_stride * 2u;
+    // DMA side: lane l fills physical 16-byte slot l & 7 of row l >> 3 of its piece
+    const int drow = lane >> 3;
+    const int dls = (lane & 7) ^ (((lane >> 4) & 1) << 2);
+    const bool ci_ok = ci0 + dls * 8 < a.Cin, co_ok = co0 + dls * 8 < a.Cout;
+    unsigned dv[4], hv[HJ];
+    struct Pf { __amdgpu_buffer_rsrc_t rx, rdy; };
+    auto prep_patch = [&](int patch, bool live) __attribute__((always_inline)) {
+        Pf f;
+        const int tx = patch % a.tiles_x;
+        const int r = patch / a.tiles_x;
+        const int ty = r % a.tiles_y, n = r / a.tiles_y;
+        const int y0 = ty * TH, x0 = tx * TW;
+        f.rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)n * a.H * a.W * a.in_stride), 0, x_img_bytes, 0x00020000);
+        f.rdy = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + (int64_t)n * a.H * a.W * a.out_stride), 0, dy_img_bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = (wave + 8 * j) * 8 + drow;
+            const int gy = y0 + (p >> TWS), gx = x0 + (p & (TW - 1));
+            const bool ok = live && co_ok && gy < a.H && gx < a.W;
+            dv[j] = ok ? (unsigned)(((gy * a.W + gx) * a.out_stride + a.out_coff + co0 + dls * 8) * 2) : VOOB;
+        }
+#pragma unroll
+        for (int j = 0; j < HJ; ++j) {
+            const int hp = (wave + 8 * j) * 8 + drow;
+            const int hy = hp / HWD, hx = hp - hy * HWD;
+            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+            const bool ok = live && ci_ok && hp < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            hv[j] = ok ? (unsigned)(((gy * a.W + gx) * a.in_stride + a.in_coff + ci0 + dls * 8) * 2) : VOOB;
+        }
+        return f;
+    };
+    // piece slot k (compile-time, 0 .. 4+HJ-1) of the prepared patch into buffer nb
+    auto issue_piece = [&](const Pf& f, int k, unsigned nb) __attribute__((always_inline)) {
+        if (k < 4) {
+            w3_dma_piece16(f.rdy, smem + nb * DY_B + (unsigned)(wave + 8 * k) * 1024u, dv[k < 4 ? k : 0]);
+        } else if (k - 4 < HJ) {
+            const int j = k - 4 < HJ ? k - 4 : 0;
+            const int q = wave + 8 * j;
+            w3_dma_piece16(f.rx, smem + HALO_OFF + nb * HALO_B + (unsigned)(q < HPC ? q : HPC) * 1024u, hv[j]);
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // transposed-read lane addressing (as wgrad3x3_kernel) on the swizzled image, in bytes
+    const int G = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int krow = 8 * (G >> 1) + q;
+    const int chn = 16 * (G & 1) + 4 * pp;
+    unsigned a_base0 = (unsigned)((grp * 16 + krow) * 128 + (((wm ^ ((q >> 1) & 1)) * 32 + chn) * 2));
+    unsigned b_base0[4];                       // by (constant row offset & 3)
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4)
+        b_base0[c4] = (unsigned)(HALO_OFF + (grp * 16 + krow) * 128 + (((wn ^ (((c4 + q) >> 1) & 1)) * 32 + chn) * 2));
+
+    {
+        const Pf f0 = prep_patch(p_begin, true);
+#pragma unroll
+        for (int k = 0; k < 4 + HJ; ++k) issue_piece(f0, k, 0u);
+    }
+    for (int patch = p_begin; patch < p_end; ++patch) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of the patch have landed
+        __builtin_amdgcn_s_barrier();                              // ... everybody's; the other buffer is free
+        asm volatile("" ::: "memory");
+        const unsigned buf = (unsigned)(patch - p_begin) & 1u;
+        const bool more = patch + 1 < p_end;
+        const Pf pf = prep_patch(more ? patch + 1 : patch, more);
+        unsigned ab = a_base0 + buf * DY_B, bb[4];
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) { bb[c4] = b_base0[c4] + buf * HALO_B; w3_opaque(bb[c4]); }
+        w3_opaque(ab);
+        const LDS_AS unsigned char* lds = (const LDS_AS unsigned char*)smem;
+        // 72 steps (patch row s = this group's 16 pixels, tap); the X fragment of step i+PD (and the dY fragment of the next
+        // row) is read while the MFMA of step i runs: left to itself hipcc reads each fragment right in front of its MFMA
+        // behind lgkmcnt(0) and the LDS latency is exposed 72 times per patch
+        constexpr int PD = 3;                                      // X fragments in flight ahead of their MFMA
+        V8 afr[2], bfr[PD + 1];
+        auto load_a = [&](int s, V8& dst) __attribute__((always_inline)) {
+            dst = tr_read8<DT>((const LDS_AS unsigned short*)(lds + ab + s * 32 * 128),
+                               (const LDS_AS unsigned short*)(lds + ab + (s * 32 + 4) * 128));
+        };
+        auto load_b = [&](int step, V8& dst) __attribute__((always_inline)) {
+            const int s = step / 9, tap = step - 9 * s;
+            const int C = (s + tap / 3) * HWD + tap % 3;           // halo row of pixel column 0 of this group, before + 16*grp
+            dst = tr_read8<DT>((const LDS_AS unsigned short*)(lds + bb[C & 3] + C * 128),
+                               (const LDS_AS unsigned short*)(lds + bb[C & 3] + (C + 4) * 128));
+        };
+        load_a(0, afr[0]);
+#pragma unroll
+        for (int i = 0; i < PD; ++i) load_b(i, bfr[i]);
+#pragma unroll
+        for (int step = 0; step < 72; ++step) {
+            const int s = step / 9, tap = step - 9 * s;
+            if (step + PD < 72) load_b(step + PD, bfr[(step + PD) % (PD + 1)]);
+            if (tap == 4 && s + 1 < 8) load_a(s + 1, afr[(s + 1) & 1]);
+            if (tap == 1) issue_piece(pf, s, buf ^ 1u);
+            if (tap == 6 && s < 2) issue_piece(pf, 8 + s, buf ^ 1u);
+            acc[tap] = Elem<DT>::mfma32(afr[s & 1], bfr[step % (PD + 1)], acc[tap]);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // the MFMA, then the reads of the next step in its shadow
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // in-block K reduction: group 1 hands its nine tiles over through LDS, group 0 adds (fixed order) and stores
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the (empty) pieces behind the last patch
+    __syncthreads();
+    float* xch = reinterpret_cast<float*>(smem) + (wave & 3) * (9 * 16 * 64) + lane;
+    if (grp == 1) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xch[(tap * 16 + r) * 64] = acc[tap][r];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int ci = ci0 + wn * 32 + l31;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc[tap][r] + xch[(tap * 16 + r) * 64];
+            const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (ci < a.Cin && co < a.Cout) {
+                float* qd = a.dw + ((int64_t)tap * a.Cout + co) * a.Cin + ci;
+                if (a.slab_stride > 0) qd[(int64_t)ks * a.slab_stride] = v;
+                else atomicAdd(qd, v);
+            }
+        }
+}
 }  // namespace
 
-static int w3_ksplit(int N, int H, int W, int Cin, int Cout, int* pps_out, int* npatches_out) {
-    const int tw = (W >= 24) ? 32 : 16, th = W3_BM / tw;
+// the LDS-DMA kernel covers the 2-D layers with 32-wide patches (GSSEG_W3_DMA=0 switches it off)
+static bool w3_use_dma(int W, int D) {
+    static const int env = getenv("GSSEG_W3_DMA") ? atoi(getenv("GSSEG_W3_DMA")) : 1;
+    return env != 0 && W >= 24 && D == 1;
+}
+
+static int w3_ksplit(int N, int H, int W, int Cin, int Cout, int* pps_out, int* npatches_out, bool dma) {
+    const int tw = (W >= 24) ? 32 : 16, th = dma ? 8 : W3_BM / tw;
     const int npatches = N * cdiv(W, tw) * cdiv(H, th);
     const int pairs = cdiv(Cout, 64) * cdiv(Cin, 64);
-    static const int target = getenv("GSSEG_W3_GRID") ? atoi(getenv("GSSEG_W3_GRID")) : 512;
+    static const int target_env = getenv("GSSEG_W3_GRID") ? atoi(getenv("GSSEG_W3_GRID")) : 0;
+    const int target = target_env > 0 ? target_env : (dma ? 256 : 512);     // one 8-wave / two 4-wave blocks per CU
     // every part writes a 9 x 64 x 64 fp32 tile per (co, ci) pair (147 KB) that the ordered reduction reads back: a part
     // must cover a few patches for that to be worth it (batch 2: 512 one-patch parts cost more than the MFMAs)
-    static const int min_pps = getenv("GSSEG_W3_MINPPS") ? atoi(getenv("GSSEG_W3_MINPPS")) : 4;
+    static const int min_pps_env = getenv("GSSEG_W3_MINPPS") ? atoi(getenv("GSSEG_W3_MINPPS")) : 4;
+    const int min_pps = dma ? (min_pps_env + 1) / 2 : min_pps_env;            // in patches of this kernel (256 / 128 pixels)
     int ksplit = cdiv(target, pairs);
     if (ksplit > npatches / min_pps) ksplit = npatches / min_pps;
     if (ksplit < 1) ksplit = 1;
@@ -191,7 +390,7 @@ static int w3_ksplit(int N, int H, int W, int Cin, int Cout, int* pps_out, int* 
 
 static int wgrad3x3_launch(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin,
                            int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff, int dtype,
-                           void* stream, int D, int dz, int64_t slab_stride = 0) {
+                           void* stream, int D, int dz, int64_t slab_stride = 0, bool volume = false) {
     GS_CHECK_ARG(x && dy && dw, "gs_conv3x3_wgrad: null pointer");
     GS_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 8 == 0, "gs_conv3x3_wgrad: bad dims");
     GS_CHECK_ARG(in_pix_stride >= in_coff + Cin && in_pix_stride % 8 == 0 && in_coff % 8 == 0, "gs_conv3x3_wgrad: bad x stride");
@@ -204,17 +403,25 @@ static int wgrad3x3_launch(const void* x, const void* dy, float* dw, int N, int 
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.in_stride = in_pix_stride; a.in_coff = in_coff;
     a.Cout = Cout; a.out_stride = out_pix_stride; a.out_coff = out_coff;
     a.D = D; a.dz = dz; a.slab_stride = slab_stride;
-    const int tw = (W >= 24) ? 32 : 16, th = W3_BM / tw;
+    const bool dma = !volume && w3_use_dma(W, D);      // the 3-D entry points size their slabs for the 4-wave kernel
+    const int tw = (W >= 24) ? 32 : 16, th = dma ? 8 : W3_BM / tw;
     a.tiles_x = cdiv(W, tw); a.tiles_y = cdiv(H, th);
     a.npatches = N * a.tiles_x * a.tiles_y;
     a.ncob = cdiv(Cout, 64); a.ncib = cdiv(Cin, 64);
     const int pairs = a.ncob * a.ncib;
     {
         int pps = 0, np = 0;
-        a.ksplit = w3_ksplit(N, H, W, Cin, Cout, &pps, &np);
+        a.ksplit = w3_ksplit(N, H, W, Cin, Cout, &pps, &np, dma);
         a.pps = pps;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (dma) {
+        dim3 dgrid(pairs * a.ksplit);
+        if (dtype == GS_F16) wgrad3x3_dma_kernel<GS_F16><<<dgrid, 512, 0, s>>>(a);
+        else wgrad3x3_dma_kernel<GS_BF16><<<dgrid, 512, 0, s>>>(a);
+        GS_CHECK_LAUNCH("gs_conv3x3_wgrad");
+        return GS_OK;
+    }
     dim3 grid(pairs * a.ksplit), block(256);
     if (dtype == GS_F16) {
         if (tw == 32) wgrad3x3_kernel<GS_F16, 32><<<grid, block, 0, s>>>(a);
@@ -242,7 +449,7 @@ extern "C" int gs_conv3d_3x3x3_wgrad(const void* x, const void* dy, float* dw, i
     for (int kd = 0; kd < 3; ++kd) {
         if (D == 1 && kd != 1) continue;               // a one-slice volume only sees the centre depth tap
         int rc = wgrad3x3_launch(x, dy, dw + (int64_t)kd * 9 * Cout * Cin, NB * D, H, W, Cin, in_pix_stride, in_coff, Cout,
-                                 out_pix_stride, out_coff, dtype, stream, D, kd - 1);
+                                 out_pix_stride, out_coff, dtype, stream, D, kd - 1, 0, true);
         if (rc) return rc;
     }
     return GS_OK;
@@ -256,7 +463,7 @@ extern "C" int gs_conv3d_3x3x3_wgrad(const void* x, const void* dy, float* dw, i
 //   order dependent), the zero fill in front of them and the separate gs_unpack_wgrad pass.
 extern "C" int64_t gs_conv3x3_wgrad_ws_floats(int N, int H, int W, int Cin, int Cout) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
-    return (int64_t)w3_ksplit(N, H, W, Cin, Cout, nullptr, nullptr) * 9 * Cout * Cin;
+    return (int64_t)w3_ksplit(N, H, W, Cin, Cout, nullptr, nullptr, w3_use_dma(W, 1)) * 9 * Cout * Cin;
 }
 
 extern "C" int gs_conv3x3_wgrad_slabs(const void* x, const void* dy, float* ws, int N, int H, int W, int Cin,
@@ -330,18 +537,18 @@ extern "C" int gs_wgrad_reduce_unpack(const float* ws, int nparts, float* grad, 
 }
 
 extern "C" int gs_conv3x3_wgrad_parts(int N, int H, int W, int Cin, int Cout) {
-    return w3_ksplit(N, H, W, Cin, Cout, nullptr, nullptr);
+    return w3_ksplit(N, H, W, Cin, Cout, nullptr, nullptr, w3_use_dma(W, 1));
 }
 
 // 3-D form of the deterministic weight gradient: the three depth-tap launches store their parts into one set of slabs
 // ws[part][27][Cout][Cin]; gs_wgrad_reduce_unpack(taps = 27) then writes [Cout][Cin][3][3][3].
 extern "C" int64_t gs_conv3d_3x3x3_wgrad_ws_floats(int NB, int D, int H, int W, int Cin, int Cout) {
     if (NB <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
-    return (int64_t)w3_ksplit(NB * D, H, W, Cin, Cout, nullptr, nullptr) * 27 * Cout * Cin;
+    return (int64_t)w3_ksplit(NB * D, H, W, Cin, Cout, nullptr, nullptr, false) * 27 * Cout * Cin;
 }
 
 extern "C" int gs_conv3d_3x3x3_wgrad_parts(int NB, int D, int H, int W, int Cin, int Cout) {
-    return w3_ksplit(NB * D, H, W, Cin, Cout, nullptr, nullptr);
+    return w3_ksplit(NB * D, H, W, Cin, Cout, nullptr, nullptr, false);
 }
 
 extern "C" int gs_conv3d_3x3x3_wgrad_slabs(const void* x, const void* dy, float* ws, int NB, int D, int H, int W, int Cin,
@@ -352,14 +559,14 @@ extern "C" int gs_conv3d_3x3x3_wgrad_slabs(const void* x, const void* dy, float*
     for (int kd = 0; kd < 3; ++kd) {
         if (D == 1 && kd != 1) {
             // a one-slice volume never pairs with the outer depth taps: their slots must still be defined (zeros)
-            const int parts = w3_ksplit(NB * D, H, W, Cin, Cout, nullptr, nullptr);
+            const int parts = w3_ksplit(NB * D, H, W, Cin, Cout, nullptr, nullptr, false);
             for (int p = 0; p < parts; ++p)
                 if (hipMemsetAsync(ws + p * slab + (int64_t)kd * 9 * Cout * Cin, 0, (size_t)9 * Cout * Cin * 4, (hipStream_t)stream) != hipSuccess)
                     return GS_ELAUNCH;
             continue;
         }
         int rc = wgrad3x3_launch(x, dy, ws + (int64_t)kd * 9 * Cout * Cin, NB * D, H, W, Cin, in_pix_stride, in_coff, Cout,
-                                 out_pix_stride, out_coff, dtype, stream, D, kd - 1, slab);
+                                 out_pix_stride, out_coff, dtype, stream, D, kd - 1, slab, true);
         if (rc) return rc;
     }
     return GS_OK;
