@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 27
+#define GS_ABI_VERSION 28
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -100,6 +100,10 @@ int gs_upconv2x2_fwd(const void* x, const void* w, const float* bias, void* y, i
  * Same operands as gs_conv_igemm; tap t reads input pixel (y + tap_dy[t], x + tap_dx[t]), offsets in [-1,1];
  * bn_partials is [gs_conv3x3_mtiles][2][Cout] (one tile per spatial patch). */
 int gs_conv3x3_mtiles(int N, int H, int W, int Cout);
+/* Diagnostics (process-wide, not part of the data path): which form of the 2-D kernel gs_conv3x3 launches where several
+ * apply: -1 chosen by CU fill (default), 0 the register-staged big-K-step kernel, 4 / 8 the LDS-DMA kernel with that many
+ * waves per block, 2 two 4-wave LDS-DMA blocks per CU.  Every form computes the same sums in a form-specific order. */
+int gs_conv3x3_set_kernel_form(int form);
 int gs_conv3x3(const void* x, const void* w, void* y, const float* bias, float* bn_partials, int N, int H, int W,
                int Cin, int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff,
                const int32_t* tap_dy, const int32_t* tap_dx, int act, int dtype, void* stream);

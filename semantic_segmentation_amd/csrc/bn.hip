@@ -4,6 +4,8 @@
 //   backward: gs_bn_act_bwd_reduce -> gs_bn_bwd_coeffs -> gs_bn_act_bwd_apply
 // Reference semantics: torch.nn.BatchNorm2d(train) + ReLU/LeakyReLU + MaxPool2d(2) + torch.cat
 // (unet/unet_parts.py:17-21,34,67 ; models_pix2pix/networks.py:583-586,606-607,642-657).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
@@ -103,6 +105,14 @@ __global__ __launch_bounds__(256) void bn_bwd_coeffs_kernel(const double* __rest
     c2[c] = (float)(s2 / count);
 }
 
+// Traversal direction of the three element-wise passes (GSSEG_BN_REV bit mask: 1 forward apply, 2 backward reduce, 4 backward
+// apply run tail first).  Each pass streams a tensor that the previous kernel has just written (or read) head to tail: its
+// tail is what the 256 MB Infinity Cache still holds, so a pass that starts there takes part of its reads from the cache.
+static int bn_traversal() {
+    static const int v = getenv("GSSEG_BN_REV") ? atoi(getenv("GSSEG_BN_REV")) : 3;     // measured: 14.62 -> 14.53 ms per step
+    return v;
+}
+
 // ---- forward apply -------------------------------------------------------------------------------
 struct ApplyArgs {
     const unsigned short* y;
@@ -113,6 +123,7 @@ struct ApplyArgs {
     const uint8_t* keep;
     float keep_scale;
     int act, N, H, W, C, zs, zc;
+    int rev;                      // traverse the tensor tail first (see bn_traversal())
 };
 
 template <int DT, bool POOL, bool GENERIC>
@@ -122,8 +133,9 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(const ApplyArgs a) {
     const int nch = a.C >> 3;
     const int PH = POOL ? (a.H + 1) / 2 : a.H, PW = POOL ? (a.W + 1) / 2 : a.W;
     const int64_t total = (int64_t)a.N * PH * PW * nch;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t lidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; lidx < total;
+         lidx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t idx = a.rev ? total - 1 - lidx : lidx;
         const int ch = (int)(idx % nch);
         int64_t pidx = idx / nch;
         const int px = (int)(pidx % PW); pidx /= PW;
@@ -197,6 +209,7 @@ struct BwdArgs {
     unsigned short* dy;
     int sa, ca, act, bn, N, H, W, C;
     int tile_units;   // work units (pixels or 2x2 windows) per tile
+    int rev;          // blocks take the tiles last to first (see bn_traversal())
 };
 
 // gradient w.r.t. z at one pixel for 8 channels: concat/skip part + max-pool routed part.
@@ -220,7 +233,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
     const int lanes_per_unit = nch < 256 ? nch : 256;      // threads covering the channel chunks of one unit
     const int unit_lanes = 256 / lanes_per_unit;           // units processed concurrently per block
     const int chl = threadIdx.x % lanes_per_unit, ul = threadIdx.x / lanes_per_unit;
-    const int u0 = blockIdx.x * a.tile_units;
+    const int tile = a.rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+    const int u0 = tile * a.tile_units;
     int u1 = u0 + a.tile_units < units ? u0 + a.tile_units : units;
     if (ul >= unit_lanes) u1 = u0;   // leftover threads (256 % lanes_per_unit) only join the barriers
     constexpr int UNR = 4;           // plain path: four pixels per lane in flight (memory-level parallelism)
@@ -365,7 +379,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
                 if (ch - chl + cl >= nch) continue;
                 float tsum = 0.f;
                 for (int k = 0; k < unit_lanes; ++k) tsum += red[st][k * lanes_per_unit + cl][i];
-                a.partials[(int64_t)blockIdx.x * 2 * a.C + st * a.C + (ch - chl + cl) * 8 + i] = tsum;
+                a.partials[(int64_t)tile * 2 * a.C + st * a.C + (ch - chl + cl) * 8 + i] = tsum;
             }
         }
     }
@@ -494,7 +508,7 @@ extern "C" int gs_bn_act_apply(const void* y, const float* scale, const float* s
     GS_CHECK_ARG((scale == nullptr) == (shift == nullptr), "gs_bn_act_apply: scale/shift must both be given or NULL");
     GS_CHECK_ARG(!(zp && keep_mask), "gs_bn_act_apply: pool + dropout not supported together");
     ApplyArgs a{(const unsigned short*)y, scale, shift, (unsigned short*)z, (unsigned short*)zp, keep_mask, keep_scale,
-                act, N, H, W, C, z_pix_stride, z_coff};
+                act, N, H, W, C, z_pix_stride, z_coff, bn_traversal() & 1};
     const bool pool = zp != nullptr;
     const int PH = pool ? (H + 1) / 2 : H, PW = pool ? (W + 1) / 2 : W;
     const int64_t total = (int64_t)N * PH * PW * (C / 8);
@@ -539,6 +553,7 @@ extern "C" int gs_bn_bwd_tiles(int N, int H, int W) {
 
 static int launch_bwd(const BwdArgs& a0, bool apply, int dtype, hipStream_t s, int* ntiles_out) {
     BwdArgs a = a0;
+    a.rev = (bn_traversal() >> (apply ? 2 : 1)) & 1;
     const bool pool = a.dzp != nullptr;
     const int PH = pool ? (a.H + 1) / 2 : a.H, PW = pool ? (a.W + 1) / 2 : a.W;
     const int64_t units = (int64_t)a.N * PH * PW;

@@ -14,6 +14,7 @@
 //            the next chunk's halo is fetched into registers while the 9 taps run (issue early, write late).
 //   epilogue as igemm.hip: bias/act, 16-bit NHWC store (strided), per-patch BatchNorm partial sums.
 #include <stdlib.h>
+#include <atomic>
 #include <type_traits>
 
 #include "common.hpp"
@@ -1039,21 +1040,30 @@ __device__ __forceinline__ void dma_piece16(const __amdgpu_buffer_rsrc_t& rs, un
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)dst, 16, voff, soff, 0, 0);
 }
 
-template <int DT, int NWV>
-__global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a) {
+template <int DT, int NWV, int KC>
+__global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel(const C3Args a) {
     typedef typename Elem<DT>::V8 V8;
     constexpr int BN = 64, TW = 32, TH = 2 * NWV, TWS = 5;
     constexpr int HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;
-    constexpr int HI = (HP + 15) / 16;                     // halo pieces that hold real rows
+    constexpr int ROWB = KC * 2;                           // bytes per LDS row (one pixel / one cout, KC channels)
+    constexpr int SPR = ROWB / 16, RPP = 64 / SPR;         // 16-byte slots per row, rows per 1-KiB piece
+    constexpr int KSTEPS = KC / 16, NSTEP = 9 * KSTEPS;    // MFMA steps (tap, k half) per stage
+    constexpr int HI = (HP + RPP - 1) / RPP;               // halo pieces that hold real rows
     constexpr int HJ = (HI + NWV - 1) / NWV;               // halo pieces per wave (the tail ones are spare)
-    constexpr int NWP = (NWV == 4) ? 9 : 5;                // weight pieces per wave
-    constexpr int HALO_B = HJ * NWV * 1024, W_B = 9 * BN * 64, STAGE_B = HALO_B + W_B;
+    constexpr int WG = BN / RPP;                           // weight pieces (row groups) per tap
+    constexpr int WP = 9 * WG;                             // weight pieces per stage
+    constexpr int NWP = (WP + NWV - 1) / NWV;              // ... per wave
+    constexpr int HALO_B = HJ * NWV * 1024, W_B = 9 * BN * ROWB, STAGE_B = HALO_B + W_B;
     constexpr int STG_EL = 32 * C3_LDR;
     constexpr unsigned VOOB = 0x80000000u;
-    static_assert(2 * STAGE_B <= 160 * 1024, "two stages must fit in LDS");
-    static_assert(NWV * STG_EL * 2 + NWV * 2 * BN * 4 <= HALO_B, "epilogue staging overlays the second halo buffer");
-    static_assert(NWP + HJ <= 18, "one DMA piece per MFMA step");
-    static_assert(NWV == 4 || HI < HJ * NWV, "the 8-wave variant parks its odd weight piece in the spare halo piece");
+    // LDS: [weights 0 | halo 0 | halo 1 | weights 1]; the epilogue staging overlays halo 1 + weights 1 (the last stage of an
+    // item always sits in buffer 1, the next item's first stage is on its way into buffer 0)
+    constexpr int H0_OFF = W_B, W1_OFF = W_B + 2 * HALO_B;
+    static_assert(2 * STAGE_B * (KC == 16 ? 2 : 1) <= 160 * 1024, "two stages (per resident block) must fit in LDS");
+    static_assert(NWV * STG_EL * 2 + NWV * 2 * BN * 4 <= HALO_B + W_B, "epilogue staging overlays the second stage buffer");
+    static_assert(NWP + HJ <= NSTEP, "one DMA piece per MFMA step");
+    static_assert(NWV % WG == 0, "a wave's weight pieces all belong to one row group");
+    static_assert(WP % NWV == 0 || HI < HJ * NWV, "a surplus weight slot parks its (empty) piece in the spare halo piece");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE_B];
 
     const int t = threadIdx.x, lane = t & 63;
@@ -1062,67 +1072,83 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
     const int nitems = a.nblocks;
     const int act = a.act & 0xff;
     const int dbg = a.act >> 8;                            // ablation bits (GSSEG_C3_DEBUG=1): 1 no stores, 2 no MFMAs, 4 no epilogue
-    const int nstage = a.Cin >> 5;
+    const int nstage = a.Cin / KC;
     const unsigned img_bytes = (unsigned)a.H * a.W * a.in_stride * 2u;
     const unsigned tap_stride = (unsigned)a.Cout * a.Cin * 2u;
     const bool flip = a.tap_dy[0] > 0;                     // data-gradient table: geometric tap g uses weight slot 8 - g
     const int tiles_y8 = (a.H + 7) >> 3;                   // BatchNorm partial rows are numbered in 8x32 patches
 
+#ifdef GS_C3_PHASE_TIMING
+    long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tq = clock64();
+#define PH(i) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = clock64(); ph[i] += t_ - tq; tq = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PH(i) do {} while (0)
+#endif
     struct Item { int n, y0, x0, n0, mt; };
     const __amdgpu_buffer_rsrc_t w_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)(9u * a.Cout * a.Cin * 2u), 0x00020000);
 
-    // ---- DMA side: lane l of a piece fills physical slot l & 3 of row l >> 2 ----
-    const int drow = lane >> 2;
-    const int dls = (lane & 3) ^ ((lane >> 4) & 3);
+    // ---- DMA side: lane l of a piece fills physical slot l % SPR of row l / SPR; the logical slot (8 channels) that belongs
+    // there is the physical one xor-ed with the row's swizzle key ((row >> 2) & 3 for 64-byte rows, (row >> 3) & 1 for 32) ----
+    const int drow = lane / SPR;
+    const int dls = (lane % SPR) ^ ((lane >> 4) & (SPR - 1));
     unsigned hv[HJ], wv;
     auto setup_item = [&](const Item& itn) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < HJ; ++j) {
-            const int r = (wave + j * NWV) * 16 + drow;
+            const int r = (wave + j * NWV) * RPP + drow;
             const int hy = r / HWD, hx = r - hy * HWD;
             const int gy = itn.y0 + hy - 1, gx = itn.x0 + hx - 1;
             const bool ok = r < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
             hv[j] = ok ? (unsigned)(((gy * a.W + gx) * a.in_stride + a.in_coff + dls * 8) * 2) : VOOB;
         }
-        const int co = itn.n0 + (wave & 3) * 16 + drow;
+        const int co = itn.n0 + (wave % WG) * RPP + drow;
         wv = co < a.Cout ? (unsigned)((co * a.Cin + dls * 8) * 2) : VOOB;
     };
     // LDS: [halo 0 | halo 1 | weights 0 | weights 1] -- every fragment read is (per-lane base register) + (16-bit immediate)
     // piece k (compile-time) of stage (image rx, channel byte offset sc) into buffer bb
     auto issue_piece = [&](int k, const __amdgpu_buffer_rsrc_t& rx, unsigned sc, unsigned bb, unsigned kill) __attribute__((always_inline)) {
         if (k < NWP) {
-            const int tap = (NWV == 8) ? 2 * k + (wave >> 2) : k;
-            const bool real = tap < 9;                     // 8 waves: waves 4..7 have four weight pieces only
+            const int pc = wave + NWV * k;                 // piece = tap * WG + row group; the group is wave % WG for every k
+            const int tap = pc / WG;
+            const bool real = pc < WP;                     // surplus slots of the last round carry an empty piece
             const int slot = flip ? 8 - tap : tap;
-            const unsigned dst = real ? (unsigned)(2 * HALO_B + tap * 4096 + (wave & 3) * 1024) + bb * W_B
-                                      : (unsigned)(HALO_B - 1024) + bb * HALO_B;
-            dma_piece16(w_rsrc, smem + dst, real ? (wv | kill) : VOOB, (unsigned)slot * tap_stride + sc);
+            const unsigned dst = real ? (unsigned)(pc * 1024) + bb * W1_OFF
+                                      : (unsigned)(H0_OFF + HALO_B - 1024) + bb * HALO_B;
+            dma_piece16(w_rsrc, smem + dst, real ? (wv | kill) : VOOB, (unsigned)(real ? slot : 0) * tap_stride + sc);
         } else if (k - NWP < HJ) {
             const int j = k - NWP < HJ ? k - NWP : 0;
-            const unsigned dst = bb * HALO_B + (unsigned)(wave + j * NWV) * 1024u;
+            const unsigned dst = H0_OFF + bb * HALO_B + (unsigned)(wave + j * NWV) * 1024u;
             dma_piece16(rx, smem + dst, hv[j] | kill, sc);
         }
     };
 
     // ---- MFMA side: fragment byte addresses inside a stage buffer (item independent) ----
     // (kept opaque: hipcc otherwise materialises every base + constant combination of both buffers in its own register)
-    unsigned aaddr[2][4][3];                               // [k half][halo row 2*wave + e, e = i + dy + 1][column l31 + dx + 1]
+    unsigned aaddr[KSTEPS][4][3];                          // [k half][halo row 2*wave + e, e = i + dy + 1][column l31 + dx + 1]
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int r = (2 * wave + e) * HWD + l31 + d;
-            aaddr[0][e][d] = (unsigned)(r * 64 + ((h ^ ((r >> 2) & 3)) << 4));
-            aaddr[1][e][d] = aaddr[0][e][d] ^ 32u;
-            opaque_vgpr(aaddr[0][e][d]); opaque_vgpr(aaddr[1][e][d]);
+            const int key = (KC == 32) ? ((r >> 2) & 3) : ((r >> 3) & 1);
+            aaddr[0][e][d] = (unsigned)(H0_OFF + r * ROWB + ((h ^ key) << 4));
+            opaque_vgpr(aaddr[0][e][d]);
+            if (KSTEPS == 2) {
+                aaddr[KSTEPS - 1][e][d] = aaddr[0][e][d] ^ 32u;
+                opaque_vgpr(aaddr[KSTEPS - 1][e][d]);
+            }
         }
-    unsigned baddr[2][2];                                  // [buffer][k half]
+    unsigned baddr[2][KSTEPS];                             // [buffer][k half]
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        baddr[b][0] = (unsigned)(2 * HALO_B + b * W_B + l31 * 64 + ((h ^ ((l31 >> 2) & 3)) << 4));
-        baddr[b][1] = baddr[b][0] ^ 32u;
-        opaque_vgpr(baddr[b][0]); opaque_vgpr(baddr[b][1]);
+        const int key = (KC == 32) ? ((l31 >> 2) & 3) : ((l31 >> 3) & 1);
+        baddr[b][0] = (unsigned)(b * W1_OFF + l31 * ROWB + ((h ^ key) << 4));
+        opaque_vgpr(baddr[b][0]);
+        if (KSTEPS == 2) {
+            baddr[b][KSTEPS - 1] = baddr[b][0] ^ 32u;
+            opaque_vgpr(baddr[b][KSTEPS - 1]);
+        }
     }
 
     f32x16 acc[2][2];
@@ -1135,7 +1161,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     };
 
-    // one stage: 18 steps (tap, k half) of 4 MFMAs out of buffer BUF; the pieces of the next stage (image rx_n, channel
+    // one stage: NSTEP steps (tap, k half) of 4 MFMAs out of buffer BUF; the pieces of the next stage (image rx_n, channel
     // offset sc_n) go into the other buffer, one per step
     auto run_stage = [&](auto buf_tag, const __amdgpu_buffer_rsrc_t& rx_n, unsigned sc_n, unsigned kill) __attribute__((always_inline)) {
         constexpr int BUF = decltype(buf_tag)::value;
@@ -1147,18 +1173,18 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
         }
         V8 af[2][2], bf[2][2];
         auto frag_load = [&](int step, V8 (&fa)[2], V8 (&fb)[2]) __attribute__((always_inline)) {
-            const int tap = step >> 1, kh = step & 1;
+            const int tap = step / KSTEPS, kh = step % KSTEPS;
             const int dyi = tap / 3, dxi = tap - 3 * dyi;
             fa[0] = *reinterpret_cast<const V8*>(smem + aaddr[kh][dyi][dxi] + BUF * HALO_B);
-            fb[0] = *reinterpret_cast<const V8*>(smem + baddr[BUF][kh] + tap * 4096);
+            fb[0] = *reinterpret_cast<const V8*>(smem + baddr[BUF][kh] + tap * (64 * ROWB));
             fa[1] = *reinterpret_cast<const V8*>(smem + aaddr[kh][dyi + 1][dxi] + BUF * HALO_B);
-            fb[1] = *reinterpret_cast<const V8*>(smem + baddr[BUF][kh] + tap * 4096 + 2048);
+            fb[1] = *reinterpret_cast<const V8*>(smem + baddr[BUF][kh] + tap * (64 * ROWB) + 32 * ROWB);
         };
         frag_load(0, af[0], bf[0]);
 #pragma unroll
-        for (int step = 0; step < 18; ++step) {
+        for (int step = 0; step < NSTEP; ++step) {
             const int cur = step & 1;
-            if (step + 1 < 18) frag_load(step + 1, af[cur ^ 1], bf[cur ^ 1]);
+            if (step + 1 < NSTEP) frag_load(step + 1, af[cur ^ 1], bf[cur ^ 1]);
             issue_piece(step, rx_n, sc_n, NB, kill);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -1183,9 +1209,9 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
     // (A counted wait at the item boundary -- vmcnt(8) = "all but the eight output stores issued behind the last piece" --
     // instead of draining the stores measured the same: 4.36 / 4.32 vs 4.35 / 4.31 ms over the 13 layer shapes.)
 
-    // ---- epilogue: as conv3x3_big_kernel (staging overlays the second halo buffer, which the last stage has just left) ----
-    unsigned short* stg = reinterpret_cast<unsigned short*>(smem + HALO_B) + wave * STG_EL;
-    float* red = reinterpret_cast<float*>(smem + HALO_B + NWV * STG_EL * 2);           // [NWV][2][64]
+    // ---- epilogue: as conv3x3_big_kernel (staging overlays the second stage buffer, which the last stage has just left) ----
+    unsigned short* stg = reinterpret_cast<unsigned short*>(smem + H0_OFF + HALO_B) + wave * STG_EL;
+    float* red = reinterpret_cast<float*>(smem + H0_OFF + HALO_B + NWV * STG_EL * 2);  // [NWV][2][64]
     const bool odd = lane & 1;
     const unsigned int psel = odd ? 0x03020706u : 0x05040100u;
     const float neg_slope = act == GS_ACT_RELU ? 0.f : (act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
@@ -1349,23 +1375,36 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
         if (more_items) nxt = advance_item();
         for (int sp = 0; sp < nstage; sp += 2) {
             const bool last = sp + 2 >= nstage;
+            PH(7);
             stage_sync();
-            run_stage(std::integral_constant<int, 0>{}, image_rsrc(cur.n), (unsigned)(sp + 1) * 64u, 0u);
+            PH(0);
+            run_stage(std::integral_constant<int, 0>{}, image_rsrc(cur.n), (unsigned)(sp + 1) * ROWB, 0u);
+            PH(1);
             stage_sync();
+            PH(2);
             if (last && more_items) setup_item(nxt);
-            run_stage(std::integral_constant<int, 1>{}, image_rsrc(last ? nxt.n : cur.n), last ? 0u : (unsigned)(sp + 2) * 64u,
+            run_stage(std::integral_constant<int, 1>{}, image_rsrc(last ? nxt.n : cur.n), last ? 0u : (unsigned)(sp + 2) * ROWB,
                       (last && !more_items) ? VOOB : 0u);
+            PH(3);
         }
         __builtin_amdgcn_s_barrier();              // every wave has left the second buffer: staging may overlay it
         asm volatile("" ::: "memory");
+        PH(4);
         if (!(dbg & 4)) epilogue(cur);
         zero_acc();
+        PH(5);
         __syncthreads();
+        PH(6);
         finish_stats(cur);
         if (!more_items) break;
         it = nit;
         cur = nxt;
     }
+#ifdef GS_C3_PHASE_TIMING
+    if (blockIdx.x == 0 && lane == 0 && a.bnp != nullptr)           // debug build only: the partials double as sink
+        for (int i = 0; i < 8; ++i) a.bnp[wave * 8 + i] = (float)ph[i];
+#endif
+#undef PH
 }
 
 struct C3Plan { int bn, tw, th, tiles_x, tiles_y; };
@@ -1386,6 +1425,17 @@ C3Plan c3_plan(int H, int W, int Cout) {
 }
 
 }  // namespace
+
+// form of the LDS-DMA kernel: -1 = by CU fill (default), 0 = off (big K-step kernel), 4 / 8 = waves per block, 2 = two 4-wave
+// blocks per CU with 16-channel stages (measured slower; kept for the record).  GSSEG_C3_DMA presets it; tests and tools
+// switch it through gs_conv3x3_set_kernel_form() to compare the forms on the same operands.
+static std::atomic<int> c3_dma_form{getenv("GSSEG_C3_DMA") ? atoi(getenv("GSSEG_C3_DMA")) : -1};
+
+extern "C" int gs_conv3x3_set_kernel_form(int form) {
+    GS_CHECK_ARG(form == -1 || form == 0 || form == 2 || form == 4 || form == 8, "gs_conv3x3_set_kernel_form: form must be -1, 0, 2, 4 or 8");
+    c3_dma_form.store(form, std::memory_order_relaxed);
+    return GS_OK;
+}
 
 static int c3_variant() {          // 0 = v1 one patch per block, 1 = persistent (v2), 2 = big K-step (v3)
     static const int v = getenv("GSSEG_C3") ? atoi(getenv("GSSEG_C3")) : 2;
@@ -1477,7 +1527,7 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
         // LDS-DMA kernel (conv3x3_dma_kernel) for the 2-D layers it covers; GSSEG_C3_DMA = 0 (off) / 4 / 8 forces a form.
         // Default: the 8-wave form (16x32-pixel items, -11..13 % against the big K-step kernel over the U-Net layer shapes)
         // unless its items -- twice the work each -- fill the 256 CUs worse than the 4-wave form's (-2 %) do.
-        static const int dma_env = getenv("GSSEG_C3_DMA") ? atoi(getenv("GSSEG_C3_DMA")) : -1;
+        const int dma_env = c3_dma_form.load(std::memory_order_relaxed);
         bool std_taps = true, flip_taps = true;
         for (int i = 0; i < 9; ++i) {
             std_taps = std_taps && tap_dy[i] == i / 3 - 1 && tap_dx[i] == i % 3 - 1;
@@ -1488,21 +1538,24 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
             const int64_t items4 = (int64_t)N * a.tiles_x * cdiv(H, 8) * a.ntn, items8 = (int64_t)N * a.tiles_x * cdiv(H, 16) * a.ntn;
             const double cost4 = 0.98 * (double)((items4 + big_blocks - 1) / big_blocks);
             const double cost8 = 0.87 * 2.0 * (double)((items8 + big_blocks - 1) / big_blocks);
-            dma_waves = (dma_env == 4 || dma_env == 8) ? dma_env : (cost8 <= cost4 ? 8 : 4);
+            dma_waves = (dma_env == 4 || dma_env == 8 || dma_env == 2) ? dma_env : (cost8 <= cost4 ? 8 : 4);   // 2: two 4-wave blocks per CU
         }
         if (dma_waves != 0) {
             if (dma_waves == 8) {
                 a.tiles_y = cdiv(H, 16);
                 a.nblocks = N * a.tiles_x * a.tiles_y * a.ntn;
             }
-            dim3 dgrid(a.nblocks < big_blocks ? a.nblocks : big_blocks);
+            const int dblocks = dma_waves == 2 ? 2 * big_blocks : big_blocks;
+            dim3 dgrid(a.nblocks < dblocks ? a.nblocks : dblocks);
             a.xcd_order = (xcd_env && (dgrid.x % 8) == 0 && a.ntn > 1 && (int64_t)N * H * W > (int64_t)18 * Cout) ? 1 : 0;
             if (dtype == GS_F16) {
-                if (dma_waves == 8) conv3x3_dma_kernel<GS_F16, 8><<<dgrid, 512, 0, bs>>>(a);
-                else conv3x3_dma_kernel<GS_F16, 4><<<dgrid, 256, 0, bs>>>(a);
+                if (dma_waves == 8) conv3x3_dma_kernel<GS_F16, 8, 32><<<dgrid, 512, 0, bs>>>(a);
+                else if (dma_waves == 2) conv3x3_dma_kernel<GS_F16, 4, 16><<<dgrid, 256, 0, bs>>>(a);
+                else conv3x3_dma_kernel<GS_F16, 4, 32><<<dgrid, 256, 0, bs>>>(a);
             } else {
-                if (dma_waves == 8) conv3x3_dma_kernel<GS_BF16, 8><<<dgrid, 512, 0, bs>>>(a);
-                else conv3x3_dma_kernel<GS_BF16, 4><<<dgrid, 256, 0, bs>>>(a);
+                if (dma_waves == 8) conv3x3_dma_kernel<GS_BF16, 8, 32><<<dgrid, 512, 0, bs>>>(a);
+                else if (dma_waves == 2) conv3x3_dma_kernel<GS_BF16, 4, 16><<<dgrid, 256, 0, bs>>>(a);
+                else conv3x3_dma_kernel<GS_BF16, 4, 32><<<dgrid, 256, 0, bs>>>(a);
             }
             GS_CHECK_LAUNCH("gs_conv3x3");
             return GS_OK;

@@ -246,6 +246,12 @@ def conv3x3_mtiles(N, H, W, Cout) -> int:
     return _lib.load().gs_conv3x3_mtiles(N, H, W, Cout)
 
 
+def conv3x3_set_kernel_form(form: int = -1) -> None:
+    """Diagnostics: pin the form of the 2-D conv3x3 kernel (-1 auto, 0 register-staged, 4 / 8 LDS-DMA waves per block, 2 two
+    LDS-DMA blocks per CU).  Process-wide; tests compare the forms on the same operands and restore -1."""
+    _lib.call("gs_conv3x3_set_kernel_form", int(form))
+
+
 def conv3x3(x, w, y, N, H, W, Cin, Cout, taps=TAPS3_FWD, bias=None, bn_partials=None, act=ACT_NONE,
             in_stride=None, in_coff=0, out_stride=None, out_coff=0):
     """3x3/s1/p1 convolution (or its data gradient with TAPS3_DGRAD + the dgrad weight pack) on the

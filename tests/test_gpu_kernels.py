@@ -800,3 +800,50 @@ def _unpack_merged(pf, cin, cout):
             t = (ky >> 1) * 4 + (kx >> 1)
             w[:, :, ky, kx] = pf[c, t].t()
     return w
+
+
+@pytest.mark.parametrize("dtn,dt", DTS)
+@pytest.mark.parametrize("form", [0, 4, 8, 2])
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 37, 41, 64, 64), (1, 17, 33, 128, 72), (3, 9, 100, 64, 128), (2, 48, 32, 192, 64)])
+def test_conv3x3_kernel_forms(dtn, dt, form, N, H, W, Cin, Cout):
+    """every form of the 2-D kernel (register-staged big-K-step, LDS-DMA with 4 / 8 waves, two LDS-DMA blocks per CU) on the
+    same operands: forward with BatchNorm partials into a strided slice (ragged patches, a partial cout tile, an odd
+    number of 8-row halves), bias + ReLU epilogue, and the data gradient (flipped tap table)"""
+    from semantic_segmentation_amd import ops
+    from semantic_segmentation_amd._lib import ACT_RELU
+    g = torch.Generator().manual_seed(31)
+    x = rnd(g, N, Cin, H, W, dt=dt).requires_grad_(True)
+    w = rnd(g, Cout, Cin, 3, 3, dt=dt, scale=0.05).requires_grad_(True)
+    b = rnd(g, Cout)
+    ref = F.conv2d(x, w, None, padding=1)
+    dy = rnd(g, N, Cout, H, W, dt=dt)
+    ref.backward(dy)
+    wf = torch.empty(9, Cout, Cin, dtype=dt, device=dev())
+    wd = torch.empty(9, Cin, Cout, dtype=dt, device=dev())
+    ops.pack_weight(w.detach().to(dev()), wf, wd, False)
+    mt = ops.conv3x3_mtiles(N, H, W, Cout)
+    part = torch.zeros(ops.bn_partials_numel(mt, Cout), dtype=torch.float32, device=dev())
+    xin = torch.zeros(N, H, W, Cin + 16, dtype=dt, device=dev()); xin[..., 16:] = nhwc(x.detach(), dt)
+    y = torch.zeros(N, H, W, Cout + 8, dtype=dt, device=dev())
+    y2 = torch.empty(N, H, W, Cout, dtype=dt, device=dev())
+    dx = torch.empty(N, H, W, Cin, dtype=dt, device=dev())
+    ops.conv3x3_set_kernel_form(form)
+    try:
+        for _ in range(2):          # the second launch runs on warm caches: same result
+            ops.conv3x3(xin, wf, y, N, H, W, Cin, Cout, ops.TAPS3_FWD, None, part, in_stride=Cin + 16, in_coff=16,
+                        out_stride=Cout + 8, out_coff=8)
+        ops.conv3x3(nhwc(x.detach(), dt), wf, y2, N, H, W, Cin, Cout, ops.TAPS3_FWD, b.to(dev()), None, act=ACT_RELU)
+        if Cout % 64 == 0:
+            ops.conv3x3(nhwc(dy, dt), wd, dx, N, H, W, Cout, Cin, ops.TAPS3_DGRAD)
+        torch.cuda.synchronize()
+    finally:
+        ops.conv3x3_set_kernel_form(-1)
+    assert rel_err(from_nhwc(y[..., 8:]), ref.detach()) < tol(dt)
+    assert float(y[..., :8].abs().max()) == 0.0
+    p = part[: mt * 2 * Cout].view(mt, 2, Cout).double().sum(0).cpu()
+    s1, s2 = ref.detach().double().sum((0, 2, 3)), (ref.detach().double() ** 2).sum((0, 2, 3))
+    assert (p[0] - s1).abs().max() < 1e-3 * max(1.0, s1.abs().max().item())
+    assert (p[1] - s2).abs().max() < 1e-3 * s2.abs().max().item()
+    assert rel_err(from_nhwc(y2), F.relu(ref.detach() + b.view(1, -1, 1, 1))) < tol(dt)
+    if Cout % 64 == 0:
+        assert rel_err(from_nhwc(dx), x.grad) < tol(dt)
