@@ -1040,7 +1040,7 @@ __device__ __forceinline__ void dma_piece16(const __amdgpu_buffer_rsrc_t& rs, un
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)dst, 16, voff, soff, 0, 0);
 }
 
-template <int DT, int NWV, int KC>
+template <int DT, int NWV, int KC, bool STATS>
 __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel(const C3Args a) {
     typedef typename Elem<DT>::V8 V8;
     constexpr int BN = 64, TW = 32, TH = 2 * NWV, TWS = 5;
@@ -1061,7 +1061,7 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
     constexpr int H0_OFF = W_B, W1_OFF = W_B + 2 * HALO_B;
     static_assert(2 * STAGE_B * (KC == 16 ? 2 : 1) <= 160 * 1024, "two stages (per resident block) must fit in LDS");
     static_assert(NWV * STG_EL * 2 + NWV * 2 * BN * 4 <= HALO_B + W_B, "epilogue staging overlays the second stage buffer");
-    static_assert(NWP + HJ <= NSTEP, "one DMA piece per MFMA step");
+    static_assert(NWP + HJ <= NSTEP && HJ + 1 <= NSTEP, "one DMA piece / one next-item offset per MFMA step");
     static_assert(NWV % WG == 0, "a wave's weight pieces all belong to one row group");
     static_assert(WP % NWV == 0 || HI < HJ * NWV, "a surplus weight slot parks its (empty) piece in the spare halo piece");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE_B];
@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
     const int l31 = lane & 31, h = lane >> 5;
     const int nitems = a.nblocks;
     const int act = a.act & 0xff;
-    const int dbg = a.act >> 8;                            // ablation bits (GSSEG_C3_DEBUG=1): 1 no stores, 2 no MFMAs, 4 no epilogue
+    const int dbg = a.act >> 8;                            // ablation bits (GSSEG_C3_DEBUG=1): 2 no MFMAs, 4 no epilogue
     const int nstage = a.Cin / KC;
     const unsigned img_bytes = (unsigned)a.H * a.W * a.in_stride * 2u;
     const unsigned tap_stride = (unsigned)a.Cout * a.Cin * 2u;
@@ -1092,18 +1092,24 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
     // there is the physical one xor-ed with the row's swizzle key ((row >> 2) & 3 for 64-byte rows, (row >> 3) & 1 for 32) ----
     const int drow = lane / SPR;
     const int dls = (lane % SPR) ^ ((lane >> 4) & (SPR - 1));
-    unsigned hv[HJ], wv;
+    unsigned hv[HJ], wv;         // this item's buffer offsets per piece slot
+    unsigned hvn[HJ], wvn;       // the next item's: computed one slot per MFMA step of every even stage (nearly free
+                                 // there; at the item boundary the same ~70 instructions ran with nothing to hide behind)
+    auto halo_voff = [&](int y0, int x0, int j) __attribute__((always_inline)) {      // j compile-time
+        const int r = (wave + j * NWV) * RPP + drow;
+        const int hy = r / HWD, hx = r - hy * HWD;
+        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool ok = r < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        return ok ? (unsigned)(((gy * a.W + gx) * a.in_stride + a.in_coff + dls * 8) * 2) : VOOB;
+    };
+    auto weight_voff = [&](int n0) __attribute__((always_inline)) {
+        const int co = n0 + (wave % WG) * RPP + drow;
+        return co < a.Cout ? (unsigned)((co * a.Cin + dls * 8) * 2) : VOOB;
+    };
     auto setup_item = [&](const Item& itn) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < HJ; ++j) {
-            const int r = (wave + j * NWV) * RPP + drow;
-            const int hy = r / HWD, hx = r - hy * HWD;
-            const int gy = itn.y0 + hy - 1, gx = itn.x0 + hx - 1;
-            const bool ok = r < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-            hv[j] = ok ? (unsigned)(((gy * a.W + gx) * a.in_stride + a.in_coff + dls * 8) * 2) : VOOB;
-        }
-        const int co = itn.n0 + (wave % WG) * RPP + drow;
-        wv = co < a.Cout ? (unsigned)((co * a.Cin + dls * 8) * 2) : VOOB;
+        for (int j = 0; j < HJ; ++j) hv[j] = halo_voff(itn.y0, itn.x0, j);
+        wv = weight_voff(itn.n0);
     };
     // LDS: [halo 0 | halo 1 | weights 0 | weights 1] -- every fragment read is (per-lane base register) + (16-bit immediate)
     // piece k (compile-time) of stage (image rx, channel byte offset sc) into buffer bb
@@ -1163,12 +1169,20 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
 
     // one stage: NSTEP steps (tap, k half) of 4 MFMAs out of buffer BUF; the pieces of the next stage (image rx_n, channel
     // offset sc_n) go into the other buffer, one per step
-    auto run_stage = [&](auto buf_tag, const __amdgpu_buffer_rsrc_t& rx_n, unsigned sc_n, unsigned kill) __attribute__((always_inline)) {
+    // FIRST: the first stage of an item starts its accumulators from the MFMA's zero C operand (no clearing pass)
+    auto run_stage = [&](auto buf_tag, auto first_tag, const __amdgpu_buffer_rsrc_t& rx_n, unsigned sc_n, unsigned kill, const Item& itn) __attribute__((always_inline)) {
         constexpr int BUF = decltype(buf_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
         constexpr unsigned NB = 1 - BUF;
         if (dbg & 2) {                                     // ablation: DMA traffic only
 #pragma unroll
             for (int k = 0; k < NWP + HJ; ++k) issue_piece(k, rx_n, sc_n, NB, kill);
+            if (BUF == 0) {
+#pragma unroll
+                for (int j = 0; j < HJ; ++j) hvn[j] = halo_voff(itn.y0, itn.x0, j);
+                wvn = weight_voff(itn.n0);
+            }
+            if (FIRST) zero_acc();
             return;
         }
         V8 af[2][2], bf[2][2];
@@ -1186,10 +1200,25 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
             const int cur = step & 1;
             if (step + 1 < NSTEP) frag_load(step + 1, af[cur ^ 1], bf[cur ^ 1]);
             issue_piece(step, rx_n, sc_n, NB, kill);
+            if (BUF == 0 && step <= HJ) {                  // the next item's piece offsets, one slot per step
+                int py0 = itn.y0, px0 = itn.x0, pn0 = itn.n0;
+                asm volatile("" : "+s"(py0), "+s"(px0), "+s"(pn0));      // keeps this arithmetic in the step (else hoisted to the item boundary)
+                if (step < HJ) hvn[step < HJ ? step : 0] = halo_voff(py0, px0, step < HJ ? step : 0);
+                else wvn = weight_voff(pn0);
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i][j] = Elem<DT>::mfma32(af[cur][i], bf[cur][j], acc[i][j]);
+                for (int i = 0; i < 2; ++i) {
+                    if (FIRST && step == 0) {
+                        f32x16 z;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                        acc[i][j] = Elem<DT>::mfma32(af[cur][i], bf[cur][j], z);
+                    } else {
+                        acc[i][j] = Elem<DT>::mfma32(af[cur][i], bf[cur][j], acc[i][j]);
+                    }
+                }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
@@ -1231,7 +1260,7 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
             }
         }
         float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-        const bool want_stats = a.bnp != nullptr;
+        constexpr bool want_stats = STATS;              // BatchNorm partial sums: a template flag (no per-element selects)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int prow0 = (wave * 2 + i) * 32;
@@ -1283,7 +1312,7 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
                 const int p = prow0 + q * 8 + (lane >> 3);
                 const int gy = e_y0 + (p >> TWS), gx = e_x0 + (p & (TW - 1));
                 const int co = e_n0 + (lane & 7) * 8;
-                const bool ok = (FULL || (gy < a.H && gx < a.W)) && co < a.Cout && !(dbg & 1);
+                const bool ok = (FULL || (gy < a.H && gx < a.W)) && co < a.Cout;
                 const unsigned off = ok ? (unsigned)(((gy * a.W + gx) * a.out_stride + a.out_coff + co) * 2) : VOOB;
                 u32x4 d;
                 d[0] = sv[q].x; d[1] = sv[q].y; d[2] = sv[q].z; d[3] = sv[q].w;
@@ -1312,7 +1341,7 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
     // partial sums of the 8x32 halves: waves 4*half .. 4*half+3
     auto finish_stats = [&](const Item& itc) __attribute__((always_inline)) {
         constexpr int NH = NWV / 4;
-        if (a.bnp != nullptr && t < NH * BN) {
+        if (STATS && t < NH * BN) {
             const int half = t >> 6, c = t & 63;
             if (itc.n0 + c < a.Cout && (itc.y0 >> 3) + half < tiles_y8) {
                 float v1 = 0.f, v2 = 0.f;
@@ -1367,7 +1396,6 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
 #pragma unroll
         for (int k = 0; k < NWP + HJ; ++k) issue_piece(k, rx0, 0u, 0u, 0u);       // stage 0 -> buffer 0
     }
-    zero_acc();
     for (;;) {
         const int nit = it + gridDim.x;
         const bool more_items = nit < nitems;
@@ -1378,20 +1406,24 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
             PH(7);
             stage_sync();
             PH(0);
-            run_stage(std::integral_constant<int, 0>{}, image_rsrc(cur.n), (unsigned)(sp + 1) * ROWB, 0u);
+            if (sp == 0) run_stage(std::integral_constant<int, 0>{}, std::true_type{}, image_rsrc(cur.n), (unsigned)(sp + 1) * ROWB, 0u, nxt);
+            else run_stage(std::integral_constant<int, 0>{}, std::false_type{}, image_rsrc(cur.n), (unsigned)(sp + 1) * ROWB, 0u, nxt);
             PH(1);
             stage_sync();
             PH(2);
-            if (last && more_items) setup_item(nxt);
-            run_stage(std::integral_constant<int, 1>{}, image_rsrc(last ? nxt.n : cur.n), last ? 0u : (unsigned)(sp + 2) * ROWB,
-                      (last && !more_items) ? VOOB : 0u);
+            if (last) {                                    // from here on the pieces belong to the next item
+#pragma unroll
+                for (int j = 0; j < HJ; ++j) hv[j] = hvn[j];
+                wv = wvn;
+            }
+            run_stage(std::integral_constant<int, 1>{}, std::false_type{}, image_rsrc(last ? nxt.n : cur.n),
+                      last ? 0u : (unsigned)(sp + 2) * ROWB, (last && !more_items) ? VOOB : 0u, nxt);
             PH(3);
         }
         __builtin_amdgcn_s_barrier();              // every wave has left the second buffer: staging may overlay it
         asm volatile("" ::: "memory");
         PH(4);
         if (!(dbg & 4)) epilogue(cur);
-        zero_acc();
         PH(5);
         __syncthreads();
         PH(6);
@@ -1548,15 +1580,24 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
             const int dblocks = dma_waves == 2 ? 2 * big_blocks : big_blocks;
             dim3 dgrid(a.nblocks < dblocks ? a.nblocks : dblocks);
             a.xcd_order = (xcd_env && (dgrid.x % 8) == 0 && a.ntn > 1 && (int64_t)N * H * W > (int64_t)18 * Cout) ? 1 : 0;
+#define C3_DMA_LAUNCH(DT)                                                                          \
+    do {                                                                                           \
+        if (bn_partials != nullptr) {                                                              \
+            if (dma_waves == 8) conv3x3_dma_kernel<DT, 8, 32, true><<<dgrid, 512, 0, bs>>>(a);     \
+            else if (dma_waves == 2) conv3x3_dma_kernel<DT, 4, 16, true><<<dgrid, 256, 0, bs>>>(a); \
+            else conv3x3_dma_kernel<DT, 4, 32, true><<<dgrid, 256, 0, bs>>>(a);                    \
+        } else {                                                                                   \
+            if (dma_waves == 8) conv3x3_dma_kernel<DT, 8, 32, false><<<dgrid, 512, 0, bs>>>(a);    \
+            else if (dma_waves == 2) conv3x3_dma_kernel<DT, 4, 16, false><<<dgrid, 256, 0, bs>>>(a); \
+            else conv3x3_dma_kernel<DT, 4, 32, false><<<dgrid, 256, 0, bs>>>(a);                   \
+        }                                                                                          \
+    } while (0)
             if (dtype == GS_F16) {
-                if (dma_waves == 8) conv3x3_dma_kernel<GS_F16, 8, 32><<<dgrid, 512, 0, bs>>>(a);
-                else if (dma_waves == 2) conv3x3_dma_kernel<GS_F16, 4, 16><<<dgrid, 256, 0, bs>>>(a);
-                else conv3x3_dma_kernel<GS_F16, 4, 32><<<dgrid, 256, 0, bs>>>(a);
+                C3_DMA_LAUNCH(GS_F16);
             } else {
-                if (dma_waves == 8) conv3x3_dma_kernel<GS_BF16, 8, 32><<<dgrid, 512, 0, bs>>>(a);
-                else if (dma_waves == 2) conv3x3_dma_kernel<GS_BF16, 4, 16><<<dgrid, 256, 0, bs>>>(a);
-                else conv3x3_dma_kernel<GS_BF16, 4, 32><<<dgrid, 256, 0, bs>>>(a);
+                C3_DMA_LAUNCH(GS_BF16);
             }
+#undef C3_DMA_LAUNCH
             GS_CHECK_LAUNCH("gs_conv3x3");
             return GS_OK;
         }
