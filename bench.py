@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0
 
 
 # KernelTimer class -> kernel-name prefix in the committed rocprofv3 PMC summary (tools/profile_step.sh)
-PMC_PREFIX = {"conv3x3_halo": "conv3x3_", "wgrad3x3_halo": "wgrad3x3_kernel", "igemm_fwd": "igemm_fwd_kernel",
+PMC_PREFIX = {"conv3x3_halo": "conv3x3_", "wgrad3x3_halo": "wgrad3x3_", "igemm_fwd": "igemm_fwd_kernel",
               "igemm_wgrad": "igemm_wgrad_kernel"}
 
 
