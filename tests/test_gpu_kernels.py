@@ -847,3 +847,50 @@ def test_conv3x3_kernel_forms(dtn, dt, form, N, H, W, Cin, Cout):
     assert rel_err(from_nhwc(y2), F.relu(ref.detach() + b.view(1, -1, 1, 1))) < tol(dt)
     if Cout % 64 == 0:
         assert rel_err(from_nhwc(dx), x.grad) < tol(dt)
+
+
+def test_dma_kernels_repeatable_under_memory_noise():
+    """the LDS-DMA kernels read LDS that a DMA filled: a read that overtook its DMA would show up as rare wrong tiles.
+    The same launches repeated (every other one racing a large copy on a second stream) must be bit-identical
+    (tools/race_screen.py is the long form: 5.5k launches, profiles/r02_race_screen.txt)."""
+    from semantic_segmentation_amd import ops
+    dt = torch.float16
+    side = torch.cuda.Stream()
+    src = torch.randn(16 * 1024 * 1024, device=dev())
+    dst = torch.empty_like(src)
+    for (N, H, W, Cin, Cout) in [(8, 64, 64, 128, 128), (3, 37, 41, 64, 72)]:
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(N, H, W, Cin, generator=g).to(dt).to(dev())
+        dy = torch.randn(N, H, W, Cout, generator=g).to(dt).to(dev())
+        wf = (0.05 * torch.randn(9, Cout, Cin, generator=g)).to(dt).to(dev())
+        mt = ops.conv3x3_mtiles(N, H, W, Cout)
+        ws = torch.empty(ops.conv3x3_wgrad_ws_floats(N, H, W, Cin, Cout), dtype=torch.float32, device=dev())
+        try:
+            for form in (8, 4, 2):
+                ops.conv3x3_set_kernel_form(form)
+                ref = None
+                for it in range(30):
+                    y = torch.empty(N, H, W, Cout, dtype=dt, device=dev())
+                    part = torch.zeros(ops.bn_partials_numel(mt, Cout), dtype=torch.float32, device=dev())
+                    if it % 2:
+                        with torch.cuda.stream(side):
+                            dst.copy_(src)
+                    ops.conv3x3(x, wf, y, N, H, W, Cin, Cout, ops.TAPS3_FWD, None, part)
+                    if ref is None:
+                        ref = (y, part)
+                    else:
+                        assert torch.equal(y, ref[0]) and torch.equal(part, ref[1]), (form, it)
+        finally:
+            ops.conv3x3_set_kernel_form(-1)
+        refg = None
+        for it in range(30):
+            gout = torch.empty(Cout, Cin, 3, 3, dtype=torch.float32, device=dev())
+            if it % 2:
+                with torch.cuda.stream(side):
+                    dst.copy_(src)
+            ops.conv3x3_wgrad_det(x, dy, ws, gout, N, H, W, Cin, Cout, 1.0)
+            if refg is None:
+                refg = gout
+            else:
+                assert torch.equal(gout, refg), it
+        torch.cuda.synchronize()
