@@ -1030,7 +1030,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
 //   NWV       : 4 waves = 8x32 pixels (one wave per SIMD) or 8 waves = 16x32 pixels (two per SIMD, weights fetched
 //               once per 512 pixels); BatchNorm partials are always written per 8x32 half (gs_conv3x3_mtiles()).
 // Requires Cin % 64 == 0 (an even number of stages keeps the buffer parity fixed per item), W >= 24, the forward or the
-// data-gradient (flipped) tap table, 2-D; everything else stays on conv3x3_big_kernel.
+// data-gradient (flipped) tap table.  Conv3d 3x3x3: the stages run over (depth tap, channel chunk) -- stage (dz, c) fetches the
+// halo of slice n + dz (empty pieces outside the volume) and the nine weight slots of that depth tap.  Everything else (the
+// 16x16 level, the precise mode, Cin % 64 != 0) stays on conv3x3_big_kernel.
 // ---------------------------------------------------------------------------------------------------
 // (a "v" constraint inside the kernel body itself would make the host-side instantiation of the launch stub invalid)
 __device__ __forceinline__ void opaque_vgpr(unsigned& x) { asm volatile("" : "+v"(x)); }
@@ -1072,7 +1074,7 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
     const int nitems = a.nblocks;
     const int act = a.act & 0xff;
     const int dbg = a.act >> 8;                            // ablation bits (GSSEG_C3_DEBUG=1): 2 no MFMAs, 4 no epilogue
-    const int nstage = a.Cin / KC;
+    const int nstage = a.ndz * (a.Cin / KC);               // even: Cin % 64 == 0
     const unsigned img_bytes = (unsigned)a.H * a.W * a.in_stride * 2u;
     const unsigned tap_stride = (unsigned)a.Cout * a.Cin * 2u;
     const bool flip = a.tap_dy[0] > 0;                     // data-gradient table: geometric tap g uses weight slot 8 - g
@@ -1086,7 +1088,7 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
 #endif
     struct Item { int n, y0, x0, n0, mt; };
     const __amdgpu_buffer_rsrc_t w_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)(9u * a.Cout * a.Cin * 2u), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)(9u * a.ndz * a.Cout * a.Cin * 2u), 0x00020000);
 
     // ---- DMA side: lane l of a piece fills physical slot l % SPR of row l / SPR; the logical slot (8 channels) that belongs
     // there is the physical one xor-ed with the row's swizzle key ((row >> 2) & 3 for 64-byte rows, (row >> 3) & 1 for 32) ----
@@ -1113,7 +1115,10 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
     };
     // LDS: [halo 0 | halo 1 | weights 0 | weights 1] -- every fragment read is (per-lane base register) + (16-bit immediate)
     // piece k (compile-time) of stage (image rx, channel byte offset sc) into buffer bb
-    auto issue_piece = [&](int k, const __amdgpu_buffer_rsrc_t& rx, unsigned sc, unsigned bb, unsigned kill) __attribute__((always_inline)) {
+    // (sc / wsc: scalar byte offsets of the stage's channel chunk in the image / of its chunk and depth-tap group in the pack;
+    // hkill: the depth tap points outside the volume -- the halo pieces carry zeros)
+    auto issue_piece = [&](int k, const __amdgpu_buffer_rsrc_t& rx, unsigned sc, unsigned wsc, unsigned bb, unsigned hkill,
+                           unsigned kill) __attribute__((always_inline)) {
         if (k < NWP) {
             const int pc = wave + NWV * k;                 // piece = tap * WG + row group; the group is wave % WG for every k
             const int tap = pc / WG;
@@ -1121,12 +1126,31 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
             const int slot = flip ? 8 - tap : tap;
             const unsigned dst = real ? (unsigned)(pc * 1024) + bb * W1_OFF
                                       : (unsigned)(H0_OFF + HALO_B - 1024) + bb * HALO_B;
-            dma_piece16(w_rsrc, smem + dst, real ? (wv | kill) : VOOB, (unsigned)(real ? slot : 0) * tap_stride + sc);
+            dma_piece16(w_rsrc, smem + dst, real ? (wv | kill) : VOOB, (unsigned)(real ? slot : 0) * tap_stride + wsc);
         } else if (k - NWP < HJ) {
             const int j = k - NWP < HJ ? k - NWP : 0;
             const unsigned dst = H0_OFF + bb * HALO_B + (unsigned)(wave + j * NWV) * 1024u;
-            dma_piece16(rx, smem + dst, hv[j] | kill, sc);
+            dma_piece16(rx, smem + dst, hv[j] | kill | hkill, sc);
         }
+    };
+    // stage c of an item in slice n: 2-D: channel chunk c; Conv3d: (depth tap c / nchunk, chunk c % nchunk) reads slice n + dz
+    // and the nine weight slots of that depth tap
+    struct Src { int n; unsigned sc, wsc, hkill; };
+    const int nchunk = a.Cin / KC;
+    auto stage_src = [&](int n, int c) __attribute__((always_inline)) {
+        Src r;
+        r.n = n; r.sc = (unsigned)c * ROWB; r.wsc = r.sc; r.hkill = 0u;
+        if (a.ndz > 1) {
+            const int dzi = c / nchunk, cc = c - dzi * nchunk;
+            const int dz = a.tap_dz[dzi];
+            const int d = n % a.D;
+            const bool inside = (unsigned)(d + dz) < (unsigned)a.D;
+            r.n = inside ? n + dz : n;
+            r.hkill = inside ? 0u : VOOB;
+            r.sc = (unsigned)cc * ROWB;
+            r.wsc = (unsigned)(dzi * 9) * tap_stride + r.sc;
+        }
+        return r;
     };
 
     // ---- MFMA side: fragment byte addresses inside a stage buffer (item independent) ----
@@ -1170,13 +1194,14 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
     // one stage: NSTEP steps (tap, k half) of 4 MFMAs out of buffer BUF; the pieces of the next stage (image rx_n, channel
     // offset sc_n) go into the other buffer, one per step
     // FIRST: the first stage of an item starts its accumulators from the MFMA's zero C operand (no clearing pass)
-    auto run_stage = [&](auto buf_tag, auto first_tag, const __amdgpu_buffer_rsrc_t& rx_n, unsigned sc_n, unsigned kill, const Item& itn) __attribute__((always_inline)) {
+    auto run_stage = [&](auto buf_tag, auto first_tag, const __amdgpu_buffer_rsrc_t& rx_n, const Src& sn, unsigned kill, const Item& itn) __attribute__((always_inline)) {
+        const unsigned sc_n = sn.sc, wsc_n = sn.wsc, hkill_n = sn.hkill;
         constexpr int BUF = decltype(buf_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value;
         constexpr unsigned NB = 1 - BUF;
         if (dbg & 2) {                                     // ablation: DMA traffic only
 #pragma unroll
-            for (int k = 0; k < NWP + HJ; ++k) issue_piece(k, rx_n, sc_n, NB, kill);
+            for (int k = 0; k < NWP + HJ; ++k) issue_piece(k, rx_n, sc_n, wsc_n, NB, hkill_n, kill);
             if (BUF == 0) {
 #pragma unroll
                 for (int j = 0; j < HJ; ++j) hvn[j] = halo_voff(itn.y0, itn.x0, j);
@@ -1199,7 +1224,7 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
         for (int step = 0; step < NSTEP; ++step) {
             const int cur = step & 1;
             if (step + 1 < NSTEP) frag_load(step + 1, af[cur ^ 1], bf[cur ^ 1]);
-            issue_piece(step, rx_n, sc_n, NB, kill);
+            issue_piece(step, rx_n, sc_n, wsc_n, NB, hkill_n, kill);
             if (BUF == 0 && step <= HJ) {                  // the next item's piece offsets, one slot per step
                 int py0 = itn.y0, px0 = itn.x0, pn0 = itn.n0;
                 asm volatile("" : "+s"(py0), "+s"(px0), "+s"(pn0));      // keeps this arithmetic in the step (else hoisted to the item boundary)
@@ -1392,9 +1417,10 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
     Item cur = make_item();
     setup_item(cur);
     {
-        const __amdgpu_buffer_rsrc_t rx0 = image_rsrc(cur.n);
+        const Src s0 = stage_src(cur.n, 0);
+        const __amdgpu_buffer_rsrc_t rx0 = image_rsrc(s0.n);
 #pragma unroll
-        for (int k = 0; k < NWP + HJ; ++k) issue_piece(k, rx0, 0u, 0u, 0u);       // stage 0 -> buffer 0
+        for (int k = 0; k < NWP + HJ; ++k) issue_piece(k, rx0, s0.sc, s0.wsc, 0u, s0.hkill, 0u);       // stage 0 -> buffer 0
     }
     for (;;) {
         const int nit = it + gridDim.x;
@@ -1406,8 +1432,9 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
             PH(7);
             stage_sync();
             PH(0);
-            if (sp == 0) run_stage(std::integral_constant<int, 0>{}, std::true_type{}, image_rsrc(cur.n), (unsigned)(sp + 1) * ROWB, 0u, nxt);
-            else run_stage(std::integral_constant<int, 0>{}, std::false_type{}, image_rsrc(cur.n), (unsigned)(sp + 1) * ROWB, 0u, nxt);
+            const Src s1 = stage_src(cur.n, sp + 1);
+            if (sp == 0) run_stage(std::integral_constant<int, 0>{}, std::true_type{}, image_rsrc(s1.n), s1, 0u, nxt);
+            else run_stage(std::integral_constant<int, 0>{}, std::false_type{}, image_rsrc(s1.n), s1, 0u, nxt);
             PH(1);
             stage_sync();
             PH(2);
@@ -1416,8 +1443,8 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
                 for (int j = 0; j < HJ; ++j) hv[j] = hvn[j];
                 wv = wvn;
             }
-            run_stage(std::integral_constant<int, 1>{}, std::false_type{}, image_rsrc(last ? nxt.n : cur.n),
-                      last ? 0u : (unsigned)(sp + 2) * ROWB, (last && !more_items) ? VOOB : 0u, nxt);
+            const Src s2 = stage_src(last ? nxt.n : cur.n, last ? 0 : sp + 2);
+            run_stage(std::integral_constant<int, 1>{}, std::false_type{}, image_rsrc(s2.n), s2, (last && !more_items) ? VOOB : 0u, nxt);
             PH(3);
         }
         __builtin_amdgcn_s_barrier();              // every wave has left the second buffer: staging may overlay it
@@ -1566,7 +1593,7 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
             flip_taps = flip_taps && tap_dy[i] == 1 - i / 3 && tap_dx[i] == 1 - i % 3;
         }
         int dma_waves = 0;
-        if (dma_env != 0 && ndz == 1 && D == 1 && tw == 32 && Cin % 64 == 0 && (std_taps || flip_taps)) {
+        if (dma_env != 0 && tw == 32 && Cin % 64 == 0 && (std_taps || flip_taps)) {      // 2-D and Conv3d (depth taps = stages)
             const int64_t items4 = (int64_t)N * a.tiles_x * cdiv(H, 8) * a.ntn, items8 = (int64_t)N * a.tiles_x * cdiv(H, 16) * a.ntn;
             const double cost4 = 0.98 * (double)((items4 + big_blocks - 1) / big_blocks);
             const double cost8 = 0.87 * 2.0 * (double)((items8 + big_blocks - 1) / big_blocks);

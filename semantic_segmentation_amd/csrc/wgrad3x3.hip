@@ -240,7 +240,9 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_dma_kernel(const W3Args a) {
         const int r = patch / a.tiles_x;
         const int ty = r % a.tiles_y, n = r / a.tiles_y;
         const int y0 = ty * TH, x0 = tx * TW;
-        f.rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)n * a.H * a.W * a.in_stride), 0, x_img_bytes, 0x00020000);
+        const int d = a.D > 1 ? n % a.D : 0;                       // Conv3d: X comes from slice n + dz (zeros outside the volume)
+        const bool xin = (unsigned)(d + a.dz) < (unsigned)a.D;
+        f.rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)(xin ? n + a.dz : n) * a.H * a.W * a.in_stride), 0, x_img_bytes, 0x00020000);
         f.rdy = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + (int64_t)n * a.H * a.W * a.out_stride), 0, dy_img_bytes, 0x00020000);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_dma_kernel(const W3Args a) {
             const int hp = (wave + 8 * j) * 8 + drow;
             const int hy = hp / HWD, hx = hp - hy * HWD;
             const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-            const bool ok = live && ci_ok && hp < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            const bool ok = live && xin && ci_ok && hp < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
             hv[j] = ok ? (unsigned)(((gy * a.W + gx) * a.in_stride + a.in_coff + ci0 + dls * 8) * 2) : VOOB;
         }
         return f;
@@ -363,10 +365,10 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_dma_kernel(const W3Args a) {
 }
 }  // namespace
 
-// the LDS-DMA kernel covers the 2-D layers with 32-wide patches (GSSEG_W3_DMA=0 switches it off)
-static bool w3_use_dma(int W, int D) {
+// the LDS-DMA kernel covers the layers with 32-wide patches, 2-D and Conv3d (GSSEG_W3_DMA=0 switches it off)
+static bool w3_use_dma(int W) {
     static const int env = getenv("GSSEG_W3_DMA") ? atoi(getenv("GSSEG_W3_DMA")) : 1;
-    return env != 0 && W >= 24 && D == 1;
+    return env != 0 && W >= 24;
 }
 
 static int w3_ksplit(int N, int H, int W, int Cin, int Cout, int* pps_out, int* npatches_out, bool dma) {
@@ -390,7 +392,7 @@ static int w3_ksplit(int N, int H, int W, int Cin, int Cout, int* pps_out, int* 
 
 static int wgrad3x3_launch(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin,
                            int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff, int dtype,
-                           void* stream, int D, int dz, int64_t slab_stride = 0, bool volume = false) {
+                           void* stream, int D, int dz, int64_t slab_stride = 0) {
     GS_CHECK_ARG(x && dy && dw, "gs_conv3x3_wgrad: null pointer");
     GS_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 8 == 0, "gs_conv3x3_wgrad: bad dims");
     GS_CHECK_ARG(in_pix_stride >= in_coff + Cin && in_pix_stride % 8 == 0 && in_coff % 8 == 0, "gs_conv3x3_wgrad: bad x stride");
@@ -403,7 +405,7 @@ static int wgrad3x3_launch(const void* x, const void* dy, float* dw, int N, int 
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.in_stride = in_pix_stride; a.in_coff = in_coff;
     a.Cout = Cout; a.out_stride = out_pix_stride; a.out_coff = out_coff;
     a.D = D; a.dz = dz; a.slab_stride = slab_stride;
-    const bool dma = !volume && w3_use_dma(W, D);      // the 3-D entry points size their slabs for the 4-wave kernel
+    const bool dma = w3_use_dma(W);
     const int tw = (W >= 24) ? 32 : 16, th = dma ? 8 : W3_BM / tw;
     a.tiles_x = cdiv(W, tw); a.tiles_y = cdiv(H, th);
     a.npatches = N * a.tiles_x * a.tiles_y;
@@ -449,7 +451,7 @@ extern "C" int gs_conv3d_3x3x3_wgrad(const void* x, const void* dy, float* dw, i
     for (int kd = 0; kd < 3; ++kd) {
         if (D == 1 && kd != 1) continue;               // a one-slice volume only sees the centre depth tap
         int rc = wgrad3x3_launch(x, dy, dw + (int64_t)kd * 9 * Cout * Cin, NB * D, H, W, Cin, in_pix_stride, in_coff, Cout,
-                                 out_pix_stride, out_coff, dtype, stream, D, kd - 1, 0, true);
+                                 out_pix_stride, out_coff, dtype, stream, D, kd - 1);
         if (rc) return rc;
     }
     return GS_OK;
@@ -463,7 +465,7 @@ extern "C" int gs_conv3d_3x3x3_wgrad(const void* x, const void* dy, float* dw, i
 //   order dependent), the zero fill in front of them and the separate gs_unpack_wgrad pass.
 extern "C" int64_t gs_conv3x3_wgrad_ws_floats(int N, int H, int W, int Cin, int Cout) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
-    return (int64_t)w3_ksplit(N, H, W, Cin, Cout, nullptr, nullptr, w3_use_dma(W, 1)) * 9 * Cout * Cin;
+    return (int64_t)w3_ksplit(N, H, W, Cin, Cout, nullptr, nullptr, w3_use_dma(W)) * 9 * Cout * Cin;
 }
 
 extern "C" int gs_conv3x3_wgrad_slabs(const void* x, const void* dy, float* ws, int N, int H, int W, int Cin,
@@ -537,18 +539,18 @@ extern "C" int gs_wgrad_reduce_unpack(const float* ws, int nparts, float* grad, 
 }
 
 extern "C" int gs_conv3x3_wgrad_parts(int N, int H, int W, int Cin, int Cout) {
-    return w3_ksplit(N, H, W, Cin, Cout, nullptr, nullptr, w3_use_dma(W, 1));
+    return w3_ksplit(N, H, W, Cin, Cout, nullptr, nullptr, w3_use_dma(W));
 }
 
 // 3-D form of the deterministic weight gradient: the three depth-tap launches store their parts into one set of slabs
 // ws[part][27][Cout][Cin]; gs_wgrad_reduce_unpack(taps = 27) then writes [Cout][Cin][3][3][3].
 extern "C" int64_t gs_conv3d_3x3x3_wgrad_ws_floats(int NB, int D, int H, int W, int Cin, int Cout) {
     if (NB <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
-    return (int64_t)w3_ksplit(NB * D, H, W, Cin, Cout, nullptr, nullptr, false) * 27 * Cout * Cin;
+    return (int64_t)w3_ksplit(NB * D, H, W, Cin, Cout, nullptr, nullptr, w3_use_dma(W)) * 27 * Cout * Cin;
 }
 
 extern "C" int gs_conv3d_3x3x3_wgrad_parts(int NB, int D, int H, int W, int Cin, int Cout) {
-    return w3_ksplit(NB * D, H, W, Cin, Cout, nullptr, nullptr, false);
+    return w3_ksplit(NB * D, H, W, Cin, Cout, nullptr, nullptr, w3_use_dma(W));
 }
 
 extern "C" int gs_conv3d_3x3x3_wgrad_slabs(const void* x, const void* dy, float* ws, int NB, int D, int H, int W, int Cin,
@@ -559,14 +561,14 @@ extern "C" int gs_conv3d_3x3x3_wgrad_slabs(const void* x, const void* dy, float*
     for (int kd = 0; kd < 3; ++kd) {
         if (D == 1 && kd != 1) {
             // a one-slice volume never pairs with the outer depth taps: their slots must still be defined (zeros)
-            const int parts = w3_ksplit(NB * D, H, W, Cin, Cout, nullptr, nullptr, false);
+            const int parts = w3_ksplit(NB * D, H, W, Cin, Cout, nullptr, nullptr, w3_use_dma(W));
             for (int p = 0; p < parts; ++p)
                 if (hipMemsetAsync(ws + p * slab + (int64_t)kd * 9 * Cout * Cin, 0, (size_t)9 * Cout * Cin * 4, (hipStream_t)stream) != hipSuccess)
                     return GS_ELAUNCH;
             continue;
         }
         int rc = wgrad3x3_launch(x, dy, ws + (int64_t)kd * 9 * Cout * Cin, NB * D, H, W, Cin, in_pix_stride, in_coff, Cout,
-                                 out_pix_stride, out_coff, dtype, stream, D, kd - 1, slab, true);
+                                 out_pix_stride, out_coff, dtype, stream, D, kd - 1, slab);
         if (rc) return rc;
     }
     return GS_OK;
