@@ -233,32 +233,59 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_dma_kernel(const W3Args a) {
     const int dls = (lane & 7) ^ (((lane >> 4) & 1) << 2);
     const bool ci_ok = ci0 + dls * 8 < a.Cin, co_ok = co0 + dls * 8 < a.Cout;
     unsigned dv[4], hv[HJ];
+    // Per patch only the origin changes: each slot keeps its byte offset RELATIVE to the patch origin (computed once; the
+    // per-patch part is a scalar base + two compares + a select per slot -- recomputing (gy * W + gx) * stride per slot per
+    // patch cost ~150 instructions with exec-masked branches at the top of every patch, with no MFMA in flight)
+    unsigned rel_d[4], rel_h[HJ];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = (wave + 8 * j) * 8 + drow;
+        rel_d[j] = (unsigned)((((p >> TWS) * a.W + (p & (TW - 1))) * a.out_stride + a.out_coff + co0 + dls * 8) * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < HJ; ++j) {
+        const int hp = (wave + 8 * j) * 8 + drow;
+        const int hy = hp / HWD, hx = hp - hy * HWD;
+        rel_h[j] = (unsigned)((((hy - 1) * a.W + (hx - 1)) * a.in_stride + a.in_coff + ci0 + dls * 8) * 2);   // may wrap: added mod 2^32
+    }
     struct Pf { __amdgpu_buffer_rsrc_t rx, rdy; };
-    auto prep_patch = [&](int patch, bool live) __attribute__((always_inline)) {
+    // patch position, stepped with carries (tx fastest)
+    int pt_x, pt_y, pt_n;
+    {
+        pt_x = p_begin % a.tiles_x;
+        const int r = p_begin / a.tiles_x;
+        pt_y = r % a.tiles_y; pt_n = r / a.tiles_y;
+    }
+    auto prep_patch = [&](bool live) __attribute__((always_inline)) {      // prepares (pt_x, pt_y, pt_n), then steps to the next patch
         Pf f;
-        const int tx = patch % a.tiles_x;
-        const int r = patch / a.tiles_x;
-        const int ty = r % a.tiles_y, n = r / a.tiles_y;
-        const int y0 = ty * TH, x0 = tx * TW;
+        const int n = pt_n, y0 = pt_y * TH, x0 = pt_x * TW;
         const int d = a.D > 1 ? n % a.D : 0;                       // Conv3d: X comes from slice n + dz (zeros outside the volume)
         const bool xin = (unsigned)(d + a.dz) < (unsigned)a.D;
         f.rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)(xin ? n + a.dz : n) * a.H * a.W * a.in_stride), 0, x_img_bytes, 0x00020000);
         f.rdy = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + (int64_t)n * a.H * a.W * a.out_stride), 0, dy_img_bytes, 0x00020000);
+        const unsigned base_d = (unsigned)((y0 * a.W + x0) * a.out_stride * 2), base_h = (unsigned)((y0 * a.W + x0) * a.in_stride * 2);
+        const int ylim = a.H - y0, xlim = a.W - x0;                 // rows / columns of the patch inside the image
+        const bool dlive = live && co_ok, hlive = live && xin && ci_ok;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int p = (wave + 8 * j) * 8 + drow;
-            const int gy = y0 + (p >> TWS), gx = x0 + (p & (TW - 1));
-            const bool ok = live && co_ok && gy < a.H && gx < a.W;
-            dv[j] = ok ? (unsigned)(((gy * a.W + gx) * a.out_stride + a.out_coff + co0 + dls * 8) * 2) : VOOB;
+            const bool ok = dlive && (p >> TWS) < ylim && (p & (TW - 1)) < xlim;
+            const unsigned v = base_d + rel_d[j];
+            dv[j] = ok ? v : VOOB;
         }
 #pragma unroll
         for (int j = 0; j < HJ; ++j) {
             const int hp = (wave + 8 * j) * 8 + drow;
             const int hy = hp / HWD, hx = hp - hy * HWD;
-            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-            const bool ok = live && xin && ci_ok && hp < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-            hv[j] = ok ? (unsigned)(((gy * a.W + gx) * a.in_stride + a.in_coff + ci0 + dls * 8) * 2) : VOOB;
+            const bool ok = hlive && hp < HP && (unsigned)(hy + y0 - 1) < (unsigned)a.H && (unsigned)(hx + x0 - 1) < (unsigned)a.W;
+            const unsigned v = base_h + rel_h[j];
+            hv[j] = ok ? v : VOOB;
         }
+        int c = ++pt_x == a.tiles_x ? 1 : 0;
+        pt_x -= c * a.tiles_x;
+        pt_y += c; c = pt_y == a.tiles_y ? 1 : 0;
+        pt_y -= c * a.tiles_y;
+        pt_n += c;
         return f;
     };
     // piece slot k (compile-time, 0 .. 4+HJ-1) of the prepared patch into buffer nb
@@ -289,7 +316,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_dma_kernel(const W3Args a) {
         b_base0[c4] = (unsigned)(HALO_OFF + (grp * 16 + krow) * 128 + (((wn ^ (((c4 + q) >> 1) & 1)) * 32 + chn) * 2));
 
     {
-        const Pf f0 = prep_patch(p_begin, true);
+        const Pf f0 = prep_patch(true);
 #pragma unroll
         for (int k = 0; k < 4 + HJ; ++k) issue_piece(f0, k, 0u);
     }
@@ -299,7 +326,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_dma_kernel(const W3Args a) {
         asm volatile("" ::: "memory");
         const unsigned buf = (unsigned)(patch - p_begin) & 1u;
         const bool more = patch + 1 < p_end;
-        const Pf pf = prep_patch(more ? patch + 1 : patch, more);
+        const Pf pf = prep_patch(more);        // (behind the range: empty pieces, the position is not used again)
         unsigned ab = a_base0 + buf * DY_B, bb[4];
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4) { bb[c4] = b_base0[c4] + buf * HALO_B; w3_opaque(bb[c4]); }
@@ -328,9 +355,13 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_dma_kernel(const W3Args a) {
             const int s = step / 9, tap = step - 9 * s;
             if (step + PD < 72) load_b(step + PD, bfr[(step + PD) % (PD + 1)]);
             if (tap == 4 && s + 1 < 8) load_a(s + 1, afr[(s + 1) & 1]);
+#if !defined(GS_W3_ABLATE) || GS_W3_ABLATE != 1          // ablation 1: no DMA traffic (stale LDS), 2: no MFMAs / fragment reads
             if (tap == 1) issue_piece(pf, s, buf ^ 1u);
             if (tap == 6 && s < 2) issue_piece(pf, 8 + s, buf ^ 1u);
+#endif
+#if !defined(GS_W3_ABLATE) || GS_W3_ABLATE != 2
             acc[tap] = Elem<DT>::mfma32(afr[s & 1], bfr[step % (PD + 1)], acc[tap]);
+#endif
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // the MFMA, then the reads of the next step in its shadow
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
             __builtin_amdgcn_sched_barrier(0);
