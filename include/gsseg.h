@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 28
+#define GS_ABI_VERSION 29
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -94,6 +94,15 @@ int gs_conv_igemm_batch(int n, const GsConvGeom* const* g, const void* x, const 
 int gs_upconv2x2_fwd(const void* x, const void* w, const float* bias, void* y, int N, int D, int IH, int IW, int Cin,
                      int in_pix_stride, int in_coff, int Cout, int Dout, int OH, int OW, int out_pix_stride,
                      int out_coff, int ooz, int ooy, int oox, int act, int dtype, void* stream);
+
+/* Data gradient of the same ConvTranspose2d(kernel 2, stride 2) (unet/unet_parts.py:51,57; autograd of :57):
+ * dx[n,iy,ix,ci] = sum_{a,b,co} dy[n, 2*iy+a+ooy, 2*ix+b+oox, co] * w[ci][co][a][b];  wd = the data-gradient pack [4][Cin][Cout]
+ * of gs_pack_weight(transposed).  LDS-DMA GEMM over K = (sub-pixel class, co); covers power-of-two IH / IW, N*IH*IW % 256 == 0,
+ * Cin % 128 == 0, Cout % 64 == 0, strides / offsets % 8 == 0 -- returns GS_EUNSUPPORTED for other shapes (no error string is
+ * set; run gs_conv_igemm on the 4-tap stride-2 geometry instead). */
+int gs_upconv2x2_dgrad(const void* dy, const void* wd, void* dx, int N, int IH, int IW, int Cin, int Cout, int OH, int OW,
+                       int dy_pix_stride, int dy_coff, int ooy, int oox, int dx_pix_stride, int dx_coff, int dtype,
+                       void* stream);
 
 /* ---- 3x3 / stride 1 / pad 1 convolution with LDS halo reuse (the U-Net DoubleConv hot loop,
  * unet_parts.py:16,19) and its data gradient (pass flipped taps and the [9][Cin][Cout] pack).

@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 GS_F16, GS_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH = 0, 1, 2, 3
 GS_MAX_TAPS = 64
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 
 class GsConvGeom(ctypes.Structure):
@@ -40,6 +40,7 @@ PROTOTYPES = {
     "gs_conv_igemm_batch": (c_int, [c_int, POINTER(POINTER(GsConvGeom)), _P, POINTER(c_void_p), _P, _F, POINTER(c_void_p),
                                     c_int, c_int, _F, c_int64, c_void_p]),
     "gs_upconv2x2_fwd": (c_int, [_P, _P, _F, _P] + [c_int] * 18 + [c_void_p]),
+    "gs_upconv2x2_dgrad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 14 + [c_void_p]),
     "gs_conv3x3_mtiles": (c_int, [c_int, c_int, c_int, c_int]),
     "gs_conv3x3_set_kernel_form": (c_int, [c_int]),
     "gs_conv3d_3x3x3_mtiles": (c_int, [c_int] * 5),
@@ -158,6 +159,9 @@ def load():
         raise RuntimeError(f"libgsseg_hip.so ABI {lib.gs_abi_version()} != binding {ABI_VERSION}: rebuild")
     _lib = lib
     return lib
+
+
+GS_EUNSUPPORTED = -3          # include/gsseg.h GsStatus
 
 
 def check(rc: int, what: str = "") -> None:

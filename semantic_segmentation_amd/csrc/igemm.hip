@@ -897,6 +897,9 @@ extern "C" int gs_conv_igemm_batch(int n, const GsConvGeom* const* g, const void
 static int upconv2x2_impl(const void* x, const void* w, const float* bias, void* y, void* y_lo, int in_wrap, int N, int D,
                           int IH, int IW, int Cin, int in_pix_stride, int in_coff, int Cout, int Dout, int OH, int OW,
                           int out_pix_stride, int out_coff, int ooz, int ooy, int oox, int act, int dtype, void* stream);
+int pw_upconv2x2_fwd_fast(const void* x, const void* w, const float* bias, void* y, int N, int IH, int IW, int Cin,
+                          int in_pix_stride, int in_coff, int Cout, int OH, int OW, int out_pix_stride, int out_coff, int ooy,
+                          int oox, int act, int dtype, void* stream);
 
 extern "C" int gs_upconv2x2_fwd(const void* x, const void* w, const float* bias, void* y, int N, int D, int IH, int IW,
                                 int Cin, int in_pix_stride, int in_coff, int Cout, int Dout, int OH, int OW,
@@ -933,6 +936,13 @@ static int upconv2x2_impl(const void* x, const void* w, const float* bias, void*
                  "gs_upconv2x2_fwd: Cout / output stride / offset must be multiples of 8");
     GS_CHECK_ARG(2 * IH - 1 + ooy < OH && 2 * IW - 1 + oox < OW && (is3d ? 2 * D - 1 + ooz < Dout : (Dout == 1 && ooz == 0)),
                  "gs_upconv2x2_fwd: output patch exceeds the output tensor");
+    if (!is3d && y_lo == nullptr && in_wrap == 0 && in_pix_stride >= in_coff + Cin && ooy >= 0 && oox >= 0) {
+        // LDS-DMA pointwise GEMM (pwgemm.hip) for the shapes it covers; everything else: the generic engine below
+        const int rc = pw_upconv2x2_fwd_fast(x, w, bias, y, N, IH, IW, Cin, in_pix_stride, in_coff, Cout, OH, OW, out_pix_stride,
+                                             out_coff, ooy, oox, act, dtype, stream);
+        if (rc == 1) return GS_OK;
+        if (rc != 0) return GS_ELAUNCH;
+    }
     GsConvGeom g{};
     g.N = N; g.IH = IH; g.IW = IW; g.Cin = Cin; g.in_pix_stride = in_pix_stride; g.in_coff = in_coff;
     g.OHg = IH; g.OWg = IW; g.Cout = ncls * Cout; g.OH = OH; g.OW = OW;

@@ -308,6 +308,24 @@ def upconv2x2_fwd(x, w, bias, y, N, D, IH, IW, Cin, Cout, Dout, OH, OW, in_strid
         TIMER.stop("igemm_fwd", ev, 2.0 * N * D * IH * IW * Cin * ncls * Cout)
 
 
+def upconv2x2_dgrad(geom, dy, wd, dx, N, IH, IW, Cin, Cout, OH, OW, dy_stride, dy_coff, ooy, oox):
+    """Data gradient of ConvTranspose2d(k 2, s 2): the LDS-DMA GEMM over (sub-pixel class, co) where it covers the shape
+    (gs_upconv2x2_dgrad), else the generic engine on `geom` (the 4-tap stride-2 geometry of the same layer).  Both are HIP
+    kernels; dx dense [N, IH, IW, Cin]."""
+    _dev(dy)
+    if not (dy.dtype == wd.dtype == dx.dtype):
+        raise TypeError("upconv2x2_dgrad: dy, wd, dx must share one 16-bit dtype")
+    ev = TIMER.start() if TIMER is not None else None
+    rc = _lib.load().gs_upconv2x2_dgrad(_p(dy), _p(wd), _p(dx), N, IH, IW, Cin, Cout, OH, OW, dy_stride, dy_coff, ooy, oox,
+                                        Cin, 0, dt_code(dy), _stream())
+    if rc == _lib.GS_EUNSUPPORTED:            # shape outside the DMA GEMM: the generic engine (it times itself)
+        return conv_igemm(geom, dy, wd, dx)
+    if rc != 0:
+        _lib.check(rc, "gs_upconv2x2_dgrad")
+    if ev is not None:
+        TIMER.stop("igemm_fwd", ev, 2.0 * N * IH * IW * Cin * 4 * Cout)
+
+
 def conv3d3_eligible(Cin, Cout, out_stride=None, out_coff=0) -> bool:
     """shapes the 3-D halo kernels take (others go through conv_igemm with depth taps)"""
     os_ = Cout if out_stride is None else out_stride

@@ -647,7 +647,7 @@ class UNetEngine:
             ops.conv_wgrad_det(u.geom_wg if u.geom_wg is not None else u.geom_bwd, dcat, u.zin, wg_ws, dw, u.cin, u.cout,
                                4, inv_s)
             dz = empty(N, u.h, u.w, u.cin)
-            ops.conv_igemm(u.geom_bwd, dcat, u.wd, dz)
+            ops.upconv2x2_dgrad(u.geom_bwd, dcat, u.wd, dz, N, u.h, u.w, u.cin, u.cout, u.H2, u.W2, 2 * cout_t, cout_t, u.pt, u.pl)
             emit(wkey, dw)
             emit(prefix + ".up.bias", db)
 

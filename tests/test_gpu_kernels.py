@@ -894,3 +894,64 @@ def test_dma_kernels_repeatable_under_memory_noise():
             else:
                 assert torch.equal(gout, refg), it
         torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dtn,dt", DTS)
+@pytest.mark.parametrize("N,h,w,Cin,Cout,pad", [(2, 8, 16, 128, 64, (0, 0)), (4, 16, 8, 256, 192, (2, 2)), (8, 32, 32, 128, 64, (1, 0)),
+                                                 (1, 16, 16, 384, 128, (0, 0))])
+def test_upconv2x2_dma_gemm_path(dtn, dt, N, h, w, Cin, Cout, pad):
+    """shapes the LDS-DMA pointwise GEMM (csrc/pwgemm.hip) takes -- power-of-two maps, N*h*w % 256 == 0, Cin % 128 == 0,
+    Cout % 64 == 0: several pixel / column tiles, column tiles spanning one, two or four sub-pixel classes, a channel
+    slice as input, F.pad offsets, the skip half of the concat buffer untouched"""
+    from semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(16)
+    H2, W2 = 2 * h + pad[0], 2 * w + pad[1]
+    pt, pl = pad[0] // 2, pad[1] // 2
+    x = rnd(g, N, Cin, h, w, dt=dt)
+    wt = rnd(g, Cin, Cout, 2, 2, dt=dt, scale=0.05)
+    b = rnd(g, Cout)
+    ref = F.pad(F.conv_transpose2d(x, wt, b, stride=2), [pl, pad[1] - pl, pt, pad[0] - pt])
+    wf = torch.empty(4, Cout, Cin, dtype=dt, device=dev())
+    ops.pack_weight(wt.to(dev()), wf, None, True)
+    xin = torch.full((N, h, w, Cin + 24), 7.0, dtype=dt, device=dev())          # poison around the slice
+    xin[..., 8:8 + Cin] = nhwc(x, dt)
+    cat = torch.zeros(N, H2, W2, 2 * Cout, dtype=dt, device=dev())
+    for _ in range(2):
+        ops.upconv2x2_fwd(xin, wf, b.to(dev()), cat, N, 1, h, w, Cin, Cout, 1, H2, W2, in_stride=Cin + 24, in_coff=8,
+                          out_stride=2 * Cout, out_coff=Cout, ooy=pt, oox=pl)
+    torch.cuda.synchronize()
+    got = from_nhwc(cat[..., Cout:])
+    inner = torch.zeros_like(ref, dtype=torch.bool)
+    inner[:, :, pt:pt + 2 * h, pl:pl + 2 * w] = True
+    assert rel_err(got[inner], ref[inner]) < tol(dt)
+    assert float(got[~inner].abs().max() if (~inner).any() else 0.0) == 0.0
+    assert float(cat[..., :Cout].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtn,dt", DTS)
+@pytest.mark.parametrize("N,h,w,Cin,Cout,pad", [(2, 8, 16, 128, 64, (0, 0)), (4, 16, 8, 256, 192, (2, 2)), (8, 32, 32, 128, 64, (1, 0)),
+                                                 (1, 16, 16, 384, 128, (0, 0)), (2, 5, 6, 128, 64, (1, 1))])
+def test_upconv2x2_dgrad(dtn, dt, N, h, w, Cin, Cout, pad):
+    """data gradient of ConvTranspose2d(k2, s2) out of the up half of a concat-gradient buffer: the LDS-DMA GEMM over
+    (sub-pixel class, co) on the shapes it covers (a partial last column tile at Cin = 128 / 384), the generic engine on
+    the rest (last case) -- both through ops.upconv2x2_dgrad"""
+    from semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(17)
+    H2, W2 = 2 * h + pad[0], 2 * w + pad[1]
+    pt, pl = pad[0] // 2, pad[1] // 2
+    x = rnd(g, N, Cin, h, w, dt=dt).requires_grad_(True)
+    wt = rnd(g, Cin, Cout, 2, 2, dt=dt, scale=0.05)
+    dyf = rnd(g, N, Cout, H2, W2, dt=dt)
+    out = F.pad(F.conv_transpose2d(x, wt, None, stride=2), [pl, pad[1] - pl, pt, pad[0] - pt])
+    out.backward(dyf)
+    wf = torch.empty(4, Cout, Cin, dtype=dt, device=dev())
+    wd = torch.empty(4, Cin, Cout, dtype=dt, device=dev())
+    ops.pack_weight(wt.to(dev()), wf, wd, True)
+    dcat = torch.full((N, H2, W2, 2 * Cout), 3.0, dtype=dt, device=dev())          # the skip half must not be read
+    dcat[..., Cout:] = nhwc(dyf, dt)
+    taps = [(py + pt, px + pl) for py in range(2) for px in range(2)]
+    geom = ops.make_geom(N, H2, W2, Cout, h, w, Cin, h, w, taps, isy=2, isx=2, in_stride=2 * Cout, in_coff=Cout)
+    dz = torch.full((N, h, w, Cin), float("nan"), dtype=dt, device=dev())
+    ops.upconv2x2_dgrad(geom, dcat, wd, dz, N, h, w, Cin, Cout, H2, W2, 2 * Cout, Cout, pt, pl)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(dz), x.grad) < tol(dt)
