@@ -1042,7 +1042,7 @@ __device__ __forceinline__ void dma_piece16(const __amdgpu_buffer_rsrc_t& rs, un
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)dst, 16, voff, soff, 0, 0);
 }
 
-template <int DT, int NWV, int KC, bool STATS>
+template <int DT, int NWV, int KC, bool STATS, bool PREC = false>
 __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel(const C3Args a) {
     typedef typename Elem<DT>::V8 V8;
     constexpr int BN = 64, TW = 32, TH = 2 * NWV, TWS = 5;
@@ -1062,7 +1062,9 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
     // item always sits in buffer 1, the next item's first stage is on its way into buffer 0)
     constexpr int H0_OFF = W_B, W1_OFF = W_B + 2 * HALO_B;
     static_assert(2 * STAGE_B * (KC == 16 ? 2 : 1) <= 160 * 1024, "two stages (per resident block) must fit in LDS");
-    static_assert(NWV * STG_EL * 2 + NWV * 2 * BN * 4 <= HALO_B + W_B, "epilogue staging overlays the second stage buffer");
+    // PREC (precise mode): K is a concatenation of segments over the same input channels (stage c reads
+    // input chunk c mod wrap) and the result leaves as a hi / lo pair (a second staging area and store stream)
+    static_assert((PREC ? 2 : 1) * NWV * STG_EL * 2 + NWV * 2 * BN * 4 <= HALO_B + W_B, "epilogue staging overlays the second stage buffer");
     static_assert(NWP + HJ <= NSTEP && HJ + 1 <= NSTEP, "one DMA piece / one next-item offset per MFMA step");
     static_assert(NWV % WG == 0, "a wave's weight pieces all belong to one row group");
     static_assert(WP % NWV == 0 || HI < HJ * NWV, "a surplus weight slot parks its (empty) piece in the spare halo piece");
@@ -1140,6 +1142,7 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
     auto stage_src = [&](int n, int c) __attribute__((always_inline)) {
         Src r;
         r.n = n; r.sc = (unsigned)c * ROWB; r.wsc = r.sc; r.hkill = 0u;
+        if (PREC && a.in_wrap > 0 && c >= 2 * a.in_wrap) r.sc = (unsigned)(c - 2 * a.in_wrap) * ROWB;    // in_wrap counts 64-channel chunks
         if (a.ndz > 1) {
             const int dzi = c / nchunk, cc = c - dzi * nchunk;
             const int dz = a.tap_dz[dzi];
@@ -1265,7 +1268,8 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
 
     // ---- epilogue: as conv3x3_big_kernel (staging overlays the second stage buffer, which the last stage has just left) ----
     unsigned short* stg = reinterpret_cast<unsigned short*>(smem + H0_OFF + HALO_B) + wave * STG_EL;
-    float* red = reinterpret_cast<float*>(smem + H0_OFF + HALO_B + NWV * STG_EL * 2);  // [NWV][2][64]
+    unsigned short* stg_lo = stg + NWV * STG_EL;                                        // PREC: the lo halves
+    float* red = reinterpret_cast<float*>(smem + H0_OFF + HALO_B + (PREC ? 2 : 1) * NWV * STG_EL * 2);  // [NWV][2][64]
     const bool odd = lane & 1;
     const unsigned int psel = odd ? 0x03020706u : 0x05040100u;
     const float neg_slope = act == GS_ACT_RELU ? 0.f : (act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
@@ -1276,6 +1280,8 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
         asm volatile("" : "+s"(e_y0), "+s"(e_x0), "+s"(e_n), "+s"(e_n0));
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(a.y + (int64_t)e_n * a.H * a.W * a.out_stride), 0, (unsigned)a.H * a.W * a.out_stride * 2u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ry_lo = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((PREC ? a.y_lo : a.y) + (int64_t)e_n * a.H * a.W * a.out_stride), 0, (unsigned)a.H * a.W * a.out_stride * 2u, 0x00020000);
         float bv[2] = {0.f, 0.f};
         if (!PLAIN) {
 #pragma unroll
@@ -1325,6 +1331,14 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
                     const unsigned int pk = __builtin_amdgcn_perm(oth, own, psel);
                     const int row = rowa + (odd ? 1 : 0);
                     *reinterpret_cast<unsigned int*>(stg + row * C3_LDR + j * 32 + (l31 & ~1)) = pk;
+                    if (PREC) {                               // lo = 16-bit(value - hi): the pair carries ~22 bits
+                        const float l0 = v0 - Elem<DT>::to_f((unsigned short)(own & 0xffffu));
+                        const float l1 = v1 - Elem<DT>::to_f((unsigned short)(own >> 16));
+                        const unsigned int own_l = Elem<DT>::pack2(l0, l1);
+                        const unsigned int oth_l = dpp_xor1(own_l);
+                        const unsigned int pk_l = __builtin_amdgcn_perm(oth_l, own_l, psel);
+                        *reinterpret_cast<unsigned int*>(stg_lo + row * C3_LDR + j * 32 + (l31 & ~1)) = pk_l;
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -1342,6 +1356,12 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
                 u32x4 d;
                 d[0] = sv[q].x; d[1] = sv[q].y; d[2] = sv[q].z; d[3] = sv[q].w;
                 __builtin_amdgcn_raw_buffer_store_b128(d, ry, off, 0, 0);
+                if (PREC) {
+                    const uint4 lv = *reinterpret_cast<const uint4*>(stg_lo + (q * 8 + (lane >> 3)) * C3_LDR + (lane & 7) * 8);
+                    u32x4 dl;
+                    dl[0] = lv.x; dl[1] = lv.y; dl[2] = lv.z; dl[3] = lv.w;
+                    __builtin_amdgcn_raw_buffer_store_b128(dl, ry_lo, off, 0, 0);
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -1572,6 +1592,40 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
         a.xcd_order = (xcd_env && (bgrid.x % 8) == 0 && a.ntn > 1 && (int64_t)N * H * W > (int64_t)18 * Cout) ? 1 : 0;
         hipStream_t bs = (hipStream_t)stream;
         const bool wres = (Cin <= 64 && a.ntn == 1 && ndz == 1);   // one stage, one N tile: weights stay resident in LDS
+        static const int prec_dma_env = getenv("GSSEG_C3_PREC_DMA") ? atoi(getenv("GSSEG_C3_PREC_DMA")) : 1;
+        if (prec && prec_dma_env != 0 && c3_dma_form.load(std::memory_order_relaxed) != 0 && tw == 32 && Cin % 64 == 0) {
+            bool std_taps = true;
+            for (int i = 0; i < 9; ++i) std_taps = std_taps && tap_dy[i] == i / 3 - 1 && tap_dx[i] == i % 3 - 1;
+            if (std_taps) {
+                // the precise forward on the LDS-DMA kernel: same form choice as the default mode
+                const int64_t items4 = (int64_t)N * a.tiles_x * cdiv(H, 8) * a.ntn, items8 = (int64_t)N * a.tiles_x * cdiv(H, 16) * a.ntn;
+                const double cost4 = 0.98 * (double)((items4 + big_blocks - 1) / big_blocks);
+                const double cost8 = 0.87 * 2.0 * (double)((items8 + big_blocks - 1) / big_blocks);
+                const int forced = c3_dma_form.load(std::memory_order_relaxed);
+                const int waves = (forced == 4 || forced == 8) ? forced : (cost8 <= cost4 ? 8 : 4);
+                if (waves == 8) {
+                    a.tiles_y = cdiv(H, 16);
+                    a.nblocks = N * a.tiles_x * a.tiles_y * a.ntn;
+                }
+                dim3 dgrid(a.nblocks < big_blocks ? a.nblocks : big_blocks);
+                a.xcd_order = (xcd_env && (dgrid.x % 8) == 0 && a.ntn > 1 && (int64_t)N * H * W > (int64_t)18 * Cout) ? 1 : 0;
+#define C3_DMA_PREC(DT)                                                                                      \
+    do {                                                                                                     \
+        if (bn_partials != nullptr) {                                                                        \
+            if (waves == 8) conv3x3_dma_kernel<DT, 8, 32, true, true><<<dgrid, 512, 0, bs>>>(a);             \
+            else conv3x3_dma_kernel<DT, 4, 32, true, true><<<dgrid, 256, 0, bs>>>(a);                        \
+        } else {                                                                                             \
+            if (waves == 8) conv3x3_dma_kernel<DT, 8, 32, false, true><<<dgrid, 512, 0, bs>>>(a);            \
+            else conv3x3_dma_kernel<DT, 4, 32, false, true><<<dgrid, 256, 0, bs>>>(a);                       \
+        }                                                                                                    \
+    } while (0)
+                if (dtype == GS_F16) C3_DMA_PREC(GS_F16);
+                else C3_DMA_PREC(GS_BF16);
+#undef C3_DMA_PREC
+                GS_CHECK_LAUNCH("gs_conv3x3_precise");
+                return GS_OK;
+            }
+        }
         if (prec) {
             if (dtype == GS_F16) {
                 if (tw == 32) conv3x3_big_kernel<GS_F16, 32, false, true><<<bgrid, 256, 0, bs>>>(a);
