@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 29
+#define GS_ABI_VERSION 30
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -246,6 +246,17 @@ int gs_colsum(const void* t, int pix_stride, int coff, int N, int H, int W, int 
  * OVERWRITING grad. */
 int gs_pack_weight(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int taps, int transposed,
                    int dtype, void* stream);
+
+/* The same packs for several conv weights in ONE launch (3x3 convs: taps = 9, k2/s2 transposed convs: taps = 4): a training
+ * step re-packs every conv weight of the network after the optimiser step (unet/unet_model.py: 18 + 4 tensors); 22 launches of
+ * a few microseconds each were launch-bound.  w_fwd or w_dgrad may be NULL. */
+typedef struct GsPackDesc {
+    const float* w;     /* fp32 parameter in the reference layout */
+    void* w_fwd;        /* [taps][Cout][Cin] 16-bit, or NULL */
+    void* w_dgrad;      /* [taps][Cin][Cout] 16-bit, or NULL */
+    int32_t Cout, Cin, taps, transposed;
+} GsPackDesc;
+int gs_pack_weight_multi(int n, const GsPackDesc* descs, int dtype, void* stream);
 int gs_unpack_wgrad(const float* dw, float* grad, int A, int B, int taps, int transposed, float gscale, void* stream);
 
 /* Fake-image post-processing of the Unet step (running_files/train_end2end_jsrt.py:197-200): global min-max scaling to

@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 GS_F16, GS_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH = 0, 1, 2, 3
 GS_MAX_TAPS = 64
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 
 class GsConvGeom(ctypes.Structure):
@@ -30,6 +30,11 @@ class GsConvGeom(ctypes.Structure):
 
 
 # name -> (restype, argtypes): exactly the declarations of include/gsseg.h
+class GsPackDesc(ctypes.Structure):
+    _fields_ = [("w", c_void_p), ("w_fwd", c_void_p), ("w_dgrad", c_void_p)] + [
+        (n, c_int32) for n in ("Cout", "Cin", "taps", "transposed")]
+
+
 _P, _F = c_void_p, c_void_p   # device pointers are passed as integers
 PROTOTYPES = {
     "gs_last_error": (c_char_p, []),
@@ -92,6 +97,7 @@ PROTOTYPES = {
     "gs_maxpool3d_bwd": (c_int, [_P, c_int, c_int, _P, _P, c_int, c_int, _P] + [c_int] * 6 + [c_void_p]),
     "gs_colsum": (c_int, [_P, c_int, c_int] + [c_int] * 8 + [c_float, _F, _F, c_int, c_void_p]),
     "gs_pack_weight": (c_int, [_F, _P, _P, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "gs_pack_weight_multi": (c_int, [c_int, POINTER(GsPackDesc), c_int, c_void_p]),
     "gs_unpack_wgrad": (c_int, [_F, _F, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "gs_upconv_merge_pack": (c_int, [_F, _F, _F, _F, _P, _P, _F, c_int, c_int, c_int, c_void_p]),
     "gs_fake_postprocess_ws_floats": (c_int64, [c_int]),

@@ -48,6 +48,46 @@ __global__ __launch_bounds__(256) void pack_weight_rows_kernel(const float* __re
     }
 }
 
+// All conv weights of a network in ONE launch (a U-Net step re-packs 21 tensors after every optimiser step: 21 launches of
+// 5-8 us each were launch-bound).  Descriptor d owns blocks [first[d], first[d+1]); inside, the row-wise scheme above.
+constexpr int PACK_MULTI_MAX = 32;
+struct PackMultiArgs {
+    const float* w[PACK_MULTI_MAX];
+    unsigned short* p_ab[PACK_MULTI_MAX];
+    unsigned short* p_ba[PACK_MULTI_MAX];
+    int A[PACK_MULTI_MAX], B[PACK_MULTI_MAX], T[PACK_MULTI_MAX], first[PACK_MULTI_MAX + 1];
+    int n;
+};
+
+template <int DT, int T>
+__device__ __forceinline__ void pack_rows_body(const float* __restrict__ w, unsigned short* dst, int A, int B, bool ba,
+                                               int block, int nblocks) {
+    const int64_t n = (int64_t)A * B;
+    for (int64_t i = (int64_t)block * 256 + threadIdx.x; i < n; i += (int64_t)nblocks * 256) {
+        int a, b;
+        if (!ba) { b = (int)(i % B); a = (int)(i / B); }
+        else { a = (int)(i % A); b = (int)(i / A); }
+        const float* src = w + ((int64_t)a * B + b) * T;
+        float v[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) v[t] = src[t];
+#pragma unroll
+        for (int t = 0; t < T; ++t) dst[(int64_t)t * n + i] = Elem<DT>::from_f(v[t]);
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackMultiArgs a) {
+    int d = 0;
+    while (d + 1 < a.n && (int)blockIdx.x >= a.first[d + 1]) ++d;
+    const bool ba = blockIdx.y == 1;
+    unsigned short* dst = ba ? a.p_ba[d] : a.p_ab[d];
+    if (dst == nullptr) return;
+    const int block = blockIdx.x - a.first[d], nblocks = a.first[d + 1] - a.first[d];
+    if (a.T[d] == 9) pack_rows_body<DT, 9>(a.w[d], dst, a.A[d], a.B[d], ba, block, nblocks);
+    else pack_rows_body<DT, 4>(a.w[d], dst, a.A[d], a.B[d], ba, block, nblocks);
+}
+
 __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ dw, float* __restrict__ grad,
                                                            int A, int B, int T, int transposed, float gscale) {
     const int64_t total = (int64_t)A * B * T;
@@ -133,6 +173,39 @@ extern "C" int gs_pack_weight(const float* w, void* w_fwd, void* w_dgrad, int Co
                                                                      Cout, Cin, taps, transposed);
     else GS_CHECK_ARG(false, "gs_pack_weight: bad dtype");
     GS_CHECK_LAUNCH("gs_pack_weight");
+    return GS_OK;
+}
+
+extern "C" int gs_pack_weight_multi(int n, const GsPackDesc* descs, int dtype, void* stream) {
+    GS_CHECK_ARG(n > 0 && descs != nullptr, "gs_pack_weight_multi: no descriptors");
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_pack_weight_multi: bad dtype");
+    hipStream_t s = (hipStream_t)stream;
+    for (int base = 0; base < n; base += PACK_MULTI_MAX) {
+        PackMultiArgs a;
+        a.n = n - base < PACK_MULTI_MAX ? n - base : PACK_MULTI_MAX;
+        int blocks = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const GsPackDesc& d = descs[base + i];
+            GS_CHECK_ARG(d.w && (d.w_fwd || d.w_dgrad) && d.Cout > 0 && d.Cin > 0 && (d.taps == 9 || d.taps == 4),
+                         "gs_pack_weight_multi: descriptor %d: needs w, a pack, positive dims and 9 or 4 taps", base + i);
+            // source [A][B][T]: Conv2d A=Cout,B=Cin (P_ab = fwd pack, P_ba = dgrad pack); ConvTranspose2d A=Cin,B=Cout
+            a.w[i] = d.w;
+            a.A[i] = d.transposed ? d.Cin : d.Cout;
+            a.B[i] = d.transposed ? d.Cout : d.Cin;
+            a.T[i] = d.taps;
+            a.p_ab[i] = (unsigned short*)(d.transposed ? d.w_dgrad : d.w_fwd);
+            a.p_ba[i] = (unsigned short*)(d.transposed ? d.w_fwd : d.w_dgrad);
+            a.first[i] = blocks;
+            int b = ew_blocks((int64_t)a.A[i] * a.B[i]);
+            if (b > 512) b = 512;
+            blocks += b;
+        }
+        a.first[a.n] = blocks;
+        dim3 grid(blocks, 2);
+        if (dtype == GS_F16) pack_weight_multi_kernel<GS_F16><<<grid, 256, 0, s>>>(a);
+        else pack_weight_multi_kernel<GS_BF16><<<grid, 256, 0, s>>>(a);
+        GS_CHECK_LAUNCH("gs_pack_weight_multi");
+    }
     return GS_OK;
 }
 

@@ -683,6 +683,26 @@ def pack_weight(w, w_fwd, w_dgrad, transposed: bool):
     _lib.call("gs_pack_weight", _p(w), _p(w_fwd), _p(w_dgrad), Cout, Cin, taps, int(transposed), dt_code(ref), _stream())
 
 
+def pack_weight_multi(items):
+    """items: (w, w_fwd, w_dgrad, transposed) tuples as for pack_weight (3x3 convs and k2/s2 transposed convs): one launch."""
+    if not items:
+        return
+    descs = (_lib.GsPackDesc * len(items))()
+    ref = None
+    for d, (w, w_fwd, w_dgrad, transposed) in zip(descs, items):
+        _dev(w)
+        _f32(w, "weight")
+        r = w_fwd if w_fwd is not None else w_dgrad
+        if ref is None:
+            ref = r
+        elif r.dtype != ref.dtype:
+            raise TypeError("pack_weight_multi: all packs must share one 16-bit dtype")
+        cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+        d.w, d.w_fwd, d.w_dgrad = _p(w), _p(w_fwd), _p(w_dgrad)
+        d.Cout, d.Cin, d.taps, d.transposed = cout, cin, w.shape[2] * w.shape[3], int(transposed)
+    _lib.call("gs_pack_weight_multi", len(items), descs, dt_code(ref), _stream())
+
+
 def unpack_wgrad(dw, grad, A, B, taps, transposed: bool, gscale):
     _f32(dw, "dw"); _f32(grad, "grad")
     _lib.call("gs_unpack_wgrad", _p(dw), _p(grad), A, B, taps, int(transposed), float(gscale), _stream())

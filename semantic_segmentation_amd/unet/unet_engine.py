@@ -109,6 +109,36 @@ class UNetEngine:
         """Drop the cached 16-bit weight packs (they are otherwise reused until a Parameter changes)."""
         self._packs.clear()
 
+    def _prepack(self, params: Dict[str, torch.Tensor], need_dgrad: bool):
+        """Re-pack every stale 3x3 / k2-s2 conv weight of the network in ONE launch (after an optimiser step all of them are
+        stale: 21 pack launches of 5-8 us each were launch-bound); _packed() below then finds them cached."""
+        items, fresh = [], []
+        for name, w in params.items():
+            if not name.endswith(".weight") or w.dim() != 4:
+                continue
+            transposed = name.endswith(".up.weight")
+            if transposed:
+                if tuple(w.shape[2:]) != (2, 2):
+                    continue
+                cin, cout = w.shape[0], w.shape[1]
+            else:
+                if tuple(w.shape[2:]) != (3, 3) or w.shape[1] % 8 != 0:      # the image-end layer is not packed
+                    continue
+                cout, cin = w.shape[0], w.shape[1]
+            key = _pack_key(w)
+            ent = self._packs.get(name)
+            if ent is not None and ent[0] == key and (ent[2] is not None or not need_dgrad):
+                continue
+            taps = w.shape[2] * w.shape[3]
+            wf = torch.empty((taps, cout, cin), dtype=self.tdt, device=w.device)
+            wd = torch.empty((taps, cin, cout), dtype=self.tdt, device=w.device) if need_dgrad else None
+            items.append((w.detach(), wf, wd, transposed))
+            fresh.append((name, key, wf, wd))
+        if len(items) > 1:
+            ops.pack_weight_multi(items)
+            for name, key, wf, wd in fresh:
+                self._packs[name] = (key, wf, wd)
+
     def _packed(self, name: str, w: torch.Tensor, transposed: bool, need_dgrad: bool):
         """16-bit K-major packs of a conv weight, cached until the Parameter is modified."""
         key = _pack_key(w)
@@ -168,6 +198,8 @@ class UNetEngine:
         ws_ = [W >> i for i in range(5)]
         bilinear = bool(net.bilinear)
         C = [64, 128, 256, 512, 1024 // (2 if bilinear else 1)]      # unet_model.py:18-19
+        if training or need_grad:
+            self._prepack(params, need_grad)                          # every stale weight pack in one launch
 
         def empty(*shape, dtype=tdt):
             return torch.empty(shape, dtype=dtype, device=dev)

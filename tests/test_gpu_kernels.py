@@ -955,3 +955,32 @@ def test_upconv2x2_dgrad(dtn, dt, N, h, w, Cin, Cout, pad):
     ops.upconv2x2_dgrad(geom, dcat, wd, dz, N, h, w, Cin, Cout, H2, W2, 2 * Cout, Cout, pt, pl)
     torch.cuda.synchronize()
     assert rel_err(from_nhwc(dz), x.grad) < tol(dt)
+
+
+@pytest.mark.parametrize("dtn,dt", DTS)
+def test_pack_weight_multi_matches_single(dtn, dt):
+    """gs_pack_weight_multi (all stale conv weights of a network in one launch) == gs_pack_weight per tensor, bit for bit:
+    3x3 convs and k2/s2 transposed convs of mixed sizes, with and without the data-gradient pack"""
+    from semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(21)
+    shapes = [((64, 64, 3, 3), False), ((128, 64, 3, 3), False), ((72, 40, 3, 3), False), ((256, 128, 2, 2), True),
+              ((1024, 512, 2, 2), True), ((512, 1024, 3, 3), False)]
+    items, singles = [], []
+    for k, (shp, tr) in enumerate(shapes):
+        w = torch.randn(*shp, generator=g).to(dev())
+        cin, cout = (shp[0], shp[1]) if tr else (shp[1], shp[0])
+        taps = shp[2] * shp[3]
+        need_d = k % 3 != 1
+        wf = torch.full((taps, cout, cin), 7.0, dtype=dt, device=dev())
+        wd = torch.full((taps, cin, cout), 7.0, dtype=dt, device=dev()) if need_d else None
+        wf1 = torch.empty_like(wf)
+        wd1 = torch.empty_like(wd) if need_d else None
+        ops.pack_weight(w, wf1, wd1, tr)
+        items.append((w, wf, wd, tr))
+        singles.append((wf1, wd1))
+    ops.pack_weight_multi(items)
+    torch.cuda.synchronize()
+    for (w, wf, wd, tr), (wf1, wd1) in zip(items, singles):
+        assert torch.equal(wf, wf1)
+        if wd is not None:
+            assert torch.equal(wd, wd1)
