@@ -1042,10 +1042,16 @@ __device__ __forceinline__ void dma_piece16(const __amdgpu_buffer_rsrc_t& rs, un
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)dst, 16, voff, soff, 0, 0);
 }
 
-template <int DT, int NWV, int KC, bool STATS, bool PREC = false>
-__global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel(const C3Args a) {
+// NB = 2 (8 waves, 16-channel stages): 128 couts per item, every wave 64 pixels x 128 couts -- 8 MFMAs per six fragment reads
+// instead of 4 per four, and the weights are fetched once per 512 pixels x 128 couts: 97 B of DMA and 0.75 KB of LDS reads per
+// MFMA instead of 133 B and 1 KB.  Built because the ablation (tools/_dma_ablate.py) shows the deep layers 28-31 % faster
+// with the DMA pieces switched off; measured 2-3 % SLOWER than NB = 1 (245-256 VGPRs, a few spills with the statistics
+// epilogue, one step of fragment prefetch = 8 MFMAs): kept selectable, not the default.
+template <int DT, int NWV, int KC, bool STATS, bool PREC = false, int NB = 1>
+__global__ __launch_bounds__(64 * NWV, (KC == 16 && NB == 1) ? 2 : 1) void conv3x3_dma_kernel(const C3Args a) {
     typedef typename Elem<DT>::V8 V8;
-    constexpr int BN = 64, TW = 32, TH = 2 * NWV, TWS = 5;
+    constexpr int BN = 64 * NB, TW = 32, TH = 2 * NWV, TWS = 5;
+    static_assert(NB == 1 || (KC == 16 && NWV == 8 && !PREC), "the 128-cout form: 8 waves, 16-channel stages");
     constexpr int HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;
     constexpr int ROWB = KC * 2;                           // bytes per LDS row (one pixel / one cout, KC channels)
     constexpr int SPR = ROWB / 16, RPP = 64 / SPR;         // 16-byte slots per row, rows per 1-KiB piece
@@ -1061,7 +1067,7 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
     // LDS: [weights 0 | halo 0 | halo 1 | weights 1]; the epilogue staging overlays halo 1 + weights 1 (the last stage of an
     // item always sits in buffer 1, the next item's first stage is on its way into buffer 0)
     constexpr int H0_OFF = W_B, W1_OFF = W_B + 2 * HALO_B;
-    static_assert(2 * STAGE_B * (KC == 16 ? 2 : 1) <= 160 * 1024, "two stages (per resident block) must fit in LDS");
+    static_assert(2 * STAGE_B * ((KC == 16 && NB == 1) ? 2 : 1) <= 160 * 1024, "two stages (per resident block) must fit in LDS");
     // PREC (precise mode): K is a concatenation of segments over the same input channels (stage c reads
     // input chunk c mod wrap) and the result leaves as a hi / lo pair (a second staging area and store stream)
     static_assert((PREC ? 2 : 1) * NWV * STG_EL * 2 + NWV * 2 * BN * 4 <= HALO_B + W_B, "epilogue staging overlays the second stage buffer");
@@ -1128,11 +1134,11 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
             const int slot = flip ? 8 - tap : tap;
             const unsigned dst = real ? (unsigned)(pc * 1024) + bb * W1_OFF
                                       : (unsigned)(H0_OFF + HALO_B - 1024) + bb * HALO_B;
-            dma_piece16(w_rsrc, smem + dst, real ? (wv | kill) : VOOB, (unsigned)(real ? slot : 0) * tap_stride + wsc);
+            dma_piece16(w_rsrc, smem + dst, (real && !(dbg & 8)) ? (wv | kill) : VOOB, (unsigned)(real ? slot : 0) * tap_stride + wsc);   // dbg 8: ablation, no weight traffic
         } else if (k - NWP < HJ) {
             const int j = k - NWP < HJ ? k - NWP : 0;
             const unsigned dst = H0_OFF + bb * HALO_B + (unsigned)(wave + j * NWV) * 1024u;
-            dma_piece16(rx, smem + dst, hv[j] | kill | hkill, sc);
+            dma_piece16(rx, smem + dst, (dbg & 16) ? VOOB : (hv[j] | kill | hkill), sc);                 // dbg 16: no halo traffic
         }
     };
     // stage c of an item in slice n: 2-D: channel chunk c; Conv3d: (depth tap c / nchunk, chunk c % nchunk) reads slice n + dz
@@ -1184,12 +1190,12 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
         }
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][2 * NB];
     auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2 * NB; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     };
@@ -1201,10 +1207,10 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
         const unsigned sc_n = sn.sc, wsc_n = sn.wsc, hkill_n = sn.hkill;
         constexpr int BUF = decltype(buf_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value;
-        constexpr unsigned NB = 1 - BUF;
+        constexpr unsigned OBUF = 1 - BUF;           // the buffer the next stage is fetched into
         if (dbg & 2) {                                     // ablation: DMA traffic only
 #pragma unroll
-            for (int k = 0; k < NWP + HJ; ++k) issue_piece(k, rx_n, sc_n, wsc_n, NB, hkill_n, kill);
+            for (int k = 0; k < NWP + HJ; ++k) issue_piece(k, rx_n, sc_n, wsc_n, OBUF, hkill_n, kill);
             if (BUF == 0) {
 #pragma unroll
                 for (int j = 0; j < HJ; ++j) hvn[j] = halo_voff(itn.y0, itn.x0, j);
@@ -1213,21 +1219,27 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
             if (FIRST) zero_acc();
             return;
         }
-        V8 af[2][2], bf[2][2];
-        auto frag_load = [&](int step, V8 (&fa)[2], V8 (&fb)[2]) __attribute__((always_inline)) {
+        V8 af[2][2], bf[2][2 * NB];
+        auto frag_load = [&](int step, V8 (&fa)[2], V8 (&fb)[2 * NB]) __attribute__((always_inline)) {
             const int tap = step / KSTEPS, kh = step % KSTEPS;
             const int dyi = tap / 3, dxi = tap - 3 * dyi;
             fa[0] = *reinterpret_cast<const V8*>(smem + aaddr[kh][dyi][dxi] + BUF * HALO_B);
-            fb[0] = *reinterpret_cast<const V8*>(smem + baddr[BUF][kh] + tap * (64 * ROWB));
+            fb[0] = *reinterpret_cast<const V8*>(smem + baddr[BUF][kh] + tap * (BN * ROWB));
             fa[1] = *reinterpret_cast<const V8*>(smem + aaddr[kh][dyi + 1][dxi] + BUF * HALO_B);
-            fb[1] = *reinterpret_cast<const V8*>(smem + baddr[BUF][kh] + tap * (64 * ROWB) + 32 * ROWB);
+            fb[1] = *reinterpret_cast<const V8*>(smem + baddr[BUF][kh] + tap * (BN * ROWB) + 32 * ROWB);
+            if (NB == 2) {
+                fb[2 * NB - 2] = *reinterpret_cast<const V8*>(smem + baddr[BUF][kh] + tap * (BN * ROWB) + 64 * ROWB);
+                fb[2 * NB - 1] = *reinterpret_cast<const V8*>(smem + baddr[BUF][kh] + tap * (BN * ROWB) + 96 * ROWB);
+            }
         };
         frag_load(0, af[0], bf[0]);
 #pragma unroll
         for (int step = 0; step < NSTEP; ++step) {
             const int cur = step & 1;
             if (step + 1 < NSTEP) frag_load(step + 1, af[cur ^ 1], bf[cur ^ 1]);
-            issue_piece(step, rx_n, sc_n, wsc_n, NB, hkill_n, kill);
+            // (two pieces per step, i.e. everything issued in the first half of the stage, measured the same or 1 % slower
+            // on the deep layers: the pieces are not late)
+            issue_piece(step, rx_n, sc_n, wsc_n, OBUF, hkill_n, kill);
             if (BUF == 0 && step <= HJ) {                  // the next item's piece offsets, one slot per step
                 int py0 = itn.y0, px0 = itn.x0, pn0 = itn.n0;
                 asm volatile("" : "+s"(py0), "+s"(px0), "+s"(pn0));      // keeps this arithmetic in the step (else hoisted to the item boundary)
@@ -1235,7 +1247,7 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
                 else wvn = weight_voff(pn0);
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2 * NB; ++j)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     if (FIRST && step == 0) {
@@ -1248,10 +1260,11 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
                     }
                 }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 2 + 2 * NB; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // one LDS fragment read in its shadow
             }
+            if (NB == 2) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);           // the DMA piece of this step
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1269,7 +1282,7 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
     // ---- epilogue: as conv3x3_big_kernel (staging overlays the second stage buffer, which the last stage has just left) ----
     unsigned short* stg = reinterpret_cast<unsigned short*>(smem + H0_OFF + HALO_B) + wave * STG_EL;
     unsigned short* stg_lo = stg + NWV * STG_EL;                                        // PREC: the lo halves
-    float* red = reinterpret_cast<float*>(smem + H0_OFF + HALO_B + (PREC ? 2 : 1) * NWV * STG_EL * 2);  // [NWV][2][64]
+    float* red = reinterpret_cast<float*>(smem + H0_OFF + HALO_B + (PREC ? 2 : 1) * NWV * STG_EL * 2);  // [NWV][2][BN]
     const bool odd = lane & 1;
     const unsigned int psel = odd ? 0x03020706u : 0x05040100u;
     const float neg_slope = act == GS_ACT_RELU ? 0.f : (act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
@@ -1282,16 +1295,19 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
             (void*)(a.y + (int64_t)e_n * a.H * a.W * a.out_stride), 0, (unsigned)a.H * a.W * a.out_stride * 2u, 0x00020000);
         const __amdgpu_buffer_rsrc_t ry_lo = __builtin_amdgcn_make_buffer_rsrc(
             (void*)((PREC ? a.y_lo : a.y) + (int64_t)e_n * a.H * a.W * a.out_stride), 0, (unsigned)a.H * a.W * a.out_stride * 2u, 0x00020000);
+        constexpr bool want_stats = STATS;              // BatchNorm partial sums: a template flag (no per-element selects)
+#pragma unroll
+      for (int jj = 0; jj < NB; ++jj) {                  // one 64-cout half of the item at a time
+        const int e_nj = e_n0 + jj * 64;
         float bv[2] = {0.f, 0.f};
         if (!PLAIN) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int co = e_n0 + j * 32 + l31;
+                const int co = e_nj + j * 32 + l31;
                 bv[j] = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
             }
         }
         float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-        constexpr bool want_stats = STATS;              // BatchNorm partial sums: a template flag (no per-element selects)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int prow0 = (wave * 2 + i) * 32;
@@ -1309,7 +1325,7 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    float v0 = acc[i][j][r0], v1 = acc[i][j][r0 + 1];
+                    float v0 = acc[i][2 * jj + j][r0], v1 = acc[i][2 * jj + j][r0 + 1];
                     if (want_stats) {
                         if (FULL) {
                             s1[j] += v0 + v1;
@@ -1350,7 +1366,7 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
             for (int q = 0; q < 4; ++q) {
                 const int p = prow0 + q * 8 + (lane >> 3);
                 const int gy = e_y0 + (p >> TWS), gx = e_x0 + (p & (TW - 1));
-                const int co = e_n0 + (lane & 7) * 8;
+                const int co = e_nj + (lane & 7) * 8;
                 const bool ok = (FULL || (gy < a.H && gx < a.W)) && co < a.Cout;
                 const unsigned off = ok ? (unsigned)(((gy * a.W + gx) * a.out_stride + a.out_coff + co) * 2) : VOOB;
                 u32x4 d;
@@ -1371,11 +1387,12 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
                 s1[j] += __shfl_xor(s1[j], 32, 64);
                 s2[j] += __shfl_xor(s2[j], 32, 64);
                 if (h == 0) {
-                    red[(wave * 2 + 0) * BN + j * 32 + l31] = s1[j];
-                    red[(wave * 2 + 1) * BN + j * 32 + l31] = s2[j];
+                    red[(wave * 2 + 0) * BN + jj * 64 + j * 32 + l31] = s1[j];
+                    red[(wave * 2 + 1) * BN + jj * 64 + j * 32 + l31] = s2[j];
                 }
             }
         }
+      }
     };
     const bool plain = (a.bias == nullptr && act == GS_ACT_NONE);
     auto epilogue = [&](const Item& itc) __attribute__((always_inline)) {
@@ -1387,7 +1404,7 @@ __global__ __launch_bounds__(64 * NWV, KC == 16 ? 2 : 1) void conv3x3_dma_kernel
     auto finish_stats = [&](const Item& itc) __attribute__((always_inline)) {
         constexpr int NH = NWV / 4;
         if (STATS && t < NH * BN) {
-            const int half = t >> 6, c = t & 63;
+            const int half = t / BN, c = t % BN;
             if (itc.n0 + c < a.Cout && (itc.y0 >> 3) + half < tiles_y8) {
                 float v1 = 0.f, v2 = 0.f;
 #pragma unroll
@@ -1511,9 +1528,17 @@ C3Plan c3_plan(int H, int W, int Cout) {
 static std::atomic<int> c3_dma_form{getenv("GSSEG_C3_DMA") ? atoi(getenv("GSSEG_C3_DMA")) : -1};
 
 extern "C" int gs_conv3x3_set_kernel_form(int form) {
-    GS_CHECK_ARG(form == -1 || form == 0 || form == 2 || form == 4 || form == 8, "gs_conv3x3_set_kernel_form: form must be -1, 0, 2, 4 or 8");
+    GS_CHECK_ARG(form == -1 || form == 0 || form == 2 || form == 4 || form == 8 || form == 16,
+                 "gs_conv3x3_set_kernel_form: form must be -1, 0, 2, 4, 8 or 16");
     c3_dma_form.store(form, std::memory_order_relaxed);
     return GS_OK;
+}
+
+// the 128-cout form (16) is not chosen automatically: measured 4.55-4.57 ms against 4.43-4.47 for the 64-cout 8-wave form over
+// the 13 layer shapes (GSSEG_C3_WIDE=1 or gs_conv3x3_set_kernel_form(16) select it)
+static bool c3_wide_auto() {
+    static const int v = getenv("GSSEG_C3_WIDE") ? atoi(getenv("GSSEG_C3_WIDE")) : 0;
+    return v != 0;
 }
 
 static int c3_variant() {          // 0 = v1 one patch per block, 1 = persistent (v2), 2 = big K-step (v3)
@@ -1652,9 +1677,17 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
             const double cost4 = 0.98 * (double)((items4 + big_blocks - 1) / big_blocks);
             const double cost8 = 0.87 * 2.0 * (double)((items8 + big_blocks - 1) / big_blocks);
             dma_waves = (dma_env == 4 || dma_env == 8 || dma_env == 2) ? dma_env : (cost8 <= cost4 ? 8 : 4);   // 2: two 4-wave blocks per CU
+            // 16: the 8-wave form with 128 couts per item (16-channel stages) where the layer has them
+            if ((dma_env == 16 || (dma_env == -1 && dma_waves == 8 && c3_wide_auto())) && Cout % 128 == 0) {
+                const int64_t items16 = (int64_t)N * a.tiles_x * cdiv(H, 16) * (Cout / 128);
+                if (dma_env == 16 || items16 >= big_blocks) dma_waves = 16;
+            } else if (dma_env == 16) {
+                dma_waves = 8;
+            }
         }
         if (dma_waves != 0) {
-            if (dma_waves == 8) {
+            if (dma_waves == 16) a.ntn = Cout / 128;
+            if (dma_waves == 8 || dma_waves == 16) {
                 a.tiles_y = cdiv(H, 16);
                 a.nblocks = N * a.tiles_x * a.tiles_y * a.ntn;
             }
@@ -1664,11 +1697,13 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
 #define C3_DMA_LAUNCH(DT)                                                                          \
     do {                                                                                           \
         if (bn_partials != nullptr) {                                                              \
-            if (dma_waves == 8) conv3x3_dma_kernel<DT, 8, 32, true><<<dgrid, 512, 0, bs>>>(a);     \
+            if (dma_waves == 16) conv3x3_dma_kernel<DT, 8, 16, true, false, 2><<<dgrid, 512, 0, bs>>>(a); \
+            else if (dma_waves == 8) conv3x3_dma_kernel<DT, 8, 32, true><<<dgrid, 512, 0, bs>>>(a); \
             else if (dma_waves == 2) conv3x3_dma_kernel<DT, 4, 16, true><<<dgrid, 256, 0, bs>>>(a); \
             else conv3x3_dma_kernel<DT, 4, 32, true><<<dgrid, 256, 0, bs>>>(a);                    \
         } else {                                                                                   \
-            if (dma_waves == 8) conv3x3_dma_kernel<DT, 8, 32, false><<<dgrid, 512, 0, bs>>>(a);    \
+            if (dma_waves == 16) conv3x3_dma_kernel<DT, 8, 16, false, false, 2><<<dgrid, 512, 0, bs>>>(a); \
+            else if (dma_waves == 8) conv3x3_dma_kernel<DT, 8, 32, false><<<dgrid, 512, 0, bs>>>(a); \
             else if (dma_waves == 2) conv3x3_dma_kernel<DT, 4, 16, false><<<dgrid, 256, 0, bs>>>(a); \
             else conv3x3_dma_kernel<DT, 4, 32, false><<<dgrid, 256, 0, bs>>>(a);                   \
         }                                                                                          \

@@ -803,8 +803,9 @@ def _unpack_merged(pf, cin, cout):
 
 
 @pytest.mark.parametrize("dtn,dt", DTS)
-@pytest.mark.parametrize("form", [0, 4, 8, 2])
-@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 37, 41, 64, 64), (1, 17, 33, 128, 72), (3, 9, 100, 64, 128), (2, 48, 32, 192, 64)])
+@pytest.mark.parametrize("form", [0, 4, 8, 2, 16])
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 37, 41, 64, 64), (1, 17, 33, 128, 72), (3, 9, 100, 64, 128), (2, 48, 32, 192, 64),
+                                            (2, 33, 40, 128, 256)])
 def test_conv3x3_kernel_forms(dtn, dt, form, N, H, W, Cin, Cout):
     """every form of the 2-D kernel (register-staged big-K-step, LDS-DMA with 4 / 8 waves, two LDS-DMA blocks per CU) on the
     same operands: forward with BatchNorm partials into a strided slice (ragged patches, a partial cout tile, an odd
