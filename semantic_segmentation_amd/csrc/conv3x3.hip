@@ -1044,7 +1044,7 @@ __device__ __forceinline__ void dma_piece16(const __amdgpu_buffer_rsrc_t& rs, un
 
 // NB = 2 (8 waves, 16-channel stages): 128 couts per item, every wave 64 pixels x 128 couts -- 8 MFMAs per six fragment reads
 // instead of 4 per four, and the weights are fetched once per 512 pixels x 128 couts: 97 B of DMA and 0.75 KB of LDS reads per
-// MFMA instead of 133 B and 1 KB.  Built because the ablation (tools/_dma_ablate.py) shows the deep layers 28-31 % faster
+// MFMA instead of 133 B and 1 KB.  Built because the ablation (tools/ablate_conv_dma.py) shows the deep layers 28-31 % faster
 // with the DMA pieces switched off; measured 2-3 % SLOWER than NB = 1 (245-256 VGPRs, a few spills with the statistics
 // epilogue, one step of fragment prefetch = 8 MFMAs): kept selectable, not the default.
 template <int DT, int NWV, int KC, bool STATS, bool PREC = false, int NB = 1>

@@ -1,0 +1,30 @@
+"""per-layer conv3x3 fwd / dgrad TFLOP/s for the current GSSEG_C3_DMA setting."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from semantic_segmentation_amd import ops
+import ctypes
+LAYERS = [("inc.3", 256, 64, 64), ("d1.0", 128, 64, 128), ("d1.3", 128, 128, 128), ("d2.0", 64, 128, 256),
+          ("d2.3", 64, 256, 256), ("d3.0", 32, 256, 512), ("d3.3", 32, 512, 512), ("d4.0", 16, 512, 1024),
+          ("d4.3", 16, 1024, 1024), ("u1.0", 32, 1024, 512), ("u2.0", 64, 512, 256), ("u3.0", 128, 256, 128), ("u4.0", 256, 128, 64)]
+def timeit(fn, iters=10):
+    fn(); fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+dev = torch.device("cuda:0"); dt = torch.float16; N = int(os.environ.get("NB", "32"))
+tot = 0.0
+print("DMA =", os.environ.get("GSSEG_C3_DMA", "auto"), "N =", N)
+for name, H, Cin, Cout in LAYERS:
+    x = torch.randn(N, H, H, Cin, device=dev).to(dt); dy = torch.randn(N, H, H, Cout, device=dev).to(dt)
+    wf = (0.05 * torch.randn(9, Cout, Cin, device=dev)).to(dt); wd = (0.05 * torch.randn(9, Cin, Cout, device=dev)).to(dt)
+    y = torch.empty(N, H, H, Cout, device=dev, dtype=dt); dx = torch.empty(N, H, H, Cin, device=dev, dtype=dt)
+    part = torch.empty(ops.bn_partials_numel(ops.conv3x3_mtiles(N, H, H, Cout), Cout), device=dev)
+    fl = 2.0 * N * H * H * Cout * Cin * 9
+    tf = timeit(lambda: ops.conv3x3(x, wf, y, N, H, H, Cin, Cout, ops.TAPS3_FWD, None, part))
+    td = timeit(lambda: ops.conv3x3(dy, wd, dx, N, H, H, Cout, Cin, ops.TAPS3_DGRAD))
+    tot += tf + td
+    print(f"{name:6s} fwd {fl/tf/1e12:7.1f}  dgrad {fl/td/1e12:7.1f} TF   ({tf*1e6:6.1f} / {td*1e6:6.1f} us)", flush=True)
+print("sum ms %.3f" % (tot * 1e3))
