@@ -29,6 +29,10 @@ from .._lib import ACT_NONE, ACT_RELU
 _TORCH_DT = {"f16": torch.float16, "bf16": torch.bfloat16}
 # eval-mode forward without a graph: fold BatchNorm into the conv weights (GSSEG_FOLD_BN=0 keeps the two-pass form)
 FOLD_BN_INFERENCE = os.environ.get("GSSEG_FOLD_BN", "1") != "0"
+# Weight gradients on a second HIP stream (opt-in, GSSEG_WGRAD_STREAM=1): +1.6 % on the bs=32 256^2 step (14.00 -> 13.78 ms),
+# but concurrent kernels stretch each other's event-bracketed durations (conv3x3 5.67 -> 5.83 ms "per kernel"), so the
+# per-kernel roofline figures of bench.py / rocprof stop being clean: the headline runs single-stream.
+WGRAD_SIDE_STREAM = os.environ.get("GSSEG_WGRAD_STREAM", "0") != "0"
 
 
 class _ConvRec:
@@ -70,6 +74,7 @@ class UNetEngine:
         self.dynamic_loss_scale = os.environ.get("GSSEG_DYNAMIC_LOSS_SCALE", "0") == "1"
         self.tdt = _TORCH_DT[dtype]
         self._packs: Dict[str, tuple] = {}
+        self._side_streams: Dict[torch.device, torch.cuda.Stream] = {}     # weight-gradient stream per device
         # data-parallel hooks (parallel.GradReducer): grads are allocated inside the reducer's flat buckets,
         # announced as soon as they are final (so the RCCL all-reduce overlaps the rest of backward), and
         # `after_backward` makes the compute stream wait for the collectives.
@@ -104,6 +109,12 @@ class UNetEngine:
 
     def submodule(self, key: str):
         return self._index()[2][key]
+
+    def _side_stream(self, dev):
+        st = self._side_streams.get(dev)
+        if st is None:
+            st = self._side_streams[dev] = torch.cuda.Stream(device=dev)
+        return st
 
     def invalidate_packs(self):
         """Drop the cached 16-bit weight packs (they are otherwise reused until a Parameter changes)."""
@@ -555,6 +566,44 @@ class UNetEngine:
             if self.grad_ready_hook is not None:
                 self.grad_ready_hook(name, g)
 
+        # The MFMA weight gradients (and their ordered slab reductions) run on a SECOND stream: nothing downstream in the
+        # backward pass needs them, so they overlap the HBM-bound BatchNorm passes of the next stage on the main stream
+        # (the BatchNorm kernels take no LDS and few registers and share the CUs with the 8-wave MFMA blocks).  dY is
+        # handed over with an event; tensors the side stream reads are recorded on it (caching allocator); the main stream
+        # joins at the end.  With a gradient-ready hook (bucketed all-reduce) a weight gradient is announced one stage
+        # later, after the main stream has waited for its event.  GSSEG_WGRAD_STREAM=0 keeps everything on one stream.
+        main_stream = torch.cuda.current_stream(dev)
+        side = self._side_stream(dev) if WGRAD_SIDE_STREAM else None
+        deferred = []                # (name, grad, event) of side-stream gradients not yet announced
+
+        def flush_deferred(upto_all: bool):
+            while deferred and (upto_all or len(deferred) > 1):
+                name, g, ev = deferred.pop(0)
+                main_stream.wait_event(ev)
+                emit(name, g)
+
+        def on_side(inputs, fn, name, g):
+            """run fn() (launches that read `inputs`, already complete on the main stream, and write g) on the side stream"""
+            if side is None:
+                fn()
+                emit(name, g)
+                return
+            ev = torch.cuda.Event()
+            ev.record(main_stream)
+            for t_ in inputs:
+                t_.record_stream(side)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                fn()
+                if self.grad_ready_hook is not None:
+                    done = torch.cuda.Event()
+                    done.record(side)
+                    deferred.append((name, g, done))
+            if self.grad_ready_hook is None:
+                grads[name] = g
+            else:
+                flush_deferred(False)
+
         def galloc(name, like, zero=False):
             if self.grad_alloc is not None:
                 g = self.grad_alloc(name, like)
@@ -634,9 +683,12 @@ class UNetEngine:
                     ops.conv_smallcin_dgrad(dy, wparam.detach().contiguous(), dinp, 3, 1, 1, inv_s)
             else:
                 dw = galloc(rec.wkey, wparam)
-                if rec.name in det_recs:
+                wgrad_on_side = rec.name in det_recs
+                if wgrad_on_side:
                     # split-K parts in slabs + ordered reduction fused with scale / unpack: deterministic, no atomics
-                    ops.conv3x3_wgrad_det(rec.inp, dy, wg_ws, dw, N, h, w, cin, cout, inv_s, in_stride=rec.inp_stride)
+                    on_side((rec.inp, dy, wg_ws, dw),
+                            lambda: ops.conv3x3_wgrad_det(rec.inp, dy, wg_ws, dw, N, h, w, cin, cout, inv_s, in_stride=rec.inp_stride),
+                            rec.wkey, dw)
                 else:
                     dwp = dw_take(wparam.numel())
                     if ops.USE_HALO_CONV and cin % 8 == 0 and cout % 8 == 0:
@@ -650,7 +702,8 @@ class UNetEngine:
                         ops.conv3x3(dy, rec.wd, dinp, N, h, w, cout, cin, ops.TAPS3_DGRAD)
                     else:
                         ops.conv_igemm(ops.geom_conv_dgrad_s1(N, h, w, cin, cout, 3, 1), dy, rec.wd, dinp)
-            emit(rec.wkey, dw)
+            if rec.inp_is_image or not wgrad_on_side:
+                emit(rec.wkey, dw)
             emit(rec.bnkey + ".weight", dgamma)
             emit(rec.bnkey + ".bias", dbeta)
             return dinp
@@ -676,11 +729,12 @@ class UNetEngine:
             db = galloc(prefix + ".up.bias", params[prefix + ".up.bias"])
             ops.colsum(dcat, 2 * cout_t, cout_t, N, u.H2, u.W2, u.pt, u.pl, 2 * u.h, 2 * u.w, cout_t, inv_s, col_ws, db)
             dw = galloc(wkey, wparam)
-            ops.conv_wgrad_det(u.geom_wg if u.geom_wg is not None else u.geom_bwd, dcat, u.zin, wg_ws, dw, u.cin, u.cout,
-                               4, inv_s)
+            on_side((dcat, u.zin, wg_ws, dw),
+                    lambda u=u, dcat=dcat, dw=dw: ops.conv_wgrad_det(u.geom_wg if u.geom_wg is not None else u.geom_bwd, dcat, u.zin,
+                                                                     wg_ws, dw, u.cin, u.cout, 4, inv_s),
+                    wkey, dw)
             dz = empty(N, u.h, u.w, u.cin)
             ops.upconv2x2_dgrad(u.geom_bwd, dcat, u.wd, dz, N, u.h, u.w, u.cin, u.cout, u.H2, u.W2, 2 * cout_t, cout_t, u.pt, u.pl)
-            emit(wkey, dw)
             emit(prefix + ".up.bias", db)
 
         # ---- encoder, reversed ----
@@ -698,6 +752,9 @@ class UNetEngine:
                 dpool = dinp
             else:
                 dx = dinp
+        if side is not None:
+            flush_deferred(True)
+            main_stream.wait_stream(side)          # every weight gradient is complete before anything downstream reads it
         if renorm is not None:
             # data-parallel note: the bucket all-reduces were issued on the renormalised gradients of THIS rank; with the
             # dynamic scale every rank must use the same factor, so it is only supported without a reducer

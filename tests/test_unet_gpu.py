@@ -587,3 +587,35 @@ def test_fused_eval_jaccard_matches_oracle():
     want = oracle.jaccard_index(pred.squeeze(), mask.float().squeeze())
     got = eval_jaccard(logits.cuda(), mask.cuda())
     assert abs(got.item() - want.item()) < 2e-7, (got.item(), want.item())
+
+
+def test_weight_gradients_on_side_stream_are_identical(monkeypatch):
+    """GSSEG_WGRAD_STREAM=1 runs the MFMA weight gradients on a second HIP stream (events + record_stream hand-over): the
+    gradients must be bit-identical to the single-stream backward, for every parameter, over repeated steps"""
+    import torch
+    from oracle import oracle
+    from semantic_segmentation_amd.losses import seg_loss
+    from semantic_segmentation_amd.unet import UNet, unet_engine
+    dev = torch.device("cuda:0")
+    sd = oracle.unet_state_dict(1, 2, seed=11)
+    x, mask = oracle.synthetic_batch(4, 64, seed=5)
+
+    def grads(side):
+        monkeypatch.setattr(unet_engine, "WGRAD_SIDE_STREAM", side)
+        net = UNet(1, 2).to(dev)
+        net.load_state_dict(sd, strict=True)
+        net.train()
+        out = []
+        for _ in range(3):
+            for p in net.parameters():
+                p.grad = None
+            loss = seg_loss(net(x.to(dev)), mask.to(dev))
+            loss.backward()
+            torch.cuda.synchronize()
+            out.append({n: p.grad.clone() for n, p in net.named_parameters()})
+        return out
+
+    a, b = grads(False), grads(True)
+    for ga, gb in zip(a, b):
+        for n in ga:
+            assert torch.equal(ga[n], gb[n]), n
