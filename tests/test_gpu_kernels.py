@@ -867,7 +867,7 @@ def test_dma_kernels_repeatable_under_memory_noise():
         mt = ops.conv3x3_mtiles(N, H, W, Cout)
         ws = torch.empty(ops.conv3x3_wgrad_ws_floats(N, H, W, Cin, Cout), dtype=torch.float32, device=dev())
         try:
-            for form in (8, 4, 2):
+            for form in (8, 4, 2, 16):
                 ops.conv3x3_set_kernel_form(form)
                 ref = None
                 for it in range(30):
