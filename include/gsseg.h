@@ -111,8 +111,8 @@ int gs_upconv2x2_dgrad(const void* dy, const void* wd, void* dx, int N, int IH, 
 int gs_conv3x3_mtiles(int N, int H, int W, int Cout);
 /* Diagnostics (process-wide, not part of the data path): which form of the 2-D kernel gs_conv3x3 launches where several
  * apply: -1 chosen by CU fill (default), 0 the register-staged big-K-step kernel, 4 / 8 the LDS-DMA kernel with that many
- * waves per block, 2 two 4-wave LDS-DMA blocks per CU, 16 the 8-wave form with 128 couts per item (layers with Cout % 128
- * == 0, others fall to 8).  Every form computes the same sums in a form-specific order. */
+ * waves per block, 2 two 4-wave LDS-DMA blocks per CU, 16 / 32 the 8-wave form with 128 couts per item and 16- / 32-channel
+ * stages (layers with Cout % 128 == 0, others fall to 8).  Every form computes the same sums in a form-specific order. */
 int gs_conv3x3_set_kernel_form(int form);
 int gs_conv3x3(const void* x, const void* w, void* y, const float* bias, float* bn_partials, int N, int H, int W,
                int Cin, int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff,

@@ -1051,7 +1051,13 @@ template <int DT, int NWV, int KC, bool STATS, bool PREC = false, int NB = 1>
 __global__ __launch_bounds__(64 * NWV, (KC == 16 && NB == 1) ? 2 : 1) void conv3x3_dma_kernel(const C3Args a) {
     typedef typename Elem<DT>::V8 V8;
     constexpr int BN = 64 * NB, TW = 32, TH = 2 * NWV, TWS = 5;
-    static_assert(NB == 1 || (KC == 16 && NWV == 8 && !PREC), "the 128-cout form: 8 waves, 16-channel stages");
+    static_assert(NB == 1 || (NWV == 8 && !PREC), "the 128-cout forms: 8 waves");
+    // WS (NB = 2 with 32-channel stages): the nine 128-cout weight slabs of a stage (72 KB) are SINGLE-buffered in two halves
+    // -- taps 0..4 and taps 5..8 -- with a second hand-over in the middle of the stage: while taps 0..4 are multiplied the
+    // slabs of taps 5..8 of the SAME stage land, while taps 5..8 are multiplied the slabs of taps 0..4 and the halo of the
+    // NEXT stage land.  Two barriers per 144 MFMAs per wave (the same density as the 64-cout form), 97 B of DMA per MFMA in
+    // 64-byte segments instead of 133 B, 0.75 KB of fragment reads per MFMA instead of 1 KB.
+    constexpr bool WS = (NB == 2 && KC == 32);
     constexpr int HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;
     constexpr int ROWB = KC * 2;                           // bytes per LDS row (one pixel / one cout, KC channels)
     constexpr int SPR = ROWB / 16, RPP = 64 / SPR;         // 16-byte slots per row, rows per 1-KiB piece
@@ -1067,14 +1073,19 @@ __global__ __launch_bounds__(64 * NWV, (KC == 16 && NB == 1) ? 2 : 1) void conv3
     // LDS: [weights 0 | halo 0 | halo 1 | weights 1]; the epilogue staging overlays halo 1 + weights 1 (the last stage of an
     // item always sits in buffer 1, the next item's first stage is on its way into buffer 0)
     constexpr int H0_OFF = W_B, W1_OFF = W_B + 2 * HALO_B;
-    static_assert(2 * STAGE_B * ((KC == 16 && NB == 1) ? 2 : 1) <= 160 * 1024, "two stages (per resident block) must fit in LDS");
+    constexpr int NSTEP_A = WS ? 5 * KSTEPS : NSTEP;       // WS: steps of the first weight half (taps 0..4)
+    constexpr int WB_OFF = 5 * BN * ROWB;                  // WS: [weights taps 0..4 | weights taps 5..8 | halo 0 | halo 1]
+    constexpr int LDS_B = WS ? W_B + 2 * HALO_B : 2 * STAGE_B;
+    static_assert(LDS_B * ((KC == 16 && NB == 1) ? 2 : 1) <= 160 * 1024, "the stage buffers (per resident block) must fit in LDS");
+    static_assert(!WS || (WP == 9 * NWV && NWV * STG_EL * 2 <= HALO_B && NWV * 2 * BN * 4 <= W_B - WB_OFF),
+                  "WS: one weight piece per wave and tap; staging in halo 1, partial sums in the second weight half");
     // PREC (precise mode): K is a concatenation of segments over the same input channels (stage c reads
     // input chunk c mod wrap) and the result leaves as a hi / lo pair (a second staging area and store stream)
-    static_assert((PREC ? 2 : 1) * NWV * STG_EL * 2 + NWV * 2 * BN * 4 <= HALO_B + W_B, "epilogue staging overlays the second stage buffer");
+    static_assert(WS || (PREC ? 2 : 1) * NWV * STG_EL * 2 + NWV * 2 * BN * 4 <= HALO_B + W_B, "epilogue staging overlays the second stage buffer");
     static_assert(NWP + HJ <= NSTEP && HJ + 1 <= NSTEP, "one DMA piece / one next-item offset per MFMA step");
     static_assert(NWV % WG == 0, "a wave's weight pieces all belong to one row group");
     static_assert(WP % NWV == 0 || HI < HJ * NWV, "a surplus weight slot parks its (empty) piece in the spare halo piece");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE_B];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_B];
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1173,7 +1184,7 @@ __global__ __launch_bounds__(64 * NWV, (KC == 16 && NB == 1) ? 2 : 1) void conv3
             const int key = (KC == 32) ? ((r >> 2) & 3) : ((r >> 3) & 1);
             aaddr[0][e][d] = (unsigned)(H0_OFF + r * ROWB + ((h ^ key) << 4));
             opaque_vgpr(aaddr[0][e][d]);
-            if (KSTEPS == 2) {
+            if (KSTEPS == 2 && NB == 1) {                 // (NB = 2 is short of registers: the second k half is formed at the read)
                 aaddr[KSTEPS - 1][e][d] = aaddr[0][e][d] ^ 32u;
                 opaque_vgpr(aaddr[KSTEPS - 1][e][d]);
             }
@@ -1182,7 +1193,7 @@ __global__ __launch_bounds__(64 * NWV, (KC == 16 && NB == 1) ? 2 : 1) void conv3
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int key = (KC == 32) ? ((l31 >> 2) & 3) : ((l31 >> 3) & 1);
-        baddr[b][0] = (unsigned)(b * W1_OFF + l31 * ROWB + ((h ^ key) << 4));
+        baddr[b][0] = (unsigned)(b * (WS ? WB_OFF : W1_OFF) + l31 * ROWB + ((h ^ key) << 4));      // WS: b = weight half
         opaque_vgpr(baddr[b][0]);
         if (KSTEPS == 2) {
             baddr[b][KSTEPS - 1] = baddr[b][0] ^ 32u;
@@ -1203,7 +1214,23 @@ __global__ __launch_bounds__(64 * NWV, (KC == 16 && NB == 1) ? 2 : 1) void conv3
     // one stage: NSTEP steps (tap, k half) of 4 MFMAs out of buffer BUF; the pieces of the next stage (image rx_n, channel
     // offset sc_n) go into the other buffer, one per step
     // FIRST: the first stage of an item starts its accumulators from the MFMA's zero C operand (no clearing pass)
-    auto run_stage = [&](auto buf_tag, auto first_tag, const __amdgpu_buffer_rsrc_t& rx_n, const Src& sn, unsigned kill, const Item& itn) __attribute__((always_inline)) {
+    // WS: piece slot k of a half -- first half (k < 4): weight taps 5..8 of the CURRENT stage (scalar offset wsc_cur); second half
+    // (k < 10): weight taps 0..4 and the halo of the NEXT stage
+    auto issue_ws = [&](bool second, int k, const __amdgpu_buffer_rsrc_t& rx, unsigned sc, unsigned wsc, unsigned bb, unsigned hkill,
+                        unsigned kill) __attribute__((always_inline)) {
+        if (!second) {
+            const int tap = 5 + k, slot = flip ? 8 - tap : tap;
+            dma_piece16(w_rsrc, smem + WB_OFF + (unsigned)(k * NWV + wave) * 1024u, wv, (unsigned)slot * tap_stride + wsc);
+        } else if (k < 5) {
+            const int slot = flip ? 8 - k : k;
+            dma_piece16(w_rsrc, smem + (unsigned)(k * NWV + wave) * 1024u, wv | kill, (unsigned)slot * tap_stride + wsc);
+        } else {
+            const int j = k - 5 < HJ ? k - 5 : 0;
+            dma_piece16(rx, smem + H0_OFF + bb * HALO_B + (unsigned)(wave + j * NWV) * 1024u, hv[j] | kill | hkill, sc);
+        }
+    };
+    auto run_stage = [&](auto buf_tag, auto first_tag, const __amdgpu_buffer_rsrc_t& rx_n, const Src& sn, unsigned kill, const Item& itn,
+                         unsigned wsc_cur = 0u, bool swap_mid = false) __attribute__((always_inline)) {
         const unsigned sc_n = sn.sc, wsc_n = sn.wsc, hkill_n = sn.hkill;
         constexpr int BUF = decltype(buf_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value;
@@ -1223,23 +1250,49 @@ __global__ __launch_bounds__(64 * NWV, (KC == 16 && NB == 1) ? 2 : 1) void conv3
         auto frag_load = [&](int step, V8 (&fa)[2], V8 (&fb)[2 * NB]) __attribute__((always_inline)) {
             const int tap = step / KSTEPS, kh = step % KSTEPS;
             const int dyi = tap / 3, dxi = tap - 3 * dyi;
-            fa[0] = *reinterpret_cast<const V8*>(smem + aaddr[kh][dyi][dxi] + BUF * HALO_B);
-            fb[0] = *reinterpret_cast<const V8*>(smem + baddr[BUF][kh] + tap * (BN * ROWB));
-            fa[1] = *reinterpret_cast<const V8*>(smem + aaddr[kh][dyi + 1][dxi] + BUF * HALO_B);
-            fb[1] = *reinterpret_cast<const V8*>(smem + baddr[BUF][kh] + tap * (BN * ROWB) + 32 * ROWB);
+            const int wsel = WS ? (tap >= 5 ? 1 : 0) : BUF;              // weight buffer (WS: weight half)
+            const int wtap = WS ? tap - 5 * wsel : tap;
+            const unsigned a0 = (NB == 2 && kh == 1) ? (aaddr[0][dyi][dxi] ^ 32u) : aaddr[NB == 2 ? 0 : kh][dyi][dxi];
+            const unsigned a1 = (NB == 2 && kh == 1) ? (aaddr[0][dyi + 1][dxi] ^ 32u) : aaddr[NB == 2 ? 0 : kh][dyi + 1][dxi];
+            fa[0] = *reinterpret_cast<const V8*>(smem + a0 + BUF * HALO_B);
+            fb[0] = *reinterpret_cast<const V8*>(smem + baddr[wsel][kh] + wtap * (BN * ROWB));
+            fa[1] = *reinterpret_cast<const V8*>(smem + a1 + BUF * HALO_B);
+            fb[1] = *reinterpret_cast<const V8*>(smem + baddr[wsel][kh] + wtap * (BN * ROWB) + 32 * ROWB);
             if (NB == 2) {
-                fb[2 * NB - 2] = *reinterpret_cast<const V8*>(smem + baddr[BUF][kh] + tap * (BN * ROWB) + 64 * ROWB);
-                fb[2 * NB - 1] = *reinterpret_cast<const V8*>(smem + baddr[BUF][kh] + tap * (BN * ROWB) + 96 * ROWB);
+                fb[2 * NB - 2] = *reinterpret_cast<const V8*>(smem + baddr[wsel][kh] + wtap * (BN * ROWB) + 64 * ROWB);
+                fb[2 * NB - 1] = *reinterpret_cast<const V8*>(smem + baddr[wsel][kh] + wtap * (BN * ROWB) + 96 * ROWB);
             }
         };
         frag_load(0, af[0], bf[0]);
 #pragma unroll
         for (int step = 0; step < NSTEP; ++step) {
             const int cur = step & 1;
-            if (step + 1 < NSTEP) frag_load(step + 1, af[cur ^ 1], bf[cur ^ 1]);
+            if (WS && step == NSTEP_A) {
+                // second hand-over: the weight slabs of taps 5..8 have landed everywhere, nobody reads taps 0..4 any more
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (swap_mid) {                            // last stage of the item: the pieces from here on belong to the next item
+#pragma unroll
+                    for (int j = 0; j < HJ; ++j) hv[j] = hvn[j];
+                    wv = wvn;
+                }
+                frag_load(step, af[cur], bf[cur]);         // (not prefetched across the hand-over)
+            }
+            if (step + 1 < NSTEP && !(WS && step + 1 == NSTEP_A)) frag_load(step + 1, af[cur ^ 1], bf[cur ^ 1]);
             // (two pieces per step, i.e. everything issued in the first half of the stage, measured the same or 1 % slower
             // on the deep layers: the pieces are not late)
-            issue_piece(step, rx_n, sc_n, wsc_n, OBUF, hkill_n, kill);
+            if (WS) {
+                if (step < 4) issue_ws(false, step, rx_n, sc_n, wsc_cur, OBUF, hkill_n, kill);
+                else if (step == NSTEP_A || step == NSTEP_A + 1) {
+                    issue_ws(true, 2 * (step - NSTEP_A), rx_n, sc_n, wsc_n, OBUF, hkill_n, kill);
+                    issue_ws(true, 2 * (step - NSTEP_A) + 1, rx_n, sc_n, wsc_n, OBUF, hkill_n, kill);
+                } else if (step > NSTEP_A + 1 && step - NSTEP_A + 2 < 5 + HJ) {
+                    issue_ws(true, step - NSTEP_A + 2, rx_n, sc_n, wsc_n, OBUF, hkill_n, kill);
+                }
+            } else {
+                issue_piece(step, rx_n, sc_n, wsc_n, OBUF, hkill_n, kill);
+            }
             if (BUF == 0 && step <= HJ) {                  // the next item's piece offsets, one slot per step
                 int py0 = itn.y0, px0 = itn.x0, pn0 = itn.n0;
                 asm volatile("" : "+s"(py0), "+s"(px0), "+s"(pn0));      // keeps this arithmetic in the step (else hoisted to the item boundary)
@@ -1282,7 +1335,7 @@ __global__ __launch_bounds__(64 * NWV, (KC == 16 && NB == 1) ? 2 : 1) void conv3
     // ---- epilogue: as conv3x3_big_kernel (staging overlays the second stage buffer, which the last stage has just left) ----
     unsigned short* stg = reinterpret_cast<unsigned short*>(smem + H0_OFF + HALO_B) + wave * STG_EL;
     unsigned short* stg_lo = stg + NWV * STG_EL;                                        // PREC: the lo halves
-    float* red = reinterpret_cast<float*>(smem + H0_OFF + HALO_B + (PREC ? 2 : 1) * NWV * STG_EL * 2);  // [NWV][2][BN]
+    float* red = reinterpret_cast<float*>(smem + (WS ? WB_OFF : H0_OFF + HALO_B + (PREC ? 2 : 1) * NWV * STG_EL * 2));  // [NWV][2][BN]
     const bool odd = lane & 1;
     const unsigned int psel = odd ? 0x03020706u : 0x05040100u;
     const float neg_slope = act == GS_ACT_RELU ? 0.f : (act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
@@ -1456,8 +1509,13 @@ __global__ __launch_bounds__(64 * NWV, (KC == 16 && NB == 1) ? 2 : 1) void conv3
     {
         const Src s0 = stage_src(cur.n, 0);
         const __amdgpu_buffer_rsrc_t rx0 = image_rsrc(s0.n);
+        if (WS) {
 #pragma unroll
-        for (int k = 0; k < NWP + HJ; ++k) issue_piece(k, rx0, s0.sc, s0.wsc, 0u, s0.hkill, 0u);       // stage 0 -> buffer 0
+            for (int k = 0; k < 5 + HJ; ++k) issue_ws(true, k, rx0, s0.sc, s0.wsc, 0u, s0.hkill, 0u);   // taps 0..4 + halo of stage 0
+        } else {
+#pragma unroll
+            for (int k = 0; k < NWP + HJ; ++k) issue_piece(k, rx0, s0.sc, s0.wsc, 0u, s0.hkill, 0u);   // stage 0 -> buffer 0
+        }
     }
     for (;;) {
         const int nit = it + gridDim.x;
@@ -1470,18 +1528,20 @@ __global__ __launch_bounds__(64 * NWV, (KC == 16 && NB == 1) ? 2 : 1) void conv3
             stage_sync();
             PH(0);
             const Src s1 = stage_src(cur.n, sp + 1);
-            if (sp == 0) run_stage(std::integral_constant<int, 0>{}, std::true_type{}, image_rsrc(s1.n), s1, 0u, nxt);
-            else run_stage(std::integral_constant<int, 0>{}, std::false_type{}, image_rsrc(s1.n), s1, 0u, nxt);
+            const unsigned wsc0 = WS ? stage_src(cur.n, sp).wsc : 0u;
+            if (sp == 0) run_stage(std::integral_constant<int, 0>{}, std::true_type{}, image_rsrc(s1.n), s1, 0u, nxt, wsc0, false);
+            else run_stage(std::integral_constant<int, 0>{}, std::false_type{}, image_rsrc(s1.n), s1, 0u, nxt, wsc0, false);
             PH(1);
             stage_sync();
             PH(2);
-            if (last) {                                    // from here on the pieces belong to the next item
+            if (last && !WS) {                             // from here on the pieces belong to the next item (WS: from mid-stage on)
 #pragma unroll
                 for (int j = 0; j < HJ; ++j) hv[j] = hvn[j];
                 wv = wvn;
             }
             const Src s2 = stage_src(last ? nxt.n : cur.n, last ? 0 : sp + 2);
-            run_stage(std::integral_constant<int, 1>{}, std::false_type{}, image_rsrc(s2.n), s2, (last && !more_items) ? VOOB : 0u, nxt);
+            run_stage(std::integral_constant<int, 1>{}, std::false_type{}, image_rsrc(s2.n), s2, (last && !more_items) ? VOOB : 0u, nxt,
+                      WS ? stage_src(cur.n, sp + 1).wsc : 0u, WS && last);
             PH(3);
         }
         __builtin_amdgcn_s_barrier();              // every wave has left the second buffer: staging may overlay it
@@ -1528,8 +1588,8 @@ C3Plan c3_plan(int H, int W, int Cout) {
 static std::atomic<int> c3_dma_form{getenv("GSSEG_C3_DMA") ? atoi(getenv("GSSEG_C3_DMA")) : -1};
 
 extern "C" int gs_conv3x3_set_kernel_form(int form) {
-    GS_CHECK_ARG(form == -1 || form == 0 || form == 2 || form == 4 || form == 8 || form == 16,
-                 "gs_conv3x3_set_kernel_form: form must be -1, 0, 2, 4, 8 or 16");
+    GS_CHECK_ARG(form == -1 || form == 0 || form == 2 || form == 4 || form == 8 || form == 16 || form == 32,
+                 "gs_conv3x3_set_kernel_form: form must be -1, 0, 2, 4, 8, 16 or 32");
     c3_dma_form.store(form, std::memory_order_relaxed);
     return GS_OK;
 }
@@ -1678,16 +1738,18 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
             const double cost8 = 0.87 * 2.0 * (double)((items8 + big_blocks - 1) / big_blocks);
             dma_waves = (dma_env == 4 || dma_env == 8 || dma_env == 2) ? dma_env : (cost8 <= cost4 ? 8 : 4);   // 2: two 4-wave blocks per CU
             // 16: the 8-wave form with 128 couts per item (16-channel stages) where the layer has them
-            if ((dma_env == 16 || (dma_env == -1 && dma_waves == 8 && c3_wide_auto())) && Cout % 128 == 0) {
+            // 32: the same 128-cout items with 32-channel stages and split single-buffered weights (WS)
+            if ((dma_env == 16 || dma_env == 32 || (dma_env == -1 && dma_waves == 8 && c3_wide_auto())) && Cout % 128 == 0) {
                 const int64_t items16 = (int64_t)N * a.tiles_x * cdiv(H, 16) * (Cout / 128);
-                if (dma_env == 16 || items16 >= big_blocks) dma_waves = 16;
-            } else if (dma_env == 16) {
+                if (dma_env == 16) dma_waves = 16;
+                else if (dma_env == 32 || items16 >= big_blocks) dma_waves = 32;
+            } else if (dma_env == 16 || dma_env == 32) {
                 dma_waves = 8;
             }
         }
         if (dma_waves != 0) {
-            if (dma_waves == 16) a.ntn = Cout / 128;
-            if (dma_waves == 8 || dma_waves == 16) {
+            if (dma_waves == 16 || dma_waves == 32) a.ntn = Cout / 128;
+            if (dma_waves == 8 || dma_waves == 16 || dma_waves == 32) {
                 a.tiles_y = cdiv(H, 16);
                 a.nblocks = N * a.tiles_x * a.tiles_y * a.ntn;
             }
@@ -1697,12 +1759,14 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
 #define C3_DMA_LAUNCH(DT)                                                                          \
     do {                                                                                           \
         if (bn_partials != nullptr) {                                                              \
-            if (dma_waves == 16) conv3x3_dma_kernel<DT, 8, 16, true, false, 2><<<dgrid, 512, 0, bs>>>(a); \
+            if (dma_waves == 32) conv3x3_dma_kernel<DT, 8, 32, true, false, 2><<<dgrid, 512, 0, bs>>>(a); \
+            else if (dma_waves == 16) conv3x3_dma_kernel<DT, 8, 16, true, false, 2><<<dgrid, 512, 0, bs>>>(a); \
             else if (dma_waves == 8) conv3x3_dma_kernel<DT, 8, 32, true><<<dgrid, 512, 0, bs>>>(a); \
             else if (dma_waves == 2) conv3x3_dma_kernel<DT, 4, 16, true><<<dgrid, 256, 0, bs>>>(a); \
             else conv3x3_dma_kernel<DT, 4, 32, true><<<dgrid, 256, 0, bs>>>(a);                    \
         } else {                                                                                   \
-            if (dma_waves == 16) conv3x3_dma_kernel<DT, 8, 16, false, false, 2><<<dgrid, 512, 0, bs>>>(a); \
+            if (dma_waves == 32) conv3x3_dma_kernel<DT, 8, 32, false, false, 2><<<dgrid, 512, 0, bs>>>(a); \
+            else if (dma_waves == 16) conv3x3_dma_kernel<DT, 8, 16, false, false, 2><<<dgrid, 512, 0, bs>>>(a); \
             else if (dma_waves == 8) conv3x3_dma_kernel<DT, 8, 32, false><<<dgrid, 512, 0, bs>>>(a); \
             else if (dma_waves == 2) conv3x3_dma_kernel<DT, 4, 16, false><<<dgrid, 256, 0, bs>>>(a); \
             else conv3x3_dma_kernel<DT, 4, 32, false><<<dgrid, 256, 0, bs>>>(a);                   \

@@ -803,7 +803,7 @@ def _unpack_merged(pf, cin, cout):
 
 
 @pytest.mark.parametrize("dtn,dt", DTS)
-@pytest.mark.parametrize("form", [0, 4, 8, 2, 16])
+@pytest.mark.parametrize("form", [0, 4, 8, 2, 16, 32])
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 37, 41, 64, 64), (1, 17, 33, 128, 72), (3, 9, 100, 64, 128), (2, 48, 32, 192, 64),
                                             (2, 33, 40, 128, 256)])
 def test_conv3x3_kernel_forms(dtn, dt, form, N, H, W, Cin, Cout):
@@ -867,7 +867,7 @@ def test_dma_kernels_repeatable_under_memory_noise():
         mt = ops.conv3x3_mtiles(N, H, W, Cout)
         ws = torch.empty(ops.conv3x3_wgrad_ws_floats(N, H, W, Cin, Cout), dtype=torch.float32, device=dev())
         try:
-            for form in (8, 4, 2, 16):
+            for form in (8, 4, 2, 16, 32):
                 ops.conv3x3_set_kernel_form(form)
                 ref = None
                 for it in range(30):
