@@ -1136,6 +1136,7 @@ __global__ __launch_bounds__(64 * NWV, (KC == 16 && NB == 1) ? 2 : 1) void conv3
     // piece k (compile-time) of stage (image rx, channel byte offset sc) into buffer bb
     // (sc / wsc: scalar byte offsets of the stage's channel chunk in the image / of its chunk and depth-tap group in the pack;
     // hkill: the depth tap points outside the volume -- the halo pieces carry zeros)
+    // (issuing the halo pieces before the weight pieces measured the same)
     auto issue_piece = [&](int k, const __amdgpu_buffer_rsrc_t& rx, unsigned sc, unsigned wsc, unsigned bb, unsigned hkill,
                            unsigned kill) __attribute__((always_inline)) {
         if (k < NWP) {

@@ -356,8 +356,11 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_dma_kernel(const W3Args a) {
             if (step + PD < 72) load_b(step + PD, bfr[(step + PD) % (PD + 1)]);
             if (tap == 4 && s + 1 < 8) load_a(s + 1, afr[(s + 1) & 1]);
 #if !defined(GS_W3_ABLATE) || GS_W3_ABLATE != 1          // ablation 1: no DMA traffic (stale LDS), 2: no MFMAs / fragment reads
-            if (tap == 1) issue_piece(pf, s, buf ^ 1u);
-            if (tap == 6 && s < 2) issue_piece(pf, 8 + s, buf ^ 1u);
+            // the ten pieces of the next patch go out in the first rows: spread over the whole patch (one per row) the last
+            // ones had a fraction of the patch time to land before the hand-over -- the full-resolution layers stream
+            // both operands from HBM (64->64 @256^2: 178 -> 163 us, 128->64 @256^2: 300 -> 284 us; all shapes 2.51 -> 2.45 ms)
+            // (all ten in the first two rows: the same)
+            if (s < 4 && (tap == 1 || tap == 4 || tap == 7) && 3 * s + tap / 3 < 4 + HJ) issue_piece(pf, 3 * s + tap / 3, buf ^ 1u);
 #endif
 #if !defined(GS_W3_ABLATE) || GS_W3_ABLATE != 2
             acc[tap] = Elem<DT>::mfma32(afr[s & 1], bfr[step % (PD + 1)], acc[tap]);
