@@ -5,6 +5,8 @@
 //               image directly (no separate layout pass), writes 16-bit NHWC + BatchNorm partial sums.
 //   small-Cout: OutConv 1x1 (64->n_classes; unet_parts.py:74) and the PatchGAN last conv (512->1, 4x4;
 //               networks.py:661).  Reads 16-bit NHWC, writes fp32 NCHW logits.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
@@ -178,6 +180,131 @@ __global__ __launch_bounds__(256) void smallcin_fwd64_kernel(const SCArgs a) {
         }
     }
     __syncthreads();
+    }
+}
+
+// Cout == 64, nine taps (the 3x3 one-channel U-Net stem, unet_parts.py:16 with in_channels = 1), slope-family activation:
+// ONE pixel at a time per thread -- all 64 output channels are accumulated, then the pixel's whole 128-byte line is written by
+// eight back-to-back 16-byte stores.  (smallcin_fwd64x4_kernel below writes a pixel's line in four 32-byte instalments spread
+// over the whole kernel: with every lane holding four lines open, the partial lines are evicted from L2 before they are
+// complete -- rocprofv3 WRITE_SIZE 657 MB for a 268 MB output.)  The BatchNorm partial sums do not need the 64 outputs at all:
+// y[p][co] = sum_t x_t(p) w[co][t], so  sum_p y = sum_t w[co][t] S[t]  and  sum_p y^2 = sum_{t,t'} w[co][t] w[co][t'] G[t][t']
+// with the tap sums S[t] = sum_p x_t(p) and the 9 x 9 tap Gram matrix G (45 accumulators per thread instead of 128; the
+// per-channel quadratic forms are evaluated once per block).  Same tile (SC_TILE pixels) and partial layout as the other kernels.
+// Hides a value from the optimiser (in a __device__ helper: an asm constraint in a __global__ template body loses the host stub).
+__device__ __forceinline__ int sc_opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+
+template <int DT>
+__global__ __launch_bounds__(256) void smallcin_fwd64_line_kernel(const SCArgs a) {
+    constexpr int TT = 9, NG = TT * (TT + 1) / 2;
+    __shared__ float wl[TT * 64];                   // [tap][co]
+    __shared__ float part[4][TT + NG];              // per-wave tap sums and Gram entries
+    __shared__ float bl[64];                        // bias (zeros without one): read per use -- as registers the 64 values spill
+    for (int i = threadIdx.x; i < TT * 64; i += 256) {
+        const int co = i & 63, tap = i >> 6;
+        wl[i] = a.w[co * TT + tap];
+    }
+    if (threadIdx.x < 64) bl[threadIdx.x] = a.bias ? a.bias[threadIdx.x] : 0.f;
+    const int M = a.N * a.OH * a.OW;                // host guarantees < 2^31
+    const float slope = a.act == GS_ACT_RELU ? 0.f : (a.act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
+    float S[TT], G[NG];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) S[t] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) G[i] = 0.f;
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < SC_TILE / 256; ++k) {
+        const int m = blockIdx.x * SC_TILE + k * 256 + threadIdx.x;
+        const bool live = m < M;
+        const int mm = live ? m : 0;
+        const int ox = mm % a.OW;
+        const int r = mm / a.OW;
+        const int oy = r % a.OH;
+        const int n = r / a.OH;
+        const float* xn = a.x + (int64_t)n * a.IH * a.IW;
+        float xv[TT];
+#pragma unroll
+        for (int tap = 0; tap < TT; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int iy = oy - 1 + ky, ix = ox - 1 + kx;
+            const bool ok = live && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+            xv[tap] = ok ? xn[iy * a.IW + ix] : 0.f;
+        }
+        if (a.bnp) {
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                S[t] += xv[t];
+#pragma unroll
+                for (int u = t; u < TT; ++u) G[t * TT - t * (t - 1) / 2 + (u - t)] += xv[t] * xv[u];      // upper triangle, row-major
+            }
+        }
+        unsigned short* dst = a.y + (int64_t)mm * 64;
+#pragma unroll 1
+        for (int g = 0; g < 4; ++g) {                       // 16 channels at a time, a runtime loop: unrolled, the compiler hoists all
+            const float* wk = wl + sc_opaque(g * 16);       // 144 weight reads above the FMAs and spills the accumulators
+            float acc[16];
+            {
+                const float4* bp = reinterpret_cast<const float4*>(bl + sc_opaque(g * 16));
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const float4 b = bp[c4];
+                    acc[4 * c4] = b.x; acc[4 * c4 + 1] = b.y; acc[4 * c4 + 2] = b.z; acc[4 * c4 + 3] = b.w;
+                }
+            }
+#pragma unroll
+            for (int tap = 0; tap < TT; ++tap) {
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {            // wave-uniform addresses: broadcast reads
+                    const float4 w4 = reinterpret_cast<const float4*>(wk + tap * 64)[c4];
+                    acc[4 * c4] += xv[tap] * w4.x; acc[4 * c4 + 1] += xv[tap] * w4.y;
+                    acc[4 * c4 + 2] += xv[tap] * w4.z; acc[4 * c4 + 3] += xv[tap] * w4.w;
+                }
+            }
+            if (live) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float o[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const float v = acc[8 * i + c];
+                        o[c] = v > 0.f ? v : v * slope;
+                    }
+                    *reinterpret_cast<uint4*>(dst + g * 16 + 8 * i) = pack8<DT>(o);
+                }
+            }
+        }
+    }
+    if (a.bnp) {
+        const int wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const float v = wave_sum(S[t]);
+            if ((threadIdx.x & 63) == 0) part[wv][t] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const float v = wave_sum(G[i]);
+            if ((threadIdx.x & 63) == 0) part[wv][TT + i] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < TT + NG)                       // the four waves' sums, in wave order
+            part[0][threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int co = threadIdx.x;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll 1
+            for (int t = 0; t < TT; ++t) {
+                const float wt = wl[t * 64 + co];
+                s1 += wt * part[0][t];
+                const int row = TT + t * TT - t * (t - 1) / 2 - t;
+#pragma unroll 1
+                for (int u = t; u < TT; ++u) s2 += (u == t ? 1.f : 2.f) * wt * wl[u * 64 + co] * part[0][row + u];
+            }
+            a.bnp[(int64_t)blockIdx.x * 128 + co] = s1;
+            a.bnp[(int64_t)blockIdx.x * 128 + 64 + co] = s2;
+        }
     }
 }
 
@@ -814,7 +941,11 @@ extern "C" int gs_conv_smallcin_fwd(const float* x, const float* w, const float*
     GS_CHECK_ARG((int64_t)N * OH * OW < 2147483647LL && (int64_t)Cin * IH * IW < 2147483647LL, "gs_conv_smallcin_fwd: too many pixels");
     const size_t lds = ((size_t)Cin * k * k * 64 + 256 * SC64_PAD) * sizeof(float);
     const int T = Cin * k * k;
-    if (Cout == 64 && T <= 16 && act != GS_ACT_TANH) {
+    static const int line_env = getenv("GSSEG_STEM_LINE") ? atoi(getenv("GSSEG_STEM_LINE")) : 1;
+    if (line_env && Cout == 64 && Cin == 1 && k == 3 && stride == 1 && pad == 1 && act != GS_ACT_TANH) {
+        if (dtype == GS_F16) smallcin_fwd64_line_kernel<GS_F16><<<nb, 256, 0, s>>>(a);
+        else smallcin_fwd64_line_kernel<GS_BF16><<<nb, 256, 0, s>>>(a);
+    } else if (Cout == 64 && T <= 16 && act != GS_ACT_TANH) {
         const int tt = T <= 9 ? 9 : 16;
         const size_t lds4 = ((size_t)tt * 64 + 256 * 17) * sizeof(float);
         if (dtype == GS_F16) {

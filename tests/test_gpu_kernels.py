@@ -325,11 +325,12 @@ def test_bn_relu_pool_fwd_bwd(dtn, dt, N, H, W, C, pool):
 
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtn,dt", DTS)
-@pytest.mark.parametrize("Cin,k,s,p,bias", [(1, 3, 1, 1, False), (2, 4, 2, 1, True), (1, 4, 2, 1, False), (3, 3, 1, 1, False)])
-def test_smallcin(dtn, dt, Cin, k, s, p, bias):
+@pytest.mark.parametrize("Cin,k,s,p,bias", [(1, 3, 1, 1, False), (1, 3, 1, 1, True), (2, 4, 2, 1, True), (1, 4, 2, 1, False), (3, 3, 1, 1, False)])
+@pytest.mark.parametrize("H,W", [(18, 22), (45, 53)])       # one ragged tile; several tiles with a ragged last one
+def test_smallcin(dtn, dt, Cin, k, s, p, bias, H, W):
     from semantic_segmentation_amd import ops
     g = torch.Generator().manual_seed(7)
-    N, H, W, Cout = 2, 18, 22, 64
+    N, Cout = 2, 64
     x = torch.randn(N, Cin, H, W, generator=g).requires_grad_(True)
     w = (0.2 * torch.randn(Cout, Cin, k, k, generator=g)).requires_grad_(True)
     b = torch.randn(Cout, generator=g) if bias else None
