@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 30
+#define GS_ABI_VERSION 31
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -238,6 +238,14 @@ int gs_maxpool2x2_fwd(const void* z, int z_pix_stride, int z_coff, void* zp, int
  * unet_parts.py:53, excluding the F.pad border of unet_parts.py:59-61).  ws: fp32 [1024*C] workspace. */
 int gs_colsum(const void* t, int pix_stride, int coff, int N, int H, int W, int y0, int x0, int h, int w, int C,
               float gscale, float* ws, float* out, int dtype, void* stream);
+
+/* The same bias gradient taken from the tile partials of the convolution that WROTE the tensor (gs_conv3x3 with
+ * bn_partials, [ntiles][2][Cfull], sized by gs_bn_partials_floats): out[c] (OVERWRITE) = gscale * sum_tiles
+ * partials[tile][0][coff + c].  For the un-padded case (the transposed convolution's output covers the whole skip
+ * size, unet_parts.py:59-61 pads nothing): the data-gradient convolution's epilogue already holds the per-channel
+ * sums in fp32, so the separate pass of gs_colsum over the tensor is not needed.  ntiles = gs_conv3x3_mtiles(...). */
+int gs_bn_partials_colsum(const float* partials, int ntiles, int Cfull, int coff, int C, float gscale, float* out,
+                          void* stream);
 
 /* ---- weight packing ------------------------------------------------------------------------
  * Conv2d weight fp32 [Cout][Cin][kh][kw] -> fwd pack [kh*kw][Cout][Cin] and dgrad pack

@@ -40,13 +40,17 @@ __global__ __launch_bounds__(256) void reduce_partials_stage1(const float* __res
 }
 
 // sum of the stage-1 slices for 32 channels per block: 8 slice-lanes per channel through LDS (fixed order)
-__device__ __forceinline__ void sum_slices_32x8(const double* __restrict__ s, int nslices, int C, double& s1, double& s2) {
+// (T = double: the stage-1 slices; T = float: the tile partials themselves, where there are few enough to skip stage 1)
+template <typename T>
+__device__ __forceinline__ void sum_slices_32x8(const T* __restrict__ s, int nslices, int C, double& s1, double& s2) {
     __shared__ double red[2][8][32];
     const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double a = 0.0, b = 0.0;
-    if (c < C)
-        for (int i = tl; i < nslices; i += 8) { a += s[((int64_t)i * 2 + 0) * C + c]; b += s[((int64_t)i * 2 + 1) * C + c]; }
+    if (c < C) {
+#pragma unroll 4
+        for (int i = tl; i < nslices; i += 8) { a += (double)s[((int64_t)i * 2 + 0) * C + c]; b += (double)s[((int64_t)i * 2 + 1) * C + c]; }
+    }
     red[0][tl][cl] = a;
     red[1][tl][cl] = b;
     __syncthreads();
@@ -55,7 +59,8 @@ __device__ __forceinline__ void sum_slices_32x8(const double* __restrict__ s, in
     for (int i = 0; i < 8; ++i) { s1 += red[0][i][cl]; s2 += red[1][i][cl]; }
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ s, int nslices, int C, double count,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const T* __restrict__ s, int nslices, int C, double count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* running_mean, float* running_var, float momentum,
                                                           float eps, float* scale, float* shift, float* mean_out,
@@ -93,7 +98,8 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* be
     invstd[c] = is;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_coeffs_kernel(const double* __restrict__ s, int nslices, int C, double count,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_coeffs_kernel(const T* __restrict__ s, int nslices, int C, double count,
                                                             float gscale, float* dgamma, float* dbeta, float* c1, float* c2) {
     double s1, s2;
     sum_slices_32x8(s, nslices, C, s1, s2);
@@ -456,6 +462,56 @@ __global__ __launch_bounds__(256) void colsum_stage2(const float* ws, int nblock
     }
 }
 
+// Column sums out of a convolution's tile partials ([ntiles][2][Cfull], sum slot): the bias gradient of the transposed
+// convolution whose output is the channel range [coff, coff + C) of the tensor that convolution wrote.
+// stage 1: grid (ceil(C/32), nslices) -> out1[slice][C] (double); final: the slices (T = double) or the tiles (T = float).
+__global__ __launch_bounds__(256) void partials_colsum_stage1(const float* __restrict__ part, int ntiles, int Cfull, int coff, int C,
+                                                              int tiles_per_slice, double* __restrict__ out1) {
+    __shared__ double red[8][32];
+    const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    const int t0 = blockIdx.y * tiles_per_slice, t1 = min(ntiles, t0 + tiles_per_slice);
+    double s1 = 0.0;
+    if (c < C)
+        for (int tt = t0 + tl; tt < t1; tt += 8) s1 += (double)part[(int64_t)tt * 2 * Cfull + coff + c];
+    red[tl][cl] = s1;
+    __syncthreads();
+    if (tl == 0 && c < C) {
+        double a = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a += red[i][cl];
+        out1[(int64_t)blockIdx.y * C + c] = a;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void partials_colsum_final(const T* __restrict__ s, int n, int64_t stride, int C, float gscale,
+                                                             float* __restrict__ out) {
+    __shared__ double red[8][32];
+    const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double a = 0.0;
+    if (c < C) {
+#pragma unroll 4
+        for (int i = tl; i < n; i += 8) a += (double)s[(int64_t)i * stride + c];
+    }
+    red[tl][cl] = a;
+    __syncthreads();
+    if (tl == 0 && c < C) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[i][cl];
+        out[c] = (float)(t * gscale);
+    }
+}
+
+// Up to this many tiles the finalising kernels sum the tile partials themselves (one launch instead of two: each is at the
+// ~5 us launch floor, and the deep levels and the batch-2 steps of config 3 have few tiles); GSSEG_BN_DIRECT_TILES overrides.
+int direct_tiles() {
+    static const int v = getenv("GSSEG_BN_DIRECT_TILES") ? atoi(getenv("GSSEG_BN_DIRECT_TILES")) : 512;
+    return v;
+}
+
 int reduce_partials(const float* partials, int ntiles, int C, double** out, int* nslices, hipStream_t s) {
     // stage-1 output lives right behind the partials: [ntiles][2][C] floats, then [64][2][C] doubles
     int slices = ntiles < RED_SLICES ? ntiles : RED_SLICES;
@@ -482,10 +538,16 @@ extern "C" int gs_bn_finalize(const float* partials, int ntiles, int C, double c
     GS_CHECK_ARG(partials && scale && shift && mean && invstd && ntiles > 0 && C > 0 && count > 0,
                  "gs_bn_finalize: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    if (ntiles <= direct_tiles()) {
+        bn_finalize_kernel<float><<<cdiv(C, 32), 256, 0, s>>>(partials, ntiles, C, count, gamma, beta, running_mean, running_var,
+                                                               momentum, eps, scale, shift, mean, invstd);
+        GS_CHECK_LAUNCH("gs_bn_finalize");
+        return GS_OK;
+    }
     double* o1; int ns;
     reduce_partials(partials, ntiles, C, &o1, &ns, s);
-    bn_finalize_kernel<<<cdiv(C, 32), 256, 0, s>>>(o1, ns, C, count, gamma, beta, running_mean, running_var,
-                                                    momentum, eps, scale, shift, mean, invstd);
+    bn_finalize_kernel<double><<<cdiv(C, 32), 256, 0, s>>>(o1, ns, C, count, gamma, beta, running_mean, running_var,
+                                                            momentum, eps, scale, shift, mean, invstd);
     GS_CHECK_LAUNCH("gs_bn_finalize");
     return GS_OK;
 }
@@ -615,9 +677,14 @@ extern "C" int gs_bn_bwd_coeffs(const float* partials, int ntiles, int C, double
                                 float* dbeta, float* c1, float* c2, void* stream) {
     GS_CHECK_ARG(partials && c1 && c2 && ntiles > 0 && C > 0 && count > 0, "gs_bn_bwd_coeffs: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    if (ntiles <= direct_tiles()) {
+        bn_bwd_coeffs_kernel<float><<<cdiv(C, 32), 256, 0, s>>>(partials, ntiles, C, count, gscale, dgamma, dbeta, c1, c2);
+        GS_CHECK_LAUNCH("gs_bn_bwd_coeffs");
+        return GS_OK;
+    }
     double* o1; int ns;
     reduce_partials(partials, ntiles, C, &o1, &ns, s);
-    bn_bwd_coeffs_kernel<<<cdiv(C, 32), 256, 0, s>>>(o1, ns, C, count, gscale, dgamma, dbeta, c1, c2);
+    bn_bwd_coeffs_kernel<double><<<cdiv(C, 32), 256, 0, s>>>(o1, ns, C, count, gscale, dgamma, dbeta, c1, c2);
     GS_CHECK_LAUNCH("gs_bn_bwd_coeffs");
     return GS_OK;
 }
@@ -642,6 +709,25 @@ extern "C" int gs_bn_act_bwd_apply(const void* y, const void* dz_a, int sa, int 
     a.N = N; a.H = H; a.W = W; a.C = C;
     launch_bwd(a, true, dtype, (hipStream_t)stream, nullptr);
     GS_CHECK_LAUNCH("gs_bn_act_bwd_apply");
+    return GS_OK;
+}
+
+extern "C" int gs_bn_partials_colsum(const float* partials, int ntiles, int Cfull, int coff, int C, float gscale, float* out,
+                                     void* stream) {
+    GS_CHECK_ARG(partials && out && ntiles > 0 && Cfull > 0 && C > 0 && coff >= 0 && coff + C <= Cfull,
+                 "gs_bn_partials_colsum: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (ntiles <= direct_tiles()) {
+        partials_colsum_final<float><<<cdiv(C, 32), 256, 0, s>>>(partials + coff, ntiles, (int64_t)2 * Cfull, C, gscale, out);
+    } else {
+        int slices = ntiles < RED_SLICES ? ntiles : RED_SLICES;
+        const int tps = cdiv(ntiles, slices);
+        slices = cdiv(ntiles, tps);
+        double* o1 = (double*)((char*)partials + (((size_t)ntiles * 2 * Cfull * sizeof(float) + 15) & ~(size_t)15));   // stage-1 area
+        partials_colsum_stage1<<<dim3(cdiv(C, 32), slices), 256, 0, s>>>(partials, ntiles, Cfull, coff, C, tps, o1);
+        partials_colsum_final<double><<<cdiv(C, 32), 256, 0, s>>>(o1, slices, (int64_t)C, C, gscale, out);
+    }
+    GS_CHECK_LAUNCH("gs_bn_partials_colsum");
     return GS_OK;
 }
 

@@ -662,6 +662,15 @@ def maxpool3d_bwd(z, dzp, dres, dz, NB, D, H, W, C, z_stride=None, z_coff=0, res
               res_coff, _p(dz), NB, D, H, W, C, dt_code(z), _stream())
 
 
+def bn_partials_colsum(partials, ntiles, Cfull, coff, C, gscale, out):
+    """out[c] = gscale * sum over tiles of partials[tile][0][coff + c]: the column sums of a tensor, taken from the tile
+    partials of the convolution that wrote it (ConvTranspose2d bias gradient without a pass over the tensor)."""
+    _f32(partials, "partials"); _f32(out, "out")
+    if partials.numel() < bn_partials_numel(ntiles, Cfull) or out.numel() < C:
+        raise ValueError("bn_partials_colsum: buffer too small")
+    _lib.call("gs_bn_partials_colsum", _p(partials), ntiles, Cfull, coff, C, float(gscale), _p(out), _stream())
+
+
 def colsum(t, pix_stride, coff, N, H, W, y0, x0, h, w, C, gscale, ws, out):
     _f32(ws, "ws"); _f32(out, "out")
     if ws.numel() < 1024 * C:

@@ -33,6 +33,9 @@ FOLD_BN_INFERENCE = os.environ.get("GSSEG_FOLD_BN", "1") != "0"
 # but concurrent kernels stretch each other's event-bracketed durations (conv3x3 5.67 -> 5.83 ms "per kernel"), so the
 # per-kernel roofline figures of bench.py / rocprof stop being clean: the headline runs single-stream.
 WGRAD_SIDE_STREAM = os.environ.get("GSSEG_WGRAD_STREAM", "0") != "0"
+# ConvTranspose2d bias gradients out of the epilogue sums of the data-gradient convolution that writes d(concat), instead of
+# a column-sum pass over that tensor (un-padded case; GSSEG_UP_BIAS_FUSED=0 restores the pass).
+FUSED_UP_BIAS_GRAD = os.environ.get("GSSEG_UP_BIAS_FUSED", "1") != "0"
 
 
 class _ConvRec:
@@ -643,6 +646,8 @@ class UNetEngine:
         npart = 0
         for i in range(5):
             npart = max(npart, ops.bn_partials_numel(ops.bn_bwd_tiles(N, hs[i], ws_[i]), C[i]))
+            if i < 4 and ops.USE_HALO_CONV:          # the data-gradient convolution's partials over d(concat) (fused bias gradient)
+                npart = max(npart, ops.bn_partials_numel(ops.conv3x3_mtiles(N, hs[i], ws_[i], 2 * C[i]), 2 * C[i]))
         partials = empty(npart, dtype=torch.float32)
         col_ws = empty(1024 * 1024, dtype=torch.float32)
 
@@ -657,8 +662,10 @@ class UNetEngine:
         emit("outc.conv.weight", dwo)
         emit("outc.conv.bias", dbo)
 
-        def conv_stage_bwd(rec: _ConvRec, dz_a, sa, ca, dzp, need_dinp: bool):
-            """Backward of conv -> BN -> ReLU.  Returns d(input) (dense NHWC) or None."""
+        def conv_stage_bwd(rec: _ConvRec, dz_a, sa, ca, dzp, need_dinp: bool, colsum=None):
+            """Backward of conv -> BN -> ReLU.  Returns d(input) (dense NHWC) or None.
+            colsum = (coff, C, out): also out[c] = inv_s * sum over pixels of d(input)[..., coff + c], from the data-gradient
+            convolution's epilogue sums (the bias gradient of the transposed convolution that feeds this stage)."""
             h, w, cin, cout = rec.h, rec.w, rec.cin, rec.cout
             coef = rec.coef
             pooled = dzp is not None
@@ -698,7 +705,10 @@ class UNetEngine:
                     ops.unpack_wgrad(dwp, dw, cout, cin, 9, False, inv_s)
                 if need_dinp:
                     dinp = empty(N, h, w, cin)
-                    if ops.USE_HALO_CONV:
+                    if ops.USE_HALO_CONV and colsum is not None:
+                        ops.conv3x3(dy, rec.wd, dinp, N, h, w, cout, cin, ops.TAPS3_DGRAD, bn_partials=partials)
+                        ops.bn_partials_colsum(partials, ops.conv3x3_mtiles(N, h, w, cin), cin, colsum[0], colsum[1], inv_s, colsum[2])
+                    elif ops.USE_HALO_CONV:
                         ops.conv3x3(dy, rec.wd, dinp, N, h, w, cout, cin, ops.TAPS3_DGRAD)
                     else:
                         ops.conv_igemm(ops.geom_conv_dgrad_s1(N, h, w, cin, cout, 3, 1), dy, rec.wd, dinp)
@@ -716,9 +726,16 @@ class UNetEngine:
             cout_t = C[lvl]
             r3, r0 = recs[prefix + ".conv.3"], recs[prefix + ".conv.0"]
             dmid = conv_stage_bwd(r3, dz, r3.cout, 0, None, True)
-            dcat = conv_stage_bwd(r0, dmid, r0.cout, 0, None, True)
-            dcats[lvl] = dcat
             u = ups[prefix]
+            # un-padded transposed convolution: its bias gradient is a column sum of d(concat) over every pixel, which the
+            # data-gradient convolution writing d(concat) sums in its epilogue (no separate pass over the tensor)
+            db_fused = None
+            if (u.geom_bwd is not None and ops.USE_HALO_CONV and FUSED_UP_BIAS_GRAD and u.pt == 0 and u.pl == 0
+                    and 2 * u.h == u.H2 and 2 * u.w == u.W2):
+                db_fused = galloc(prefix + ".up.bias", params[prefix + ".up.bias"])
+            dcat = conv_stage_bwd(r0, dmid, r0.cout, 0, None, True,
+                                  colsum=None if db_fused is None else (cout_t, cout_t, db_fused))
+            dcats[lvl] = dcat
             if u.geom_bwd is None:                                    # bilinear up-sampling: transposed interpolation
                 dz = empty(N, u.h, u.w, u.cin)
                 ops.upsample2x_bilinear_bwd(dcat, dz, N, u.h, u.w, u.cin, u.H2, u.W2, dy_stride=2 * cout_t,
@@ -726,8 +743,11 @@ class UNetEngine:
                 continue
             wkey = prefix + ".up.weight"
             wparam = params[wkey]
-            db = galloc(prefix + ".up.bias", params[prefix + ".up.bias"])
-            ops.colsum(dcat, 2 * cout_t, cout_t, N, u.H2, u.W2, u.pt, u.pl, 2 * u.h, 2 * u.w, cout_t, inv_s, col_ws, db)
+            if db_fused is not None:
+                db = db_fused
+            else:
+                db = galloc(prefix + ".up.bias", params[prefix + ".up.bias"])
+                ops.colsum(dcat, 2 * cout_t, cout_t, N, u.H2, u.W2, u.pt, u.pl, 2 * u.h, 2 * u.w, cout_t, inv_s, col_ws, db)
             dw = galloc(wkey, wparam)
             on_side((dcat, u.zin, wg_ws, dw),
                     lambda u=u, dcat=dcat, dw=dw: ops.conv_wgrad_det(u.geom_wg if u.geom_wg is not None else u.geom_bwd, dcat, u.zin,

@@ -121,6 +121,37 @@ def test_conv3x3_dgrad_wgrad(dtn, dt, N, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("dtn,dt", DTS)
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 32, 32, 128, 64), (2, 160, 160, 128, 64), (1, 16, 16, 64, 64)])
+def test_dgrad_partials_give_upconv_bias_gradient(dtn, dt, N, H, W, Cin, Cout):
+    """ConvTranspose2d bias gradient (unet_parts.py:53) = column sums of the second half of d(concat): taken from the tile
+    partials of the data-gradient convolution that writes d(concat) (few tiles: one launch; many: two-stage)."""
+    from semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(31)
+    w = rnd(g, Cout, Cin, 3, 3, dt=dt, scale=0.05)
+    dy = rnd(g, N, Cout, H, W, dt=dt)
+    ref = F.conv_transpose2d(dy.float(), w.float(), None, padding=1)            # = data gradient of conv2d(pad 1)
+    wd = torch.empty(9, Cin, Cout, dtype=dt, device=dev())
+    ops.pack_weight(w.to(dev()), None, wd, False)
+    mt = ops.conv3x3_mtiles(N, H, W, Cin)
+    part = torch.full((ops.bn_partials_numel(mt, Cin),), float("nan"), dtype=torch.float32, device=dev())
+    dx = torch.empty(N, H, W, Cin, dtype=dt, device=dev())
+    ops.conv3x3(nhwc(dy, dt), wd, dx, N, H, W, Cout, Cin, ops.TAPS3_DGRAD, bn_partials=part)
+    half = Cin // 2
+    db = torch.full((half,), float("nan"), dtype=torch.float32, device=dev())
+    ops.bn_partials_colsum(part, mt, Cin, half, half, 0.5, db)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(dx), ref) < tol(dt)
+    want = ref.double().sum((0, 2, 3))[half:]
+    assert (db.double().cpu() * 2 - want).abs().max() < 2e-3 * max(1.0, want.abs().max().item())
+    # and it agrees with the column-sum pass over the stored 16-bit tensor up to that tensor's rounding
+    ws = torch.empty(1024 * half, dtype=torch.float32, device=dev())
+    db2 = torch.empty(half, dtype=torch.float32, device=dev())
+    ops.colsum(dx, Cin, half, N, H, W, 0, 0, H, W, half, 0.5, ws, db2)
+    torch.cuda.synchronize()
+    assert (db - db2).abs().max().item() < 2e-3 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("dtn,dt", DTS)
 def test_wgrad_large_k_split(dtn, dt):
     """many pixels, 64 channels: exercises split-K + atomics and the 1x4 wave arrangement"""
     from semantic_segmentation_amd import ops
