@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 31
+#define GS_ABI_VERSION 32
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -161,7 +161,20 @@ int gs_conv_smallcin_mtiles(int N, int OH, int OW);
 int gs_conv_smallcin_fwd(const float* x, const float* w, const float* bias, void* y, float* bn_partials,
                          int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int k, int stride, int pad,
                          int act, int dtype, void* stream);
-int64_t gs_conv_direct_wgrad_ws_floats(int N, int OH, int OW, int Cin, int Cout, int k);   /* workspace of the two below */
+int64_t gs_conv_direct_wgrad_ws_floats(int N, int OH, int OW, int Cin, int Cout, int k);   /* Stem backward in one pass (unet/unet_parts.py:16-18 with in_channels = 1, first stage of `inc`; the image needs no
+ * gradient): BatchNorm(train)/activation backward apply fused with the weight gradient of the 1-channel 3x3/s1/p1
+ * convolution with 64 outputs.  y [N,H,W,64] 16-bit = the convolution's output, dz = gradient w.r.t. the activation's
+ * output ([N,H,W,*], pixel stride dz_stride, channel offset dz_coff), x fp32 [N,1,H,W]; scale/shift/mean/invstd from
+ * gs_bn_finalize, c1/c2 from gs_bn_bwd_coeffs.  dw fp32 [64][1][3][3] += gscale * sum_pixels dy * x_tap with
+ * dy = scale*(dz*act'(scale*y+shift) - c1 - xhat*c2) kept in fp32 registers -- the tensor dy is never materialised
+ * (it replaces gs_bn_act_bwd_apply + gs_conv_smallcin_wgrad).  ws: gs_conv_direct_wgrad_ws_floats(N,H,W,1,64,3) floats.
+ * Returns GS_EUNSUPPORTED (no error string) when the image is too wide for the LDS strip; the caller then runs the two
+ * kernels it replaces. */
+int gs_stem_bn_bwd_wgrad(const void* y, const void* dz, int dz_stride, int dz_coff, const float* x, const float* scale,
+                         const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2,
+                         int act, float* dw, float* ws, int N, int H, int W, float gscale, int dtype, void* stream);
+
+/* workspace of the two below */
 int gs_conv_smallcin_wgrad(const float* x, const void* dy, float* dw, float* ws, int N, int Cin, int IH, int IW,
                            int Cout, int OH, int OW, int k, int stride, int pad, float gscale, int dtype, void* stream);
 int gs_conv_smallcin_dgrad(const void* dy, const float* w, float* dx, int N, int Cin, int IH, int IW, int Cout,

@@ -191,6 +191,8 @@ __global__ __launch_bounds__(256) void smallcin_fwd64_kernel(const SCArgs a) {
 // y[p][co] = sum_t x_t(p) w[co][t], so  sum_p y = sum_t w[co][t] S[t]  and  sum_p y^2 = sum_{t,t'} w[co][t] w[co][t'] G[t][t']
 // with the tap sums S[t] = sum_p x_t(p) and the 9 x 9 tap Gram matrix G (45 accumulators per thread instead of 128; the
 // per-channel quadratic forms are evaluated once per block).  Same tile (SC_TILE pixels) and partial layout as the other kernels.
+// Measured and dropped (batch 32, 256^2, 151 us as is): two pixels per thread so that every LDS weight read feeds both -- 220 us;
+// the wave's 64 lines collected in LDS and written as eight 1 KB stores of complete lines -- 219 us.
 // Hides a value from the optimiser (in a __device__ helper: an asm constraint in a __global__ template body loses the host stub).
 __device__ __forceinline__ int sc_opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 
@@ -488,6 +490,108 @@ __global__ __launch_bounds__(256) void smallcin_wgrad_kernel(const SCWArgs a) {
                     a.dw[(int64_t)blockIdx.x * a.Cout * T + (int64_t)co * T + tap] = s;
                 }
             }
+        }
+    }
+}
+
+// ---- stem backward: BatchNorm/ReLU backward apply + weight gradient of the one-channel 3x3 stem in ONE pass ------------
+// (unet_parts.py:16-18 with in_channels = 1, the first stage of `inc`.)  The image needs no gradient, so the gradient
+// w.r.t. the stem convolution's output has exactly one consumer -- this weight gradient: it is formed in registers
+//   dy = scale * (dz * relu'(scale*y + shift) - c1 - xhat * c2),  xhat = (y - mean) * invstd      (as bn_act_bwd_kernel)
+// and multiplied with the nine image taps at once; the 268 MB tensor dy (batch 32, 256^2) is neither written nor read
+// back.  The block's strip of the image (its pixels plus one row and one pixel either side) is staged in LDS once; a
+// thread owns 8 channels and every 32nd pixel of the block.  Partial slabs [block][64*9] as smallcin_wgrad_kernel.
+struct SBWArgs {
+    const unsigned short* y; const unsigned short* dz; const float* x;
+    const float *scale, *shift, *mean, *invstd, *c1, *c2;
+    float* slabs;
+    int dz_stride, dz_coff, N, H, W, act;
+    int64_t pix_per_block;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void stem_bn_bwd_wgrad_kernel(const SBWArgs a) {
+    extern __shared__ float sbw_smem[];
+    const int M = a.N * a.H * a.W;                                 // host guarantees < 2^31
+    const int ppb = (int)a.pix_per_block;
+    const int m0 = blockIdx.x * ppb;
+    const int m1 = m0 + ppb < M ? m0 + ppb : M;
+    const int nx = ppb + 2 * a.W + 2;
+    float* xs = sbw_smem;                                          // xs[i] = image[m0 - W - 1 + i] (flat over N*H*W)
+    float* red = sbw_smem + ((nx + 3) & ~3);                       // [256][25]
+    for (int i = threadIdx.x; i < nx; i += 256) {
+        const int idx = m0 - a.W - 1 + i;
+        xs[i] = (idx >= 0 && idx < M) ? a.x[idx] : 0.f;
+    }
+    const int ch = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int c0 = ch * 8;
+    const float slope = a.act == GS_ACT_RELU ? 0.f : (a.act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
+    float sc[8], sh[8], mu[8], is[8], k1[8], k2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        sc[i] = a.scale[c0 + i]; sh[i] = a.shift[c0 + i]; mu[i] = a.mean[c0 + i];
+        is[i] = a.invstd[c0 + i]; k1[i] = a.c1[c0 + i]; k2[i] = a.c2[c0 + i];
+    }
+    float acc[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[t][i] = 0.f;
+    __syncthreads();
+    constexpr int UNR = 4;
+    for (int mb = m0 + pl; mb < m1; mb += 32 * UNR) {
+        uint4 ry[UNR], rg[UNR];
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            const int m = mb + 32 * k;
+            const int64_t mm = m < m1 ? m : mb;
+            ry[k] = *reinterpret_cast<const uint4*>(a.y + mm * 64 + c0);
+            rg[k] = *reinterpret_cast<const uint4*>(a.dz + mm * a.dz_stride + a.dz_coff + c0);
+        }
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            const int m = mb + 32 * k;
+            const bool ok = m < m1;
+            const int mm = ok ? m : mb;
+            const int ox = mm % a.W;
+            const int oy = (mm / a.W) % a.H;
+            const float* xc = xs + (mm - m0 + a.W + 1);
+            float xv[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy_ = t / 3 - 1, dx_ = t % 3 - 1;
+                const bool in = ok && (unsigned)(oy + dy_) < (unsigned)a.H && (unsigned)(ox + dx_) < (unsigned)a.W;
+                xv[t] = in ? xc[dy_ * a.W + dx_] : 0.f;
+            }
+            float yv[8], g[8];
+            unpack8<DT>(ry[k], yv);
+            unpack8<DT>(rg[k], g);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float v = yv[i] * sc[i] + sh[i];
+                const float gh = g[i] * (v > 0.f ? 1.f : slope);
+                const float xh = (yv[i] - mu[i]) * is[i];
+                const float d = sc[i] * (gh - k1[i] - xh * k2[i]);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[t][i] += d * xv[t];     // xv = 0 for a masked pixel
+            }
+        }
+    }
+    // the 32 pixel lanes of every channel chunk, three taps per pass
+#pragma unroll
+    for (int t0 = 0; t0 < 9; t0 += 3) {
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) red[threadIdx.x * 25 + t * 8 + i] = acc[t0 + t][i];
+        __syncthreads();
+        if (threadIdx.x < 192) {                 // (tap of the pass, channel): sums the 32 pixel lanes
+            const int t = threadIdx.x >> 6, co = threadIdx.x & 63;
+            float sum = 0.f;
+#pragma unroll 8
+            for (int q = 0; q < 32; ++q) sum += red[(q * 8 + (co >> 3)) * 25 + t * 8 + (co & 7)];
+            a.slabs[(int64_t)blockIdx.x * 576 + co * 9 + t0 + t] = sum;
         }
     }
 }
@@ -905,12 +1009,27 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 
 }  // namespace
 
+// pixels per block of the two slab-writing weight-gradient kernels (stem and head): many blocks, each writes its partial
+// slab, a second kernel sums the slabs in order.  GSSEG_DIRECT_WGRAD_BLOCKS overrides the block count.
+// (measured at batch 32, 256^2: stem weight gradient 136 / 124 / 145 us and head weight gradient 73 / 64 / 69 us with
+// 2048 / 1024 / 512 blocks; the fused stem backward 136 / 127 / 118 us -- GSSEG_STEM_BWD_BLOCKS, default 512.)
+static int64_t direct_wgrad_ppb(int64_t M) {
+    static const int blocks = getenv("GSSEG_DIRECT_WGRAD_BLOCKS") ? atoi(getenv("GSSEG_DIRECT_WGRAD_BLOCKS")) : 1024;
+    int64_t ppb = cdiv64(M, blocks > 0 ? blocks : 1024);
+    if (ppb < 64) ppb = 64;
+    return ppb;
+}
+static int64_t stem_bwd_ppb(int64_t M) {
+    static const int blocks = getenv("GSSEG_STEM_BWD_BLOCKS") ? atoi(getenv("GSSEG_STEM_BWD_BLOCKS")) : 512;
+    int64_t ppb = cdiv64(M, blocks > 0 ? blocks : 512);
+    if (ppb < 64) ppb = 64;
+    return ppb;
+}
+
 extern "C" int64_t gs_conv_direct_wgrad_ws_floats(int N, int OH, int OW, int Cin, int Cout, int k) {
     const int64_t M = (int64_t)N * OH * OW;
-    int64_t ppb = cdiv64(M, 2048);
-    if (ppb < 64) ppb = 64;
-    const int64_t nb = cdiv64(M, ppb);
-    return nb * ((int64_t)Cout * Cin * k * k + 4);
+    const int64_t nb1 = cdiv64(M, direct_wgrad_ppb(M)), nb2 = cdiv64(M, stem_bwd_ppb(M));
+    return (nb1 > nb2 ? nb1 : nb2) * ((int64_t)Cout * Cin * k * k + 4);
 }
 
 extern "C" int gs_conv_smallcin_mtiles(int N, int OH, int OW) {
@@ -973,8 +1092,7 @@ extern "C" int gs_conv_smallcin_wgrad(const float* x, const void* dy, float* dw,
     if (rc) return rc;
     GS_CHECK_ARG(x && dy && dw && ws, "gs_conv_smallcin_wgrad: null pointer");
     const int64_t M = (int64_t)N * OH * OW;
-    int64_t ppb = cdiv64(M, 2048);      // many blocks, each writes its partial slab; a second kernel sums them in order
-    if (ppb < 64) ppb = 64;
+    const int64_t ppb = direct_wgrad_ppb(M);
     SCWArgs a{x, (const unsigned short*)dy, ws, N, Cin, IH, IW, Cout, OH, OW, k, stride, pad, gscale, ppb};
     const int nb = (int)cdiv64(M, ppb);
     hipStream_t s = (hipStream_t)stream;
@@ -990,6 +1108,30 @@ extern "C" int gs_conv_smallcin_wgrad(const float* x, const void* dy, float* dw,
     const int n = Cout * Cin * k * k;
     slab_reduce_kernel<<<cdiv(n, 32), 256, 0, s>>>(ws, nb, n, n, gscale, dw);
     GS_CHECK_LAUNCH("gs_conv_smallcin_wgrad");
+    return GS_OK;
+}
+
+extern "C" int gs_stem_bn_bwd_wgrad(const void* y, const void* dz, int dz_stride, int dz_coff, const float* x,
+                                    const float* scale, const float* shift, const float* mean, const float* invstd,
+                                    const float* c1, const float* c2, int act, float* dw, float* ws, int N, int H, int W,
+                                    float gscale, int dtype, void* stream) {
+    GS_CHECK_ARG(y && dz && x && scale && shift && mean && invstd && c1 && c2 && dw && ws, "gs_stem_bn_bwd_wgrad: null pointer");
+    GS_CHECK_ARG(N > 0 && H > 0 && W > 0 && (int64_t)N * H * W < 2147483647LL / 64, "gs_stem_bn_bwd_wgrad: bad dims");
+    GS_CHECK_ARG(dz_stride % 8 == 0 && dz_coff % 8 == 0 && dz_stride >= dz_coff + 64, "gs_stem_bn_bwd_wgrad: bad gradient layout");
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_stem_bn_bwd_wgrad: bad dtype");
+    GS_CHECK_ARG(act == GS_ACT_NONE || act == GS_ACT_RELU || act == GS_ACT_LEAKY02, "gs_stem_bn_bwd_wgrad: bad activation");
+    const int64_t M = (int64_t)N * H * W;
+    const int64_t ppb = stem_bwd_ppb(M);
+    const size_t lds = ((size_t)((ppb + 2 * W + 2 + 3) & ~(int64_t)3) + 256 * 25) * sizeof(float);
+    if (lds > 64 * 1024) return GS_EUNSUPPORTED;        // very wide images: the caller runs the two-kernel path
+    SBWArgs a{(const unsigned short*)y, (const unsigned short*)dz, x, scale, shift, mean, invstd, c1, c2, ws,
+              dz_stride, dz_coff, N, H, W, act, ppb};
+    const int nb = (int)cdiv64(M, ppb);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GS_F16) stem_bn_bwd_wgrad_kernel<GS_F16><<<nb, 256, lds, s>>>(a);
+    else stem_bn_bwd_wgrad_kernel<GS_BF16><<<nb, 256, lds, s>>>(a);
+    slab_reduce_kernel<<<cdiv(576, 32), 256, 0, s>>>(ws, nb, 576, 576, gscale, dw);
+    GS_CHECK_LAUNCH("gs_stem_bn_bwd_wgrad");
     return GS_OK;
 }
 
@@ -1074,8 +1216,7 @@ extern "C" int gs_conv_smallcout_bwd(const void* x, const float* w, const float*
     if (dw) {
         GS_CHECK_ARG(x != nullptr && ws != nullptr, "gs_conv_smallcout_bwd: dw needs x and a workspace");
         const int64_t M = (int64_t)N * OH * OW;
-        int64_t ppb = cdiv64(M, 2048);
-        if (ppb < 64) ppb = 64;
+        const int64_t ppb = direct_wgrad_ppb(M);
         a.pix_per_block = ppb;
         const int nb = (int)cdiv64(M, ppb);
         const int n = Cout * Cin * k * k;

@@ -559,6 +559,29 @@ def conv_smallcin_wgrad(x, dy, dw, k, stride, pad, gscale):
               float(gscale), dt_code(dy), _stream())
 
 
+def stem_bn_bwd_wgrad(y, dz, dz_stride, dz_coff, x, scale, shift, mean, invstd, c1, c2, act, dw, gscale) -> bool:
+    """BatchNorm/activation backward apply + weight gradient of the one-channel 3x3 stem in one pass (dw += ...; the gradient
+    w.r.t. the convolution's output stays in registers).  Returns False when the shape is outside the kernel (very wide
+    images): the caller then runs bn_act_bwd_apply + conv_smallcin_wgrad."""
+    _dev(y)
+    _f32(x, "x"); _f32(dw, "dw")
+    for n, t in (("scale", scale), ("shift", shift), ("mean", mean), ("invstd", invstd), ("c1", c1), ("c2", c2)):
+        _f32(t, n)
+    N, H, W, C = y.shape
+    if C != 64 or tuple(x.shape) != (N, 1, H, W) or dw.numel() != 576 or y.dtype != dz.dtype:
+        raise ValueError("stem_bn_bwd_wgrad: y [N,H,W,64], x [N,1,H,W], dw [64,1,3,3], one 16-bit dtype")
+    if not (y.is_contiguous() and x.is_contiguous() and dw.is_contiguous()):
+        raise ValueError("stem_bn_bwd_wgrad: y, x, dw must be contiguous")
+    ws = _direct_wgrad_ws(N, H, W, 1, 64, 3, y.device)
+    rc = _lib.load().gs_stem_bn_bwd_wgrad(_p(y), _p(dz), dz_stride, dz_coff, _p(x), _p(scale), _p(shift), _p(mean), _p(invstd),
+                                          _p(c1), _p(c2), act, _p(dw), _p(ws), N, H, W, float(gscale), dt_code(y), _stream())
+    if rc == _lib.GS_EUNSUPPORTED:
+        return False
+    if rc != 0:
+        _lib.check(rc, "gs_stem_bn_bwd_wgrad")
+    return True
+
+
 def conv_smallcin_dgrad(dy, w, dx, k, stride, pad, gscale):
     _f32(w, "w"); _f32(dx, "dx")
     N, Cin, IH, IW = dx.shape

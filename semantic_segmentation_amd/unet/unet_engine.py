@@ -35,6 +35,9 @@ FOLD_BN_INFERENCE = os.environ.get("GSSEG_FOLD_BN", "1") != "0"
 WGRAD_SIDE_STREAM = os.environ.get("GSSEG_WGRAD_STREAM", "0") != "0"
 # ConvTranspose2d bias gradients out of the epilogue sums of the data-gradient convolution that writes d(concat), instead of
 # a column-sum pass over that tensor (un-padded case; GSSEG_UP_BIAS_FUSED=0 restores the pass).
+# Stem backward (one input channel, image without gradient): BatchNorm backward apply + weight gradient in one pass
+# (GSSEG_STEM_BWD_FUSED=0 restores bn_act_bwd_apply + conv_smallcin_wgrad).
+FUSED_STEM_BWD = os.environ.get("GSSEG_STEM_BWD_FUSED", "1") != "0"
 FUSED_UP_BIAS_GRAD = os.environ.get("GSSEG_UP_BIAS_FUSED", "1") != "0"
 
 
@@ -677,13 +680,25 @@ class UNetEngine:
             ops.bn_bwd_coeffs(partials, ntiles, cout, N * h * w, inv_s, dgamma, dbeta, c12[0], c12[1])
             if not rec.train_stats:
                 c12.zero_()          # eval-mode BN: statistics are constants
+            wparam = params[rec.wkey]
+            dw_stem = None
+            if (rec.inp_is_image and not need_dinp and not pooled and FUSED_STEM_BWD and cin == 1 and cout == 64
+                    and rec.inp.is_contiguous()):
+                # one-channel stem, image without gradient: d(conv output) has one consumer, the weight gradient -- both
+                # in one pass, the tensor is never written
+                dw_stem = galloc(rec.wkey, wparam, zero=True)
+                if ops.stem_bn_bwd_wgrad(rec.y, dz_a, sa, ca, rec.inp, coef[0], coef[1], coef[2], coef[3], c12[0], c12[1],
+                                         ACT_RELU, dw_stem, inv_s):
+                    emit(rec.wkey, dw_stem)
+                    emit(rec.bnkey + ".weight", dgamma)
+                    emit(rec.bnkey + ".bias", dbeta)
+                    return None
             dy = empty(N, h, w, cout)
             ops.bn_act_bwd_apply(rec.y, dz_a, sa, ca, dzp, coef[0], coef[1], coef[2], coef[3], c12[0], c12[1],
                                  ACT_RELU, True, dy)
-            wparam = params[rec.wkey]
             dinp = None
             if rec.inp_is_image:
-                dw = galloc(rec.wkey, wparam, zero=True)
+                dw = dw_stem if dw_stem is not None else galloc(rec.wkey, wparam, zero=True)
                 ops.conv_smallcin_wgrad(rec.inp, dy, dw, 3, 1, 1, inv_s)
                 if need_dinp:
                     dinp = torch.empty_like(rec.inp)

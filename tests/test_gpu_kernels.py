@@ -390,6 +390,59 @@ def test_smallcin(dtn, dt, Cin, k, s, p, bias, H, W):
 
 
 @pytest.mark.parametrize("dtn,dt", DTS)
+@pytest.mark.parametrize("N,H,W,sa,ca", [(2, 18, 22, 64, 0), (3, 45, 53, 128, 64), (2, 64, 96, 64, 0)])
+def test_stem_bn_bwd_wgrad_fused(dtn, dt, N, H, W, sa, ca):
+    """BatchNorm/ReLU backward apply + one-channel stem weight gradient in one pass (unet_parts.py:16-18, in_channels=1):
+    against a torch fp32 autograd reference of conv -> BN(train) -> ReLU and against the two kernels it replaces."""
+    from semantic_segmentation_amd import ops
+    from semantic_segmentation_amd._lib import ACT_RELU
+    g = torch.Generator().manual_seed(41)
+    C = 64
+    x = torch.randn(N, 1, H, W, generator=g)
+    w = (0.3 * torch.randn(C, 1, 3, 3, generator=g)).requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    y_ref = F.conv2d(x, w, None, padding=1)
+    y16 = y_ref.detach().to(dt).float()                     # the stored convolution output
+    yl = y16.clone().requires_grad_(True)
+    z = F.relu(F.batch_norm(yl, None, None, gamma, beta, True, 0.1, 1e-5))
+    dz = rnd(g, N, C, H, W, dt=dt)
+    z.backward(dz)
+    want_dy = yl.grad                                       # gradient w.r.t. the convolution output (fp32)
+    want_dw = torch.nn.grad.conv2d_weight(x, w.shape, want_dy, padding=1)
+    # device side: statistics of the stored y, coefficients, then the fused pass
+    mean = y16.mean((0, 2, 3)); var = y16.var((0, 2, 3), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale = gamma.detach() * invstd; shift = beta.detach() - mean * scale
+    yd = nhwc(y16, dt)
+    dzbuf = torch.zeros(N, H, W, sa, dtype=dt, device=dev())
+    dzbuf[..., ca:ca + C] = nhwc(dz, dt)
+    coef = torch.stack([scale, shift, mean, invstd]).to(dev()).contiguous()
+    part = torch.zeros(ops.bn_partials_numel(ops.bn_bwd_tiles(N, H, W), C), dtype=torch.float32, device=dev())
+    ops.bn_act_bwd_reduce(yd, dzbuf, sa, ca, None, coef[0], coef[1], coef[2], coef[3], ACT_RELU, part)
+    dgamma = torch.empty(C, device=dev()); dbeta = torch.empty(C, device=dev())
+    c12 = torch.empty(2, C, device=dev())
+    ops.bn_bwd_coeffs(part, ops.bn_bwd_tiles_used(N, H, W, False), C, N * H * W, 1.0, dgamma, dbeta, c12[0], c12[1])
+    xd = x.to(dev())
+    dw = torch.zeros(C, 1, 3, 3, dtype=torch.float32, device=dev())
+    assert ops.stem_bn_bwd_wgrad(yd, dzbuf, sa, ca, xd, coef[0], coef[1], coef[2], coef[3], c12[0], c12[1], ACT_RELU, dw, 0.5)
+    # the two kernels it replaces
+    dy = torch.empty(N, H, W, C, dtype=dt, device=dev())
+    ops.bn_act_bwd_apply(yd, dzbuf, sa, ca, None, coef[0], coef[1], coef[2], coef[3], c12[0], c12[1], ACT_RELU, True, dy)
+    dw2 = torch.zeros(C, 1, 3, 3, dtype=torch.float32, device=dev())
+    ops.conv_smallcin_wgrad(xd, dy, dw2, 3, 1, 1, 0.5)
+    torch.cuda.synchronize()
+    assert rel_err(dgamma, gamma.grad) < 5e-3 and rel_err(dbeta, beta.grad) < 5e-3
+    e_fused, e_two = rel_err(dw.cpu() * 2, want_dw), rel_err(dw2.cpu() * 2, want_dw)
+    assert e_fused < (2e-3 if dt == torch.float16 else 1e-2), e_fused
+    assert e_fused <= e_two * 1.2 + 1e-5, (e_fused, e_two)          # fp32 dy in registers: no worse than via the 16-bit tensor
+    # accumulation contract: dw += ...
+    assert ops.stem_bn_bwd_wgrad(yd, dzbuf, sa, ca, xd, coef[0], coef[1], coef[2], coef[3], c12[0], c12[1], ACT_RELU, dw, 0.5)
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu(), want_dw) < (2e-3 if dt == torch.float16 else 1e-2)
+
+
+@pytest.mark.parametrize("dtn,dt", DTS)
 @pytest.mark.parametrize("Cin,Cout,k,p", [(64, 2, 1, 0), (64, 1, 1, 0), (512, 1, 4, 1)])
 def test_smallcout(dtn, dt, Cin, Cout, k, p):
     from semantic_segmentation_amd import ops
