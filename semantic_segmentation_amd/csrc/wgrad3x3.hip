@@ -560,6 +560,48 @@ __global__ __launch_bounds__(256) void wgrad_reduce_unpack_kernel(const float* _
         }
     }
 }
+// Few parts, many weights (the deep layers: 4..32 slabs of 0.6..9.4 MB): one thread per (a, b) sums its T taps over the
+// parts -- every load instruction of a wave reads 256 contiguous bytes of one slab row, 4 x T loads in flight -- and the
+// block writes its 256 x T results, contiguous in the reference layout [a][b][t], through LDS in whole rows.  (The kernel
+// above spreads 128 floats x 8 part lanes over a block and scatters 4-byte stores T floats apart: launch- and store-bound
+// here, 17 us for 37.7 MB.)
+template <int T>
+__global__ __launch_bounds__(256) void wgrad_reduce_rows_kernel(const float* __restrict__ ws, int nparts, int64_t stride,
+                                                                float* __restrict__ grad, int AB, float gscale) {
+    constexpr int TP = T | 1;                                  // odd row stride: conflict-free both ways
+    __shared__ float sm[256 * TP];
+    const int r0 = blockIdx.x * 256, r = r0 + threadIdx.x;
+    float acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = 0.f;
+    if (r < AB) {
+        int p = 0;
+        for (; p + 3 < nparts; p += 4) {
+            float v[4][T];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < T; ++t) v[u][t] = ws[(int64_t)(p + u) * stride + (int64_t)t * AB + r];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < T; ++t) acc[t] += v[u][t];
+        }
+        for (; p < nparts; ++p)
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[t] += ws[(int64_t)p * stride + (int64_t)t * AB + r];
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) sm[threadIdx.x * TP + t] = acc[t] * gscale;
+    __syncthreads();
+    const int64_t n = (int64_t)AB * T, o0 = (int64_t)r0 * T;
+#pragma unroll
+    for (int k = 0; k < T; ++k) {
+        const int e = k * 256 + threadIdx.x;                  // element of the block's output: row e / T, tap e % T
+        const int64_t o = o0 + e;
+        if (o < n) grad[o] = sm[(e / T) * TP + e % T];
+    }
+}
 }  // namespace
 
 extern "C" int gs_wgrad_reduce_unpack(const float* ws, int nparts, float* grad, int A, int B, int taps, int transposed,
@@ -567,6 +609,17 @@ extern "C" int gs_wgrad_reduce_unpack(const float* ws, int nparts, float* grad, 
     GS_CHECK_ARG(ws && grad && nparts > 0 && A > 0 && B > 0 && taps > 0, "gs_wgrad_reduce_unpack: bad arguments");
     const int64_t n = (int64_t)taps * A * B;
     GS_CHECK_ARG(n % 4 == 0 && (((uintptr_t)ws) & 15) == 0, "gs_wgrad_reduce_unpack: taps*A*B must be a multiple of 4 and ws 16-byte aligned");
+    static const int rows_parts = getenv("GSSEG_WGRAD_REDUCE_ROWS") ? atoi(getenv("GSSEG_WGRAD_REDUCE_ROWS")) : 32;
+    const int64_t AB = (int64_t)A * B;
+    if (!transposed && nparts <= rows_parts && AB >= 256 * 64 && AB < 2147483647LL / 64 && (taps == 9 || taps == 16 || taps == 4)) {
+        const int nb = (int)cdiv64(AB, 256);
+        hipStream_t s = (hipStream_t)stream;
+        if (taps == 9) wgrad_reduce_rows_kernel<9><<<nb, 256, 0, s>>>(ws, nparts, n, grad, (int)AB, gscale);
+        else if (taps == 16) wgrad_reduce_rows_kernel<16><<<nb, 256, 0, s>>>(ws, nparts, n, grad, (int)AB, gscale);
+        else wgrad_reduce_rows_kernel<4><<<nb, 256, 0, s>>>(ws, nparts, n, grad, (int)AB, gscale);
+        GS_CHECK_LAUNCH("gs_wgrad_reduce_unpack");
+        return GS_OK;
+    }
     wgrad_reduce_unpack_kernel<<<(int)cdiv64(n, 128), 256, 0, (hipStream_t)stream>>>(ws, nparts, n, grad, A, B, taps, transposed, gscale);
     GS_CHECK_LAUNCH("gs_wgrad_reduce_unpack");
     return GS_OK;

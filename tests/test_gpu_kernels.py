@@ -615,6 +615,28 @@ def test_conv3x3_halo_wgrad(dtn, dt, N, H, W, Cin, Cout):
     assert rel_err(g1.cpu() * 4, w.grad) < 2e-3
 
 
+@pytest.mark.parametrize("A,B,T,parts,transposed", [(128, 128, 9, 4, 0), (256, 128, 9, 32, 0), (160, 130, 9, 3, 0), (128, 128, 16, 5, 0),
+                                                    (128, 256, 4, 2, 0), (512, 512, 9, 1, 0), (128, 128, 9, 40, 0), (128, 256, 4, 2, 1),
+                                                    (64, 64, 9, 7, 0)])
+def test_wgrad_reduce_unpack_layouts(A, B, T, parts, transposed):
+    """gs_wgrad_reduce_unpack: slabs [part][tap][A][B] -> reference layout [A][B][tap] ([B][A][tap] transposed) * gscale, in the
+    few-parts row kernel (deep layers) and the many-parts kernel; overwrite semantics, repeatable bit for bit."""
+    from semantic_segmentation_amd import _lib
+    from semantic_segmentation_amd.ops import _p, _stream
+    g = torch.Generator().manual_seed(17)
+    ws = torch.randn(parts, T, A, B, generator=g).to(dev())
+    want = ws.double().sum(0).permute(2, 1, 0) if transposed else ws.double().sum(0).permute(1, 2, 0)    # [B][A][T] / [A][B][T]
+    outs = []
+    for _ in range(2):
+        grad = torch.full((A * B * T,), float("nan"), dtype=torch.float32, device=dev())
+        _lib.call("gs_wgrad_reduce_unpack", _p(ws), parts, _p(grad), A, B, T, transposed, 0.5, _stream())
+        torch.cuda.synchronize()
+        outs.append(grad)
+    assert torch.equal(outs[0], outs[1])
+    got = outs[0].double().cpu().view(*want.shape) * 2
+    assert (got - want.cpu()).abs().max().item() < 1e-5 * max(1.0, want.abs().max().item())
+
+
 @pytest.mark.parametrize("dtn,dt", DTS)
 @pytest.mark.parametrize("NB,D,H,W,Cin,Cout", [(1, 4, 8, 8, 64, 64), (2, 3, 9, 13, 128, 72), (1, 1, 16, 16, 64, 8),
                                                (1, 5, 33, 20, 192, 64), (1, 4, 12, 12, 32, 64), (1, 3, 8, 8, 72, 32)])

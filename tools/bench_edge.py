@@ -35,6 +35,8 @@ dw = torch.empty(C, 1, 3, 3, dtype=torch.float32, device=dev)
 mb = 2.0 * B * H * W * C / 1e6
 t = timeit(lambda: ops.conv_smallcin_fwd(x, w, None, y, part, 3, 1, 1))
 print(f"stem fwd (+BN partials)   {t:7.1f} us  {mb / t:6.2f} TB/s of the {mb:.0f} MB output")
+t = timeit(lambda: ops.conv_smallcin_fwd(x, w, None, y, None, 3, 1, 1))
+print(f"stem fwd (no partials)    {t:7.1f} us  {mb / t:6.2f} TB/s")
 t = timeit(lambda: ops.conv_smallcin_wgrad(x, dy, dw, 3, 1, 1, 1.0))
 print(f"stem wgrad                {t:7.1f} us  {mb / t:6.2f} TB/s of the {mb:.0f} MB gradient read")
 for ncls in (2, 1):
