@@ -1361,7 +1361,10 @@ __global__ __launch_bounds__(64 * NWV, (KC == 16 && NB == 1) ? 2 : 1) void conv3
                 bv[j] = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
             }
         }
-        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+        // (even row, odd row) sums in packed fp32 math: the statistics cost +7..8 % on the 64-channel layers with four scalar
+        // operations per pair, +5 % with two packed ones; the rest is the reduction / hand-over behind the epilogue
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 s1v[2] = {{0.f, 0.f}, {0.f, 0.f}}, s2v[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int prow0 = (wave * 2 + i) * 32;
@@ -1381,14 +1384,10 @@ __global__ __launch_bounds__(64 * NWV, (KC == 16 && NB == 1) ? 2 : 1) void conv3
                 for (int j = 0; j < 2; ++j) {
                     float v0 = acc[i][2 * jj + j][r0], v1 = acc[i][2 * jj + j][r0 + 1];
                     if (want_stats) {
-                        if (FULL) {
-                            s1[j] += v0 + v1;
-                            s2[j] += v0 * v0 + v1 * v1;
-                        } else {
-                            const float u0 = v0 * w0, u1 = v1 * w1;
-                            s1[j] += u0 + u1;
-                            s2[j] += u0 * u0 + u1 * u1;
-                        }
+                        f32x2 vv = {v0, v1};
+                        if (!FULL) vv *= f32x2{w0, w1};
+                        s1v[j] += vv;
+                        s2v[j] += vv * vv;
                     }
                     if (!PLAIN) {
                         v0 += bv[j];
@@ -1438,11 +1437,12 @@ __global__ __launch_bounds__(64 * NWV, (KC == 16 && NB == 1) ? 2 : 1) void conv3
         if (want_stats) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                s1[j] += __shfl_xor(s1[j], 32, 64);
-                s2[j] += __shfl_xor(s2[j], 32, 64);
+                float t1 = s1v[j].x + s1v[j].y, t2 = s2v[j].x + s2v[j].y;
+                t1 += __shfl_xor(t1, 32, 64);
+                t2 += __shfl_xor(t2, 32, 64);
                 if (h == 0) {
-                    red[(wave * 2 + 0) * BN + jj * 64 + j * 32 + l31] = s1[j];
-                    red[(wave * 2 + 1) * BN + jj * 64 + j * 32 + l31] = s2[j];
+                    red[(wave * 2 + 0) * BN + jj * 64 + j * 32 + l31] = t1;
+                    red[(wave * 2 + 1) * BN + jj * 64 + j * 32 + l31] = t2;
                 }
             }
         }
