@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 32
+#define GS_ABI_VERSION 33
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -251,6 +251,19 @@ int gs_maxpool2x2_fwd(const void* z, int z_pix_stride, int z_coff, void* zp, int
  * unet_parts.py:53, excluding the F.pad border of unet_parts.py:59-61).  ws: fp32 [1024*C] workspace. */
 int gs_colsum(const void* t, int pix_stride, int coff, int N, int H, int W, int y0, int x0, int h, int w, int C,
               float gscale, float* ws, float* out, int dtype, void* stream);
+
+/* BatchNorm + activation backward of the stage in FRONT of a pointwise head (unet/unet_parts.py:19-21 followed by the
+ * OutConv of :74, n_classes <= 4): the gradient w.r.t. the activation's output is dz[p][c] = sum_k dl[n][k][h][w] *
+ * w_head[k][c].  These two entry points take dl (fp32 [N,ncls,H,W], the logit gradient) and w_head (fp32 [ncls][C], the
+ * head's weight) instead of a dz tensor and form dz on the fly in fp32 -- the head's data-gradient kernel
+ * (gs_conv_smallcout_bwd with dx) and the 2 x N*H*W*C*2 bytes it writes and these passes read back drop out.  Same
+ * partials / dy semantics as gs_bn_act_bwd_reduce / gs_bn_act_bwd_apply (bn = 1, plain pixels, no second source). */
+int gs_bn_act_bwd_reduce_head(const void* y, const float* dl, const float* w_head, int ncls, const float* scale,
+                              const float* shift, const float* mean, const float* invstd, int act, float* partials, int N,
+                              int H, int W, int C, int dtype, void* stream);
+int gs_bn_act_bwd_apply_head(const void* y, const float* dl, const float* w_head, int ncls, const float* scale,
+                             const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2,
+                             int act, void* dy, int N, int H, int W, int C, int dtype, void* stream);
 
 /* The same bias gradient taken from the tile partials of the convolution that WROTE the tensor (gs_conv3x3 with
  * bn_partials, [ntiles][2][Cfull], sized by gs_bn_partials_floats): out[c] (OVERWRITE) = gscale * sum_tiles

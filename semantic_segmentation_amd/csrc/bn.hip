@@ -216,6 +216,12 @@ struct BwdArgs {
     int sa, ca, act, bn, N, H, W, C;
     int tile_units;   // work units (pixels or 2x2 windows) per tile
     int rev;          // blocks take the tiles last to first (see bn_traversal())
+    // HEAD source (instead of dza): the gradient w.r.t. this activation is that of a pointwise head with <= 4 outputs,
+    // dz[p][c] = sum_k head_dl[n][k][hw] * head_w[k][c] -- formed here from the 2..16 MB of logit gradients instead of
+    // being written as a [N,H,W,C] tensor by the head's data-gradient kernel and read back twice
+    const float* head_dl;
+    const float* head_w;
+    int head_n;
 };
 
 // gradient w.r.t. z at one pixel for 8 channels: concat/skip part + max-pool routed part.
@@ -224,8 +230,9 @@ struct BwdArgs {
 // GENERIC = some activation is tanh (runtime switch per element); otherwise the activations are the slope family
 // (identity / ReLU / LeakyReLU) and their value / derivative is one compare + select -- the per-element uniform
 // `switch` of act_fwd/act_grad costs a scalar branch per element and held these kernels at ~3 TB/s.
-template <int DT, bool POOL, bool APPLY, bool GENERIC>
+template <int DT, bool POOL, bool APPLY, bool GENERIC, bool HEAD = false>
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
+    static_assert(!HEAD || (!POOL && !GENERIC), "the head source: plain pixels, slope-family activation");
     __shared__ float red[2][256 * 8 / 8][8];   // [stat][thread][8 channels] -- reduced below
     const float slope_a = a.act == GS_ACT_RELU ? 0.f : (a.act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
     const float slope_b = a.act_b == GS_ACT_RELU ? 0.f : (a.act_b == GS_ACT_LEAKY02 ? 0.2f : 1.f);
@@ -262,6 +269,14 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
         float s1[8], s2[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+        float hw[4][8];                                     // HEAD: the head's weights for this channel chunk
+        if (HEAD) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) hw[k][i] = k < a.head_n ? a.head_w[k * a.C + c0 + i] : 0.f;
+        }
+        const int HWp = a.H * a.W;
 
         if (!POOL) {
             // a unit IS a pixel: no index decomposition at all
@@ -269,13 +284,21 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
                 uint4 ry[UNR], rg[UNR], rb[UNR];
                 uint2 rk[UNR];
                 bool ok[UNR];
+                float hd[UNR][4];
 #pragma unroll
                 for (int k = 0; k < UNR; ++k) {
                     const int u = ub + k * unit_lanes;
                     ok[k] = u < u1;
                     const int64_t pix = ok[k] ? u : u0;
                     ry[k] = *reinterpret_cast<const uint4*>(a.y + pix * a.C + c0);
-                    rg[k] = a.dza ? *reinterpret_cast<const uint4*>(a.dza + pix * a.sa + a.ca + c0) : make_uint4(0, 0, 0, 0);
+                    if (HEAD) {
+                        const int n = (int)pix / HWp, hwp = (int)pix - n * HWp;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) hd[k][q] = q < a.head_n ? a.head_dl[((int64_t)n * a.head_n + q) * HWp + hwp] : 0.f;
+                        rg[k] = make_uint4(0, 0, 0, 0);
+                    } else {
+                        rg[k] = a.dza ? *reinterpret_cast<const uint4*>(a.dza + pix * a.sa + a.ca + c0) : make_uint4(0, 0, 0, 0);
+                    }
                     rb[k] = a.dzb ? *reinterpret_cast<const uint4*>(a.dzb + pix * a.C + c0) : make_uint4(0, 0, 0, 0);
                     rk[k] = a.keep ? *reinterpret_cast<const uint2*>(a.keep + pix * a.C + c0) : make_uint2(0, 0);
                 }
@@ -287,6 +310,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
                     unpack8<DT>(ry[k], yv);
                     unpack8<DT>(rg[k], g);
                     unpack8<DT>(rb[k], gb);
+                    if (HEAD) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            g[i] = (hd[k][0] * hw[0][i] + hd[k][1] * hw[1][i]) + (hd[k][2] * hw[2][i] + hd[k][3] * hw[3][i]);
+                    }
                     if (a.keep) {
                         const unsigned int kw[2] = {rk[k].x, rk[k].y};
 #pragma unroll
@@ -636,6 +664,16 @@ static int launch_bwd(const BwdArgs& a0, bool apply, int dtype, hipStream_t s, i
             else bn_act_bwd_kernel<DT, false, false, G><<<ntiles, 256, 0, s>>>(a);                      \
         }                                                                                               \
     } while (0)
+    if (a.head_dl != nullptr) {                            // the head source: plain pixels, slope-family activation (host checks)
+        if (dtype == GS_F16) {
+            if (apply) bn_act_bwd_kernel<GS_F16, false, true, false, true><<<ntiles, 256, 0, s>>>(a);
+            else bn_act_bwd_kernel<GS_F16, false, false, false, true><<<ntiles, 256, 0, s>>>(a);
+        } else {
+            if (apply) bn_act_bwd_kernel<GS_BF16, false, true, false, true><<<ntiles, 256, 0, s>>>(a);
+            else bn_act_bwd_kernel<GS_BF16, false, false, false, true><<<ntiles, 256, 0, s>>>(a);
+        }
+        return 0;
+    }
     if (dtype == GS_F16) { if (generic) LAUNCH(GS_F16, true); else LAUNCH(GS_F16, false); }
     else { if (generic) LAUNCH(GS_BF16, true); else LAUNCH(GS_BF16, false); }
 #undef LAUNCH
@@ -709,6 +747,49 @@ extern "C" int gs_bn_act_bwd_apply(const void* y, const void* dz_a, int sa, int 
     a.N = N; a.H = H; a.W = W; a.C = C;
     launch_bwd(a, true, dtype, (hipStream_t)stream, nullptr);
     GS_CHECK_LAUNCH("gs_bn_act_bwd_apply");
+    return GS_OK;
+}
+
+// BatchNorm backward of the stage in front of a pointwise head (unet/unet_parts.py:74 after :19-21): the gradient source is
+// the head's logit gradient and weight, not a tensor (see BwdArgs::head_dl).
+static int bn_head_args(const char* who, BwdArgs& a, const void* y, const float* dl, const float* w_head, int ncls,
+                        const float* scale, const float* shift, const float* mean, const float* invstd, int act, int N, int H,
+                        int W, int C, int dtype) {
+    GS_CHECK_ARG(y && dl && w_head && ncls >= 1 && ncls <= 4 && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= 2048,
+                 "%s: bad arguments", who);
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "%s: bad dtype", who);
+    GS_CHECK_ARG((int64_t)N * H * W < 2147483647LL, "%s: more than 2^31 pixels", who);
+    GS_CHECK_ARG(act == GS_ACT_NONE || act == GS_ACT_RELU || act == GS_ACT_LEAKY02, "%s: activation %d not supported", who, act);
+    GS_CHECK_ARG(scale && shift && mean && invstd, "%s: needs the BatchNorm coefficients", who);
+    a.y = (const unsigned short*)y; a.head_dl = dl; a.head_w = w_head; a.head_n = ncls;
+    a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.act = act; a.bn = 1;
+    a.N = N; a.H = H; a.W = W; a.C = C;
+    return GS_OK;
+}
+
+extern "C" int gs_bn_act_bwd_reduce_head(const void* y, const float* dl, const float* w_head, int ncls, const float* scale,
+                                         const float* shift, const float* mean, const float* invstd, int act, float* partials,
+                                         int N, int H, int W, int C, int dtype, void* stream) {
+    BwdArgs a{};
+    int rc = bn_head_args("gs_bn_act_bwd_reduce_head", a, y, dl, w_head, ncls, scale, shift, mean, invstd, act, N, H, W, C, dtype);
+    if (rc) return rc;
+    GS_CHECK_ARG(partials != nullptr, "gs_bn_act_bwd_reduce_head: null partials");
+    a.partials = partials;
+    launch_bwd(a, false, dtype, (hipStream_t)stream, nullptr);
+    GS_CHECK_LAUNCH("gs_bn_act_bwd_reduce_head");
+    return GS_OK;
+}
+
+extern "C" int gs_bn_act_bwd_apply_head(const void* y, const float* dl, const float* w_head, int ncls, const float* scale,
+                                        const float* shift, const float* mean, const float* invstd, const float* c1,
+                                        const float* c2, int act, void* dy, int N, int H, int W, int C, int dtype, void* stream) {
+    BwdArgs a{};
+    int rc = bn_head_args("gs_bn_act_bwd_apply_head", a, y, dl, w_head, ncls, scale, shift, mean, invstd, act, N, H, W, C, dtype);
+    if (rc) return rc;
+    GS_CHECK_ARG(dy && c1 && c2, "gs_bn_act_bwd_apply_head: null pointer");
+    a.c1 = c1; a.c2 = c2; a.dy = (unsigned short*)dy;
+    launch_bwd(a, true, dtype, (hipStream_t)stream, nullptr);
+    GS_CHECK_LAUNCH("gs_bn_act_bwd_apply_head");
     return GS_OK;
 }
 

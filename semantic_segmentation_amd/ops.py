@@ -685,6 +685,29 @@ def maxpool3d_bwd(z, dzp, dres, dz, NB, D, H, W, C, z_stride=None, z_coff=0, res
               res_coff, _p(dz), NB, D, H, W, C, dt_code(z), _stream())
 
 
+def bn_act_bwd_reduce_head(y, dl, w_head, scale, shift, mean, invstd, act, partials):
+    """bn_act_bwd_reduce with the gradient source dz = dl . w_head formed on the fly (the stage in front of a pointwise head)."""
+    _dev(y)
+    _f32(dl, "dl"); _f32(w_head, "w_head"); _f32(partials, "partials")
+    N, H, W, C = y.shape
+    ncls = dl.shape[1]
+    if tuple(dl.shape) != (N, ncls, H, W) or w_head.numel() != ncls * C or not (dl.is_contiguous() and w_head.is_contiguous()):
+        raise ValueError("bn_act_bwd_reduce_head: dl [N,ncls,H,W] and w_head [ncls,C] contiguous fp32")
+    _lib.call("gs_bn_act_bwd_reduce_head", _p(y), _p(dl), _p(w_head), ncls, _p(scale), _p(shift), _p(mean), _p(invstd), act,
+              _p(partials), N, H, W, C, dt_code(y), _stream())
+
+
+def bn_act_bwd_apply_head(y, dl, w_head, scale, shift, mean, invstd, c1, c2, act, dy):
+    _dev(y)
+    _f32(dl, "dl"); _f32(w_head, "w_head")
+    N, H, W, C = y.shape
+    ncls = dl.shape[1]
+    if tuple(dl.shape) != (N, ncls, H, W) or w_head.numel() != ncls * C or not (dl.is_contiguous() and w_head.is_contiguous()):
+        raise ValueError("bn_act_bwd_apply_head: dl [N,ncls,H,W] and w_head [ncls,C] contiguous fp32")
+    _lib.call("gs_bn_act_bwd_apply_head", _p(y), _p(dl), _p(w_head), ncls, _p(scale), _p(shift), _p(mean), _p(invstd),
+              _p(c1), _p(c2), act, _p(dy), N, H, W, C, dt_code(y), _stream())
+
+
 def bn_partials_colsum(partials, ntiles, Cfull, coff, C, gscale, out):
     """out[c] = gscale * sum over tiles of partials[tile][0][coff + c]: the column sums of a tensor, taken from the tile
     partials of the convolution that wrote it (ConvTranspose2d bias gradient without a pass over the tensor)."""

@@ -38,6 +38,8 @@ WGRAD_SIDE_STREAM = os.environ.get("GSSEG_WGRAD_STREAM", "0") != "0"
 # Stem backward (one input channel, image without gradient): BatchNorm backward apply + weight gradient in one pass
 # (GSSEG_STEM_BWD_FUSED=0 restores bn_act_bwd_apply + conv_smallcin_wgrad).
 FUSED_STEM_BWD = os.environ.get("GSSEG_STEM_BWD_FUSED", "1") != "0"
+# Head backward: the data gradient of the 1x1 head is formed inside the BatchNorm backward of the last stage.
+FUSED_HEAD_BWD = os.environ.get("GSSEG_HEAD_BWD_FUSED", "1") != "0"
 FUSED_UP_BIAS_GRAD = os.environ.get("GSSEG_UP_BIAS_FUSED", "1") != "0"
 
 
@@ -660,20 +662,33 @@ class UNetEngine:
         wout = params["outc.conv.weight"]
         dwo = galloc("outc.conv.weight", wout, zero=True)
         dbo = galloc("outc.conv.bias", params["outc.conv.bias"], zero=True)
-        dz = empty(N, H, W, 64)
-        ops.conv_smallcout_bwd(z_last, wout.detach().contiguous(), dl, dz, dwo, dbo, gscale=inv_s)
+        # the data gradient of the head (dl . W, 268 MB at batch 32) is not written: the BatchNorm backward of the last stage
+        # forms it from dl (GSSEG_HEAD_BWD_FUSED=0 restores the tensor)
+        head_src = None
+        wout_c = wout.detach().contiguous()
+        if FUSED_HEAD_BWD and wout.shape[0] <= 4 and dl.is_contiguous():
+            head_src = (dl, wout_c)
+            dz = None
+            ops.conv_smallcout_bwd(z_last, wout_c, dl, None, dwo, dbo, gscale=inv_s)
+        else:
+            dz = empty(N, H, W, 64)
+            ops.conv_smallcout_bwd(z_last, wout_c, dl, dz, dwo, dbo, gscale=inv_s)
         emit("outc.conv.weight", dwo)
         emit("outc.conv.bias", dbo)
 
-        def conv_stage_bwd(rec: _ConvRec, dz_a, sa, ca, dzp, need_dinp: bool, colsum=None):
+        def conv_stage_bwd(rec: _ConvRec, dz_a, sa, ca, dzp, need_dinp: bool, colsum=None, head=None):
             """Backward of conv -> BN -> ReLU.  Returns d(input) (dense NHWC) or None.
             colsum = (coff, C, out): also out[c] = inv_s * sum over pixels of d(input)[..., coff + c], from the data-gradient
-            convolution's epilogue sums (the bias gradient of the transposed convolution that feeds this stage)."""
+            convolution's epilogue sums (the bias gradient of the transposed convolution that feeds this stage).
+            head = (dl, w_head): the gradient source is the pointwise head's logit gradient and weight instead of dz_a."""
             h, w, cin, cout = rec.h, rec.w, rec.cin, rec.cout
             coef = rec.coef
             pooled = dzp is not None
             ntiles = ops.bn_bwd_tiles_used(N, h, w, pooled)
-            ops.bn_act_bwd_reduce(rec.y, dz_a, sa, ca, dzp, coef[0], coef[1], coef[2], coef[3], ACT_RELU, partials)
+            if head is not None:
+                ops.bn_act_bwd_reduce_head(rec.y, head[0], head[1], coef[0], coef[1], coef[2], coef[3], ACT_RELU, partials)
+            else:
+                ops.bn_act_bwd_reduce(rec.y, dz_a, sa, ca, dzp, coef[0], coef[1], coef[2], coef[3], ACT_RELU, partials)
             dgamma = galloc(rec.bnkey + ".weight", params[rec.bnkey + ".weight"])
             dbeta = galloc(rec.bnkey + ".bias", params[rec.bnkey + ".bias"])
             c12 = empty(2, cout, dtype=torch.float32)
@@ -694,8 +709,11 @@ class UNetEngine:
                     emit(rec.bnkey + ".bias", dbeta)
                     return None
             dy = empty(N, h, w, cout)
-            ops.bn_act_bwd_apply(rec.y, dz_a, sa, ca, dzp, coef[0], coef[1], coef[2], coef[3], c12[0], c12[1],
-                                 ACT_RELU, True, dy)
+            if head is not None:
+                ops.bn_act_bwd_apply_head(rec.y, head[0], head[1], coef[0], coef[1], coef[2], coef[3], c12[0], c12[1], ACT_RELU, dy)
+            else:
+                ops.bn_act_bwd_apply(rec.y, dz_a, sa, ca, dzp, coef[0], coef[1], coef[2], coef[3], c12[0], c12[1],
+                                     ACT_RELU, True, dy)
             dinp = None
             if rec.inp_is_image:
                 dw = dw_stem if dw_stem is not None else galloc(rec.wkey, wparam, zero=True)
@@ -740,7 +758,7 @@ class UNetEngine:
             prefix = f"up{j}"
             cout_t = C[lvl]
             r3, r0 = recs[prefix + ".conv.3"], recs[prefix + ".conv.0"]
-            dmid = conv_stage_bwd(r3, dz, r3.cout, 0, None, True)
+            dmid = conv_stage_bwd(r3, dz, r3.cout, 0, None, True, head=head_src if j == 4 else None)
             u = ups[prefix]
             # un-padded transposed convolution: its bias gradient is a column sum of d(concat) over every pixel, which the
             # data-gradient convolution writing d(concat) sums in its epilogue (no separate pass over the tensor)

@@ -390,6 +390,56 @@ def test_smallcin(dtn, dt, Cin, k, s, p, bias, H, W):
 
 
 @pytest.mark.parametrize("dtn,dt", DTS)
+@pytest.mark.parametrize("N,H,W,C,ncls", [(2, 18, 22, 64, 2), (3, 45, 53, 64, 1), (2, 40, 40, 32, 4)])
+def test_bn_bwd_head_source(dtn, dt, N, H, W, C, ncls):
+    """BatchNorm/ReLU backward of the stage in front of the 1x1 head (unet_parts.py:19-21 then :74) with the gradient source
+    formed from the logit gradient and the head weight: against a torch fp32 autograd reference, and against the path through
+    the head's data-gradient tensor."""
+    from semantic_segmentation_amd import ops
+    from semantic_segmentation_amd._lib import ACT_RELU
+    g = torch.Generator().manual_seed(43)
+    y16 = rnd(g, N, C, H, W, dt=dt)
+    yl = y16.clone().requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    wh = 0.3 * torch.randn(ncls, C, 1, 1, generator=g)
+    z = F.relu(F.batch_norm(yl, None, None, gamma, beta, True, 0.1, 1e-5))
+    dl = torch.randn(N, ncls, H, W, generator=g)
+    F.conv2d(z, wh).backward(dl)
+    mean = y16.mean((0, 2, 3)); var = y16.var((0, 2, 3), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale = gamma.detach() * invstd; shift = beta.detach() - mean * scale
+    coef = torch.stack([scale, shift, mean, invstd]).to(dev()).contiguous()
+    yd = nhwc(y16, dt)
+    dld, whd = dl.to(dev()), wh.to(dev())
+    part = torch.zeros(ops.bn_partials_numel(ops.bn_bwd_tiles(N, H, W), C), dtype=torch.float32, device=dev())
+    nt = ops.bn_bwd_tiles_used(N, H, W, False)
+    res = []
+    for fused in (True, False):
+        dgamma = torch.empty(C, device=dev()); dbeta = torch.empty(C, device=dev())
+        c12 = torch.empty(2, C, device=dev())
+        dy = torch.full((N, H, W, C), float("nan"), dtype=dt, device=dev())
+        if fused:
+            ops.bn_act_bwd_reduce_head(yd, dld, whd, coef[0], coef[1], coef[2], coef[3], ACT_RELU, part)
+            ops.bn_bwd_coeffs(part, nt, C, N * H * W, 1.0, dgamma, dbeta, c12[0], c12[1])
+            ops.bn_act_bwd_apply_head(yd, dld, whd, coef[0], coef[1], coef[2], coef[3], c12[0], c12[1], ACT_RELU, dy)
+        else:
+            if C != 64:
+                continue                    # the head's data-gradient kernel under test elsewhere; compare where it is the fast one
+            dz = torch.empty(N, H, W, C, dtype=dt, device=dev())
+            ops.conv_smallcout_bwd(None, whd, dld, dz, None, None)
+            ops.bn_act_bwd_reduce(yd, dz, C, 0, None, coef[0], coef[1], coef[2], coef[3], ACT_RELU, part)
+            ops.bn_bwd_coeffs(part, nt, C, N * H * W, 1.0, dgamma, dbeta, c12[0], c12[1])
+            ops.bn_act_bwd_apply(yd, dz, C, 0, None, coef[0], coef[1], coef[2], coef[3], c12[0], c12[1], ACT_RELU, True, dy)
+        torch.cuda.synchronize()
+        res.append((rel_err(dgamma, gamma.grad), rel_err(dbeta, beta.grad), rel_err(from_nhwc(dy), yl.grad)))
+    t = 3e-3 if dt == torch.float16 else 2e-2
+    assert res[0][0] < 5e-3 and res[0][1] < 5e-3 and res[0][2] < t, res
+    if len(res) == 2:                       # fp32 gradient source: no worse than through the 16-bit tensor
+        assert res[0][2] <= res[1][2] * 1.2 + 1e-5, res
+
+
+@pytest.mark.parametrize("dtn,dt", DTS)
 @pytest.mark.parametrize("N,H,W,sa,ca", [(2, 18, 22, 64, 0), (3, 45, 53, 128, 64), (2, 64, 96, 64, 0)])
 def test_stem_bn_bwd_wgrad_fused(dtn, dt, N, H, W, sa, ca):
     """BatchNorm/ReLU backward apply + one-channel stem weight gradient in one pass (unet_parts.py:16-18, in_channels=1):
