@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 33
+#define GS_ABI_VERSION 34
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -251,6 +251,18 @@ int gs_maxpool2x2_fwd(const void* z, int z_pix_stride, int z_coff, void* zp, int
  * unet_parts.py:53, excluding the F.pad border of unet_parts.py:59-61).  ws: fp32 [1024*C] workspace. */
 int gs_colsum(const void* t, int pix_stride, int coff, int N, int H, int W, int y0, int x0, int h, int w, int C,
               float gscale, float* ws, float* out, int dtype, void* stream);
+
+/* The 1x1 head (OutConv, unet/unet_parts.py:74, 64 input channels, <= 4 classes) taking the last stage's convolution
+ * OUTPUT y_conv [N,H,W,64] 16-bit plus that stage's BatchNorm scale / shift (gs_bn_finalize) and slope-family activation
+ * (unet_parts.py:20-21): z = act(y_conv * scale + shift) is formed on the load path, in fp32 -- gs_bn_act_apply of the
+ * last stage and the 2 x N*H*W*64*2 bytes of its output written and read back drop out.  _fwd: logits fp32 [N,Cout,H,W]
+ * = z . w^T + bias.  _wgrad: dw [Cout][64] += gscale * sum_p dl[p] z[p], db += gscale * sum_p dl (ws as
+ * gs_conv_smallcout_bwd: gs_conv_direct_wgrad_ws_floats(N,H,W,64,Cout,1)). */
+int gs_head1x1_bn_fwd(const void* y_conv, const float* bn_scale, const float* bn_shift, int act, const float* w,
+                      const float* bias, float* logits, int N, int H, int W, int Cout, int dtype, void* stream);
+int gs_head1x1_bn_wgrad(const void* y_conv, const float* bn_scale, const float* bn_shift, int act, const float* w,
+                        const float* dl, float* dw, float* db, float* ws, int N, int H, int W, int Cout, float gscale,
+                        int dtype, void* stream);
 
 /* BatchNorm + activation backward of the stage in FRONT of a pointwise head (unet/unet_parts.py:19-21 followed by the
  * OutConv of :74, n_classes <= 4): the gradient w.r.t. the activation's output is dz[p][c] = sum_k dl[n][k][h][w] *

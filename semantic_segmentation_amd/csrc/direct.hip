@@ -651,7 +651,21 @@ struct HArgs {
     const unsigned short* x; const float* w; const float* bias; float* y;
     const float* dy; unsigned short* dx; float* dw; float* db;
     int N, IH, IW, Cin, Cout, OH, OW, k, stride, pad; float gscale; int64_t pix_per_block;
+    // head1x1 kernels only: x is the convolution OUTPUT of the last stage and z = act(x * bn_scale + bn_shift) is formed on
+    // the load path (gs_head1x1_bn_fwd / gs_head1x1_bn_wgrad): the activation tensor is neither written nor read
+    const float* bn_scale; const float* bn_shift; float bn_slope;
 };
+
+// the last stage's BatchNorm + slope activation on eight loaded channels (no-op without coefficients)
+__device__ __forceinline__ void head_bn_act(const HArgs& a, const float* sc, const float* sh, float* v) {
+    if (a.bn_scale != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float t = v[i] * sc[i] + sh[i];
+            v[i] = t > 0.f ? t : t * a.bn_slope;
+        }
+    }
+}
 
 // wl layout [c][tap][Cin]
 __device__ __forceinline__ void load_head_weights(const HArgs& a, float* wl) {
@@ -771,6 +785,12 @@ __global__ __launch_bounds__(256) void head1x1_fwd_kernel(const HArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) w[c][i] = c < a.Cout ? a.w[c * 64 + ch * 8 + i] : 0.f;
     }
+    float sc[8], sh[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        sc[i] = a.bn_scale ? a.bn_scale[ch * 8 + i] : 1.f;
+        sh[i] = a.bn_scale ? a.bn_shift[ch * 8 + i] : 0.f;
+    }
     const int M = a.N * a.OH * a.OW, ohw = a.OH * a.OW;              // host guarantees < 2^31
     constexpr int UNR = 4;
     for (int mb = blockIdx.x * (32 * UNR) + pl; mb < M; mb += gridDim.x * (32 * UNR)) {
@@ -785,6 +805,7 @@ __global__ __launch_bounds__(256) void head1x1_fwd_kernel(const HArgs a) {
             const int m = mb + 32 * u;
             float v[8], s[4];
             unpack8<DT>(r[u], v);
+            head_bn_act(a, sc, sh, v);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 float t = 0.f;
@@ -847,6 +868,12 @@ __global__ __launch_bounds__(256) void head1x1_wgrad_kernel(const HArgs a) {
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[c][i] = 0.f;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        sc[i] = a.bn_scale ? a.bn_scale[ch * 8 + i] : 1.f;
+        sh[i] = a.bn_scale ? a.bn_shift[ch * 8 + i] : 0.f;
+    }
     constexpr int UNR = 4;
     for (int mb = m0 + pl; mb < m1; mb += 32 * UNR) {
         uint4 r[UNR];
@@ -865,6 +892,7 @@ __global__ __launch_bounds__(256) void head1x1_wgrad_kernel(const HArgs a) {
         for (int u = 0; u < UNR; ++u) {
             float v[8];
             unpack8<DT>(r[u], v);
+            head_bn_act(a, sc, sh, v);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 sb[c] += g[u][c];
@@ -1164,14 +1192,15 @@ static int check_head(const char* who, int N, int IH, int IW, int Cin, int Cout,
     return GS_OK;
 }
 
-extern "C" int gs_conv_smallcout_fwd(const void* x, const float* w, const float* bias, float* y, int N, int IH, int IW,
-                                     int Cin, int Cout, int OH, int OW, int k, int stride, int pad, int dtype,
-                                     void* stream) {
+static int smallcout_fwd_impl(const void* x, const float* w, const float* bias, float* y, int N, int IH, int IW,
+                              int Cin, int Cout, int OH, int OW, int k, int stride, int pad, int dtype,
+                              void* stream, const float* bn_scale, const float* bn_shift, float bn_slope) {
     int rc = check_head("gs_conv_smallcout_fwd", N, IH, IW, Cin, Cout, OH, OW, k, stride, pad, dtype);
     if (rc) return rc;
     GS_CHECK_ARG(x && w && y, "gs_conv_smallcout_fwd: null pointer");
     GS_CHECK_ARG((int64_t)N * OH * OW + 256 < 2147483647LL, "gs_conv_smallcout_fwd: too many pixels");
     HArgs a{};
+    a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.bn_slope = bn_slope;
     a.x = (const unsigned short*)x; a.w = w; a.bias = bias; a.y = y;
     a.N = N; a.IH = IH; a.IW = IW; a.Cin = Cin; a.Cout = Cout; a.OH = OH; a.OW = OW; a.k = k; a.stride = stride; a.pad = pad;
     const int nch = Cin / 8, gl = nch < 64 ? nch : 64, groups = 256 / gl;
@@ -1189,15 +1218,33 @@ extern "C" int gs_conv_smallcout_fwd(const void* x, const float* w, const float*
     return GS_OK;
 }
 
-extern "C" int gs_conv_smallcout_bwd(const void* x, const float* w, const float* dy, void* dx, float* dw, float* db,
-                                     float* ws, int N, int IH, int IW, int Cin, int Cout, int OH, int OW, int k,
-                                     int stride, int pad, float gscale, int dtype, void* stream) {
+extern "C" int gs_conv_smallcout_fwd(const void* x, const float* w, const float* bias, float* y, int N, int IH, int IW,
+                                     int Cin, int Cout, int OH, int OW, int k, int stride, int pad, int dtype,
+                                     void* stream) {
+    return smallcout_fwd_impl(x, w, bias, y, N, IH, IW, Cin, Cout, OH, OW, k, stride, pad, dtype, stream, nullptr, nullptr, 0.f);
+}
+
+static float head_bn_slope(int act) { return act == GS_ACT_RELU ? 0.f : (act == GS_ACT_LEAKY02 ? 0.2f : 1.f); }
+
+extern "C" int gs_head1x1_bn_fwd(const void* y_conv, const float* bn_scale, const float* bn_shift, int act, const float* w,
+                                 const float* bias, float* logits, int N, int H, int W, int Cout, int dtype, void* stream) {
+    GS_CHECK_ARG(bn_scale && bn_shift, "gs_head1x1_bn_fwd: needs the BatchNorm scale / shift");
+    GS_CHECK_ARG(act == GS_ACT_NONE || act == GS_ACT_RELU || act == GS_ACT_LEAKY02, "gs_head1x1_bn_fwd: activation %d not supported", act);
+    return smallcout_fwd_impl(y_conv, w, bias, logits, N, H, W, 64, Cout, H, W, 1, 1, 0, dtype, stream, bn_scale, bn_shift,
+                              head_bn_slope(act));
+}
+
+static int smallcout_bwd_impl(const void* x, const float* w, const float* dy, void* dx, float* dw, float* db,
+                              float* ws, int N, int IH, int IW, int Cin, int Cout, int OH, int OW, int k,
+                              int stride, int pad, float gscale, int dtype, void* stream, const float* bn_scale,
+                              const float* bn_shift, float bn_slope) {
     int rc = check_head("gs_conv_smallcout_bwd", N, IH, IW, Cin, Cout, OH, OW, k, stride, pad, dtype);
     if (rc) return rc;
     GS_CHECK_ARG(w && dy, "gs_conv_smallcout_bwd: null pointer");
     GS_CHECK_ARG((int64_t)N * IH * IW * (Cin / 8) < 2147483647LL && (int64_t)N * OH * OW < 2147483647LL,
                  "gs_conv_smallcout_bwd: too many pixels");
     HArgs a{};
+    a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.bn_slope = bn_slope;
     a.x = (const unsigned short*)x; a.w = w; a.dy = dy; a.dx = (unsigned short*)dx; a.dw = dw; a.db = db;
     a.N = N; a.IH = IH; a.IW = IW; a.Cin = Cin; a.Cout = Cout; a.OH = OH; a.OW = OW; a.k = k; a.stride = stride; a.pad = pad;
     a.gscale = gscale;
@@ -1233,4 +1280,20 @@ extern "C" int gs_conv_smallcout_bwd(const void* x, const float* w, const float*
     }
     GS_CHECK_LAUNCH("gs_conv_smallcout_bwd");
     return GS_OK;
+}
+
+extern "C" int gs_conv_smallcout_bwd(const void* x, const float* w, const float* dy, void* dx, float* dw, float* db,
+                                     float* ws, int N, int IH, int IW, int Cin, int Cout, int OH, int OW, int k,
+                                     int stride, int pad, float gscale, int dtype, void* stream) {
+    return smallcout_bwd_impl(x, w, dy, dx, dw, db, ws, N, IH, IW, Cin, Cout, OH, OW, k, stride, pad, gscale, dtype, stream,
+                              nullptr, nullptr, 0.f);
+}
+
+extern "C" int gs_head1x1_bn_wgrad(const void* y_conv, const float* bn_scale, const float* bn_shift, int act, const float* w,
+                                   const float* dl, float* dw, float* db, float* ws, int N, int H, int W, int Cout,
+                                   float gscale, int dtype, void* stream) {
+    GS_CHECK_ARG(bn_scale && bn_shift && dw, "gs_head1x1_bn_wgrad: needs the BatchNorm scale / shift and dw");
+    GS_CHECK_ARG(act == GS_ACT_NONE || act == GS_ACT_RELU || act == GS_ACT_LEAKY02, "gs_head1x1_bn_wgrad: activation %d not supported", act);
+    return smallcout_bwd_impl(y_conv, w, dl, nullptr, dw, db, ws, N, H, W, 64, Cout, H, W, 1, 1, 0, gscale, dtype, stream,
+                              bn_scale, bn_shift, head_bn_slope(act));
 }

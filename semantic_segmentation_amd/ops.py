@@ -685,6 +685,30 @@ def maxpool3d_bwd(z, dzp, dres, dz, NB, D, H, W, C, z_stride=None, z_coff=0, res
               res_coff, _p(dz), NB, D, H, W, C, dt_code(z), _stream())
 
 
+def head1x1_bn_fwd(y_conv, scale, shift, act, w, bias, logits):
+    """1x1 head on z = act(y_conv * scale + shift) formed on the load path (the last stage's activation is never stored)."""
+    _dev(y_conv)
+    _f32(scale, "scale"); _f32(shift, "shift"); _f32(w, "w"); _f32(bias, "bias"); _f32(logits, "logits")
+    N, H, W, C = y_conv.shape
+    ncls = logits.shape[1]
+    if C != 64 or tuple(logits.shape) != (N, ncls, H, W) or w.numel() != ncls * 64 or not (y_conv.is_contiguous() and logits.is_contiguous()):
+        raise ValueError("head1x1_bn_fwd: y_conv [N,H,W,64], logits [N,ncls,H,W], w [ncls,64]")
+    _lib.call("gs_head1x1_bn_fwd", _p(y_conv), _p(scale), _p(shift), act, _p(w), _p(bias), _p(logits), N, H, W, ncls,
+              dt_code(y_conv), _stream())
+
+
+def head1x1_bn_wgrad(y_conv, scale, shift, act, w, dl, dw, db, gscale=1.0):
+    _dev(y_conv)
+    _f32(scale, "scale"); _f32(shift, "shift"); _f32(w, "w"); _f32(dl, "dl"); _f32(dw, "dw"); _f32(db, "db")
+    N, H, W, C = y_conv.shape
+    ncls = dl.shape[1]
+    if C != 64 or tuple(dl.shape) != (N, ncls, H, W) or dw.numel() != ncls * 64 or not (y_conv.is_contiguous() and dl.is_contiguous()):
+        raise ValueError("head1x1_bn_wgrad: y_conv [N,H,W,64], dl [N,ncls,H,W], dw [ncls,64]")
+    ws = _direct_wgrad_ws(N, H, W, 64, ncls, 1, y_conv.device)
+    _lib.call("gs_head1x1_bn_wgrad", _p(y_conv), _p(scale), _p(shift), act, _p(w), _p(dl), _p(dw), _p(db), _p(ws), N, H, W,
+              ncls, float(gscale), dt_code(y_conv), _stream())
+
+
 def bn_act_bwd_reduce_head(y, dl, w_head, scale, shift, mean, invstd, act, partials):
     """bn_act_bwd_reduce with the gradient source dz = dl . w_head formed on the fly (the stage in front of a pointwise head)."""
     _dev(y)

@@ -39,6 +39,7 @@ WGRAD_SIDE_STREAM = os.environ.get("GSSEG_WGRAD_STREAM", "0") != "0"
 # (GSSEG_STEM_BWD_FUSED=0 restores bn_act_bwd_apply + conv_smallcin_wgrad).
 FUSED_STEM_BWD = os.environ.get("GSSEG_STEM_BWD_FUSED", "1") != "0"
 # Head backward: the data gradient of the 1x1 head is formed inside the BatchNorm backward of the last stage.
+FUSED_HEAD_FWD = os.environ.get("GSSEG_HEAD_FWD_FUSED", "1") != "0"
 FUSED_HEAD_BWD = os.environ.get("GSSEG_HEAD_BWD_FUSED", "1") != "0"
 FUSED_UP_BIAS_GRAD = os.environ.get("GSSEG_UP_BIAS_FUSED", "1") != "0"
 
@@ -299,9 +300,11 @@ class UNetEngine:
                     ops.conv_igemm(g, inp, wf, y, None, partials)
                 rec.geom, rec.wd = g, wd
             coef, rec.train_stats = bn_coeffs(bnkey, ntiles, cout, N * h * w)
-            ops.bn_act_apply(y, coef[0], coef[1], ACT_RELU, z, z_stride, z_coff, zp)
+            if z is not None:
+                ops.bn_act_apply(y, coef[0], coef[1], ACT_RELU, z, z_stride, z_coff, zp)
+            rec.y, rec.coef = y, coef               # (z is None: the caller applies BatchNorm + ReLU on its own load path)
             if need_grad:
-                rec.inp, rec.y, rec.coef = inp, y, coef
+                rec.inp = inp
                 recs.append(rec)
             return rec
 
@@ -365,13 +368,21 @@ class UNetEngine:
             cout3 = params[prefix + ".conv.double_conv.3.weight"].shape[0]
             zmid = empty(N, H2, W2, cmid)
             conv_bn_relu(prefix + ".conv", 0, cat, 2 * cout_t, cmid, H2, W2, zmid, cmid, 0, None)
-            zout = empty(N, H2, W2, cout3)
-            conv_bn_relu(prefix + ".conv", 3, zmid, cmid, cout3, H2, W2, zout, cout3, 0, None)
+            # last stage in front of the 1x1 head: its activation has one reader, the head, which applies BatchNorm + ReLU on
+            # its own load path -- the tensor is not stored (GSSEG_HEAD_FWD_FUSED=0 restores it)
+            fuse_head = (j == 4 and FUSED_HEAD_FWD and cout3 == 64 and net.n_classes <= 4
+                         and not (FOLD_BN_INFERENCE and not need_grad and not training))
+            zout = None if fuse_head else empty(N, H2, W2, cout3)
+            last_rec = conv_bn_relu(prefix + ".conv", 3, zmid, cmid, cout3, H2, W2, zout, cout3, 0, None)
             inp = zout
 
         logits = empty(N, net.n_classes, H, W, dtype=torch.float32)
-        ops.conv_smallcout_fwd(inp, params["outc.conv.weight"].detach().contiguous(),
-                               params["outc.conv.bias"].detach(), logits)
+        if inp is None:
+            ops.head1x1_bn_fwd(last_rec.y, last_rec.coef[0], last_rec.coef[1], ACT_RELU,
+                               params["outc.conv.weight"].detach().contiguous(), params["outc.conv.bias"].detach(), logits)
+        else:
+            ops.conv_smallcout_fwd(inp, params["outc.conv.weight"].detach().contiguous(),
+                                   params["outc.conv.bias"].detach(), logits)
         if nbt_pending:
             torch._foreach_add_(nbt_pending, 1)
         ctx = None
@@ -666,13 +677,20 @@ class UNetEngine:
         # forms it from dl (GSSEG_HEAD_BWD_FUSED=0 restores the tensor)
         head_src = None
         wout_c = wout.detach().contiguous()
+        rlast = recs["up4.conv.3"]
+        if z_last is None:                       # the last activation was never stored: the head's weight gradient re-forms it
+            ops.head1x1_bn_wgrad(rlast.y, rlast.coef[0], rlast.coef[1], ACT_RELU, wout_c, dl, dwo, dbo, gscale=inv_s)
         if FUSED_HEAD_BWD and wout.shape[0] <= 4 and dl.is_contiguous():
             head_src = (dl, wout_c)
             dz = None
-            ops.conv_smallcout_bwd(z_last, wout_c, dl, None, dwo, dbo, gscale=inv_s)
+            if z_last is not None:
+                ops.conv_smallcout_bwd(z_last, wout_c, dl, None, dwo, dbo, gscale=inv_s)
         else:
             dz = empty(N, H, W, 64)
-            ops.conv_smallcout_bwd(z_last, wout_c, dl, dz, dwo, dbo, gscale=inv_s)
+            if z_last is not None:
+                ops.conv_smallcout_bwd(z_last, wout_c, dl, dz, dwo, dbo, gscale=inv_s)
+            else:
+                ops.conv_smallcout_bwd(None, wout_c, dl, dz, None, None)
         emit("outc.conv.weight", dwo)
         emit("outc.conv.bias", dbo)
 

@@ -390,6 +390,43 @@ def test_smallcin(dtn, dt, Cin, k, s, p, bias, H, W):
 
 
 @pytest.mark.parametrize("dtn,dt", DTS)
+@pytest.mark.parametrize("N,H,W,ncls", [(2, 18, 22, 2), (3, 45, 53, 1), (1, 64, 64, 4)])
+def test_head1x1_on_conv_output_with_bn_relu(dtn, dt, N, H, W, ncls):
+    """OutConv (unet_parts.py:74) reading the last stage's convolution output with BatchNorm + ReLU (unet_parts.py:20-21) on
+    its load path: logits, weight and bias gradients against torch fp32 on the same stored y, and against the path through the
+    stored activation."""
+    from semantic_segmentation_amd import ops
+    from semantic_segmentation_amd._lib import ACT_RELU
+    g = torch.Generator().manual_seed(47)
+    C = 64
+    y16 = rnd(g, N, C, H, W, dt=dt)
+    scale = 1 + 0.3 * torch.randn(C, generator=g); shift = 0.3 * torch.randn(C, generator=g)
+    wh = (0.3 * torch.randn(ncls, C, 1, 1, generator=g)).requires_grad_(True)
+    bh = torch.randn(ncls, generator=g).requires_grad_(True)
+    z = F.relu(y16 * scale.view(1, C, 1, 1) + shift.view(1, C, 1, 1))
+    ref = F.conv2d(z, wh, bh)
+    dl = torch.randn(N, ncls, H, W, generator=g)
+    ref.backward(dl)
+    yd = nhwc(y16, dt)
+    sc, sh = scale.to(dev()), shift.to(dev())
+    whd, bhd, dld = wh.detach().to(dev()), bh.detach().to(dev()), dl.to(dev())
+    logits = torch.full((N, ncls, H, W), float("nan"), dtype=torch.float32, device=dev())
+    ops.head1x1_bn_fwd(yd, sc, sh, ACT_RELU, whd, bhd, logits)
+    dw = torch.zeros(ncls, C, 1, 1, device=dev()); db = torch.zeros(ncls, device=dev())
+    ops.head1x1_bn_wgrad(yd, sc, sh, ACT_RELU, whd, dld, dw, db, gscale=0.5)
+    # through the stored 16-bit activation
+    zd = torch.empty(N, H, W, C, dtype=dt, device=dev())
+    ops.bn_act_apply(yd, sc, sh, ACT_RELU, zd, C, 0, None)
+    logits2 = torch.empty_like(logits)
+    ops.conv_smallcout_fwd(zd, whd, bhd, logits2)
+    torch.cuda.synchronize()
+    e1, e2 = rel_err(logits.cpu(), ref.detach()), rel_err(logits2.cpu(), ref.detach())
+    assert e1 < 1e-5, e1                                  # fp32 activation: only the summation order differs
+    assert e1 <= e2 + 1e-6, (e1, e2)
+    assert rel_err(dw.cpu() * 2, wh.grad) < 1e-4 and rel_err(db.cpu() * 2, bh.grad) < 1e-4
+
+
+@pytest.mark.parametrize("dtn,dt", DTS)
 @pytest.mark.parametrize("N,H,W,C,ncls", [(2, 18, 22, 64, 2), (3, 45, 53, 64, 1), (2, 40, 40, 32, 4)])
 def test_bn_bwd_head_source(dtn, dt, N, H, W, C, ncls):
     """BatchNorm/ReLU backward of the stage in front of the 1x1 head (unet_parts.py:19-21 then :74) with the gradient source
