@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 34
+#define GS_ABI_VERSION 35
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -161,7 +161,32 @@ int gs_conv_smallcin_mtiles(int N, int OH, int OW);
 int gs_conv_smallcin_fwd(const float* x, const float* w, const float* bias, void* y, float* bn_partials,
                          int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int k, int stride, int pad,
                          int act, int dtype, void* stream);
-int64_t gs_conv_direct_wgrad_ws_floats(int N, int OH, int OW, int Cin, int Cout, int k);   /* Stem backward in one pass (unet/unet_parts.py:16-18 with in_channels = 1, first stage of `inc`; the image needs no
+int64_t gs_conv_direct_wgrad_ws_floats(int N, int OH, int OW, int Cin, int Cout, int k);   /* ---- the one-channel stem WITHOUT its convolution output in memory ------------------------------------------------
+ * (unet/unet_parts.py:16-18 with in_channels = 1: Conv2d(1, 64, 3, padding=1, bias=False) -> BatchNorm2d -> ReLU.)
+ * The train-mode statistics of y = conv(x) are functions of the image and the 576 weights alone (sum_p y = sum_t w_t S_t,
+ * sum_p y^2 = sum_tu w_t w_u G_tu with the tap sums S and the 9x9 tap Gram matrix G), so y need not exist:
+ *   gs_stem_stats      tile partials [gs_conv_smallcin_mtiles(N,H,W)][2][64] for gs_bn_finalize, from x and w only;
+ *   gs_stem_fwd_bn     z [N,H,W,64] 16-bit = act(conv(x) * scale + shift) in one pass (y stays in fp32 registers);
+ *   gs_stem_bn_bwd_reduce / gs_stem_bn_bwd_wgrad_recompute
+ *                      the BatchNorm backward reduce ([gs_stem_bwd_tiles(N,H,W)][2][64] partials for gs_bn_bwd_coeffs) and
+ *                      the fused backward apply + weight gradient (as gs_stem_bn_bwd_wgrad), with y re-formed from the
+ *                      image strip in LDS in the forward kernel's summation order (bit-identical to what was normalised).
+ * At batch 32, 256^2 this removes the write of y (268 MB), its read by gs_bn_act_apply and by the two backward passes.
+ * x fp32 [N,1,H,W], w fp32 [64][1][3][3].  The two backward entry points return GS_EUNSUPPORTED (no error string) when the
+ * image is too wide for the LDS strip: the caller then re-forms y with gs_conv_smallcin_fwd and runs the tensor path. */
+int gs_stem_stats(const float* x, const float* w, float* bn_partials, int N, int H, int W, void* stream);
+int gs_stem_fwd_bn(const float* x, const float* w, const float* bn_scale, const float* bn_shift, int act, void* z, int N,
+                   int H, int W, int dtype, void* stream);
+int gs_stem_bwd_tiles(int N, int H, int W);
+int gs_stem_bn_bwd_reduce(const float* x, const float* w, const void* dz, int dz_stride, int dz_coff, const float* scale,
+                          const float* shift, const float* mean, const float* invstd, int act, float* partials, int N, int H,
+                          int W, int dtype, void* stream);
+int gs_stem_bn_bwd_wgrad_recompute(const float* x, const float* w, const void* dz, int dz_stride, int dz_coff,
+                                   const float* scale, const float* shift, const float* mean, const float* invstd,
+                                   const float* c1, const float* c2, int act, float* dw, float* ws, int N, int H, int W,
+                                   float gscale, int dtype, void* stream);
+
+/* Stem backward in one pass (unet/unet_parts.py:16-18 with in_channels = 1, first stage of `inc`; the image needs no
  * gradient): BatchNorm(train)/activation backward apply fused with the weight gradient of the 1-channel 3x3/s1/p1
  * convolution with 64 outputs.  y [N,H,W,64] 16-bit = the convolution's output, dz = gradient w.r.t. the activation's
  * output ([N,H,W,*], pixel stride dz_stride, channel offset dz_coff), x fp32 [N,1,H,W]; scale/shift/mean/invstd from

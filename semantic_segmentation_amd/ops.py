@@ -582,6 +582,65 @@ def stem_bn_bwd_wgrad(y, dz, dz_stride, dz_coff, x, scale, shift, mean, invstd, 
     return True
 
 
+# ---- the one-channel stem without its convolution output in memory (see include/gsseg.h)
+def _stem_check(x, w, who):
+    _dev(x)
+    _f32(x, "x"); _f32(w, "w")
+    if x.dim() != 4 or x.shape[1] != 1 or tuple(w.shape) != (64, 1, 3, 3) or not (x.is_contiguous() and w.is_contiguous()):
+        raise ValueError(f"{who}: x [N,1,H,W] and w [64,1,3,3], contiguous fp32")
+    return x.shape[0], x.shape[2], x.shape[3]
+
+
+def stem_stats(x, w, bn_partials):
+    N, H, W = _stem_check(x, w, "stem_stats")
+    _f32(bn_partials, "bn_partials")
+    if bn_partials.numel() < bn_partials_numel(conv_smallcin_mtiles(N, H, W), 64):
+        raise ValueError("stem_stats: bn_partials too small")
+    _lib.call("gs_stem_stats", _p(x), _p(w), _p(bn_partials), N, H, W, _stream())
+
+
+def stem_fwd_bn(x, w, scale, shift, act, z):
+    N, H, W = _stem_check(x, w, "stem_fwd_bn")
+    _f32(scale, "scale"); _f32(shift, "shift")
+    if tuple(z.shape) != (N, H, W, 64) or not z.is_contiguous():
+        raise ValueError("stem_fwd_bn: z must be dense [N,H,W,64]")
+    _lib.call("gs_stem_fwd_bn", _p(x), _p(w), _p(scale), _p(shift), act, _p(z), N, H, W, dt_code(z), _stream())
+
+
+def stem_bwd_tiles(N, H, W) -> int:
+    return int(_lib.load().gs_stem_bwd_tiles(N, H, W))
+
+
+def stem_bn_bwd_reduce(x, w, dz, dz_stride, dz_coff, scale, shift, mean, invstd, act, partials) -> bool:
+    N, H, W = _stem_check(x, w, "stem_bn_bwd_reduce")
+    _f32(partials, "partials")
+    if partials.numel() < bn_partials_numel(stem_bwd_tiles(N, H, W), 64):
+        raise ValueError("stem_bn_bwd_reduce: partials too small")
+    rc = _lib.load().gs_stem_bn_bwd_reduce(_p(x), _p(w), _p(dz), dz_stride, dz_coff, _p(scale), _p(shift), _p(mean), _p(invstd),
+                                           act, _p(partials), N, H, W, dt_code(dz), _stream())
+    if rc == _lib.GS_EUNSUPPORTED:
+        return False
+    if rc != 0:
+        _lib.check(rc, "gs_stem_bn_bwd_reduce")
+    return True
+
+
+def stem_bn_bwd_wgrad_recompute(x, w, dz, dz_stride, dz_coff, scale, shift, mean, invstd, c1, c2, act, dw, gscale) -> bool:
+    N, H, W = _stem_check(x, w, "stem_bn_bwd_wgrad_recompute")
+    _f32(dw, "dw")
+    if dw.numel() != 576 or not dw.is_contiguous():
+        raise ValueError("stem_bn_bwd_wgrad_recompute: dw [64,1,3,3] contiguous")
+    ws = _direct_wgrad_ws(N, H, W, 1, 64, 3, x.device)
+    rc = _lib.load().gs_stem_bn_bwd_wgrad_recompute(_p(x), _p(w), _p(dz), dz_stride, dz_coff, _p(scale), _p(shift), _p(mean),
+                                                    _p(invstd), _p(c1), _p(c2), act, _p(dw), _p(ws), N, H, W, float(gscale),
+                                                    dt_code(dz), _stream())
+    if rc == _lib.GS_EUNSUPPORTED:
+        return False
+    if rc != 0:
+        _lib.check(rc, "gs_stem_bn_bwd_wgrad_recompute")
+    return True
+
+
 def conv_smallcin_dgrad(dy, w, dx, k, stride, pad, gscale):
     _f32(w, "w"); _f32(dx, "dx")
     N, Cin, IH, IW = dx.shape

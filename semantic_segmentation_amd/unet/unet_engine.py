@@ -39,6 +39,8 @@ WGRAD_SIDE_STREAM = os.environ.get("GSSEG_WGRAD_STREAM", "0") != "0"
 # (GSSEG_STEM_BWD_FUSED=0 restores bn_act_bwd_apply + conv_smallcin_wgrad).
 FUSED_STEM_BWD = os.environ.get("GSSEG_STEM_BWD_FUSED", "1") != "0"
 # Head backward: the data gradient of the 1x1 head is formed inside the BatchNorm backward of the last stage.
+# Stem forward without its convolution output in memory (statistics from the image, conv + BatchNorm + ReLU in one pass).
+FUSED_STEM_FWD = os.environ.get("GSSEG_STEM_FWD_FUSED", "1") != "0"
 FUSED_HEAD_FWD = os.environ.get("GSSEG_HEAD_FWD_FUSED", "1") != "0"
 FUSED_HEAD_BWD = os.environ.get("GSSEG_HEAD_BWD_FUSED", "1") != "0"
 FUSED_UP_BIAS_GRAD = os.environ.get("GSSEG_UP_BIAS_FUSED", "1") != "0"
@@ -275,7 +277,6 @@ class UNetEngine:
                 if zp is not None:
                     ops.maxpool2x2_fwd(z, zp, N, h, w, cout, z_stride=z_stride, z_coff=z_coff)
                 return None
-            y = empty(N, h, w, cout)
             rec = _ConvRec()
             rec.name, rec.wkey, rec.bnkey = f"{prefix}.{idx}", wkey, bnkey
             rec.cin, rec.cout, rec.h, rec.w, rec.inp_is_image = cin, cout, h, w, image
@@ -289,6 +290,22 @@ class UNetEngine:
             else:
                 ntiles = ops.conv_igemm_mtiles(g)
             partials = empty(ops.bn_partials_numel(ntiles, cout), dtype=torch.float32) if batch_stats else None
+            if (image and FUSED_STEM_FWD and cin == 1 and cout == 64 and z is not None and zp is None and z_stride == cout
+                    and z_coff == 0 and inp.is_contiguous()):
+                # one-channel stem: the BatchNorm statistics come from the image and the weights alone, the convolution
+                # output is normalised in registers and never stored (the backward re-forms it from the image)
+                wst = wparam.detach().contiguous()
+                if batch_stats:
+                    ops.stem_stats(inp, wst, partials)
+                coef, rec.train_stats = bn_coeffs(bnkey, ntiles, cout, N * h * w)
+                ops.stem_fwd_bn(inp, wst, coef[0], coef[1], ACT_RELU, z)
+                rec.geom, rec.wd = None, None
+                rec.y, rec.coef = None, coef
+                if need_grad:
+                    rec.inp = inp
+                    recs.append(rec)
+                return rec
+            y = empty(N, h, w, cout)
             if image:
                 ops.conv_smallcin_fwd(inp, wparam.detach().contiguous(), None, y, partials, 3, 1, 1)
                 rec.geom, rec.wd = None, None
@@ -662,6 +679,8 @@ class UNetEngine:
         npart = 0
         for i in range(5):
             npart = max(npart, ops.bn_partials_numel(ops.bn_bwd_tiles(N, hs[i], ws_[i]), C[i]))
+            if i == 0:
+                npart = max(npart, ops.bn_partials_numel(ops.stem_bwd_tiles(N, hs[i], ws_[i]), 64))
             if i < 4 and ops.USE_HALO_CONV:          # the data-gradient convolution's partials over d(concat) (fused bias gradient)
                 npart = max(npart, ops.bn_partials_numel(ops.conv3x3_mtiles(N, hs[i], ws_[i], 2 * C[i]), 2 * C[i]))
         partials = empty(npart, dtype=torch.float32)
@@ -702,6 +721,31 @@ class UNetEngine:
             h, w, cin, cout = rec.h, rec.w, rec.cin, rec.cout
             coef = rec.coef
             pooled = dzp is not None
+            if rec.y is None:
+                # the stem's convolution output was never stored: both backward passes re-form it from the image
+                wst = params[rec.wkey].detach().contiguous()
+                done = False
+                if not need_dinp and not pooled and head is None:
+                    if ops.stem_bn_bwd_reduce(rec.inp, wst, dz_a, sa, ca, coef[0], coef[1], coef[2], coef[3], ACT_RELU, partials):
+                        dgamma = galloc(rec.bnkey + ".weight", params[rec.bnkey + ".weight"])
+                        dbeta = galloc(rec.bnkey + ".bias", params[rec.bnkey + ".bias"])
+                        c12 = empty(2, cout, dtype=torch.float32)
+                        ops.bn_bwd_coeffs(partials, ops.stem_bwd_tiles(N, h, w), cout, N * h * w, inv_s, dgamma, dbeta, c12[0], c12[1])
+                        if not rec.train_stats:
+                            c12.zero_()
+                        dw = galloc(rec.wkey, params[rec.wkey], zero=True)
+                        if not ops.stem_bn_bwd_wgrad_recompute(rec.inp, wst, dz_a, sa, ca, coef[0], coef[1], coef[2], coef[3],
+                                                               c12[0], c12[1], ACT_RELU, dw, inv_s):
+                            raise RuntimeError("stem backward: the reduce pass ran but the weight-gradient pass refused the shape")
+                        emit(rec.wkey, dw)
+                        emit(rec.bnkey + ".weight", dgamma)
+                        emit(rec.bnkey + ".bias", dbeta)
+                        done = True
+                if done:
+                    return None
+                y_re = empty(N, h, w, cout)                  # image gradient wanted / very wide image: the tensor path
+                ops.conv_smallcin_fwd(rec.inp, wst, None, y_re, None, 3, 1, 1)
+                rec.y = y_re
             ntiles = ops.bn_bwd_tiles_used(N, h, w, pooled)
             if head is not None:
                 ops.bn_act_bwd_reduce_head(rec.y, head[0], head[1], coef[0], coef[1], coef[2], coef[3], ACT_RELU, partials)

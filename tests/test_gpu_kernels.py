@@ -390,6 +390,60 @@ def test_smallcin(dtn, dt, Cin, k, s, p, bias, H, W):
 
 
 @pytest.mark.parametrize("dtn,dt", DTS)
+@pytest.mark.parametrize("N,H,W", [(2, 18, 22), (3, 45, 53), (2, 64, 96)])
+def test_stem_without_conv_output_in_memory(dtn, dt, N, H, W):
+    """Conv2d(1,64,3,p1) -> BatchNorm2d(train) -> ReLU (unet_parts.py:16-18) with the convolution output never stored:
+    statistics from the image alone, fused forward, and the two backward passes re-forming y -- against torch fp32 autograd."""
+    from semantic_segmentation_amd import ops
+    from semantic_segmentation_amd._lib import ACT_RELU
+    g = torch.Generator().manual_seed(53)
+    C = 64
+    x = torch.randn(N, 1, H, W, generator=g)
+    w = (0.3 * torch.randn(C, 1, 3, 3, generator=g)).requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    y = F.conv2d(x, w, None, padding=1)
+    z = F.relu(F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5))
+    dz = rnd(g, N, C, H, W, dt=dt)
+    z.backward(dz)
+    xd, wd_ = x.to(dev()), w.detach().to(dev())
+    # statistics
+    mt = ops.conv_smallcin_mtiles(N, H, W)
+    part = torch.full((ops.bn_partials_numel(mt, C),), float("nan"), dtype=torch.float32, device=dev())
+    ops.stem_stats(xd, wd_, part)
+    coef = torch.empty(4, C, device=dev())
+    rm, rv = torch.zeros(C, device=dev()), torch.ones(C, device=dev())
+    ops.bn_finalize(part, mt, C, N * H * W, gamma.detach().to(dev()), beta.detach().to(dev()), rm, rv, 0.1, 1e-5,
+                    coef[0], coef[1], coef[2], coef[3])
+    yd_ = y.detach().double()
+    assert rel_err(coef[2], yd_.mean((0, 2, 3))) < 1e-4 + 1e-5 and rel_err(coef[3], 1 / torch.sqrt(yd_.var((0, 2, 3), unbiased=False) + 1e-5)) < 1e-4
+    # forward
+    zd = torch.full((N, H, W, C), float("nan"), dtype=dt, device=dev())
+    ops.stem_fwd_bn(xd, wd_, coef[0], coef[1], ACT_RELU, zd)
+    torch.cuda.synchronize()
+    assert (from_nhwc(zd) - z.detach()).abs().max() < (4e-3 if dt == torch.float16 else 3e-2)
+    # backward: reduce + coefficients + fused apply / weight gradient, y re-formed from the image
+    dzd = nhwc(dz, dt)
+    nt = ops.stem_bwd_tiles(N, H, W)
+    part2 = torch.full((ops.bn_partials_numel(nt, C),), float("nan"), dtype=torch.float32, device=dev())
+    assert ops.stem_bn_bwd_reduce(xd, wd_, dzd, C, 0, coef[0], coef[1], coef[2], coef[3], ACT_RELU, part2)
+    dgamma = torch.empty(C, device=dev()); dbeta = torch.empty(C, device=dev())
+    c12 = torch.empty(2, C, device=dev())
+    ops.bn_bwd_coeffs(part2, nt, C, N * H * W, 1.0, dgamma, dbeta, c12[0], c12[1])
+    dw = torch.zeros(C, 1, 3, 3, device=dev())
+    assert ops.stem_bn_bwd_wgrad_recompute(xd, wd_, dzd, C, 0, coef[0], coef[1], coef[2], coef[3], c12[0], c12[1], ACT_RELU, dw, 0.5)
+    torch.cuda.synchronize()
+    assert rel_err(dgamma, gamma.grad) < 2e-3 and rel_err(dbeta, beta.grad) < 2e-3
+    assert rel_err(dw.cpu() * 2, w.grad) < (2e-3 if dt == torch.float16 else 1e-2), rel_err(dw.cpu() * 2, w.grad)
+    # the stored-y path agrees up to the 16-bit rounding of the y it reads (normalised here with the unrounded statistics)
+    yst = nhwc(y.detach().to(dt).float(), dt)
+    dw2 = torch.zeros(C, 1, 3, 3, device=dev())
+    assert ops.stem_bn_bwd_wgrad(yst, dzd, C, 0, xd, coef[0], coef[1], coef[2], coef[3], c12[0], c12[1], ACT_RELU, dw2, 0.5)
+    torch.cuda.synchronize()
+    assert rel_err(dw, dw2) < (2e-2 if dt == torch.float16 else 8e-2)
+
+
+@pytest.mark.parametrize("dtn,dt", DTS)
 @pytest.mark.parametrize("N,H,W,ncls", [(2, 18, 22, 2), (3, 45, 53, 1), (1, 64, 64, 4)])
 def test_head1x1_on_conv_output_with_bn_relu(dtn, dt, N, H, W, ncls):
     """OutConv (unet_parts.py:74) reading the last stage's convolution output with BatchNorm + ReLU (unet_parts.py:20-21) on
