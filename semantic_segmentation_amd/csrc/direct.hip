@@ -18,6 +18,7 @@ struct SCArgs {
     const float* x; const float* w; const float* bias; unsigned short* y; float* bnp;
     int N, Cin, IH, IW, Cout, OH, OW, k, stride, pad, act;
     const float* bn_scale; const float* bn_shift;      // smallcin_fwd64_line_kernel MODE 2
+    float* sg;                                         // MODE 1: per-block tap sums + Gram entries [block][54] (may be null)
 };
 
 template <int DT>
@@ -312,6 +313,7 @@ __global__ __launch_bounds__(256) void smallcin_fwd64_line_kernel(const SCArgs a
         if (threadIdx.x < TT + NG)                       // the four waves' sums, in wave order
             part[0][threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
         __syncthreads();
+        if (MODE == 1 && a.sg != nullptr && threadIdx.x < TT + NG) a.sg[(int64_t)blockIdx.x * (TT + NG) + threadIdx.x] = part[0][threadIdx.x];
         if (threadIdx.x < 64) {
             const int co = threadIdx.x;
             float s1 = 0.f, s2 = 0.f;
@@ -615,6 +617,189 @@ __global__ __launch_bounds__(256) void stem_bn_bwd_reduce_kernel(const SBWArgs a
 #pragma unroll 8
         for (int q = 0; q < 32; ++q) sum += red[(q * 8 + (co >> 3)) * 17 + st * 8 + (co & 7)];
         a.partials[(int64_t)blockIdx.x * 128 + st * 64 + co] = sum;
+    }
+}
+
+// ONE backward pass for the y-free stem.  With g = dz * act'(.) the weight gradient is
+//   dW[c][t] = scale_c * ( A[c][t] - c1_c * S[t] - c2_c * invstd_c * (sum_u w[c][u] G[u][t] - mean_c * S[t]) ),
+//   A[c][t] = sum_p g[p][c] x_t(p),   S / G = the tap sums / tap Gram matrix of the image (from the forward's statistics pass),
+// because sum_p xhat[p][c] x_t(p) = invstd_c (sum_u w[c][u] G[u][t] - mean_c S[t]).  So neither c1, c2 nor y are needed
+// while the tensors stream by: this kernel reads z (the stored activation: sign = the activation's mask; xhat = (z - beta)/gamma
+// wherever g != 0) and dz once and accumulates A (slabs) together with sum g and sum g * xhat (partials [block][2][64]);
+// gs_bn_bwd_coeffs and stem_wgrad_finalize_kernel finish.  A channel chunk with gamma == 0 (xhat not recoverable from z)
+// re-forms y from the image strip instead.
+template <int DT>
+__global__ __launch_bounds__(256) void stem_bwd_onepass_kernel(const SBWArgs a) {
+    extern __shared__ float sbw_smem[];
+    const int M = a.N * a.H * a.W;
+    const int ppb = (int)a.pix_per_block;
+    const int m0 = blockIdx.x * ppb;
+    const int m1 = m0 + ppb < M ? m0 + ppb : M;
+    const int nx = ppb + 2 * a.W + 2;
+    float* xs = sbw_smem;
+    float* red = sbw_smem + ((nx + 3) & ~3);                       // [256][25]
+    float* wl = red + 256 * 25;                                    // [9][64] (gamma == 0 fallback)
+    for (int i = threadIdx.x; i < nx; i += 256) {
+        const int idx = m0 - a.W - 1 + i;
+        xs[i] = (idx >= 0 && idx < M) ? a.x[idx] : 0.f;
+    }
+    for (int i = threadIdx.x; i < 576; i += 256) wl[i] = a.w[(i & 63) * 9 + (i >> 6)];
+    const int ch = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int c0 = ch * 8;
+    const float slope = a.act == GS_ACT_RELU ? 0.f : (a.act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
+    const float inv_slope = slope != 0.f ? 1.f / slope : 0.f;
+    // xhat = (v - shift) / scale - mean * invstd ... written as (v - beta) / gamma with beta = shift + mean*scale, gamma = scale/invstd
+    float ig[8], bt[8], mu[8], is[8], s1[8], s2[8];
+    bool zero_gamma = false;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float sc = a.scale[c0 + i], sh = a.shift[c0 + i];
+        mu[i] = a.mean[c0 + i]; is[i] = a.invstd[c0 + i];
+        const float gamma = sc / is[i];
+        zero_gamma = zero_gamma || gamma == 0.f;
+        ig[i] = gamma != 0.f ? 1.f / gamma : 0.f;
+        bt[i] = sh + mu[i] * sc;
+        s1[i] = 0.f; s2[i] = 0.f;
+    }
+    float acc[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[t][i] = 0.f;
+    __syncthreads();
+    constexpr int UNR = 4;
+    for (int mb = m0 + pl; mb < m1; mb += 32 * UNR) {
+        uint4 rz[UNR], rg[UNR];
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            const int m = mb + 32 * k;
+            const int64_t mm = m < m1 ? m : mb;
+            rz[k] = *reinterpret_cast<const uint4*>(a.y + mm * 64 + c0);          // a.y: the stored activation z here
+            rg[k] = *reinterpret_cast<const uint4*>(a.dz + mm * a.dz_stride + a.dz_coff + c0);
+        }
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            const int m = mb + 32 * k;
+            const bool ok = m < m1;
+            const int mm = ok ? m : mb;
+            const int ox = mm % a.W;
+            const int oy = (mm / a.W) % a.H;
+            const float* xc = xs + (mm - m0 + a.W + 1);
+            float xv[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy_ = t / 3 - 1, dx_ = t % 3 - 1;
+                const bool in = ok && (unsigned)(oy + dy_) < (unsigned)a.H && (unsigned)(ox + dx_) < (unsigned)a.W;
+                xv[t] = in ? xc[dy_ * a.W + dx_] : 0.f;
+            }
+            float zv[8], g[8], xh[8];
+            unpack8<DT>(rz[k], zv);
+            unpack8<DT>(rg[k], g);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float v = zv[i] > 0.f ? zv[i] : zv[i] * inv_slope;     // pre-activation value (where it matters)
+                xh[i] = (v - bt[i]) * ig[i];
+            }
+            if (zero_gamma) {                                                // rare: xhat from the re-formed y
+                float yv[8];
+                stem_y8(wl, c0, xv, yv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xh[i] = (yv[i] - mu[i]) * is[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float gh = ok ? g[i] * (zv[i] > 0.f ? 1.f : slope) : 0.f;
+                s1[i] += gh; s2[i] += gh * xh[i];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[t][i] += gh * xv[t];
+            }
+        }
+    }
+    // block sums: the two statistics, then the nine taps three at a time
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { red[threadIdx.x * 25 + i] = s1[i]; red[threadIdx.x * 25 + 8 + i] = s2[i]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int st = threadIdx.x >> 6, co = threadIdx.x & 63;
+        float sum = 0.f;
+#pragma unroll 8
+        for (int q = 0; q < 32; ++q) sum += red[(q * 8 + (co >> 3)) * 25 + st * 8 + (co & 7)];
+        a.partials[(int64_t)blockIdx.x * 128 + st * 64 + co] = sum;
+    }
+#pragma unroll
+    for (int t0 = 0; t0 < 9; t0 += 3) {
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) red[threadIdx.x * 25 + t * 8 + i] = acc[t0 + t][i];
+        __syncthreads();
+        if (threadIdx.x < 192) {
+            const int t = threadIdx.x >> 6, co = threadIdx.x & 63;
+            float sum = 0.f;
+#pragma unroll 8
+            for (int q = 0; q < 32; ++q) sum += red[(q * 8 + (co >> 3)) * 25 + t * 8 + (co & 7)];
+            a.slabs[(int64_t)blockIdx.x * 576 + co * 9 + t0 + t] = sum;
+        }
+    }
+}
+
+// dW[c][t] += gscale * scale_c * (A - c1 S_t - c2 invstd (sum_u w[c][u] G[u][t] - mean S_t)).  18 blocks of 32 outputs: every
+// block sums the image's 54 tap-sum / Gram totals over the forward tiles (4 lanes per quantity, 8 loads in flight) and the
+// slabs of its 32 outputs (8 slab lanes, 8 loads in flight), in fixed order, fp64.
+__global__ __launch_bounds__(256) void stem_wgrad_finalize_kernel(const float* __restrict__ slabs, int nb, const float* __restrict__ sg,
+                                                                  int nsg, const float* __restrict__ w, const float* scale,
+                                                                  const float* mean, const float* invstd, const float* c1,
+                                                                  const float* c2, float gscale, float* dw) {
+    __shared__ double sgl[4][54];
+    __shared__ double SG[54];
+    __shared__ double red[8][32];
+    if (threadIdx.x < 216) {
+        const int q = threadIdx.x % 54, l = threadIdx.x / 54;
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int b = l;
+        for (; b + 28 < nsg; b += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = sg[(int64_t)(b + 4 * u) * 54 + q];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += (double)v[u];
+        }
+        for (; b < nsg; b += 4) acc[0] += (double)sg[(int64_t)b * 54 + q];
+        sgl[l][q] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    }
+    const int jl = threadIdx.x & 31, bl = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + jl;                       // 576 = 18 * 32
+    {
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int b = bl;
+        for (; b + 56 < nb; b += 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slabs[(int64_t)(b + 8 * u) * 576 + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += (double)v[u];
+        }
+        for (; b < nb; b += 8) acc[0] += (double)slabs[(int64_t)b * 576 + j];
+        red[bl][jl] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    }
+    __syncthreads();
+    if (threadIdx.x < 54) SG[threadIdx.x] = (sgl[0][threadIdx.x] + sgl[1][threadIdx.x]) + (sgl[2][threadIdx.x] + sgl[3][threadIdx.x]);
+    __syncthreads();
+    if (bl == 0) {
+        double A = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) A += red[i][jl];
+        const int c = j / 9, t = j % 9;
+        double wg = 0.0;
+        for (int u = 0; u < 9; ++u) {
+            const int lo = u < t ? u : t, hi = u < t ? t : u;           // upper triangle, row-major: row lo, column hi
+            wg += (double)w[c * 9 + u] * SG[9 + lo * 9 - lo * (lo - 1) / 2 + (hi - lo)];
+        }
+        const double St = SG[t];
+        const double r = A - (double)c1[c] * St - (double)c2[c] * (double)invstd[c] * (wg - (double)mean[c] * St);
+        dw[j] += (float)((double)gscale * (double)scale[c] * r);
     }
 }
 
@@ -1283,11 +1468,13 @@ static int stem_check(const char* who, const float* x, const float* w, int N, in
     return GS_OK;
 }
 
-extern "C" int gs_stem_stats(const float* x, const float* w, float* bn_partials, int N, int H, int W, void* stream) {
+extern "C" int gs_stem_stats(const float* x, const float* w, float* bn_partials, float* tap_sums, int N, int H, int W,
+                             void* stream) {
     int rc = stem_check("gs_stem_stats", x, w, N, H, W, GS_F16);
     if (rc) return rc;
     GS_CHECK_ARG(bn_partials != nullptr, "gs_stem_stats: null partials");
     SCArgs a{x, w, nullptr, nullptr, bn_partials, N, 1, H, W, 64, H, W, 3, 1, 1, GS_ACT_NONE};
+    a.sg = tap_sums;
     smallcin_fwd64_line_kernel<GS_F16, 1><<<gs_conv_smallcin_mtiles(N, H, W), 256, 0, (hipStream_t)stream>>>(a);
     GS_CHECK_LAUNCH("gs_stem_stats");
     return GS_OK;
@@ -1344,6 +1531,34 @@ extern "C" int gs_stem_bn_bwd_reduce(const float* x, const float* w, const void*
     if (dtype == GS_F16) stem_bn_bwd_reduce_kernel<GS_F16><<<nb, 256, lds, (hipStream_t)stream>>>(a);
     else stem_bn_bwd_reduce_kernel<GS_BF16><<<nb, 256, lds, (hipStream_t)stream>>>(a);
     GS_CHECK_LAUNCH("gs_stem_bn_bwd_reduce");
+    return GS_OK;
+}
+
+extern "C" int gs_stem_bwd_onepass(const float* x, const float* w, const void* z, const void* dz, int dz_stride, int dz_coff,
+                                   const float* scale, const float* shift, const float* mean, const float* invstd, int act,
+                                   float* partials, float* ws, int N, int H, int W, int dtype, void* stream) {
+    SBWArgs a{}; size_t lds; int nb;
+    int rc = stem_bwd_common("gs_stem_bwd_onepass", a, lds, nb, dz, dz_stride, dz_coff, x, w, scale, shift, mean, invstd, act,
+                             N, H, W, dtype);
+    if (rc) return rc;
+    GS_CHECK_ARG(z && partials && ws, "gs_stem_bwd_onepass: null pointer");
+    if (lds > 64 * 1024) return GS_EUNSUPPORTED;
+    a.y = (const unsigned short*)z; a.partials = partials; a.slabs = ws;
+    if (dtype == GS_F16) stem_bwd_onepass_kernel<GS_F16><<<nb, 256, lds, (hipStream_t)stream>>>(a);
+    else stem_bwd_onepass_kernel<GS_BF16><<<nb, 256, lds, (hipStream_t)stream>>>(a);
+    GS_CHECK_LAUNCH("gs_stem_bwd_onepass");
+    return GS_OK;
+}
+
+extern "C" int gs_stem_wgrad_finalize(const float* ws, const float* tap_sums, const float* w, const float* scale,
+                                      const float* mean, const float* invstd, const float* c1, const float* c2, float gscale,
+                                      float* dw, int N, int H, int W, void* stream) {
+    GS_CHECK_ARG(ws && tap_sums && w && scale && mean && invstd && c1 && c2 && dw && N > 0 && H > 0 && W > 0,
+                 "gs_stem_wgrad_finalize: bad arguments");
+    stem_wgrad_finalize_kernel<<<18, 256, 0, (hipStream_t)stream>>>(ws, gs_stem_bwd_tiles(N, H, W), tap_sums,
+                                                                  gs_conv_smallcin_mtiles(N, H, W), w, scale, mean, invstd, c1, c2,
+                                                                  gscale, dw);
+    GS_CHECK_LAUNCH("gs_stem_wgrad_finalize");
     return GS_OK;
 }
 

@@ -591,12 +591,39 @@ def _stem_check(x, w, who):
     return x.shape[0], x.shape[2], x.shape[3]
 
 
-def stem_stats(x, w, bn_partials):
+def stem_stats(x, w, bn_partials, tap_sums=None):
+    """BatchNorm tile partials of conv(x, w) from the image alone; tap_sums [mtiles][54] fp32 (optional) receives each tile's
+    nine tap sums and 45 Gram entries for stem_wgrad_finalize."""
     N, H, W = _stem_check(x, w, "stem_stats")
-    _f32(bn_partials, "bn_partials")
-    if bn_partials.numel() < bn_partials_numel(conv_smallcin_mtiles(N, H, W), 64):
-        raise ValueError("stem_stats: bn_partials too small")
-    _lib.call("gs_stem_stats", _p(x), _p(w), _p(bn_partials), N, H, W, _stream())
+    _f32(bn_partials, "bn_partials"); _f32(tap_sums, "tap_sums")
+    mt = conv_smallcin_mtiles(N, H, W)
+    if bn_partials.numel() < bn_partials_numel(mt, 64) or (tap_sums is not None and tap_sums.numel() < mt * 54):
+        raise ValueError("stem_stats: bn_partials / tap_sums too small")
+    _lib.call("gs_stem_stats", _p(x), _p(w), _p(bn_partials), _p(tap_sums), N, H, W, _stream())
+
+
+def stem_bwd_onepass(x, w, z, dz, dz_stride, dz_coff, scale, shift, mean, invstd, act, partials, ws) -> bool:
+    """One pass over z and dz: partials [stem_bwd_tiles][2][64] (sum g, sum g*xhat) and the slabs of A = sum g x_tap in ws."""
+    N, H, W = _stem_check(x, w, "stem_bwd_onepass")
+    _f32(partials, "partials"); _f32(ws, "ws")
+    nt = stem_bwd_tiles(N, H, W)
+    if partials.numel() < bn_partials_numel(nt, 64) or ws.numel() < nt * 576 or tuple(z.shape) != (N, H, W, 64) or not z.is_contiguous():
+        raise ValueError("stem_bwd_onepass: buffers too small or z not dense [N,H,W,64]")
+    rc = _lib.load().gs_stem_bwd_onepass(_p(x), _p(w), _p(z), _p(dz), dz_stride, dz_coff, _p(scale), _p(shift), _p(mean),
+                                         _p(invstd), act, _p(partials), _p(ws), N, H, W, dt_code(z), _stream())
+    if rc == _lib.GS_EUNSUPPORTED:
+        return False
+    if rc != 0:
+        _lib.check(rc, "gs_stem_bwd_onepass")
+    return True
+
+
+def stem_wgrad_finalize(ws, tap_sums, w, scale, mean, invstd, c1, c2, gscale, dw, N, H, W):
+    _f32(ws, "ws"); _f32(tap_sums, "tap_sums"); _f32(w, "w"); _f32(dw, "dw")
+    if dw.numel() != 576 or tap_sums.numel() < conv_smallcin_mtiles(N, H, W) * 54 or ws.numel() < stem_bwd_tiles(N, H, W) * 576:
+        raise ValueError("stem_wgrad_finalize: buffer sizes")
+    _lib.call("gs_stem_wgrad_finalize", _p(ws), _p(tap_sums), _p(w), _p(scale), _p(mean), _p(invstd), _p(c1), _p(c2),
+              float(gscale), _p(dw), N, H, W, _stream())
 
 
 def stem_fwd_bn(x, w, scale, shift, act, z):

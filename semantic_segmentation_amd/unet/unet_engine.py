@@ -49,7 +49,7 @@ FUSED_UP_BIAS_GRAD = os.environ.get("GSSEG_UP_BIAS_FUSED", "1") != "0"
 class _ConvRec:
     """Saved state of one conv -> BN -> ReLU stage."""
     __slots__ = ("name", "wkey", "bnkey", "inp", "inp_is_image", "y", "coef", "geom", "cin", "cout", "h", "w",
-                 "wd", "train_stats", "inp_stride")
+                 "wd", "train_stats", "inp_stride", "z", "tap_sums")
 
 
 class _UpRec:
@@ -295,12 +295,16 @@ class UNetEngine:
                 # one-channel stem: the BatchNorm statistics come from the image and the weights alone, the convolution
                 # output is normalised in registers and never stored (the backward re-forms it from the image)
                 wst = wparam.detach().contiguous()
+                # per-tile tap sums / Gram entries of the image: the backward's closed-form weight gradient needs their totals
+                rec.tap_sums = None
+                if need_grad:        # (eval-mode statistics: c1 = c2 = 0 multiply them, so they only have to be finite)
+                    rec.tap_sums = empty(ntiles * 54, dtype=torch.float32) if batch_stats else torch.zeros(ntiles * 54, dtype=torch.float32, device=dev)
                 if batch_stats:
-                    ops.stem_stats(inp, wst, partials)
+                    ops.stem_stats(inp, wst, partials, rec.tap_sums)
                 coef, rec.train_stats = bn_coeffs(bnkey, ntiles, cout, N * h * w)
                 ops.stem_fwd_bn(inp, wst, coef[0], coef[1], ACT_RELU, z)
                 rec.geom, rec.wd = None, None
-                rec.y, rec.coef = None, coef
+                rec.y, rec.coef, rec.z = None, coef, z
                 if need_grad:
                     rec.inp = inp
                     recs.append(rec)
@@ -726,7 +730,10 @@ class UNetEngine:
                 wst = params[rec.wkey].detach().contiguous()
                 done = False
                 if not need_dinp and not pooled and head is None:
-                    if ops.stem_bn_bwd_reduce(rec.inp, wst, dz_a, sa, ca, coef[0], coef[1], coef[2], coef[3], ACT_RELU, partials):
+                    # one pass over z and dz; the weight gradient in closed form from A = sum g x_tap, c1, c2 and the tap sums
+                    sws = empty(ops.stem_bwd_tiles(N, h, w) * 576, dtype=torch.float32)
+                    if ops.stem_bwd_onepass(rec.inp, wst, rec.z, dz_a, sa, ca, coef[0], coef[1], coef[2], coef[3], ACT_RELU,
+                                            partials, sws):
                         dgamma = galloc(rec.bnkey + ".weight", params[rec.bnkey + ".weight"])
                         dbeta = galloc(rec.bnkey + ".bias", params[rec.bnkey + ".bias"])
                         c12 = empty(2, cout, dtype=torch.float32)
@@ -734,9 +741,7 @@ class UNetEngine:
                         if not rec.train_stats:
                             c12.zero_()
                         dw = galloc(rec.wkey, params[rec.wkey], zero=True)
-                        if not ops.stem_bn_bwd_wgrad_recompute(rec.inp, wst, dz_a, sa, ca, coef[0], coef[1], coef[2], coef[3],
-                                                               c12[0], c12[1], ACT_RELU, dw, inv_s):
-                            raise RuntimeError("stem backward: the reduce pass ran but the weight-gradient pass refused the shape")
+                        ops.stem_wgrad_finalize(sws, rec.tap_sums, wst, coef[0], coef[2], coef[3], c12[0], c12[1], inv_s, dw, N, h, w)
                         emit(rec.wkey, dw)
                         emit(rec.bnkey + ".weight", dgamma)
                         emit(rec.bnkey + ".bias", dbeta)
