@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 36
+#define GS_ABI_VERSION 37
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -171,13 +171,16 @@ int64_t gs_conv_direct_wgrad_ws_floats(int N, int OH, int OW, int Cin, int Cout,
  *                      the BatchNorm backward reduce ([gs_stem_bwd_tiles(N,H,W)][2][64] partials for gs_bn_bwd_coeffs) and
  *                      the fused backward apply + weight gradient (as gs_stem_bn_bwd_wgrad), with y re-formed from the
  *                      image strip in LDS in the forward kernel's summation order (bit-identical to what was normalised).
- *   gs_stem_bwd_onepass + gs_bn_bwd_coeffs + gs_stem_wgrad_finalize
- *                      the whole backward of the stage in ONE pass over z (the stored activation) and dz: with g = dz*act'
- *                      it accumulates sum g, sum g*xhat (partials [gs_stem_bwd_tiles][2][64]; xhat = (z - beta)/gamma where
- *                      g != 0) and A[c][t] = sum_p g x_t(p) (slabs in ws); the weight gradient follows in closed form from
- *                      A, the BatchNorm backward coefficients c1, c2 and the image's tap sums S / Gram matrix G, which
- *                      gs_stem_stats also writes per tile (tap_sums [mtiles][54], may be NULL):
- *                        dW[c][t] += gscale*scale_c*(A - c1_c S_t - c2_c invstd_c (sum_u w[c][u] G[u][t] - mean_c S_t)).
+ *   gs_stem_bwd_onepass + gs_stem_bwd_finalize
+ *                      the whole backward of the stage in ONE pass over z (the stored activation: only its sign, the
+ *                      activation's mask, is used) and dz.  With g = dz*act', A[c][t] = sum_p g x_t(p), s1 = sum_p g:
+ *                        sum_p g xhat = invstd_c (sum_t w[c][t] A[c][t] - mean_c s1_c)          (y = sum_t w_t x_t exactly)
+ *                        dW[c][t] += gscale*scale_c*(A - c1_c S_t - c2_c invstd_c (sum_u w[c][u] G[u][t] - mean_c S_t))
+ *                      with S / G the image's tap sums / tap Gram matrix, which gs_stem_stats also writes per tile
+ *                      (tap_sums [mtiles][54], may be NULL there) and c1 = s1/count, c2 = sum g xhat / count (0 when
+ *                      train_stats = 0: eval-mode statistics).  _onepass writes s1_partials [gs_stem_bwd_tiles][64] and the
+ *                      A slabs ws [gs_stem_bwd_tiles][576]; _finalize (fp64) OVERWRITES dgamma / dbeta (gscale * sums; may be
+ *                      NULL) and accumulates dw.
  * At batch 32, 256^2 this removes the write of y (268 MB), its read by gs_bn_act_apply and by the two backward passes.
  * x fp32 [N,1,H,W], w fp32 [64][1][3][3].  The two backward entry points return GS_EUNSUPPORTED (no error string) when the
  * image is too wide for the LDS strip: the caller then re-forms y with gs_conv_smallcin_fwd and runs the tensor path. */
@@ -185,12 +188,11 @@ int gs_stem_stats(const float* x, const float* w, float* bn_partials, float* tap
 int gs_stem_fwd_bn(const float* x, const float* w, const float* bn_scale, const float* bn_shift, int act, void* z, int N,
                    int H, int W, int dtype, void* stream);
 int gs_stem_bwd_tiles(int N, int H, int W);
-int gs_stem_bwd_onepass(const float* x, const float* w, const void* z, const void* dz, int dz_stride, int dz_coff,
-                        const float* scale, const float* shift, const float* mean, const float* invstd, int act,
-                        float* partials, float* ws, int N, int H, int W, int dtype, void* stream);
-int gs_stem_wgrad_finalize(const float* ws, const float* tap_sums, const float* w, const float* scale, const float* mean,
-                           const float* invstd, const float* c1, const float* c2, float gscale, float* dw, int N, int H, int W,
-                           void* stream);
+int gs_stem_bwd_onepass(const float* x, const void* z, const void* dz, int dz_stride, int dz_coff, int act,
+                        float* s1_partials, float* ws, int N, int H, int W, int dtype, void* stream);
+int gs_stem_bwd_finalize(const float* ws, const float* s1_partials, const float* tap_sums, const float* w,
+                         const float* scale, const float* mean, const float* invstd, int train_stats, float gscale, float* dw,
+                         float* dgamma, float* dbeta, int N, int H, int W, void* stream);
 int gs_stem_bn_bwd_reduce(const float* x, const float* w, const void* dz, int dz_stride, int dz_coff, const float* scale,
                           const float* shift, const float* mean, const float* invstd, int act, float* partials, int N, int H,
                           int W, int dtype, void* stream);

@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 GS_F16, GS_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH = 0, 1, 2, 3
 GS_MAX_TAPS = 64
-ABI_VERSION = 36
+ABI_VERSION = 37
 
 
 class GsConvGeom(ctypes.Structure):
@@ -99,9 +99,8 @@ PROTOTYPES = {
     "gs_stem_bn_bwd_wgrad": (c_int, [_P, _P, c_int, c_int, _F, _F, _F, _F, _F, _F, _F, c_int, _F, _F, c_int, c_int, c_int,
                                      c_float, c_int, c_void_p]),
     "gs_stem_stats": (c_int, [_F, _F, _F, _F, c_int, c_int, c_int, c_void_p]),
-    "gs_stem_bwd_onepass": (c_int, [_F, _F, _P, _P, c_int, c_int, _F, _F, _F, _F, c_int, _F, _F, c_int, c_int, c_int, c_int,
-                                    c_void_p]),
-    "gs_stem_wgrad_finalize": (c_int, [_F, _F, _F, _F, _F, _F, _F, _F, c_float, _F, c_int, c_int, c_int, c_void_p]),
+    "gs_stem_bwd_onepass": (c_int, [_F, _P, _P, c_int, c_int, c_int, _F, _F, c_int, c_int, c_int, c_int, c_void_p]),
+    "gs_stem_bwd_finalize": (c_int, [_F, _F, _F, _F, _F, _F, _F, c_int, c_float, _F, _F, _F, c_int, c_int, c_int, c_void_p]),
     "gs_stem_fwd_bn": (c_int, [_F, _F, _F, _F, c_int, _P, c_int, c_int, c_int, c_int, c_void_p]),
     "gs_stem_bwd_tiles": (c_int, [c_int, c_int, c_int]),
     "gs_stem_bn_bwd_reduce": (c_int, [_F, _F, _P, c_int, c_int, _F, _F, _F, _F, c_int, _F, c_int, c_int, c_int, c_int, c_void_p]),

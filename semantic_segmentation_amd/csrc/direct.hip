@@ -620,14 +620,13 @@ __global__ __launch_bounds__(256) void stem_bn_bwd_reduce_kernel(const SBWArgs a
     }
 }
 
-// ONE backward pass for the y-free stem.  With g = dz * act'(.) the weight gradient is
-//   dW[c][t] = scale_c * ( A[c][t] - c1_c * S[t] - c2_c * invstd_c * (sum_u w[c][u] G[u][t] - mean_c * S[t]) ),
-//   A[c][t] = sum_p g[p][c] x_t(p),   S / G = the tap sums / tap Gram matrix of the image (from the forward's statistics pass),
-// because sum_p xhat[p][c] x_t(p) = invstd_c (sum_u w[c][u] G[u][t] - mean_c S[t]).  So neither c1, c2 nor y are needed
-// while the tensors stream by: this kernel reads z (the stored activation: sign = the activation's mask; xhat = (z - beta)/gamma
-// wherever g != 0) and dz once and accumulates A (slabs) together with sum g and sum g * xhat (partials [block][2][64]);
-// gs_bn_bwd_coeffs and stem_wgrad_finalize_kernel finish.  A channel chunk with gamma == 0 (xhat not recoverable from z)
-// re-forms y from the image strip instead.
+// ONE backward pass for the y-free stem.  With g = dz * act'(.), A[c][t] = sum_p g[p][c] x_t(p) and s1_c = sum_p g[p][c]:
+//   sum_p g xhat  = invstd_c (sum_t w[c][t] A[c][t] - mean_c s1_c)                      (y = sum_t w_t x_t, exactly)
+//   dW[c][t]      = scale_c (A[c][t] - c1_c S[t] - c2_c invstd_c (sum_u w[c][u] G[u][t] - mean_c S[t]))
+// with S / G the tap sums / tap Gram matrix of the image (from the forward's statistics pass) and c1 = s1/count,
+// c2 = sum g xhat / count.  So while the tensors stream by only the activation's MASK (the sign of the stored z) and dz are
+// needed: this kernel accumulates A (slabs [block][576]) and s1 (partials [block][64]); stem_bwd_finalize_kernel does the
+// rest -- BatchNorm weight / bias gradients included -- in fp64 on 640 numbers per block.
 template <int DT>
 __global__ __launch_bounds__(256) void stem_bwd_onepass_kernel(const SBWArgs a) {
     extern __shared__ float sbw_smem[];
@@ -638,30 +637,16 @@ __global__ __launch_bounds__(256) void stem_bwd_onepass_kernel(const SBWArgs a) 
     const int nx = ppb + 2 * a.W + 2;
     float* xs = sbw_smem;
     float* red = sbw_smem + ((nx + 3) & ~3);                       // [256][25]
-    float* wl = red + 256 * 25;                                    // [9][64] (gamma == 0 fallback)
     for (int i = threadIdx.x; i < nx; i += 256) {
         const int idx = m0 - a.W - 1 + i;
         xs[i] = (idx >= 0 && idx < M) ? a.x[idx] : 0.f;
     }
-    for (int i = threadIdx.x; i < 576; i += 256) wl[i] = a.w[(i & 63) * 9 + (i >> 6)];
     const int ch = threadIdx.x & 7, pl = threadIdx.x >> 3;
     const int c0 = ch * 8;
     const float slope = a.act == GS_ACT_RELU ? 0.f : (a.act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
-    const float inv_slope = slope != 0.f ? 1.f / slope : 0.f;
-    // xhat = (v - shift) / scale - mean * invstd ... written as (v - beta) / gamma with beta = shift + mean*scale, gamma = scale/invstd
-    float ig[8], bt[8], mu[8], is[8], s1[8], s2[8];
-    bool zero_gamma = false;
+    float s1[8], acc[9][8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float sc = a.scale[c0 + i], sh = a.shift[c0 + i];
-        mu[i] = a.mean[c0 + i]; is[i] = a.invstd[c0 + i];
-        const float gamma = sc / is[i];
-        zero_gamma = zero_gamma || gamma == 0.f;
-        ig[i] = gamma != 0.f ? 1.f / gamma : 0.f;
-        bt[i] = sh + mu[i] * sc;
-        s1[i] = 0.f; s2[i] = 0.f;
-    }
-    float acc[9][8];
+    for (int i = 0; i < 8; ++i) s1[i] = 0.f;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -689,43 +674,32 @@ __global__ __launch_bounds__(256) void stem_bwd_onepass_kernel(const SBWArgs a) 
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int dy_ = t / 3 - 1, dx_ = t % 3 - 1;
-                const bool in = ok && (unsigned)(oy + dy_) < (unsigned)a.H && (unsigned)(ox + dx_) < (unsigned)a.W;
+                const bool in = (unsigned)(oy + dy_) < (unsigned)a.H && (unsigned)(ox + dx_) < (unsigned)a.W;
                 xv[t] = in ? xc[dy_ * a.W + dx_] : 0.f;
             }
-            float zv[8], g[8], xh[8];
+            float zv[8], g[8];
             unpack8<DT>(rz[k], zv);
             unpack8<DT>(rg[k], g);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float v = zv[i] > 0.f ? zv[i] : zv[i] * inv_slope;     // pre-activation value (where it matters)
-                xh[i] = (v - bt[i]) * ig[i];
-            }
-            if (zero_gamma) {                                                // rare: xhat from the re-formed y
-                float yv[8];
-                stem_y8(wl, c0, xv, yv);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) xh[i] = (yv[i] - mu[i]) * is[i];
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
                 const float gh = ok ? g[i] * (zv[i] > 0.f ? 1.f : slope) : 0.f;
-                s1[i] += gh; s2[i] += gh * xh[i];
+                s1[i] += gh;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) acc[t][i] += gh * xv[t];
             }
         }
     }
-    // block sums: the two statistics, then the nine taps three at a time
+    // block sums: s1, then the nine taps three at a time
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { red[threadIdx.x * 25 + i] = s1[i]; red[threadIdx.x * 25 + 8 + i] = s2[i]; }
+    for (int i = 0; i < 8; ++i) red[threadIdx.x * 25 + i] = s1[i];
     __syncthreads();
-    if (threadIdx.x < 128) {
-        const int st = threadIdx.x >> 6, co = threadIdx.x & 63;
+    if (threadIdx.x < 64) {
+        const int co = threadIdx.x;
         float sum = 0.f;
 #pragma unroll 8
-        for (int q = 0; q < 32; ++q) sum += red[(q * 8 + (co >> 3)) * 25 + st * 8 + (co & 7)];
-        a.partials[(int64_t)blockIdx.x * 128 + st * 64 + co] = sum;
+        for (int q = 0; q < 32; ++q) sum += red[(q * 8 + (co >> 3)) * 25 + (co & 7)];
+        a.partials[(int64_t)blockIdx.x * 64 + co] = sum;
     }
 #pragma unroll
     for (int t0 = 0; t0 < 9; t0 += 3) {
@@ -745,17 +719,20 @@ __global__ __launch_bounds__(256) void stem_bwd_onepass_kernel(const SBWArgs a) 
     }
 }
 
-// dW[c][t] += gscale * scale_c * (A - c1 S_t - c2 invstd (sum_u w[c][u] G[u][t] - mean S_t)).  18 blocks of 32 outputs: every
-// block sums the image's 54 tap-sum / Gram totals over the forward tiles (4 lanes per quantity, 8 loads in flight) and the
-// slabs of its 32 outputs (8 slab lanes, 8 loads in flight), in fixed order, fp64.
-__global__ __launch_bounds__(256) void stem_wgrad_finalize_kernel(const float* __restrict__ slabs, int nb, const float* __restrict__ sg,
-                                                                  int nsg, const float* __restrict__ w, const float* scale,
-                                                                  const float* mean, const float* invstd, const float* c1,
-                                                                  const float* c2, float gscale, float* dw) {
+// 16 blocks of four channels: each sums the image's 54 tap-sum / Gram totals over the forward tiles, its 36 A entries and
+// 4 s1 entries over the backward blocks (6 lanes per quantity, 8 loads in flight, fixed order, fp64), then
+//   s2 = invstd (sum_t w A - mean s1);  c1 = s1/count, c2 = s2/count (0 with eval-mode statistics);
+//   dbeta = gscale s1, dgamma = gscale s2 (OVERWRITE);  dW += gscale scale (A - c1 S_t - c2 invstd (sum_u w_u G_ut - mean S_t)).
+__global__ __launch_bounds__(256) void stem_bwd_finalize_kernel(const float* __restrict__ slabs, const float* __restrict__ s1p, int nb,
+                                                                const float* __restrict__ sg, int nsg, const float* __restrict__ w,
+                                                                const float* scale, const float* mean, const float* invstd,
+                                                                double count, int train_stats, float gscale, float* dw,
+                                                                float* dgamma, float* dbeta) {
     __shared__ double sgl[4][54];
     __shared__ double SG[54];
-    __shared__ double red[8][32];
-    if (threadIdx.x < 216) {
+    __shared__ double red[6][40];
+    __shared__ double tot[40];
+    if (threadIdx.x < 216 && train_stats) {
         const int q = threadIdx.x % 54, l = threadIdx.x / 54;
         double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int b = l;
@@ -769,37 +746,50 @@ __global__ __launch_bounds__(256) void stem_wgrad_finalize_kernel(const float* _
         for (; b < nsg; b += 4) acc[0] += (double)sg[(int64_t)b * 54 + q];
         sgl[l][q] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     }
-    const int jl = threadIdx.x & 31, bl = threadIdx.x >> 5;
-    const int j = blockIdx.x * 32 + jl;                       // 576 = 18 * 32
-    {
+    const int cb = blockIdx.x * 4;                              // first channel of the block
+    if (threadIdx.x < 240) {
+        const int q = threadIdx.x % 40, l = threadIdx.x / 40;
+        const float* src = q < 36 ? slabs + cb * 9 + q : s1p + cb + (q - 36);
+        const int64_t stride = q < 36 ? 576 : 64;
         double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int b = bl;
-        for (; b + 56 < nb; b += 64) {
+        int b = l;
+        for (; b + 42 < nb; b += 48) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = slabs[(int64_t)(b + 8 * u) * 576 + j];
+            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(b + 6 * u) * stride];
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc[u] += (double)v[u];
         }
-        for (; b < nb; b += 8) acc[0] += (double)slabs[(int64_t)b * 576 + j];
-        red[bl][jl] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        for (; b < nb; b += 6) acc[0] += (double)src[(int64_t)b * stride];
+        red[l][q] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     }
     __syncthreads();
-    if (threadIdx.x < 54) SG[threadIdx.x] = (sgl[0][threadIdx.x] + sgl[1][threadIdx.x]) + (sgl[2][threadIdx.x] + sgl[3][threadIdx.x]);
+    if (threadIdx.x < 54) SG[threadIdx.x] = train_stats ? (sgl[0][threadIdx.x] + sgl[1][threadIdx.x]) + (sgl[2][threadIdx.x] + sgl[3][threadIdx.x]) : 0.0;
+    if (threadIdx.x >= 64 && threadIdx.x < 104) {
+        const int q = threadIdx.x - 64;
+        tot[q] = ((red[0][q] + red[1][q]) + (red[2][q] + red[3][q])) + (red[4][q] + red[5][q]);
+    }
     __syncthreads();
-    if (bl == 0) {
-        double A = 0.0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) A += red[i][jl];
-        const int c = j / 9, t = j % 9;
-        double wg = 0.0;
+    if (threadIdx.x < 36) {
+        const int cl = threadIdx.x / 9, t = threadIdx.x % 9, c = cb + cl;
+        const double s1 = tot[36 + cl];
+        double wA = 0.0, wg = 0.0;
         for (int u = 0; u < 9; ++u) {
+            const double wu = (double)w[c * 9 + u];
+            wA += wu * tot[cl * 9 + u];
             const int lo = u < t ? u : t, hi = u < t ? t : u;           // upper triangle, row-major: row lo, column hi
-            wg += (double)w[c * 9 + u] * SG[9 + lo * 9 - lo * (lo - 1) / 2 + (hi - lo)];
+            wg += wu * SG[9 + lo * 9 - lo * (lo - 1) / 2 + (hi - lo)];
         }
+        const double is = (double)invstd[c], mu = (double)mean[c];
+        const double s2 = is * (wA - mu * s1);
+        const double c1 = train_stats ? s1 / count : 0.0, c2 = train_stats ? s2 / count : 0.0;
         const double St = SG[t];
-        const double r = A - (double)c1[c] * St - (double)c2[c] * (double)invstd[c] * (wg - (double)mean[c] * St);
-        dw[j] += (float)((double)gscale * (double)scale[c] * r);
+        const double r = tot[cl * 9 + t] - c1 * St - c2 * is * (wg - mu * St);
+        dw[c * 9 + t] += (float)((double)gscale * (double)scale[c] * r);
+        if (t == 0) {
+            if (dbeta) dbeta[c] = (float)(s1 * (double)gscale);
+            if (dgamma) dgamma[c] = (float)(s2 * (double)gscale);
+        }
     }
 }
 
@@ -1534,31 +1524,37 @@ extern "C" int gs_stem_bn_bwd_reduce(const float* x, const float* w, const void*
     return GS_OK;
 }
 
-extern "C" int gs_stem_bwd_onepass(const float* x, const float* w, const void* z, const void* dz, int dz_stride, int dz_coff,
-                                   const float* scale, const float* shift, const float* mean, const float* invstd, int act,
-                                   float* partials, float* ws, int N, int H, int W, int dtype, void* stream) {
-    SBWArgs a{}; size_t lds; int nb;
-    int rc = stem_bwd_common("gs_stem_bwd_onepass", a, lds, nb, dz, dz_stride, dz_coff, x, w, scale, shift, mean, invstd, act,
-                             N, H, W, dtype);
-    if (rc) return rc;
-    GS_CHECK_ARG(z && partials && ws, "gs_stem_bwd_onepass: null pointer");
+extern "C" int gs_stem_bwd_onepass(const float* x, const void* z, const void* dz, int dz_stride, int dz_coff, int act,
+                                   float* s1_partials, float* ws, int N, int H, int W, int dtype, void* stream) {
+    GS_CHECK_ARG(x && z && dz && s1_partials && ws && N > 0 && H > 0 && W > 0 && (int64_t)N * H * W < 2147483647LL / 64,
+                 "gs_stem_bwd_onepass: bad arguments");
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_stem_bwd_onepass: bad dtype");
+    GS_CHECK_ARG(dz_stride % 8 == 0 && dz_coff % 8 == 0 && dz_stride >= dz_coff + 64, "gs_stem_bwd_onepass: bad gradient layout");
+    GS_CHECK_ARG(act == GS_ACT_NONE || act == GS_ACT_RELU || act == GS_ACT_LEAKY02, "gs_stem_bwd_onepass: bad activation");
+    const int64_t M = (int64_t)N * H * W;
+    const int64_t ppb = stem_bwd_ppb(M);
+    const size_t lds = ((size_t)((ppb + 2 * W + 2 + 3) & ~(int64_t)3) + 256 * 25) * sizeof(float);
     if (lds > 64 * 1024) return GS_EUNSUPPORTED;
-    a.y = (const unsigned short*)z; a.partials = partials; a.slabs = ws;
+    SBWArgs a{};
+    a.y = (const unsigned short*)z; a.dz = (const unsigned short*)dz; a.x = x; a.slabs = ws; a.partials = s1_partials;
+    a.dz_stride = dz_stride; a.dz_coff = dz_coff; a.N = N; a.H = H; a.W = W; a.act = act; a.pix_per_block = ppb;
+    const int nb = (int)cdiv64(M, ppb);
     if (dtype == GS_F16) stem_bwd_onepass_kernel<GS_F16><<<nb, 256, lds, (hipStream_t)stream>>>(a);
     else stem_bwd_onepass_kernel<GS_BF16><<<nb, 256, lds, (hipStream_t)stream>>>(a);
     GS_CHECK_LAUNCH("gs_stem_bwd_onepass");
     return GS_OK;
 }
 
-extern "C" int gs_stem_wgrad_finalize(const float* ws, const float* tap_sums, const float* w, const float* scale,
-                                      const float* mean, const float* invstd, const float* c1, const float* c2, float gscale,
-                                      float* dw, int N, int H, int W, void* stream) {
-    GS_CHECK_ARG(ws && tap_sums && w && scale && mean && invstd && c1 && c2 && dw && N > 0 && H > 0 && W > 0,
-                 "gs_stem_wgrad_finalize: bad arguments");
-    stem_wgrad_finalize_kernel<<<18, 256, 0, (hipStream_t)stream>>>(ws, gs_stem_bwd_tiles(N, H, W), tap_sums,
-                                                                  gs_conv_smallcin_mtiles(N, H, W), w, scale, mean, invstd, c1, c2,
-                                                                  gscale, dw);
-    GS_CHECK_LAUNCH("gs_stem_wgrad_finalize");
+extern "C" int gs_stem_bwd_finalize(const float* ws, const float* s1_partials, const float* tap_sums, const float* w,
+                                    const float* scale, const float* mean, const float* invstd, int train_stats, float gscale,
+                                    float* dw, float* dgamma, float* dbeta, int N, int H, int W, void* stream) {
+    GS_CHECK_ARG(ws && s1_partials && w && scale && mean && invstd && dw && N > 0 && H > 0 && W > 0,
+                 "gs_stem_bwd_finalize: bad arguments");
+    GS_CHECK_ARG(!train_stats || tap_sums, "gs_stem_bwd_finalize: train-mode statistics need the tap sums of gs_stem_stats");
+    stem_bwd_finalize_kernel<<<16, 256, 0, (hipStream_t)stream>>>(ws, s1_partials, gs_stem_bwd_tiles(N, H, W), tap_sums,
+                                                                gs_conv_smallcin_mtiles(N, H, W), w, scale, mean, invstd,
+                                                                (double)N * H * W, train_stats, gscale, dw, dgamma, dbeta);
+    GS_CHECK_LAUNCH("gs_stem_bwd_finalize");
     return GS_OK;
 }
 

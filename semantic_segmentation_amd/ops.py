@@ -593,7 +593,7 @@ def _stem_check(x, w, who):
 
 def stem_stats(x, w, bn_partials, tap_sums=None):
     """BatchNorm tile partials of conv(x, w) from the image alone; tap_sums [mtiles][54] fp32 (optional) receives each tile's
-    nine tap sums and 45 Gram entries for stem_wgrad_finalize."""
+    nine tap sums and 45 Gram entries for stem_bwd_finalize."""
     N, H, W = _stem_check(x, w, "stem_stats")
     _f32(bn_partials, "bn_partials"); _f32(tap_sums, "tap_sums")
     mt = conv_smallcin_mtiles(N, H, W)
@@ -602,15 +602,18 @@ def stem_stats(x, w, bn_partials, tap_sums=None):
     _lib.call("gs_stem_stats", _p(x), _p(w), _p(bn_partials), _p(tap_sums), N, H, W, _stream())
 
 
-def stem_bwd_onepass(x, w, z, dz, dz_stride, dz_coff, scale, shift, mean, invstd, act, partials, ws) -> bool:
-    """One pass over z and dz: partials [stem_bwd_tiles][2][64] (sum g, sum g*xhat) and the slabs of A = sum g x_tap in ws."""
-    N, H, W = _stem_check(x, w, "stem_bwd_onepass")
-    _f32(partials, "partials"); _f32(ws, "ws")
+def stem_bwd_onepass(x, z, dz, dz_stride, dz_coff, act, s1_partials, ws) -> bool:
+    """One pass over z (its sign = the activation's mask) and dz: s1_partials [stem_bwd_tiles][64] (sum g) and the slabs of
+    A = sum g x_tap in ws [stem_bwd_tiles][576].  False: image too wide for the LDS strip."""
+    _dev(x)
+    _f32(x, "x"); _f32(s1_partials, "s1_partials"); _f32(ws, "ws")
+    N, H, W = x.shape[0], x.shape[2], x.shape[3]
     nt = stem_bwd_tiles(N, H, W)
-    if partials.numel() < bn_partials_numel(nt, 64) or ws.numel() < nt * 576 or tuple(z.shape) != (N, H, W, 64) or not z.is_contiguous():
-        raise ValueError("stem_bwd_onepass: buffers too small or z not dense [N,H,W,64]")
-    rc = _lib.load().gs_stem_bwd_onepass(_p(x), _p(w), _p(z), _p(dz), dz_stride, dz_coff, _p(scale), _p(shift), _p(mean),
-                                         _p(invstd), act, _p(partials), _p(ws), N, H, W, dt_code(z), _stream())
+    if (x.shape[1] != 1 or not x.is_contiguous() or s1_partials.numel() < nt * 64 or ws.numel() < nt * 576
+            or tuple(z.shape) != (N, H, W, 64) or not z.is_contiguous() or z.dtype != dz.dtype):
+        raise ValueError("stem_bwd_onepass: x [N,1,H,W], z dense [N,H,W,64], buffers of stem_bwd_tiles * 64 / 576 floats")
+    rc = _lib.load().gs_stem_bwd_onepass(_p(x), _p(z), _p(dz), dz_stride, dz_coff, act, _p(s1_partials), _p(ws), N, H, W,
+                                         dt_code(z), _stream())
     if rc == _lib.GS_EUNSUPPORTED:
         return False
     if rc != 0:
@@ -618,12 +621,17 @@ def stem_bwd_onepass(x, w, z, dz, dz_stride, dz_coff, scale, shift, mean, invstd
     return True
 
 
-def stem_wgrad_finalize(ws, tap_sums, w, scale, mean, invstd, c1, c2, gscale, dw, N, H, W):
-    _f32(ws, "ws"); _f32(tap_sums, "tap_sums"); _f32(w, "w"); _f32(dw, "dw")
-    if dw.numel() != 576 or tap_sums.numel() < conv_smallcin_mtiles(N, H, W) * 54 or ws.numel() < stem_bwd_tiles(N, H, W) * 576:
-        raise ValueError("stem_wgrad_finalize: buffer sizes")
-    _lib.call("gs_stem_wgrad_finalize", _p(ws), _p(tap_sums), _p(w), _p(scale), _p(mean), _p(invstd), _p(c1), _p(c2),
-              float(gscale), _p(dw), N, H, W, _stream())
+def stem_bwd_finalize(ws, s1_partials, tap_sums, w, scale, mean, invstd, train_stats, gscale, dw, dgamma, dbeta, N, H, W):
+    """BatchNorm weight / bias gradients (overwritten) and the stem weight gradient (accumulated) from the one-pass sums."""
+    for n, t in (("ws", ws), ("s1_partials", s1_partials), ("tap_sums", tap_sums), ("w", w), ("dw", dw), ("dgamma", dgamma),
+                 ("dbeta", dbeta)):
+        _f32(t, n)
+    nt = stem_bwd_tiles(N, H, W)
+    if (dw.numel() != 576 or ws.numel() < nt * 576 or s1_partials.numel() < nt * 64
+            or (tap_sums is not None and tap_sums.numel() < conv_smallcin_mtiles(N, H, W) * 54)):
+        raise ValueError("stem_bwd_finalize: buffer sizes")
+    _lib.call("gs_stem_bwd_finalize", _p(ws), _p(s1_partials), _p(tap_sums), _p(w), _p(scale), _p(mean), _p(invstd),
+              int(bool(train_stats)), float(gscale), _p(dw), _p(dgamma), _p(dbeta), N, H, W, _stream())
 
 
 def stem_fwd_bn(x, w, scale, shift, act, z):

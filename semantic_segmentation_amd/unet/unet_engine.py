@@ -730,18 +730,17 @@ class UNetEngine:
                 wst = params[rec.wkey].detach().contiguous()
                 done = False
                 if not need_dinp and not pooled and head is None:
-                    # one pass over z and dz; the weight gradient in closed form from A = sum g x_tap, c1, c2 and the tap sums
-                    sws = empty(ops.stem_bwd_tiles(N, h, w) * 576, dtype=torch.float32)
-                    if ops.stem_bwd_onepass(rec.inp, wst, rec.z, dz_a, sa, ca, coef[0], coef[1], coef[2], coef[3], ACT_RELU,
-                                            partials, sws):
+                    # one pass over z (its sign) and dz; BatchNorm and weight gradients in closed form from A = sum g x_tap,
+                    # s1 = sum g and the image's tap sums / Gram matrix
+                    nts = ops.stem_bwd_tiles(N, h, w)
+                    sws = empty(nts * 576, dtype=torch.float32)
+                    s1p = empty(nts * 64, dtype=torch.float32)
+                    if ops.stem_bwd_onepass(rec.inp, rec.z, dz_a, sa, ca, ACT_RELU, s1p, sws):
                         dgamma = galloc(rec.bnkey + ".weight", params[rec.bnkey + ".weight"])
                         dbeta = galloc(rec.bnkey + ".bias", params[rec.bnkey + ".bias"])
-                        c12 = empty(2, cout, dtype=torch.float32)
-                        ops.bn_bwd_coeffs(partials, ops.stem_bwd_tiles(N, h, w), cout, N * h * w, inv_s, dgamma, dbeta, c12[0], c12[1])
-                        if not rec.train_stats:
-                            c12.zero_()
                         dw = galloc(rec.wkey, params[rec.wkey], zero=True)
-                        ops.stem_wgrad_finalize(sws, rec.tap_sums, wst, coef[0], coef[2], coef[3], c12[0], c12[1], inv_s, dw, N, h, w)
+                        ops.stem_bwd_finalize(sws, s1p, rec.tap_sums, wst, coef[0], coef[2], coef[3], rec.train_stats, inv_s,
+                                              dw, dgamma, dbeta, N, h, w)
                         emit(rec.wkey, dw)
                         emit(rec.bnkey + ".weight", dgamma)
                         emit(rec.bnkey + ".bias", dbeta)

@@ -436,30 +436,24 @@ def test_stem_without_conv_output_in_memory(dtn, dt, N, H, W):
     torch.cuda.synchronize()
     assert rel_err(dgamma, gamma.grad) < 2e-3 and rel_err(dbeta, beta.grad) < 2e-3
     assert rel_err(dw.cpu() * 2, w.grad) < (2e-3 if dt == torch.float16 else 1e-2), rel_err(dw.cpu() * 2, w.grad)
-    # ONE pass over z and dz + closed-form weight gradient (tap sums / Gram matrix of the image)
-    part3 = torch.full((ops.bn_partials_numel(nt, C),), float("nan"), dtype=torch.float32, device=dev())
+    # ONE pass over z (its sign) and dz + closed-form BatchNorm / weight gradients (tap sums / Gram matrix of the image)
+    s1p = torch.full((nt * 64,), float("nan"), dtype=torch.float32, device=dev())
     sws = torch.full((nt * 576,), float("nan"), dtype=torch.float32, device=dev())
-    assert ops.stem_bwd_onepass(xd, wd_, zd, dzd, C, 0, coef[0], coef[1], coef[2], coef[3], ACT_RELU, part3, sws)
-    dgamma3 = torch.empty(C, device=dev()); dbeta3 = torch.empty(C, device=dev())
-    c123 = torch.empty(2, C, device=dev())
-    ops.bn_bwd_coeffs(part3, nt, C, N * H * W, 1.0, dgamma3, dbeta3, c123[0], c123[1])
+    assert ops.stem_bwd_onepass(xd, zd, dzd, C, 0, ACT_RELU, s1p, sws)
+    dgamma3 = torch.full((C,), float("nan"), device=dev()); dbeta3 = torch.full((C,), float("nan"), device=dev())
     dw3 = torch.zeros(C, 1, 3, 3, device=dev())
-    ops.stem_wgrad_finalize(sws, taps, wd_, coef[0], coef[2], coef[3], c123[0], c123[1], 0.5, dw3, N, H, W)
+    ops.stem_bwd_finalize(sws, s1p, taps, wd_, coef[0], coef[2], coef[3], True, 0.5, dw3, dgamma3, dbeta3, N, H, W)
     torch.cuda.synchronize()
-    assert rel_err(dbeta3, beta.grad) < 2e-3
-    assert rel_err(dgamma3, gamma.grad) < (3e-3 if dt == torch.float16 else 2e-2), rel_err(dgamma3, gamma.grad)   # xhat from the 16-bit z
-    assert rel_err(dw3.cpu() * 2, w.grad) < (3e-3 if dt == torch.float16 else 2e-2), rel_err(dw3.cpu() * 2, w.grad)
-    # a zero gamma: xhat cannot come from z, the kernel re-forms y for that channel chunk
-    gz = gamma.detach().clone(); gz[5] = 0.0
-    zz = F.relu(F.batch_norm(y.detach(), None, None, gz, beta.detach(), True, 0.1, 1e-5))
-    coefz = coef.clone(); coefz[0, 5] = 0.0; coefz[1, 5] = beta.detach()[5].item()
-    ops.stem_fwd_bn(xd, wd_, coefz[0], coefz[1], ACT_RELU, zd)
-    assert ops.stem_bwd_onepass(xd, wd_, zd, dzd, C, 0, coefz[0], coefz[1], coefz[2], coefz[3], ACT_RELU, part3, sws)
-    ops.bn_bwd_coeffs(part3, nt, C, N * H * W, 1.0, dgamma3, dbeta3, c123[0], c123[1])
+    assert rel_err(dbeta3 * 2, beta.grad) < 2e-3 and rel_err(dgamma3 * 2, gamma.grad) < 2e-3, (rel_err(dbeta3 * 2, beta.grad), rel_err(dgamma3 * 2, gamma.grad))
+    assert rel_err(dw3.cpu() * 2, w.grad) < (2e-3 if dt == torch.float16 else 1e-2), rel_err(dw3.cpu() * 2, w.grad)
+    # eval-mode statistics (constants): c1 = c2 = 0, the tap sums are not read
+    dw4 = torch.zeros(C, 1, 3, 3, device=dev())
+    ops.stem_bwd_finalize(sws, s1p, None, wd_, coef[0], coef[2], coef[3], False, 1.0, dw4, dgamma3, dbeta3, N, H, W)
+    yl3 = y.detach().clone().requires_grad_(True)
+    F.relu(yl3 * coef[0].cpu().view(1, C, 1, 1) + coef[1].cpu().view(1, C, 1, 1)).backward(dz)
+    want4 = torch.nn.grad.conv2d_weight(x, w.shape, yl3.grad, padding=1)
     torch.cuda.synchronize()
-    yl2 = y.detach().clone().requires_grad_(True); gz2 = gz.clone().requires_grad_(True)
-    F.relu(F.batch_norm(yl2, None, None, gz2, beta.detach(), True, 0.1, 1e-5)).backward(dz)
-    assert abs(dgamma3[5].item() - gz2.grad[5].item()) < 2e-3 * max(1.0, abs(gz2.grad[5].item())), (dgamma3[5].item(), gz2.grad[5].item())
+    assert rel_err(dw4.cpu(), want4) < (2e-3 if dt == torch.float16 else 1e-2), rel_err(dw4.cpu(), want4)
     # the stored-y path agrees up to the 16-bit rounding of the y it reads (normalised here with the unrounded statistics)
     yst = nhwc(y.detach().to(dt).float(), dt)
     dw2 = torch.zeros(C, 1, 3, 3, device=dev())

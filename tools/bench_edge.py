@@ -86,3 +86,13 @@ t = timeit(lambda: ops.bn_act_bwd_reduce(y, dzt, C, 0, None, coef[0], coef[1], c
 print(f"bn bwd reduce (reads y, dz)  {t:7.1f} us")
 t = timeit(lambda: ops.bn_act_apply(y, coef[0], coef[1], ACT_RELU, dyt, C, 0, None))
 print(f"bn apply (y -> z)            {t:7.1f} us")
+taps_ = torch.empty(mt * 54, dtype=torch.float32, device=dev)
+ops.stem_stats(x, w, partm, taps_)
+nts = ops.stem_bwd_tiles(B, H, W)
+sws = torch.empty(nts * 576, dtype=torch.float32, device=dev)
+s1p = torch.empty(nts * 64, dtype=torch.float32, device=dev)
+t = timeit(lambda: ops.stem_bwd_onepass(x, y, dzt, C, 0, ACT_RELU, s1p, sws))
+print(f"stem bwd one pass (z, dz)    {t:7.1f} us  {2 * mb / t:6.2f} TB/s of the {2 * mb:.0f} MB read")
+dg, dbt = torch.empty(C, device=dev), torch.empty(C, device=dev)
+t = timeit(lambda: ops.stem_bwd_finalize(sws, s1p, taps_, w, coef[0], coef[2], coef[3], True, 1.0, dw, dg, dbt, B, H, W))
+print(f"stem bwd finalize            {t:7.1f} us")
