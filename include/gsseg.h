@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 37
+#define GS_ABI_VERSION 38
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -161,16 +161,14 @@ int gs_conv_smallcin_mtiles(int N, int OH, int OW);
 int gs_conv_smallcin_fwd(const float* x, const float* w, const float* bias, void* y, float* bn_partials,
                          int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int k, int stride, int pad,
                          int act, int dtype, void* stream);
-int64_t gs_conv_direct_wgrad_ws_floats(int N, int OH, int OW, int Cin, int Cout, int k);   /* ---- the one-channel stem WITHOUT its convolution output in memory ------------------------------------------------
+int64_t gs_conv_direct_wgrad_ws_floats(int N, int OH, int OW, int Cin, int Cout, int k);
+
+/* ---- the one-channel stem WITHOUT its convolution output in memory ------------------------------------------------
  * (unet/unet_parts.py:16-18 with in_channels = 1: Conv2d(1, 64, 3, padding=1, bias=False) -> BatchNorm2d -> ReLU.)
  * The train-mode statistics of y = conv(x) are functions of the image and the 576 weights alone (sum_p y = sum_t w_t S_t,
  * sum_p y^2 = sum_tu w_t w_u G_tu with the tap sums S and the 9x9 tap Gram matrix G), so y need not exist:
  *   gs_stem_stats      tile partials [gs_conv_smallcin_mtiles(N,H,W)][2][64] for gs_bn_finalize, from x and w only;
  *   gs_stem_fwd_bn     z [N,H,W,64] 16-bit = act(conv(x) * scale + shift) in one pass (y stays in fp32 registers);
- *   gs_stem_bn_bwd_reduce / gs_stem_bn_bwd_wgrad_recompute
- *                      the BatchNorm backward reduce ([gs_stem_bwd_tiles(N,H,W)][2][64] partials for gs_bn_bwd_coeffs) and
- *                      the fused backward apply + weight gradient (as gs_stem_bn_bwd_wgrad), with y re-formed from the
- *                      image strip in LDS in the forward kernel's summation order (bit-identical to what was normalised).
  *   gs_stem_bwd_onepass + gs_stem_bwd_finalize
  *                      the whole backward of the stage in ONE pass over z (the stored activation: only its sign, the
  *                      activation's mask, is used) and dz.  With g = dz*act', A[c][t] = sum_p g x_t(p), s1 = sum_p g:
@@ -182,8 +180,8 @@ int64_t gs_conv_direct_wgrad_ws_floats(int N, int OH, int OW, int Cin, int Cout,
  *                      A slabs ws [gs_stem_bwd_tiles][576]; _finalize (fp64) OVERWRITES dgamma / dbeta (gscale * sums; may be
  *                      NULL) and accumulates dw.
  * At batch 32, 256^2 this removes the write of y (268 MB), its read by gs_bn_act_apply and by the two backward passes.
- * x fp32 [N,1,H,W], w fp32 [64][1][3][3].  The two backward entry points return GS_EUNSUPPORTED (no error string) when the
- * image is too wide for the LDS strip: the caller then re-forms y with gs_conv_smallcin_fwd and runs the tensor path. */
+ * x fp32 [N,1,H,W], w fp32 [64][1][3][3].  gs_stem_bwd_onepass returns GS_EUNSUPPORTED (no error string) when the image is
+ * too wide for the LDS strip: the caller then re-forms y with gs_conv_smallcin_fwd and runs the tensor path. */
 int gs_stem_stats(const float* x, const float* w, float* bn_partials, float* tap_sums, int N, int H, int W, void* stream);
 int gs_stem_fwd_bn(const float* x, const float* w, const float* bn_scale, const float* bn_shift, int act, void* z, int N,
                    int H, int W, int dtype, void* stream);
@@ -193,13 +191,6 @@ int gs_stem_bwd_onepass(const float* x, const void* z, const void* dz, int dz_st
 int gs_stem_bwd_finalize(const float* ws, const float* s1_partials, const float* tap_sums, const float* w,
                          const float* scale, const float* mean, const float* invstd, int train_stats, float gscale, float* dw,
                          float* dgamma, float* dbeta, int N, int H, int W, void* stream);
-int gs_stem_bn_bwd_reduce(const float* x, const float* w, const void* dz, int dz_stride, int dz_coff, const float* scale,
-                          const float* shift, const float* mean, const float* invstd, int act, float* partials, int N, int H,
-                          int W, int dtype, void* stream);
-int gs_stem_bn_bwd_wgrad_recompute(const float* x, const float* w, const void* dz, int dz_stride, int dz_coff,
-                                   const float* scale, const float* shift, const float* mean, const float* invstd,
-                                   const float* c1, const float* c2, int act, float* dw, float* ws, int N, int H, int W,
-                                   float gscale, int dtype, void* stream);
 
 /* Stem backward in one pass (unet/unet_parts.py:16-18 with in_channels = 1, first stage of `inc`; the image needs no
  * gradient): BatchNorm(train)/activation backward apply fused with the weight gradient of the 1-channel 3x3/s1/p1

@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 GS_F16, GS_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH = 0, 1, 2, 3
 GS_MAX_TAPS = 64
-ABI_VERSION = 37
+ABI_VERSION = 38
 
 
 class GsConvGeom(ctypes.Structure):
@@ -103,9 +103,6 @@ PROTOTYPES = {
     "gs_stem_bwd_finalize": (c_int, [_F, _F, _F, _F, _F, _F, _F, c_int, c_float, _F, _F, _F, c_int, c_int, c_int, c_void_p]),
     "gs_stem_fwd_bn": (c_int, [_F, _F, _F, _F, c_int, _P, c_int, c_int, c_int, c_int, c_void_p]),
     "gs_stem_bwd_tiles": (c_int, [c_int, c_int, c_int]),
-    "gs_stem_bn_bwd_reduce": (c_int, [_F, _F, _P, c_int, c_int, _F, _F, _F, _F, c_int, _F, c_int, c_int, c_int, c_int, c_void_p]),
-    "gs_stem_bn_bwd_wgrad_recompute": (c_int, [_F, _F, _P, c_int, c_int, _F, _F, _F, _F, _F, _F, c_int, _F, _F, c_int, c_int,
-                                               c_int, c_float, c_int, c_void_p]),
     "gs_head1x1_bn_fwd": (c_int, [_P, _F, _F, c_int, _F, _F, _F] + [c_int] * 5 + [c_void_p]),
     "gs_head1x1_bn_wgrad": (c_int, [_P, _F, _F, c_int, _F, _F, _F, _F, _F] + [c_int] * 4 + [c_float, c_int, c_void_p]),
     "gs_bn_act_bwd_reduce_head": (c_int, [_P, _F, _F, c_int, _F, _F, _F, _F, c_int, _F] + [c_int] * 5 + [c_void_p]),

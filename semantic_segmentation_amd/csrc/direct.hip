@@ -528,97 +528,8 @@ struct SBWArgs {
     float* slabs;
     int dz_stride, dz_coff, N, H, W, act;
     int64_t pix_per_block;
-    const float* w;          // RECOMP: the stem weights [64][9] -- y is re-formed from the image strip instead of being read
-    float* partials;         // stem_bn_bwd_reduce_kernel: [block][2][64]
+    float* partials;         // stem_bwd_onepass_kernel: s1 [block][64]
 };
-
-// y of one pixel for the thread's eight channels, taps in the forward kernel's order (bit-identical to what MODE 2 normalised)
-__device__ __forceinline__ void stem_y8(const float* wl, int c0, const float* xv, float* yv) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) yv[i] = 0.f;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const float4 w0 = *reinterpret_cast<const float4*>(wl + t * 64 + c0), w1 = *reinterpret_cast<const float4*>(wl + t * 64 + c0 + 4);
-        yv[0] += xv[t] * w0.x; yv[1] += xv[t] * w0.y; yv[2] += xv[t] * w0.z; yv[3] += xv[t] * w0.w;
-        yv[4] += xv[t] * w1.x; yv[5] += xv[t] * w1.y; yv[6] += xv[t] * w1.z; yv[7] += xv[t] * w1.w;
-    }
-}
-
-// Backward reduce of the stem's BatchNorm with y re-formed from the image (the forward never stored it): per block
-// sum g and sum g * xhat over its pixels, g = dz * act'(scale*y + shift).  Same strip / thread layout as the kernel below.
-template <int DT>
-__global__ __launch_bounds__(256) void stem_bn_bwd_reduce_kernel(const SBWArgs a) {
-    extern __shared__ float sbw_smem[];
-    const int M = a.N * a.H * a.W;
-    const int ppb = (int)a.pix_per_block;
-    const int m0 = blockIdx.x * ppb;
-    const int m1 = m0 + ppb < M ? m0 + ppb : M;
-    const int nx = ppb + 2 * a.W + 2;
-    float* xs = sbw_smem;
-    float* red = sbw_smem + ((nx + 3) & ~3);                       // [256][17]
-    float* wl = red + 256 * 25;                                    // [9][64]
-    for (int i = threadIdx.x; i < nx; i += 256) {
-        const int idx = m0 - a.W - 1 + i;
-        xs[i] = (idx >= 0 && idx < M) ? a.x[idx] : 0.f;
-    }
-    for (int i = threadIdx.x; i < 576; i += 256) wl[i] = a.w[(i & 63) * 9 + (i >> 6)];
-    const int ch = threadIdx.x & 7, pl = threadIdx.x >> 3;
-    const int c0 = ch * 8;
-    const float slope = a.act == GS_ACT_RELU ? 0.f : (a.act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
-    float sc[8], sh[8], mu[8], is[8], s1[8], s2[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        sc[i] = a.scale[c0 + i]; sh[i] = a.shift[c0 + i]; mu[i] = a.mean[c0 + i]; is[i] = a.invstd[c0 + i];
-        s1[i] = 0.f; s2[i] = 0.f;
-    }
-    __syncthreads();
-    constexpr int UNR = 4;
-    for (int mb = m0 + pl; mb < m1; mb += 32 * UNR) {
-        uint4 rg[UNR];
-#pragma unroll
-        for (int k = 0; k < UNR; ++k) {
-            const int m = mb + 32 * k;
-            const int64_t mm = m < m1 ? m : mb;
-            rg[k] = *reinterpret_cast<const uint4*>(a.dz + mm * a.dz_stride + a.dz_coff + c0);
-        }
-#pragma unroll
-        for (int k = 0; k < UNR; ++k) {
-            const int m = mb + 32 * k;
-            const bool ok = m < m1;
-            const int mm = ok ? m : mb;
-            const int ox = mm % a.W;
-            const int oy = (mm / a.W) % a.H;
-            const float* xc = xs + (mm - m0 + a.W + 1);
-            float xv[9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int dy_ = t / 3 - 1, dx_ = t % 3 - 1;
-                const bool in = (unsigned)(oy + dy_) < (unsigned)a.H && (unsigned)(ox + dx_) < (unsigned)a.W;
-                xv[t] = in ? xc[dy_ * a.W + dx_] : 0.f;
-            }
-            float yv[8], g[8];
-            stem_y8(wl, c0, xv, yv);
-            unpack8<DT>(rg[k], g);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float v = yv[i] * sc[i] + sh[i];
-                const float gh = ok ? g[i] * (v > 0.f ? 1.f : slope) : 0.f;
-                const float xh = (yv[i] - mu[i]) * is[i];
-                s1[i] += gh; s2[i] += gh * xh;
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { red[threadIdx.x * 17 + i] = s1[i]; red[threadIdx.x * 17 + 8 + i] = s2[i]; }
-    __syncthreads();
-    if (threadIdx.x < 128) {                     // (statistic, channel): sums the 32 pixel lanes
-        const int st = threadIdx.x >> 6, co = threadIdx.x & 63;
-        float sum = 0.f;
-#pragma unroll 8
-        for (int q = 0; q < 32; ++q) sum += red[(q * 8 + (co >> 3)) * 17 + st * 8 + (co & 7)];
-        a.partials[(int64_t)blockIdx.x * 128 + st * 64 + co] = sum;
-    }
-}
 
 // ONE backward pass for the y-free stem.  With g = dz * act'(.), A[c][t] = sum_p g[p][c] x_t(p) and s1_c = sum_p g[p][c]:
 //   sum_p g xhat  = invstd_c (sum_t w[c][t] A[c][t] - mean_c s1_c)                      (y = sum_t w_t x_t, exactly)
@@ -793,7 +704,7 @@ __global__ __launch_bounds__(256) void stem_bwd_finalize_kernel(const float* __r
     }
 }
 
-template <int DT, bool RECOMP>
+template <int DT>
 __global__ __launch_bounds__(256) void stem_bn_bwd_wgrad_kernel(const SBWArgs a) {
     extern __shared__ float sbw_smem[];
     const int M = a.N * a.H * a.W;                                 // host guarantees < 2^31
@@ -803,13 +714,10 @@ __global__ __launch_bounds__(256) void stem_bn_bwd_wgrad_kernel(const SBWArgs a)
     const int nx = ppb + 2 * a.W + 2;
     float* xs = sbw_smem;                                          // xs[i] = image[m0 - W - 1 + i] (flat over N*H*W)
     float* red = sbw_smem + ((nx + 3) & ~3);                       // [256][25]
-    float* wl = red + 256 * 25;                                    // RECOMP: [9][64]
     for (int i = threadIdx.x; i < nx; i += 256) {
         const int idx = m0 - a.W - 1 + i;
         xs[i] = (idx >= 0 && idx < M) ? a.x[idx] : 0.f;
     }
-    if (RECOMP)
-        for (int i = threadIdx.x; i < 576; i += 256) wl[i] = a.w[(i & 63) * 9 + (i >> 6)];
     const int ch = threadIdx.x & 7, pl = threadIdx.x >> 3;
     const int c0 = ch * 8;
     const float slope = a.act == GS_ACT_RELU ? 0.f : (a.act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
@@ -832,7 +740,7 @@ __global__ __launch_bounds__(256) void stem_bn_bwd_wgrad_kernel(const SBWArgs a)
         for (int k = 0; k < UNR; ++k) {
             const int m = mb + 32 * k;
             const int64_t mm = m < m1 ? m : mb;
-            ry[k] = RECOMP ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4*>(a.y + mm * 64 + c0);
+            ry[k] = *reinterpret_cast<const uint4*>(a.y + mm * 64 + c0);
             rg[k] = *reinterpret_cast<const uint4*>(a.dz + mm * a.dz_stride + a.dz_coff + c0);
         }
 #pragma unroll
@@ -851,8 +759,7 @@ __global__ __launch_bounds__(256) void stem_bn_bwd_wgrad_kernel(const SBWArgs a)
                 xv[t] = in ? xc[dy_ * a.W + dx_] : 0.f;
             }
             float yv[8], g[8];
-            if (RECOMP) stem_y8(wl, c0, xv, yv);     // (a masked pixel: xv = 0, its d is multiplied by xv = 0 below)
-            else unpack8<DT>(ry[k], yv);
+            unpack8<DT>(ry[k], yv);
             unpack8<DT>(rg[k], g);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -1438,14 +1345,14 @@ extern "C" int gs_stem_bn_bwd_wgrad(const void* y, const void* dz, int dz_stride
     GS_CHECK_ARG(act == GS_ACT_NONE || act == GS_ACT_RELU || act == GS_ACT_LEAKY02, "gs_stem_bn_bwd_wgrad: bad activation");
     const int64_t M = (int64_t)N * H * W;
     const int64_t ppb = stem_bwd_ppb(M);
-    const size_t lds = ((size_t)((ppb + 2 * W + 2 + 3) & ~(int64_t)3) + 256 * 25 + 576) * sizeof(float);
+    const size_t lds = ((size_t)((ppb + 2 * W + 2 + 3) & ~(int64_t)3) + 256 * 25) * sizeof(float);
     if (lds > 64 * 1024) return GS_EUNSUPPORTED;        // very wide images: the caller runs the two-kernel path
     SBWArgs a{(const unsigned short*)y, (const unsigned short*)dz, x, scale, shift, mean, invstd, c1, c2, ws,
               dz_stride, dz_coff, N, H, W, act, ppb};
     const int nb = (int)cdiv64(M, ppb);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GS_F16) stem_bn_bwd_wgrad_kernel<GS_F16, false><<<nb, 256, lds, s>>>(a);
-    else stem_bn_bwd_wgrad_kernel<GS_BF16, false><<<nb, 256, lds, s>>>(a);
+    if (dtype == GS_F16) stem_bn_bwd_wgrad_kernel<GS_F16><<<nb, 256, lds, s>>>(a);
+    else stem_bn_bwd_wgrad_kernel<GS_BF16><<<nb, 256, lds, s>>>(a);
     slab_reduce_kernel<<<cdiv(576, 32), 256, 0, s>>>(ws, nb, 576, 576, gscale, dw);
     GS_CHECK_LAUNCH("gs_stem_bn_bwd_wgrad");
     return GS_OK;
@@ -1490,40 +1397,6 @@ extern "C" int gs_stem_bwd_tiles(int N, int H, int W) {
     return (N > 0 && H > 0 && W > 0) ? (int)cdiv64(M, stem_bwd_ppb(M)) : 0;
 }
 
-static int stem_bwd_common(const char* who, SBWArgs& a, size_t& lds, int& nb, const void* dz, int dz_stride, int dz_coff,
-                           const float* x, const float* w, const float* scale, const float* shift, const float* mean,
-                           const float* invstd, int act, int N, int H, int W, int dtype) {
-    int rc = stem_check(who, x, w, N, H, W, dtype);
-    if (rc) return rc;
-    GS_CHECK_ARG(dz && scale && shift && mean && invstd, "%s: null pointer", who);
-    GS_CHECK_ARG(dz_stride % 8 == 0 && dz_coff % 8 == 0 && dz_stride >= dz_coff + 64, "%s: bad gradient layout", who);
-    GS_CHECK_ARG(act == GS_ACT_NONE || act == GS_ACT_RELU || act == GS_ACT_LEAKY02, "%s: bad activation", who);
-    const int64_t M = (int64_t)N * H * W;
-    const int64_t ppb = stem_bwd_ppb(M);
-    lds = ((size_t)((ppb + 2 * W + 2 + 3) & ~(int64_t)3) + 256 * 25 + 576) * sizeof(float);
-    a = SBWArgs{nullptr, (const unsigned short*)dz, x, scale, shift, mean, invstd, nullptr, nullptr, nullptr,
-                dz_stride, dz_coff, N, H, W, act, ppb};
-    a.w = w;
-    nb = (int)cdiv64(M, ppb);
-    return GS_OK;
-}
-
-extern "C" int gs_stem_bn_bwd_reduce(const float* x, const float* w, const void* dz, int dz_stride, int dz_coff,
-                                     const float* scale, const float* shift, const float* mean, const float* invstd, int act,
-                                     float* partials, int N, int H, int W, int dtype, void* stream) {
-    SBWArgs a{}; size_t lds; int nb;
-    int rc = stem_bwd_common("gs_stem_bn_bwd_reduce", a, lds, nb, dz, dz_stride, dz_coff, x, w, scale, shift, mean, invstd, act,
-                             N, H, W, dtype);
-    if (rc) return rc;
-    GS_CHECK_ARG(partials != nullptr, "gs_stem_bn_bwd_reduce: null partials");
-    if (lds > 64 * 1024) return GS_EUNSUPPORTED;
-    a.partials = partials;
-    if (dtype == GS_F16) stem_bn_bwd_reduce_kernel<GS_F16><<<nb, 256, lds, (hipStream_t)stream>>>(a);
-    else stem_bn_bwd_reduce_kernel<GS_BF16><<<nb, 256, lds, (hipStream_t)stream>>>(a);
-    GS_CHECK_LAUNCH("gs_stem_bn_bwd_reduce");
-    return GS_OK;
-}
-
 extern "C" int gs_stem_bwd_onepass(const float* x, const void* z, const void* dz, int dz_stride, int dz_coff, int act,
                                    float* s1_partials, float* ws, int N, int H, int W, int dtype, void* stream) {
     GS_CHECK_ARG(x && z && dz && s1_partials && ws && N > 0 && H > 0 && W > 0 && (int64_t)N * H * W < 2147483647LL / 64,
@@ -1555,25 +1428,6 @@ extern "C" int gs_stem_bwd_finalize(const float* ws, const float* s1_partials, c
                                                                 gs_conv_smallcin_mtiles(N, H, W), w, scale, mean, invstd,
                                                                 (double)N * H * W, train_stats, gscale, dw, dgamma, dbeta);
     GS_CHECK_LAUNCH("gs_stem_bwd_finalize");
-    return GS_OK;
-}
-
-extern "C" int gs_stem_bn_bwd_wgrad_recompute(const float* x, const float* w, const void* dz, int dz_stride, int dz_coff,
-                                              const float* scale, const float* shift, const float* mean, const float* invstd,
-                                              const float* c1, const float* c2, int act, float* dw, float* ws, int N, int H,
-                                              int W, float gscale, int dtype, void* stream) {
-    SBWArgs a{}; size_t lds; int nb;
-    int rc = stem_bwd_common("gs_stem_bn_bwd_wgrad_recompute", a, lds, nb, dz, dz_stride, dz_coff, x, w, scale, shift, mean,
-                             invstd, act, N, H, W, dtype);
-    if (rc) return rc;
-    GS_CHECK_ARG(c1 && c2 && dw && ws, "gs_stem_bn_bwd_wgrad_recompute: null pointer");
-    if (lds > 64 * 1024) return GS_EUNSUPPORTED;
-    a.c1 = c1; a.c2 = c2; a.slabs = ws;
-    hipStream_t s = (hipStream_t)stream;
-    if (dtype == GS_F16) stem_bn_bwd_wgrad_kernel<GS_F16, true><<<nb, 256, lds, s>>>(a);
-    else stem_bn_bwd_wgrad_kernel<GS_BF16, true><<<nb, 256, lds, s>>>(a);
-    slab_reduce_kernel<<<cdiv(576, 32), 256, 0, s>>>(ws, nb, 576, 576, gscale, dw);
-    GS_CHECK_LAUNCH("gs_stem_bn_bwd_wgrad_recompute");
     return GS_OK;
 }
 

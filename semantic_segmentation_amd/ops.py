@@ -646,36 +646,6 @@ def stem_bwd_tiles(N, H, W) -> int:
     return int(_lib.load().gs_stem_bwd_tiles(N, H, W))
 
 
-def stem_bn_bwd_reduce(x, w, dz, dz_stride, dz_coff, scale, shift, mean, invstd, act, partials) -> bool:
-    N, H, W = _stem_check(x, w, "stem_bn_bwd_reduce")
-    _f32(partials, "partials")
-    if partials.numel() < bn_partials_numel(stem_bwd_tiles(N, H, W), 64):
-        raise ValueError("stem_bn_bwd_reduce: partials too small")
-    rc = _lib.load().gs_stem_bn_bwd_reduce(_p(x), _p(w), _p(dz), dz_stride, dz_coff, _p(scale), _p(shift), _p(mean), _p(invstd),
-                                           act, _p(partials), N, H, W, dt_code(dz), _stream())
-    if rc == _lib.GS_EUNSUPPORTED:
-        return False
-    if rc != 0:
-        _lib.check(rc, "gs_stem_bn_bwd_reduce")
-    return True
-
-
-def stem_bn_bwd_wgrad_recompute(x, w, dz, dz_stride, dz_coff, scale, shift, mean, invstd, c1, c2, act, dw, gscale) -> bool:
-    N, H, W = _stem_check(x, w, "stem_bn_bwd_wgrad_recompute")
-    _f32(dw, "dw")
-    if dw.numel() != 576 or not dw.is_contiguous():
-        raise ValueError("stem_bn_bwd_wgrad_recompute: dw [64,1,3,3] contiguous")
-    ws = _direct_wgrad_ws(N, H, W, 1, 64, 3, x.device)
-    rc = _lib.load().gs_stem_bn_bwd_wgrad_recompute(_p(x), _p(w), _p(dz), dz_stride, dz_coff, _p(scale), _p(shift), _p(mean),
-                                                    _p(invstd), _p(c1), _p(c2), act, _p(dw), _p(ws), N, H, W, float(gscale),
-                                                    dt_code(dz), _stream())
-    if rc == _lib.GS_EUNSUPPORTED:
-        return False
-    if rc != 0:
-        _lib.check(rc, "gs_stem_bn_bwd_wgrad_recompute")
-    return True
-
-
 def conv_smallcin_dgrad(dy, w, dx, k, stride, pad, gscale):
     _f32(w, "w"); _f32(dx, "dx")
     N, Cin, IH, IW = dx.shape

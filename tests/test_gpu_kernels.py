@@ -423,19 +423,8 @@ def test_stem_without_conv_output_in_memory(dtn, dt, N, H, W):
     ops.stem_fwd_bn(xd, wd_, coef[0], coef[1], ACT_RELU, zd)
     torch.cuda.synchronize()
     assert (from_nhwc(zd) - z.detach()).abs().max() < (4e-3 if dt == torch.float16 else 3e-2)
-    # backward: reduce + coefficients + fused apply / weight gradient, y re-formed from the image
     dzd = nhwc(dz, dt)
     nt = ops.stem_bwd_tiles(N, H, W)
-    part2 = torch.full((ops.bn_partials_numel(nt, C),), float("nan"), dtype=torch.float32, device=dev())
-    assert ops.stem_bn_bwd_reduce(xd, wd_, dzd, C, 0, coef[0], coef[1], coef[2], coef[3], ACT_RELU, part2)
-    dgamma = torch.empty(C, device=dev()); dbeta = torch.empty(C, device=dev())
-    c12 = torch.empty(2, C, device=dev())
-    ops.bn_bwd_coeffs(part2, nt, C, N * H * W, 1.0, dgamma, dbeta, c12[0], c12[1])
-    dw = torch.zeros(C, 1, 3, 3, device=dev())
-    assert ops.stem_bn_bwd_wgrad_recompute(xd, wd_, dzd, C, 0, coef[0], coef[1], coef[2], coef[3], c12[0], c12[1], ACT_RELU, dw, 0.5)
-    torch.cuda.synchronize()
-    assert rel_err(dgamma, gamma.grad) < 2e-3 and rel_err(dbeta, beta.grad) < 2e-3
-    assert rel_err(dw.cpu() * 2, w.grad) < (2e-3 if dt == torch.float16 else 1e-2), rel_err(dw.cpu() * 2, w.grad)
     # ONE pass over z (its sign) and dz + closed-form BatchNorm / weight gradients (tap sums / Gram matrix of the image)
     s1p = torch.full((nt * 64,), float("nan"), dtype=torch.float32, device=dev())
     sws = torch.full((nt * 576,), float("nan"), dtype=torch.float32, device=dev())
@@ -454,13 +443,6 @@ def test_stem_without_conv_output_in_memory(dtn, dt, N, H, W):
     want4 = torch.nn.grad.conv2d_weight(x, w.shape, yl3.grad, padding=1)
     torch.cuda.synchronize()
     assert rel_err(dw4.cpu(), want4) < (2e-3 if dt == torch.float16 else 1e-2), rel_err(dw4.cpu(), want4)
-    # the stored-y path agrees up to the 16-bit rounding of the y it reads (normalised here with the unrounded statistics)
-    yst = nhwc(y.detach().to(dt).float(), dt)
-    dw2 = torch.zeros(C, 1, 3, 3, device=dev())
-    assert ops.stem_bn_bwd_wgrad(yst, dzd, C, 0, xd, coef[0], coef[1], coef[2], coef[3], c12[0], c12[1], ACT_RELU, dw2, 0.5)
-    torch.cuda.synchronize()
-    assert rel_err(dw, dw2) < (2e-2 if dt == torch.float16 else 8e-2)
-
 
 @pytest.mark.parametrize("dtn,dt", DTS)
 @pytest.mark.parametrize("N,H,W,ncls", [(2, 18, 22, 2), (3, 45, 53, 1), (1, 64, 64, 4)])
