@@ -311,9 +311,14 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
                     unpack8<DT>(rg[k], g);
                     unpack8<DT>(rb[k], gb);
                     if (HEAD) {
+                        if (a.head_n <= 2) {                 // uniform: the one- and two-class heads of the U-Net
 #pragma unroll
-                        for (int i = 0; i < 8; ++i)
-                            g[i] = (hd[k][0] * hw[0][i] + hd[k][1] * hw[1][i]) + (hd[k][2] * hw[2][i] + hd[k][3] * hw[3][i]);
+                            for (int i = 0; i < 8; ++i) g[i] = hd[k][0] * hw[0][i] + hd[k][1] * hw[1][i];
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i)
+                                g[i] = (hd[k][0] * hw[0][i] + hd[k][1] * hw[1][i]) + (hd[k][2] * hw[2][i] + hd[k][3] * hw[3][i]);
+                        }
                     }
                     if (a.keep) {
                         const unsigned int kw[2] = {rk[k].x, rk[k].y};

@@ -76,11 +76,6 @@ t = timeit(lambda: ops.stem_stats(x, w, partm))
 print(f"stem statistics only      {t:7.1f} us")
 t = timeit(lambda: ops.stem_fwd_bn(x, w, coef[0], coef[1], ACT_RELU, y))
 print(f"stem fwd conv+BN+ReLU     {t:7.1f} us  {mb / t:6.2f} TB/s of the {mb:.0f} MB output")
-partb = torch.empty(ops.bn_partials_numel(ops.stem_bwd_tiles(B, H, W), C), dtype=torch.float32, device=dev)
-t = timeit(lambda: ops.stem_bn_bwd_reduce(x, w, dzt, C, 0, coef[0], coef[1], coef[2], coef[3], ACT_RELU, partb))
-print(f"stem bwd reduce, y re-formed {t:7.1f} us  {mb / t:6.2f} TB/s of the {mb:.0f} MB gradient read")
-t = timeit(lambda: ops.stem_bn_bwd_wgrad_recompute(x, w, dzt, C, 0, coef[0], coef[1], coef[2], coef[3], c12[0], c12[1], ACT_RELU, dw, 1.0))
-print(f"stem bwd wgrad, y re-formed  {t:7.1f} us  {mb / t:6.2f} TB/s")
 partr = torch.empty(ops.bn_partials_numel(ops.bn_bwd_tiles(B, H, W), C), dtype=torch.float32, device=dev)
 t = timeit(lambda: ops.bn_act_bwd_reduce(y, dzt, C, 0, None, coef[0], coef[1], coef[2], coef[3], ACT_RELU, partr))
 print(f"bn bwd reduce (reads y, dz)  {t:7.1f} us")
