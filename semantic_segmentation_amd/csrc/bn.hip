@@ -230,9 +230,10 @@ struct BwdArgs {
 // GENERIC = some activation is tanh (runtime switch per element); otherwise the activations are the slope family
 // (identity / ReLU / LeakyReLU) and their value / derivative is one compare + select -- the per-element uniform
 // `switch` of act_fwd/act_grad costs a scalar branch per element and held these kernels at ~3 TB/s.
-template <int DT, bool POOL, bool APPLY, bool GENERIC, bool HEAD = false>
+template <int DT, bool POOL, bool APPLY, bool GENERIC, int HEAD = 0>        // HEAD: 0 = tensor sources; 2 / 4 = a head of <= 2 / 4 outputs
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
     static_assert(!HEAD || (!POOL && !GENERIC), "the head source: plain pixels, slope-family activation");
+    constexpr int NH = HEAD ? HEAD : 1;
     __shared__ float red[2][256 * 8 / 8][8];   // [stat][thread][8 channels] -- reduced below
     const float slope_a = a.act == GS_ACT_RELU ? 0.f : (a.act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
     const float slope_b = a.act_b == GS_ACT_RELU ? 0.f : (a.act_b == GS_ACT_LEAKY02 ? 0.2f : 1.f);
@@ -269,10 +270,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
         float s1[8], s2[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-        float hw[4][8];                                     // HEAD: the head's weights for this channel chunk
+        float hw[NH][8];                                    // HEAD: the head's weights for this channel chunk
         if (HEAD) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < NH; ++k)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) hw[k][i] = k < a.head_n ? a.head_w[k * a.C + c0 + i] : 0.f;
         }
@@ -284,7 +285,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
                 uint4 ry[UNR], rg[UNR], rb[UNR];
                 uint2 rk[UNR];
                 bool ok[UNR];
-                float hd[UNR][4];
+                float hd[UNR][NH];
+                int hn = 0, hp = 0;                          // HEAD: (image, pixel in the image) of the iteration's first pixel
+                if (HEAD) { hn = ub / HWp; hp = ub - hn * HWp; }
 #pragma unroll
                 for (int k = 0; k < UNR; ++k) {
                     const int u = ub + k * unit_lanes;
@@ -292,9 +295,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
                     const int64_t pix = ok[k] ? u : u0;
                     ry[k] = *reinterpret_cast<const uint4*>(a.y + pix * a.C + c0);
                     if (HEAD) {
-                        const int n = (int)pix / HWp, hwp = (int)pix - n * HWp;
+                        int n = hn, hwp = hp + k * unit_lanes;                  // one division per iteration, then steps
+                        while (hwp >= HWp) { hwp -= HWp; ++n; }
+                        if (!ok[k]) { n = hn; hwp = hp; }
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) hd[k][q] = q < a.head_n ? a.head_dl[((int64_t)n * a.head_n + q) * HWp + hwp] : 0.f;
+                        for (int q = 0; q < NH; ++q) hd[k][q] = q < a.head_n ? a.head_dl[((int64_t)n * a.head_n + q) * HWp + hwp] : 0.f;
                         rg[k] = make_uint4(0, 0, 0, 0);
                     } else {
                         rg[k] = a.dza ? *reinterpret_cast<const uint4*>(a.dza + pix * a.sa + a.ca + c0) : make_uint4(0, 0, 0, 0);
@@ -311,13 +316,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
                     unpack8<DT>(rg[k], g);
                     unpack8<DT>(rb[k], gb);
                     if (HEAD) {
-                        if (a.head_n <= 2) {                 // uniform: the one- and two-class heads of the U-Net
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) g[i] = hd[k][0] * hw[0][i] + hd[k][1] * hw[1][i];
-                        } else {
+                        for (int i = 0; i < 8; ++i) {
+                            float t = hd[k][0] * hw[0][i];
 #pragma unroll
-                            for (int i = 0; i < 8; ++i)
-                                g[i] = (hd[k][0] * hw[0][i] + hd[k][1] * hw[1][i]) + (hd[k][2] * hw[2][i] + hd[k][3] * hw[3][i]);
+                            for (int q = 1; q < NH; ++q) t += hd[k][q] * hw[q][i];
+                            g[i] = t;
                         }
                     }
                     if (a.keep) {
@@ -670,13 +674,14 @@ static int launch_bwd(const BwdArgs& a0, bool apply, int dtype, hipStream_t s, i
         }                                                                                               \
     } while (0)
     if (a.head_dl != nullptr) {                            // the head source: plain pixels, slope-family activation (host checks)
-        if (dtype == GS_F16) {
-            if (apply) bn_act_bwd_kernel<GS_F16, false, true, false, true><<<ntiles, 256, 0, s>>>(a);
-            else bn_act_bwd_kernel<GS_F16, false, false, false, true><<<ntiles, 256, 0, s>>>(a);
-        } else {
-            if (apply) bn_act_bwd_kernel<GS_BF16, false, true, false, true><<<ntiles, 256, 0, s>>>(a);
-            else bn_act_bwd_kernel<GS_BF16, false, false, false, true><<<ntiles, 256, 0, s>>>(a);
-        }
+#define LAUNCH_HEAD(DT, NC)                                                                             \
+    do {                                                                                                \
+        if (apply) bn_act_bwd_kernel<DT, false, true, false, NC><<<ntiles, 256, 0, s>>>(a);             \
+        else bn_act_bwd_kernel<DT, false, false, false, NC><<<ntiles, 256, 0, s>>>(a);                  \
+    } while (0)
+        if (dtype == GS_F16) { if (a.head_n <= 2) LAUNCH_HEAD(GS_F16, 2); else LAUNCH_HEAD(GS_F16, 4); }
+        else { if (a.head_n <= 2) LAUNCH_HEAD(GS_BF16, 2); else LAUNCH_HEAD(GS_BF16, 4); }
+#undef LAUNCH_HEAD
         return 0;
     }
     if (dtype == GS_F16) { if (generic) LAUNCH(GS_F16, true); else LAUNCH(GS_F16, false); }
