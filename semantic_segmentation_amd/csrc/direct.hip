@@ -630,55 +630,63 @@ __global__ __launch_bounds__(256) void stem_bwd_onepass_kernel(const SBWArgs a) 
     }
 }
 
-// 16 blocks of four channels: each sums the image's 54 tap-sum / Gram totals over the forward tiles, its 36 A entries and
-// 4 s1 entries over the backward blocks (6 lanes per quantity, 8 loads in flight, fixed order, fp64), then
+// 16 blocks of four channels: each sums the image's 54 tap-sum / Gram totals over the forward tiles (16 lanes per quantity),
+// its 36 A entries and 4 s1 entries over the backward blocks (24 lanes per quantity; 8 loads in flight, fixed order, fp64), then
 //   s2 = invstd (sum_t w A - mean s1);  c1 = s1/count, c2 = s2/count (0 with eval-mode statistics);
 //   dbeta = gscale s1, dgamma = gscale s2 (OVERWRITE);  dW += gscale scale (A - c1 S_t - c2 invstd (sum_u w_u G_ut - mean S_t)).
-__global__ __launch_bounds__(256) void stem_bwd_finalize_kernel(const float* __restrict__ slabs, const float* __restrict__ s1p, int nb,
-                                                                const float* __restrict__ sg, int nsg, const float* __restrict__ w,
-                                                                const float* scale, const float* mean, const float* invstd,
-                                                                double count, int train_stats, float gscale, float* dw,
-                                                                float* dgamma, float* dbeta) {
-    __shared__ double sgl[4][54];
+__global__ __launch_bounds__(1024) void stem_bwd_finalize_kernel(const float* __restrict__ slabs, const float* __restrict__ s1p, int nb,
+                                                                 const float* __restrict__ sg, int nsg, const float* __restrict__ w,
+                                                                 const float* scale, const float* mean, const float* invstd,
+                                                                 double count, int train_stats, float gscale, float* dw,
+                                                                 float* dgamma, float* dbeta) {
+    constexpr int LS = 16, LA = 24;                             // lanes per tap-sum quantity / per slab quantity (1024 threads)
+    __shared__ double sgl[LS][54];
     __shared__ double SG[54];
-    __shared__ double red[6][40];
+    __shared__ double red[LA][40];
     __shared__ double tot[40];
-    if (threadIdx.x < 216 && train_stats) {
+    if (threadIdx.x < LS * 54 && train_stats) {
         const int q = threadIdx.x % 54, l = threadIdx.x / 54;
         double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int b = l;
-        for (; b + 28 < nsg; b += 32) {
+        for (; b + 7 * LS < nsg; b += 8 * LS) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = sg[(int64_t)(b + 4 * u) * 54 + q];
+            for (int u = 0; u < 8; ++u) v[u] = sg[(int64_t)(b + LS * u) * 54 + q];
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc[u] += (double)v[u];
         }
-        for (; b < nsg; b += 4) acc[0] += (double)sg[(int64_t)b * 54 + q];
+        for (; b < nsg; b += LS) acc[0] += (double)sg[(int64_t)b * 54 + q];
         sgl[l][q] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     }
     const int cb = blockIdx.x * 4;                              // first channel of the block
-    if (threadIdx.x < 240) {
+    if (threadIdx.x < LA * 40) {
         const int q = threadIdx.x % 40, l = threadIdx.x / 40;
         const float* src = q < 36 ? slabs + cb * 9 + q : s1p + cb + (q - 36);
         const int64_t stride = q < 36 ? 576 : 64;
         double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int b = l;
-        for (; b + 42 < nb; b += 48) {
+        for (; b + 7 * LA < nb; b += 8 * LA) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(b + 6 * u) * stride];
+            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(b + LA * u) * stride];
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc[u] += (double)v[u];
         }
-        for (; b < nb; b += 6) acc[0] += (double)src[(int64_t)b * stride];
+        for (; b < nb; b += LA) acc[0] += (double)src[(int64_t)b * stride];
         red[l][q] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     }
     __syncthreads();
-    if (threadIdx.x < 54) SG[threadIdx.x] = train_stats ? (sgl[0][threadIdx.x] + sgl[1][threadIdx.x]) + (sgl[2][threadIdx.x] + sgl[3][threadIdx.x]) : 0.0;
+    if (threadIdx.x < 54) {
+        double t = 0.0;
+        if (train_stats)
+            for (int l = 0; l < LS; ++l) t += sgl[l][threadIdx.x];
+        SG[threadIdx.x] = t;
+    }
     if (threadIdx.x >= 64 && threadIdx.x < 104) {
         const int q = threadIdx.x - 64;
-        tot[q] = ((red[0][q] + red[1][q]) + (red[2][q] + red[3][q])) + (red[4][q] + red[5][q]);
+        double t = 0.0;
+        for (int l = 0; l < LA; ++l) t += red[l][q];
+        tot[q] = t;
     }
     __syncthreads();
     if (threadIdx.x < 36) {
@@ -1424,7 +1432,7 @@ extern "C" int gs_stem_bwd_finalize(const float* ws, const float* s1_partials, c
     GS_CHECK_ARG(ws && s1_partials && w && scale && mean && invstd && dw && N > 0 && H > 0 && W > 0,
                  "gs_stem_bwd_finalize: bad arguments");
     GS_CHECK_ARG(!train_stats || tap_sums, "gs_stem_bwd_finalize: train-mode statistics need the tap sums of gs_stem_stats");
-    stem_bwd_finalize_kernel<<<16, 256, 0, (hipStream_t)stream>>>(ws, s1_partials, gs_stem_bwd_tiles(N, H, W), tap_sums,
+    stem_bwd_finalize_kernel<<<16, 1024, 0, (hipStream_t)stream>>>(ws, s1_partials, gs_stem_bwd_tiles(N, H, W), tap_sums,
                                                                 gs_conv_smallcin_mtiles(N, H, W), w, scale, mean, invstd,
                                                                 (double)N * H * W, train_stats, gscale, dw, dgamma, dbeta);
     GS_CHECK_LAUNCH("gs_stem_bwd_finalize");
