@@ -619,3 +619,48 @@ def test_weight_gradients_on_side_stream_are_identical(monkeypatch):
     for ga, gb in zip(a, b):
         for n in ga:
             assert torch.equal(ga[n], gb[n]), n
+
+
+@pytest.mark.parametrize("N,H,W,need_dx", [(2, 64, 64, False), (1, 16, 10000, False), (2, 48, 80, True)])
+def test_stem_and_head_fusions_match_the_stored_tensor_paths(monkeypatch, N, H, W, need_dx):
+    """The stem without its convolution output in memory and the head on the last stage's conv output (unet_parts.py:16-21,
+    74) against the paths that store those tensors: same logits, loss and gradients up to the 16-bit rounding the stored
+    tensors add.  A 10000-pixel-wide strip does not fit the stem backward's LDS strip (the engine re-forms y and takes the
+    tensor path), and an input that needs a gradient takes the tensor path in the stem's backward as well."""
+    from semantic_segmentation_amd.losses import seg_loss
+    from semantic_segmentation_amd.unet import UNet, unet_engine
+    dev = torch.device("cuda:0")
+    sd = oracle.unet_state_dict(1, 2, seed=23)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(N, 1, H, W, generator=g)
+    mask = (torch.rand(N, H, W, generator=g) > 0.6).long()
+
+    def run(fused):
+        for flag in ("FUSED_STEM_FWD", "FUSED_HEAD_FWD", "FUSED_HEAD_BWD", "FUSED_STEM_BWD"):
+            monkeypatch.setattr(unet_engine, flag, fused)
+        net = UNet(1, 2).to(dev)
+        net.load_state_dict(sd, strict=True)
+        net.train()
+        xd = x.to(dev).requires_grad_(need_dx)
+        logits = net(xd)
+        loss = seg_loss(logits, mask.to(dev))
+        loss.backward()
+        torch.cuda.synchronize()
+        gr = {n: p.grad.detach().float().cpu() for n, p in net.named_parameters()}
+        bufs = {n: b.detach().float().cpu() for n, b in net.named_buffers() if b.dtype.is_floating_point}
+        return logits.detach().cpu(), loss.item(), gr, bufs, (xd.grad.detach().cpu() if need_dx else None)
+
+    la, lossa, ga, ba, dxa = run(True)
+    lb, lossb, gb, bb, dxb = run(False)
+    assert float((la - lb).abs().max()) < 1.5e-2 * max(1.0, float(lb.abs().max())) and float((la - lb).abs().mean()) < 1.5e-3
+    assert abs(lossa - lossb) < 1e-3 * max(1.0, abs(lossb))
+    for n in ba:                                              # running statistics: same batch statistics
+        assert float((ba[n] - bb[n]).abs().max()) < 2e-3 * max(1.0, float(bb[n].abs().max())), n
+    for n in ga:
+        assert torch.isfinite(ga[n]).all(), n
+        num = float((ga[n].double() * gb[n].double()).sum()); den = float((gb[n].double() ** 2).sum())
+        if den > 1e-20:
+            assert 0.7 < num / den < 1.3, (n, num / den)
+    if need_dx:
+        num = float((dxa.double() * dxb.double()).sum()); den = float((dxb.double() ** 2).sum())
+        assert 0.8 < num / den < 1.2, num / den
