@@ -12,6 +12,7 @@
 namespace {
 
 constexpr int SC_TILE = 1024;       // output pixels per block / BN tile (small-Cin fwd)
+constexpr int SC_GROUP = 4;         // tiles per block of the statistics-only stem pass
 constexpr int SC_MAX_W = 8192;      // floats of weights cached in LDS
 
 struct SCArgs {
@@ -225,9 +226,12 @@ __global__ __launch_bounds__(256) void smallcin_fwd64_line_kernel(const SCArgs a
 #pragma unroll
     for (int i = 0; i < NG; ++i) G[i] = 0.f;
     __syncthreads();
+    // MODE 1 (statistics only): a block takes SC_GROUP tiles and writes their combined sums into the first tile's row (zeros
+    // into the others): the 54 wave reductions + 64 quadratic forms per block are a quarter as many (46 -> 31 us at batch 32)
+    constexpr int TPB = MODE == 1 ? SC_GROUP : 1;
 #pragma unroll 1
-    for (int k = 0; k < SC_TILE / 256; ++k) {
-        const int m = blockIdx.x * SC_TILE + k * 256 + threadIdx.x;
+    for (int k = 0; k < TPB * (SC_TILE / 256); ++k) {
+        const int m = blockIdx.x * (TPB * SC_TILE) + k * 256 + threadIdx.x;
         const bool live = m < M;
         const int mm = live ? m : 0;
         const int ox = mm % a.OW;
@@ -313,7 +317,14 @@ __global__ __launch_bounds__(256) void smallcin_fwd64_line_kernel(const SCArgs a
         if (threadIdx.x < TT + NG)                       // the four waves' sums, in wave order
             part[0][threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
         __syncthreads();
-        if (MODE == 1 && a.sg != nullptr && threadIdx.x < TT + NG) a.sg[(int64_t)blockIdx.x * (TT + NG) + threadIdx.x] = part[0][threadIdx.x];
+        const int mtiles = (M + SC_TILE - 1) / SC_TILE;
+        const int row0 = blockIdx.x * TPB;                  // rows row0+1 .. row0+TPB-1 (inside mtiles) get zeros
+        if (MODE == 1 && a.sg != nullptr && threadIdx.x < TT + NG) {
+            a.sg[(int64_t)row0 * (TT + NG) + threadIdx.x] = part[0][threadIdx.x];
+            for (int r = 1; r < TPB && row0 + r < mtiles; ++r) a.sg[(int64_t)(row0 + r) * (TT + NG) + threadIdx.x] = 0.f;
+        }
+        if (MODE == 1 && threadIdx.x >= 128)
+            for (int r = 1; r < TPB && row0 + r < mtiles; ++r) a.bnp[(int64_t)(row0 + r) * 128 + (threadIdx.x - 128)] = 0.f;
         if (threadIdx.x < 64) {
             const int co = threadIdx.x;
             float s1 = 0.f, s2 = 0.f;
@@ -325,8 +336,8 @@ __global__ __launch_bounds__(256) void smallcin_fwd64_line_kernel(const SCArgs a
 #pragma unroll 1
                 for (int u = t; u < TT; ++u) s2 += (u == t ? 1.f : 2.f) * wt * wl[u * 64 + co] * part[0][row + u];
             }
-            a.bnp[(int64_t)blockIdx.x * 128 + co] = s1;
-            a.bnp[(int64_t)blockIdx.x * 128 + 64 + co] = s2;
+            a.bnp[(int64_t)blockIdx.x * TPB * 128 + co] = s1;
+            a.bnp[(int64_t)blockIdx.x * TPB * 128 + 64 + co] = s2;
         }
     }
 }
@@ -1380,7 +1391,7 @@ extern "C" int gs_stem_stats(const float* x, const float* w, float* bn_partials,
     GS_CHECK_ARG(bn_partials != nullptr, "gs_stem_stats: null partials");
     SCArgs a{x, w, nullptr, nullptr, bn_partials, N, 1, H, W, 64, H, W, 3, 1, 1, GS_ACT_NONE};
     a.sg = tap_sums;
-    smallcin_fwd64_line_kernel<GS_F16, 1><<<gs_conv_smallcin_mtiles(N, H, W), 256, 0, (hipStream_t)stream>>>(a);
+    smallcin_fwd64_line_kernel<GS_F16, 1><<<cdiv(gs_conv_smallcin_mtiles(N, H, W), SC_GROUP), 256, 0, (hipStream_t)stream>>>(a);
     GS_CHECK_LAUNCH("gs_stem_stats");
     return GS_OK;
 }
