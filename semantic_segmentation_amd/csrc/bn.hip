@@ -230,7 +230,9 @@ struct BwdArgs {
 // GENERIC = some activation is tanh (runtime switch per element); otherwise the activations are the slope family
 // (identity / ReLU / LeakyReLU) and their value / derivative is one compare + select -- the per-element uniform
 // `switch` of act_fwd/act_grad costs a scalar branch per element and held these kernels at ~3 TB/s.
-template <int DT, bool POOL, bool APPLY, bool GENERIC, int HEAD = 0>        // HEAD: 0 = tensor sources; 2 / 4 = a head of <= 2 / 4 outputs
+// EXTRA: the second dense source (dzb) and / or the dropout keep-mask are present (Pix2Pix); without them their loads and
+// registers are compiled out (145-164 VGPRs otherwise: three waves per SIMD)
+template <int DT, bool POOL, bool APPLY, bool GENERIC, int HEAD = 0, bool EXTRA = true>   // HEAD: 0 = tensor sources; 2 / 4 = a head of <= 2 / 4 outputs
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
     static_assert(!HEAD || (!POOL && !GENERIC), "the head source: plain pixels, slope-family activation");
     constexpr int NH = HEAD ? HEAD : 1;
@@ -318,8 +320,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
                     } else {
                         rg[k] = a.dza ? *reinterpret_cast<const uint4*>(a.dza + pix * a.sa + a.ca + c0) : make_uint4(0, 0, 0, 0);
                     }
-                    rb[k] = a.dzb ? *reinterpret_cast<const uint4*>(a.dzb + pix * a.C + c0) : make_uint4(0, 0, 0, 0);
-                    rk[k] = a.keep ? *reinterpret_cast<const uint2*>(a.keep + pix * a.C + c0) : make_uint2(0, 0);
+                    rb[k] = (EXTRA && a.dzb) ? *reinterpret_cast<const uint4*>(a.dzb + pix * a.C + c0) : make_uint4(0, 0, 0, 0);
+                    rk[k] = (EXTRA && a.keep) ? *reinterpret_cast<const uint2*>(a.keep + pix * a.C + c0) : make_uint2(0, 0);
                 }
 #pragma unroll
                 for (int k = 0; k < UNR; ++k) {
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
                             g[i] = t;
                         }
                     }
-                    if (a.keep) {
+                    if (EXTRA && a.keep) {
                         const unsigned int kw[2] = {rk[k].x, rk[k].y};
 #pragma unroll
                         for (int i = 0; i < 8; ++i) g[i] *= ((kw[i >> 2] >> (8 * (i & 3))) & 0xffu) ? a.keep_scale : 0.f;
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const float v = yv[i] * sc[i] + sh[i];
-                        const float gh = g[i] * grad_a(v) + (a.dzb ? gb[i] * grad_b(v) : 0.f);
+                        const float gh = g[i] * grad_a(v) + ((EXTRA && a.dzb) ? gb[i] * grad_b(v) : 0.f);
                         const float xh = (yv[i] - mu[i]) * is[i];
                         if (APPLY) out[i] = a.bn ? sc[i] * (gh - k1[i] - xh * k2[i]) : gh;
                         else { s1[i] += gh; s2[i] += gh * xh; }
@@ -683,16 +685,19 @@ static int launch_bwd(const BwdArgs& a0, bool apply, int dtype, hipStream_t s, i
         if (pool) {                                                                                     \
             if (apply) bn_act_bwd_kernel<DT, true, true, G><<<ntiles, 256, 0, s>>>(a);                  \
             else bn_act_bwd_kernel<DT, true, false, G><<<ntiles, 256, 0, s>>>(a);                       \
-        } else {                                                                                        \
+        } else if (a.dzb != nullptr || a.keep != nullptr) {                                             \
             if (apply) bn_act_bwd_kernel<DT, false, true, G><<<ntiles, 256, 0, s>>>(a);                 \
             else bn_act_bwd_kernel<DT, false, false, G><<<ntiles, 256, 0, s>>>(a);                      \
+        } else {                                                                                        \
+            if (apply) bn_act_bwd_kernel<DT, false, true, G, 0, false><<<ntiles, 256, 0, s>>>(a);       \
+            else bn_act_bwd_kernel<DT, false, false, G, 0, false><<<ntiles, 256, 0, s>>>(a);            \
         }                                                                                               \
     } while (0)
     if (a.head_dl != nullptr) {                            // the head source: plain pixels, slope-family activation (host checks)
 #define LAUNCH_HEAD(DT, NC)                                                                             \
     do {                                                                                                \
-        if (apply) bn_act_bwd_kernel<DT, false, true, false, NC><<<ntiles, 256, 0, s>>>(a);             \
-        else bn_act_bwd_kernel<DT, false, false, false, NC><<<ntiles, 256, 0, s>>>(a);                  \
+        if (apply) bn_act_bwd_kernel<DT, false, true, false, NC, false><<<ntiles, 256, 0, s>>>(a);      \
+        else bn_act_bwd_kernel<DT, false, false, false, NC, false><<<ntiles, 256, 0, s>>>(a);           \
     } while (0)
         if (dtype == GS_F16) { if (a.head_n <= 2) LAUNCH_HEAD(GS_F16, 2); else LAUNCH_HEAD(GS_F16, 4); }
         else { if (a.head_n <= 2) LAUNCH_HEAD(GS_BF16, 2); else LAUNCH_HEAD(GS_BF16, 4); }
