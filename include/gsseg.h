@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 38
+#define GS_ABI_VERSION 39
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -448,6 +448,18 @@ int gs_mean_loss_bwd(const float* x, const float* t, float cval, int mode, int64
  * gs_bn_act_apply_split: z = act(scale * (y_hi + y_lo) + shift) -> z pair (both with z_pix_stride / z_coff), optional 2x2
  *   max-pooled pair (pixel stride zp_pix_stride).   gs_head1x1_fwd_split: OutConv on a dense pair, Cin == 64. */
 int gs_pack_weight_split(const float* w, void* pack, int Cout, int Cin, int taps, int transposed, int dtype, void* stream);
+/* Mixed-precision plans (UNet(precise="mixed"): the pair forward with the MFMA segments chosen per stage): a general segment
+ * pack.  pack[t][co][k], k over the concatenation of nseg <= GS_SEG_MAX segments; segment j = input channels
+ * [ci0[j], ci0[j] + len[j]) of hi(w) (kind 0) or lo(w) (kind 1).  [hi | hi | lo] over all channels reproduces
+ * gs_pack_weight_split; one launch packs all n descriptors. */
+#define GS_SEG_MAX 4
+typedef struct GsSegPackDesc {
+    const float* w;     /* fp32 parameter in the reference layout ([Cout][Cin][taps]; transposed: [Cin][Cout][taps]) */
+    void* pack;         /* [taps][Cout][sum of len] 16-bit */
+    int32_t Cout, Cin, taps, transposed, nseg;
+    int32_t kind[GS_SEG_MAX], ci0[GS_SEG_MAX], len[GS_SEG_MAX];
+} GsSegPackDesc;
+int gs_pack_weight_segs(int n, const GsSegPackDesc* descs, int dtype, void* stream);
 int gs_conv3x3_precise(const void* x, const void* w, void* y_hi, void* y_lo, const float* bias, float* bn_partials, int N,
                        int H, int W, int K, int in_pix_stride, int in_coff, int in_wrap, int Cout, int out_pix_stride,
                        int out_coff, const int32_t* tap_dy, const int32_t* tap_dx, int act, int dtype, void* stream);

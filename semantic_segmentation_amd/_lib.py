@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 GS_F16, GS_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH = 0, 1, 2, 3
 GS_MAX_TAPS = 64
-ABI_VERSION = 38
+ABI_VERSION = 39
 
 
 class GsConvGeom(ctypes.Structure):
@@ -33,6 +33,14 @@ class GsConvGeom(ctypes.Structure):
 class GsPackDesc(ctypes.Structure):
     _fields_ = [("w", c_void_p), ("w_fwd", c_void_p), ("w_dgrad", c_void_p)] + [
         (n, c_int32) for n in ("Cout", "Cin", "taps", "transposed")]
+
+
+GS_SEG_MAX = 4
+
+
+class GsSegPackDesc(ctypes.Structure):
+    _fields_ = [("w", c_void_p), ("pack", c_void_p)] + [(n, c_int32) for n in ("Cout", "Cin", "taps", "transposed", "nseg")] + [
+        ("kind", c_int32 * GS_SEG_MAX), ("ci0", c_int32 * GS_SEG_MAX), ("len", c_int32 * GS_SEG_MAX)]
 
 
 _P, _F = c_void_p, c_void_p   # device pointers are passed as integers
@@ -136,6 +144,7 @@ PROTOTYPES = {
     "gs_dice_loss_bwd": (c_int, [_F, _F, _F, _F, c_int64, c_void_p]),
     "gs_mean_loss_fwd": (c_int, [_F, _F, c_float, c_int, c_int64, _F, _F, c_void_p]),
     "gs_pack_weight_split": (c_int, [_F, _P, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "gs_pack_weight_segs": (c_int, [c_int, POINTER(GsSegPackDesc), c_int, c_void_p]),
     "gs_conv3x3_precise": (c_int, [_P, _P, _P, _P, _F, _F] + [c_int] * 10 + [POINTER(c_int32), POINTER(c_int32), c_int, c_int, c_void_p]),
     "gs_upconv2x2_fwd_precise": (c_int, [_P, _P, _F, _P, _P] + [c_int] * 15 + [c_void_p]),
     "gs_conv_smallcin_fwd_split": (c_int, [_F, _F, _P, _P, _F] + [c_int] * 8 + [c_void_p]),

@@ -1630,8 +1630,8 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
     GS_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0 && Cout > 0, "gs_conv3x3: bad dims");
     const bool prec = y_lo != nullptr;
     // precise mode: Cin is the K extent (segments x channels); the input holds in_wrap channels
-    GS_CHECK_ARG(!prec || (in_wrap > 0 && in_wrap % 64 == 0 && Cin % 64 == 0 && Cin > in_wrap && Cin <= 2 * in_wrap && ndz == 1),
-                 "gs_conv3x3_precise: K extent %d / wrap %d must be multiples of 64 with wrap < K <= 2*wrap", Cin, in_wrap);
+    GS_CHECK_ARG(!prec || (in_wrap > 0 && in_wrap % 64 == 0 && Cin % 64 == 0 && Cin >= in_wrap && Cin <= 2 * in_wrap && ndz == 1),
+                 "gs_conv3x3_precise: K extent %d / wrap %d must be multiples of 64 with wrap <= K <= 2*wrap", Cin, in_wrap);
     GS_CHECK_ARG(in_pix_stride >= in_coff + (prec ? in_wrap : Cin) && in_pix_stride % 8 == 0 && in_coff % 8 == 0, "gs_conv3x3: bad input stride");
     GS_CHECK_ARG(out_pix_stride >= out_coff + Cout, "gs_conv3x3: bad output stride");
     GS_CHECK_ARG((int64_t)N * H * W < 2147483000LL, "gs_conv3x3: pixel count exceeds int32");

@@ -916,8 +916,8 @@ extern "C" int gs_upconv2x2_fwd_precise(const void* x, const void* w, const floa
                                         int IH, int IW, int K, int in_pix_stride, int in_coff, int in_wrap, int Cout,
                                         int OH, int OW, int out_pix_stride, int out_coff, int ooy, int oox, int dtype,
                                         void* stream) {
-    GS_CHECK_ARG(y_lo != nullptr && in_wrap > 0 && in_wrap % 8 == 0 && K > in_wrap && K <= 2 * in_wrap,
-                 "gs_upconv2x2_fwd_precise: need y_lo and in_wrap < K <= 2*in_wrap");
+    GS_CHECK_ARG(y_lo != nullptr && in_wrap > 0 && in_wrap % 8 == 0 && K >= in_wrap && K <= 2 * in_wrap,
+                 "gs_upconv2x2_fwd_precise: need y_lo and in_wrap <= K <= 2*in_wrap");
     GS_CHECK_ARG(in_pix_stride >= in_coff + in_wrap, "gs_upconv2x2_fwd_precise: input stride smaller than the wrapped planes");
     return upconv2x2_impl(x, w, bias, y_hi, y_lo, in_wrap, N, 1, IH, IW, K, in_pix_stride, in_coff, Cout, 1, OH, OW,
                           out_pix_stride, out_coff, 0, ooy, oox, GS_ACT_NONE, dtype, stream);

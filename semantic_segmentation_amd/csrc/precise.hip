@@ -50,6 +50,50 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict
     }
 }
 
+
+// ---- generic segment pack (mixed precision plans of the U-Net forward) ---------------------------------------------
+// out[t][co][k], k running over the concatenation of up to GS_SEG_MAX segments; segment j covers input channels
+// [ci0[j], ci0[j] + len[j]) and carries hi(w) (kind 0) or lo(w) = 16-bit(w - hi(w)) (kind 1).  One launch packs every
+// descriptor (after an optimiser step all packs are stale).
+constexpr int SEGPACK_MAX = 24;
+struct SegPackArgs {
+    const float* w[SEGPACK_MAX];
+    unsigned short* out[SEGPACK_MAX];
+    int Cout[SEGPACK_MAX], Cin[SEGPACK_MAX], taps[SEGPACK_MAX], transposed[SEGPACK_MAX], K[SEGPACK_MAX];
+    int nseg[SEGPACK_MAX], kind[SEGPACK_MAX][GS_SEG_MAX], ci0[SEGPACK_MAX][GS_SEG_MAX], len[SEGPACK_MAX][GS_SEG_MAX];
+    int first[SEGPACK_MAX + 1];          // first block of each descriptor
+    int n;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void pack_segs_kernel(const SegPackArgs a) {
+    int d = 0;
+    while (d + 1 < a.n && (int)blockIdx.x >= a.first[d + 1]) ++d;
+    const int nb = a.first[d + 1] - a.first[d], b = blockIdx.x - a.first[d];
+    const int Cout = a.Cout[d], Cin = a.Cin[d], taps = a.taps[d], K = a.K[d];
+    const float* __restrict__ w = a.w[d];
+    unsigned short* __restrict__ out = a.out[d];
+    // one thread per (co, ci) pair of the SOURCE, all taps: the fp32 weights are read once, each tap written per segment
+    const int64_t pairs = (int64_t)Cout * Cin;
+    for (int64_t i = (int64_t)b * 256 + threadIdx.x; i < pairs; i += (int64_t)nb * 256) {
+        const int ci = (int)(i % Cin), co = (int)(i / Cin);
+        const float* src = a.transposed[d] ? w + ((int64_t)ci * Cout + co) * taps : w + ((int64_t)co * Cin + ci) * taps;
+        int koff = 0;
+        for (int j = 0; j < a.nseg[d]; ++j) {
+            const int c0 = a.ci0[d][j], ln = a.len[d][j];
+            if (ci >= c0 && ci < c0 + ln) {
+                const int k = koff + ci - c0;
+                for (int t = 0; t < taps; ++t) {
+                    const float v = src[t];
+                    const unsigned short hi = Elem<DT>::from_f(v);
+                    out[((int64_t)t * Cout + co) * K + k] = a.kind[d][j] ? Elem<DT>::from_f(v - Elem<DT>::to_f(hi)) : hi;
+                }
+            }
+            koff += ln;
+        }
+    }
+}
+
 // ---- first conv: fp32 NCHW image, fp32 weights, VALU; one thread per (pixel, 8-channel chunk) ----------------------
 constexpr int SCP_TILE = 1024;      // output pixels per block = per BatchNorm tile (== gs_conv_smallcin_mtiles)
 constexpr int SCP_MAX_W = 8192;
@@ -248,6 +292,41 @@ extern "C" int gs_pack_weight_split(const float* w, void* pack, int Cout, int Ci
     if (dtype == GS_F16) pack_split_kernel<GS_F16><<<(int)nb, 256, 0, s>>>(w, (unsigned short*)pack, Cout, Cin, taps, transposed);
     else pack_split_kernel<GS_BF16><<<(int)nb, 256, 0, s>>>(w, (unsigned short*)pack, Cout, Cin, taps, transposed);
     GS_CHECK_LAUNCH("gs_pack_weight_split");
+    return GS_OK;
+}
+
+
+extern "C" int gs_pack_weight_segs(int n, const GsSegPackDesc* descs, int dtype, void* stream) {
+    GS_CHECK_ARG(n > 0 && descs != nullptr, "gs_pack_weight_segs: no descriptors");
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_pack_weight_segs: bad dtype");
+    hipStream_t s = (hipStream_t)stream;
+    for (int base = 0; base < n; base += SEGPACK_MAX) {
+        SegPackArgs a;
+        a.n = n - base < SEGPACK_MAX ? n - base : SEGPACK_MAX;
+        int blocks = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const GsSegPackDesc& d = descs[base + i];
+            GS_CHECK_ARG(d.w && d.pack && d.Cout > 0 && d.Cin > 0 && d.taps > 0 && d.nseg >= 1 && d.nseg <= GS_SEG_MAX,
+                         "gs_pack_weight_segs: descriptor %d: bad arguments", base + i);
+            int K = 0;
+            for (int j = 0; j < d.nseg; ++j) {
+                GS_CHECK_ARG((d.kind[j] == 0 || d.kind[j] == 1) && d.ci0[j] >= 0 && d.len[j] > 0 && d.ci0[j] + d.len[j] <= d.Cin,
+                             "gs_pack_weight_segs: descriptor %d segment %d out of range", base + i, j);
+                a.kind[i][j] = d.kind[j]; a.ci0[i][j] = d.ci0[j]; a.len[i][j] = d.len[j];
+                K += d.len[j];
+            }
+            a.w[i] = d.w; a.out[i] = (unsigned short*)d.pack;
+            a.Cout[i] = d.Cout; a.Cin[i] = d.Cin; a.taps[i] = d.taps; a.transposed[i] = d.transposed; a.K[i] = K; a.nseg[i] = d.nseg;
+            a.first[i] = blocks;
+            int64_t b = cdiv64((int64_t)d.Cout * d.Cin, 256);
+            if (b > 1024) b = 1024;
+            blocks += (int)b;
+        }
+        a.first[a.n] = blocks;
+        if (dtype == GS_F16) pack_segs_kernel<GS_F16><<<blocks, 256, 0, s>>>(a);
+        else pack_segs_kernel<GS_BF16><<<blocks, 256, 0, s>>>(a);
+        GS_CHECK_LAUNCH("gs_pack_weight_segs");
+    }
     return GS_OK;
 }
 

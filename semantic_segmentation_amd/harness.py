@@ -55,6 +55,15 @@ class EndToEndTrainer:
         self.optimizer_D = gs_optim.Adam(netD.parameters(), lr=gan_lr, betas=(beta1, 0.999))
         self.optimizer_arch = torch.optim.Adam(networks.arch_parameters(), lr=arch_lr, betas=(0.5, 0.999), weight_decay=1e-5)
         self.global_step, self.val_best_score, self.history = 0, -1.0, []
+        # this trainer owns every update of the three networks (fused optimisers and torch's Adam: all bump the parameters'
+        # version counters; nothing writes through `.data`), so their engines may reuse version-keyed weight packs between
+        # the training forwards of one iteration (the generator runs three times between two updates of its 1.09 GB of weights)
+        for m in (net, netG, netD):
+            eng = getattr(m, "engine", None)
+            if eng is None and isinstance(m, (torch.nn.DataParallel,)):
+                eng = getattr(m.module, "engine", None)
+            if eng is not None and hasattr(eng, "trust_versions"):
+                eng.trust_versions = True
         self._train_iter, self._val_iter = _cycle(train_loader), _cycle(val_loader)
         # data parallel (one process per GPU, torch.distributed initialised by the caller, every rank feeds its own shard
         # of the loaders): replicas start from rank 0's parameters / buffers; after every backward the gradients of the

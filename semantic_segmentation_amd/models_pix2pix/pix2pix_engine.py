@@ -98,6 +98,7 @@ class GeneratorEngine:
         self.net = net
         self.dtype, self.tdt = _dtype_of(dtype)
         self.packs = _PackCache()
+        self.trust_versions = False      # see unet_engine.pack_reuse_allowed
 
     def blocks(self):
         """UnetSkipConnectionBlocks from the outermost (depth 0) to the innermost."""
@@ -155,6 +156,9 @@ class GeneratorEngine:
         dev = x.device
         x = x.contiguous().float()
         arch = arch.to(dev)
+        from ..unet.unet_engine import pack_reuse_allowed
+        if not pack_reuse_allowed(need_grad, self.trust_versions):
+            self.packs.clear()       # training forwards always re-pack: `.data` writes (Betty) bump no version counter
 
         def empty(*shape, dtype=tdt):
             return torch.empty(shape, dtype=dtype, device=dev)
@@ -338,6 +342,7 @@ class DiscriminatorEngine:
         self.net = net
         self.dtype, self.tdt = _dtype_of(dtype)
         self.packs = _PackCache()
+        self.trust_versions = False      # see unet_engine.pack_reuse_allowed
 
     def run(self, x):
         params = [p for p in self.net.parameters()]
@@ -360,6 +365,9 @@ class DiscriminatorEngine:
         x = x.contiguous().float()
         N, cin0, H, W = x.shape
         stages = self.layout()
+        from ..unet.unet_engine import pack_reuse_allowed
+        if not pack_reuse_allowed(need_grad, self.trust_versions):
+            self.packs.clear()       # training forwards always re-pack: `.data` writes (Betty) bump no version counter
         if cin0 > 4:
             raise NotImplementedError("discriminator input_nc above 4 is not supported by the direct first-layer kernel")
 

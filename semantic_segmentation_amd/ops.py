@@ -1088,6 +1088,74 @@ def upconv2x2_fwd_precise(x, w, bias, y_hi, y_lo, N, IH, IW, Cin, Cout, OH, OW, 
         TIMER.stop("igemm_fwd_precise", ev, 2.0 * N * IH * IW * Cin * 4 * Cout)
 
 
+def pack_weight_segs(items):
+    """Segment packs for the mixed-precision pair forward, all in ONE launch.  items: (w, pack, transposed, segs) with
+    segs = [(kind, ci0, len), ...] (kind 0 = hi(w), 1 = lo(w)); pack = contiguous [taps][Cout][sum len] 16-bit."""
+    if not items:
+        return
+    descs = (_lib.GsSegPackDesc * len(items))()
+    ref = items[0][1]
+    for d, (w, pack, transposed, segs) in zip(descs, items):
+        _dev(w)
+        _f32(w, "weight")
+        if pack.dtype != ref.dtype:
+            raise TypeError("pack_weight_segs: all packs must share one 16-bit dtype")
+        cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+        taps = w.shape[2] * w.shape[3]
+        if not 1 <= len(segs) <= _lib.GS_SEG_MAX:
+            raise ValueError("pack_weight_segs: 1..4 segments")
+        ktot = sum(s_[2] for s_ in segs)
+        if pack.numel() != taps * cout * ktot or not pack.is_contiguous() or not w.is_contiguous():
+            raise ValueError("pack_weight_segs: pack must be contiguous [taps][Cout][sum of segment lengths]")
+        d.w, d.pack = _p(w), _p(pack)
+        d.Cout, d.Cin, d.taps, d.transposed, d.nseg = cout, cin, taps, int(transposed), len(segs)
+        for j, (kind, ci0, ln) in enumerate(segs):
+            d.kind[j], d.ci0[j], d.len[j] = int(kind), int(ci0), int(ln)
+    _lib.call("gs_pack_weight_segs", len(items), descs, dt_code(ref), _stream())
+
+
+def conv3x3_segs(x, w, y_hi, y_lo, N, H, W, K, wrap, Cin, Cout, in_stride, in_coff=0, out_stride=None, out_coff=0,
+                 bias=None, bn_partials=None, act=ACT_NONE, taps=TAPS3_FWD):
+    """3x3/s1/p1 convolution of the pair forward with a free choice of MFMA segments: the K extent (a multiple of 64,
+    wrap <= K <= 2*wrap) runs over the input channels [in_coff, in_coff + wrap) of x and wraps to in_coff once; w is the
+    matching pack_weight_segs pack [9][Cout][K]; Cin = the layer's channels (for the FLOP count only).  Result: pair
+    y_hi / y_lo."""
+    _dev(x)
+    _f32(bias, "bias"); _f32(bn_partials, "bn_partials")
+    if not (x.dtype == w.dtype == y_hi.dtype == y_lo.dtype):
+        raise TypeError("conv3x3_segs: x, w, y must share one 16-bit dtype")
+    if K % 64 != 0 or wrap % 64 != 0 or not (wrap <= K <= 2 * wrap) or w.numel() != 9 * Cout * K:
+        raise ValueError("conv3x3_segs: K / wrap must be multiples of 64 with wrap <= K <= 2*wrap and w the [9][Cout][K] pack")
+    if bn_partials is not None and bn_partials.numel() < bn_partials_numel(conv3x3_mtiles(N, H, W, Cout), Cout):
+        raise ValueError("conv3x3_segs: bn_partials too small")
+    dy = (ctypes.c_int32 * 9)(*[t[0] for t in taps])
+    dx = (ctypes.c_int32 * 9)(*[t[1] for t in taps])
+    ev = TIMER.start() if TIMER is not None else None
+    _lib.call("gs_conv3x3_precise", _p(x), _p(w), _p(y_hi), _p(y_lo), _p(bias), _p(bn_partials), N, H, W, K,
+              in_stride, in_coff, wrap, Cout, Cout if out_stride is None else out_stride, out_coff, dy, dx, act,
+              dt_code(x), _stream())
+    if ev is not None:                       # algorithmic work of the convolution (the kernel executes K / Cin times the MFMAs)
+        TIMER.stop("conv3x3_halo_precise", ev, 2.0 * N * H * W * Cout * 9 * Cin,
+                   2.0 * (N * H * W * 2 * (Cin + Cout) + 9 * K * Cout))
+
+
+def upconv2x2_fwd_segs(x, w, bias, y_hi, y_lo, N, IH, IW, K, wrap, Cin, Cout, OH, OW, in_stride, in_coff=0, out_stride=None,
+                       out_coff=0, ooy=0, oox=0):
+    """ConvTranspose2d(k 2, s 2) of the pair forward with a free choice of segments (see conv3x3_segs); w = [4][Cout][K]."""
+    _dev(x)
+    _f32(bias, "bias")
+    if not (x.dtype == w.dtype == y_hi.dtype == y_lo.dtype):
+        raise TypeError("upconv2x2_fwd_segs: x, w, y must share one 16-bit dtype")
+    if w.numel() != 4 * Cout * K or not (wrap <= K <= 2 * wrap):
+        raise ValueError("upconv2x2_fwd_segs: w must be the [4][Cout][K] pack, wrap <= K <= 2*wrap")
+    ev = TIMER.start() if TIMER is not None else None
+    _lib.call("gs_upconv2x2_fwd_precise", _p(x), _p(w), _p(bias), _p(y_hi), _p(y_lo), N, IH, IW, K, in_stride,
+              in_coff, wrap, Cout, OH, OW, Cout if out_stride is None else out_stride, out_coff, ooy, oox,
+              dt_code(x), _stream())
+    if ev is not None:
+        TIMER.stop("igemm_fwd_precise", ev, 2.0 * N * IH * IW * Cin * 4 * Cout)
+
+
 def conv_smallcin_fwd_split(x, w, y_hi, y_lo, bn_partials, k, pad):
     """First conv (fp32 NCHW image, fp32 weights, stride 1) -> dense pair y_hi / y_lo [N,H,W,Cout]."""
     _dev(x)

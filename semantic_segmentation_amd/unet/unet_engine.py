@@ -56,11 +56,18 @@ class _UpRec:
     __slots__ = ("name", "zin", "cat", "geom_bwd", "geom_wg", "wd", "cin", "cout", "h", "w", "H2", "W2", "pt", "pl")
 
 
-# GSSEG_PACK_CACHE=0: never reuse a 16-bit weight pack.  The caches key on torch's version counters, which every torch
-# in-place op, every optimiser (torch's and the fused ones of optim.py) and load_state_dict bump -- but a write through
-# `p.data` (Betty's finite-difference perturbation does that) is invisible to them: such loops must switch the cache off or
-# call `invalidate_packs()` after the write.
-PACK_CACHE = os.environ.get("GSSEG_PACK_CACHE", "1") != "0"
+# Reuse of the 16-bit weight packs between forwards (GSSEG_PACK_CACHE):
+#   "safe" (default, also "1"): a forward that keeps a graph (training: grad mode on and something requires grad) ALWAYS
+#       re-packs -- one launch, ~0.1 ms at 31 M parameters, inside bench.py's timed region anyway.  Betty's darts hypergradient
+#       perturbs the parameters through `p.data` (running_files/train_end2end_jsrt.py:287-292: Config(type="darts")), which
+#       no version counter sees; with this default the stock script gets the perturbed weights.  Packs are reused only by
+#       forwards without a graph (eval / torch.no_grad()), keyed on (data_ptr, _version): every torch in-place op, every
+#       optimiser (torch's and optim.py's fused ones) and load_state_dict bump the version.
+#   "versions": the version-keyed reuse for training forwards too (loops that never write through `.data`).
+#   "0": never reuse.
+_PC = os.environ.get("GSSEG_PACK_CACHE", "safe")
+PACK_CACHE = _PC != "0"
+PACK_CACHE_TRAINING = _PC == "versions"
 _NOCACHE = [0]
 
 
@@ -69,6 +76,54 @@ def _pack_key(p: torch.Tensor):
         _NOCACHE[0] += 1
         return (_NOCACHE[0],)
     return (p.data_ptr(), p._version, p.dtype, tuple(p.shape))
+
+
+def pack_reuse_allowed(need_grad: bool, trust_versions: bool = False) -> bool:
+    """may a forward reuse the packs of an earlier one?  (see GSSEG_PACK_CACHE above; `trust_versions`: the engine's owner
+    vouches that parameters only change through version-bumping ops -- harness.py does, it owns the optimisers)"""
+    return PACK_CACHE and (PACK_CACHE_TRAINING or trust_versions or not need_grad)
+
+
+STAGES = (["inc.0", "inc.3"] + [f"down{i}.{k}" for i in range(1, 5) for k in (0, 3)] +
+          [s_ for j in range(1, 5) for s_ in (f"up{j}.up", f"up{j}.conv.0", f"up{j}.conv.3")])
+# MFMA segments of one stage of the pair forward: "1" = x_hi.w_hi, "x" = + x_lo.w_hi, "w" = + x_hi.w_lo, "xw" = all three
+_SEG_MODES = ("1", "x", "w", "xw")
+# Where the 16-bit error of the logits is made (tools/parity_attribution.py, profiles/r03_parity_attribution_wyz.json): the
+# 256^2 / 128^2 / 64^2 stages of the encoder and the last two decoder levels; everything at 32^2 and below contributes
+# < 5e-5 each.  "mixed" keeps all three MFMA segments there and one segment elsewhere -- every tensor still travels as a
+# hi/lo pair (the deep levels hold few bytes), so only the MFMA work is saved: 48 of the 92 GFLOP per image run three
+# segments.  fp16 only: bf16 pairs carry 16 significand bits, which every stage needs.
+MIXED_XW = ("inc.3", "down1.0", "down1.3", "down2.0", "down2.3", "up3.conv.0", "up3.conv.3", "up4.conv.0", "up4.conv.3")
+
+
+def resolve_plan(precise, dtype: str):
+    """precise: False / None -> None (default engine); True -> every stage "xw"; "mixed" -> MIXED_XW (bf16: every stage);
+    a dict {stage: mode} -> that plan (missing stages "1")."""
+    if precise is None or precise is False or precise == 0 or precise == "0" or precise == "":
+        return None
+    if precise is True or precise == 1 or precise == "1" or precise == "full":
+        return {s_: "xw" for s_ in STAGES}
+    if precise == "mixed":
+        if dtype != "f16":
+            return {s_: "xw" for s_ in STAGES}
+        return {s_: ("xw" if s_ in MIXED_XW else "1") for s_ in STAGES}
+    if isinstance(precise, dict):
+        bad = [k for k, v in precise.items() if k not in STAGES or v not in _SEG_MODES]
+        if bad:
+            raise ValueError(f"precise plan: unknown stages / modes {bad}")
+        return {s_: precise.get(s_, "1") for s_ in STAGES}
+    raise ValueError("precise must be False, True, 'mixed' or a {stage: mode} dict")
+
+
+def _segs(mode: str, cin: int):
+    """(segment list for pack_weight_segs, K extent, input wrap) of a stage reading a [hi | lo] pair of cin channels"""
+    if mode == "1":
+        return [(0, 0, cin)], cin, cin
+    if mode == "x":
+        return [(0, 0, cin), (0, 0, cin)], 2 * cin, 2 * cin
+    if mode == "w":
+        return [(0, 0, cin), (1, 0, cin)], 2 * cin, cin
+    return [(0, 0, cin), (0, 0, cin), (1, 0, cin)], 3 * cin, 2 * cin
 
 
 class UNetEngine:
@@ -81,10 +136,12 @@ class UNetEngine:
         self.dtype = dtype
         # precise forward (module docstring of forward_precise): activations / weights as hi+lo pairs of 16-bit values,
         # logits within ~1e-5 of the fp32 reference instead of ~4e-3; the backward pass is unchanged (it reads the hi halves)
-        self.precise = bool(precise)
+        self.plan = resolve_plan(precise, dtype)          # None: the default single 16-bit engine
+        self.precise = self.plan is not None
         self.dynamic_loss_scale = os.environ.get("GSSEG_DYNAMIC_LOSS_SCALE", "0") == "1"
         self.tdt = _TORCH_DT[dtype]
         self._packs: Dict[str, tuple] = {}
+        self.trust_versions = False      # True: training forwards reuse version-keyed packs (see GSSEG_PACK_CACHE)
         self._side_streams: Dict[torch.device, torch.cuda.Stream] = {}     # weight-gradient stream per device
         # data-parallel hooks (parallel.GradReducer): grads are allocated inside the reducer's flat buckets,
         # announced as soon as they are final (so the RCCL all-reduce overlaps the rest of backward), and
@@ -220,6 +277,8 @@ class UNetEngine:
         ws_ = [W >> i for i in range(5)]
         bilinear = bool(net.bilinear)
         C = [64, 128, 256, 512, 1024 // (2 if bilinear else 1)]      # unet_model.py:18-19
+        if not pack_reuse_allowed(need_grad, self.trust_versions):
+            self._packs.clear()                                       # `.data` writes are invisible to the version keys
         if training or need_grad:
             self._prepack(params, need_grad)                          # every stale weight pack in one launch
 
@@ -412,17 +471,39 @@ class UNetEngine:
         return logits, ctx
 
     # ------------------------------------------------------------------ precise forward
-    def _packed_split(self, name: str, w: torch.Tensor, transposed: bool):
-        """[taps][Cout][3*Cin] = [w_hi | w_hi | w_lo] pack of a conv weight, cached until the Parameter is modified."""
-        key = _pack_key(w)
-        ent = self._packs.get(name + "|split")
-        if ent is not None and ent[0] == key:
-            return ent[1]
-        cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
-        pack = torch.empty((w.shape[2] * w.shape[3], cout, 3 * cin), dtype=self.tdt, device=w.device)
-        ops.pack_weight_split(w.detach().contiguous(), pack, transposed)
-        self._packs[name + "|split"] = (key, pack)
-        return pack
+    def _prepack_segs(self, params: Dict[str, torch.Tensor]):
+        """Segment packs of the pair forward ([taps][Cout][K], K = the stage's concatenation of hi / lo segments), every
+        stale one re-packed in ONE launch; cached until the Parameter is modified."""
+        items, fresh = [], []
+        for st in STAGES:
+            mode = self.plan[st]
+            if st.endswith(".up"):
+                wkey, transposed = st + ".weight", True
+            else:
+                blk, idx = st.rsplit(".", 1)
+                prefix = blk if (blk == "inc" or blk.endswith(".conv")) else blk + ".maxpool_conv.1"
+                wkey, transposed = f"{prefix}.double_conv.{idx}.weight", False
+            w = params.get(wkey)
+            if w is None or w.dim() != 4:
+                continue
+            cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+            if cin % 8 != 0:                               # the image-end layer is not packed
+                continue
+            key = (_pack_key(w), mode)
+            ent = self._packs.get(wkey + "|segs")
+            if ent is not None and ent[0] == key:
+                continue
+            segs, K, _ = _segs(mode, cin)
+            pack = torch.empty((w.shape[2] * w.shape[3], cout, K), dtype=self.tdt, device=w.device)
+            items.append((w.detach().contiguous(), pack, transposed, segs))
+            fresh.append((wkey, key, pack))
+        if items:
+            ops.pack_weight_segs(items)
+            for wkey, key, pack in fresh:
+                self._packs[wkey + "|segs"] = (key, pack)
+
+    def _seg_pack(self, wkey: str):
+        return self._packs[wkey + "|segs"][1]
 
     def forward_precise(self, x: torch.Tensor, params: Dict[str, torch.Tensor], training: bool, need_grad: bool):
         """The same network with every activation and weight carried as a PAIR of 16-bit values v = hi + lo
@@ -449,6 +530,12 @@ class UNetEngine:
         hs = [H >> i for i in range(5)]
         ws_ = [W >> i for i in range(5)]
         C = [64, 128, 256, 512, 1024]
+        plan = self.plan
+        if not pack_reuse_allowed(need_grad, self.trust_versions):
+            self._packs.clear()                            # `.data` writes are invisible to the version keys
+        if need_grad:
+            self._prepack(params, True)                    # the backward's data-gradient packs, one launch
+        self._prepack_segs(params)                         # the forward's segment packs, one launch
 
         def empty(*shape, dtype=tdt):
             return torch.empty(shape, dtype=dtype, device=dev)
@@ -469,8 +556,9 @@ class UNetEngine:
             if image:
                 ops.conv_smallcin_fwd_split(inp, wparam.detach().contiguous(), y_hi, y_lo, partials, 3, 1)
             else:
-                ops.conv3x3_precise(inp, self._packed_split(wkey, wparam, False), y_hi, y_lo, N, h, w, cin, cout,
-                                    in_stride=2 * cin, bn_partials=partials)
+                _, K, wrap = _segs(plan[prefix.replace(".maxpool_conv.1", "") + f".{idx}"], cin)
+                ops.conv3x3_segs(inp, self._seg_pack(wkey), y_hi, y_lo, N, h, w, K, wrap, cin, cout, in_stride=2 * cin,
+                                 bn_partials=partials)
             coef = empty(4, cout, dtype=torch.float32)
             gamma, beta = params[bnkey + ".weight"], params[bnkey + ".bias"]
             bn_mod = self.submodule(bnkey)
@@ -536,9 +624,10 @@ class UNetEngine:
             pt, pl = (H2 - 2 * h) // 2, (W2 - 2 * w) // 2
             cat = cats[lvl]
             wkey = prefix + ".up.weight"
-            ops.upconv2x2_fwd_precise(inp, self._packed_split(wkey, params[wkey], True), params[prefix + ".up.bias"].detach(),
-                                      cat[..., cout_t:], cat[..., 3 * cout_t:], N, h, w, cin_t, cout_t, H2, W2,
-                                      in_stride=2 * cin_t, out_stride=4 * cout_t, ooy=pt, oox=pl)
+            _, K, wrap = _segs(plan[prefix + ".up"], cin_t)
+            ops.upconv2x2_fwd_segs(inp, self._seg_pack(wkey), params[prefix + ".up.bias"].detach(),
+                                   cat[..., cout_t:], cat[..., 3 * cout_t:], N, h, w, K, wrap, cin_t, cout_t, H2, W2,
+                                   in_stride=2 * cin_t, out_stride=4 * cout_t, ooy=pt, oox=pl)
             if need_grad:
                 u = _UpRec()
                 u.name, u.zin, u.cat = prefix, inp, cat

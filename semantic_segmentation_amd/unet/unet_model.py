@@ -34,9 +34,12 @@ class UNet(nn.Module):
         # MFMA rate; gradients are loss-scaled internally) or bf16.  Not part of the state dict.
         dt = compute_dtype or os.environ.get("GSSEG_DTYPE", "f16")
         # precise=True (or GSSEG_PRECISE=1): hi/lo pair forward, logits ~1e-5 from the fp32 reference at ~3x the forward MFMA
-        # work (unet_engine.forward_precise); default: single 16-bit storage, logits within ~4e-3.
+        # work (unet_engine.forward_precise); precise="mixed" (GSSEG_PRECISE=mixed): the pair forward with all three MFMA
+        # segments only on the stages that make the 16-bit error (unet_engine.MIXED_XW): max |dlogit| < 1e-3, the north
+        # star's bound; default: single 16-bit storage, logits within ~4e-3.
         if precise is None:
-            precise = os.environ.get("GSSEG_PRECISE", "0") == "1"
+            env = os.environ.get("GSSEG_PRECISE", "0")
+            precise = {"0": False, "1": True}.get(env, env)
         object.__setattr__(self, "_engine", UNetEngine(self, dt, precise=precise))
         # fp16 backward: gradients are carried times a static power-of-two scale that assumes a mean-reduced loss;
         # dynamic_loss_scale=True renormalises the incoming gradient on the device (sum-reduced losses, GradScaler, ...)

@@ -10,7 +10,7 @@ into the reference modules with ``load_state_dict(strict=True)`` -- which also
 checks that our key names and shapes are exactly the reference's.  A checksum
 of every generated tensor is stored so a drift of the PRNG stream is detected.
 
-Usage:  python tests/golden/make_golden.py [--only unet|ops|pix2pix]
+Usage:  python tests/golden/make_golden.py [--only unet|unet_b32|bilinear|ops|jaccard|pix2pix|pix2pix_b8|unet3d|unet3d_128]
 """
 import argparse
 import os
@@ -96,6 +96,62 @@ def make_unet(name, n_classes, batch, h, w, seed, mask_mode="ellipse", bilinear=
         else:
             t = F.one_hot(mask[:, 0].long(), n_classes).permute(0, 3, 1, 2).float()
             p = F.one_hot(lg.argmax(dim=1), n_classes).permute(0, 3, 1, 2).float()
+            out["eval_dice"] = multiclass_dice_coeff(p[:, 1:], t[:, 1:], reduce_batch_first=False).item()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "loss", loss.item(), "logits", tuple(logits.shape))
+
+
+def _top_positions(t: torch.Tensor, k: int = 64) -> np.ndarray:
+    """flat indices of the k largest-|t| elements (ties broken by index: deterministic)"""
+    f = t.detach().abs().flatten()
+    return torch.topk(f, k).indices.sort().values.numpy().astype(np.int64)
+
+
+def make_unet_compact(name, n_classes, batch, size, seed):
+    """BASELINE config 2 at its own size (UNet(1,2), 256x256, batch 32): a COMPACT fixture from the
+    imported reference.  Inputs are not stored -- `oracle.synthetic_batch(batch, size, seed)` regenerates them (checksums
+    stored); outputs: logits sub-sampled 8x8 plus the 64 largest-|logit| positions, the two losses, all gradient summaries,
+    the updated BatchNorm buffers, eval-mode logits (same sub-sampling) and the evaluate.py Dice.  < 1 MB."""
+    from unet import UNet
+    from util.dice_score import dice_loss, dice_coeff, multiclass_dice_coeff
+    import torch.nn.functional as F
+
+    sd = oracle.unet_state_dict(1, n_classes, seed=seed)
+    net = UNet(1, n_classes)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    x, mask = oracle.synthetic_batch(batch, size, seed=1234 + seed)
+    logits = net(x)
+    l1, l2 = ref_seg_loss(logits, mask, dice_loss)
+    loss = l1 + l2
+    loss.backward()
+    lg = logits.detach()
+    top = _top_positions(lg)
+    out = {
+        "n_classes": n_classes, "seed": seed, "batch": batch, "size": size, "data_seed": 1234 + seed,
+        "xsum": tensor_checksum(x), "masksum": tensor_checksum(mask.float()),
+        "logits_sub": lg[:, :, ::8, ::8].numpy().copy(), "top_idx": top, "top_val": lg.flatten()[torch.from_numpy(top)].numpy(),
+        "logits_absmean": lg.abs().mean().item(), "logits_sum": lg.double().sum().item(),
+        "loss_ce": l1.item(), "loss_dice": l2.item(), "loss": loss.item(),
+    }
+    for k, p in net.named_parameters():
+        out["gsum/" + k] = grad_summary(p.grad)
+    for k, b in net.named_buffers():
+        if "num_batches" not in k:
+            out["buf/" + k] = b.detach().numpy().copy()
+    for k, v in sd.items():
+        if v.is_floating_point():
+            out["wsum/" + k] = tensor_checksum(v)
+    net.eval()
+    with torch.no_grad():
+        le = net(x)
+        out["logits_eval_sub"] = le[:, :, ::8, ::8].numpy().copy()
+        if n_classes == 1:
+            pred = (torch.sigmoid(le) > 0.5).float()
+            out["eval_dice"] = dice_coeff(pred.squeeze(), mask.float().squeeze(), reduce_batch_first=False).item()
+        else:
+            t = F.one_hot(mask[:, 0].long(), n_classes).permute(0, 3, 1, 2).float()
+            p = F.one_hot(le.argmax(dim=1), n_classes).permute(0, 3, 1, 2).float()
             out["eval_dice"] = multiclass_dice_coeff(p[:, 1:], t[:, 1:], reduce_batch_first=False).item()
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print(name, "loss", loss.item(), "logits", tuple(logits.shape))
@@ -341,6 +397,44 @@ def make_unet3d(name, n_classes, batch, size, seed):
     print(name, "loss", loss.item(), "logits", tuple(logits.shape))
 
 
+def make_unet3d_compact(name, n_classes, size, seed):
+    """BASELINE config 5's per-GPU size (UNet3D(1,2), one 128^3 volume): a compact fixture from the imported reference --
+    inputs regenerated from the seed (checksums stored), logits sub-sampled 8x8x8 + the 64 largest-|logit| positions, loss,
+    gradient summaries, BatchNorm buffers."""
+    import importlib.util, types
+    sys.modules.setdefault("torchsummary", types.SimpleNamespace(summary=lambda *a, **k: None))
+    spec = importlib.util.spec_from_file_location("ref_unet3d", os.path.join(REF, "GenSeg-3D", "UNet3D", "unet3d.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    sd = oracle.unet3d_state_dict(1, n_classes, seed=seed)
+    net = mod.UNet3D(in_channels=1, num_classes=n_classes)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    g = torch.Generator().manual_seed(100 + seed)
+    x = torch.randn(1, 1, size, size, size, generator=g)
+    mask = (torch.rand(1, size, size, size, generator=g) > 0.6).long()
+    logits = net(x)
+    n, c, d, h, w = logits.shape
+    loss = oracle.seg_loss(logits.reshape(n, c, d * h, w), mask.reshape(n, d * h, w))
+    loss.backward()
+    lg = logits.detach()
+    top = _top_positions(lg)
+    out = {"n_classes": n_classes, "seed": seed, "size": size, "data_seed": 100 + seed,
+           "xsum": tensor_checksum(x), "masksum": tensor_checksum(mask.float()),
+           "logits_sub": lg[:, :, ::8, ::8, ::8].numpy().copy(), "top_idx": top,
+           "top_val": lg.flatten()[torch.from_numpy(top)].numpy(), "logits_absmean": lg.abs().mean().item(),
+           "loss": loss.item()}
+    for k, p_ in net.named_parameters():
+        out["gsum/" + k] = grad_summary(p_.grad)
+    for k, b in net.named_buffers():
+        out["buf/" + k] = b.detach().numpy().copy()
+    for k, v in sd.items():
+        if v.is_floating_point():
+            out["wsum/" + k] = tensor_checksum(v)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "loss", loss.item(), "logits", tuple(logits.shape))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -355,6 +449,8 @@ if __name__ == "__main__":
     if a.only in ("", "unet", "bilinear"):
         make_unet("unet_c1_bilinear_64", 1, 2, 64, 64, seed=7, bilinear=True)      # nn.Upsample path, unet_parts.py:49-51
         make_unet("unet_c2_bilinear_odd", 2, 2, 70, 52, seed=8, bilinear=True)     # + non-zero F.pad
+    if a.only in ("", "unet_b32"):
+        make_unet_compact("unet_c2_256_b32", 2, 32, 256, seed=9)     # BASELINE config 2 at its own size (~2 min, ~30 GB)
     if a.only in ("", "ops"):
         make_dice_cases()
         make_ops_micro()
@@ -367,3 +463,5 @@ if __name__ == "__main__":
     if a.only in ("", "unet3d"):
         make_unet3d("unet3d_c2_16", 2, 2, 16, seed=51)
         make_unet3d("unet3d_c1_16", 1, 2, 16, seed=52)
+    if a.only in ("", "unet3d_128"):
+        make_unet3d_compact("unet3d_c2_128", 2, 128, seed=53)        # BASELINE config 5, one volume per GPU

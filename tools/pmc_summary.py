@@ -24,6 +24,13 @@ def short(name):
     return re.sub(r"\(.*$", "", name)
 
 
+def source_sha16():
+    """the kernel sources this profile was taken with (bench.py compares it with the sources it runs)"""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench.source_sha16()
+
+
 def find(d, pat):
     hits = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
     if not hits:
@@ -62,7 +69,8 @@ def counter(d, name):
 def pmc(dfetch, dwrite, nsteps, out):
     fe, wr = counter(dfetch, "FETCH_SIZE"), counter(dwrite, "WRITE_SIZE")
     res = {"_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py; KiB -> MB; "
-                    "FETCH_SIZE doubled (gfx950 wide-read correction, MI355X_MICROARCH.md); averages per launch"}
+                    "FETCH_SIZE doubled (gfx950 wide-read correction, MI355X_MICROARCH.md); averages per launch",
+           "_source_sha16": source_sha16()}
     for k in sorted(fe, key=lambda k: -fe[k][1]):
         c, kib = fe[k]
         wc, wkib = wr.get(k, (0, 0.0))
