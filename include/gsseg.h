@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 39
+#define GS_ABI_VERSION 40
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -473,6 +473,17 @@ int gs_bn_act_apply_split(const void* y_hi, const void* y_lo, const float* scale
                           int H, int W, int C, int dtype, void* stream);
 int gs_head1x1_fwd_split(const void* x_hi, const void* x_lo, const float* w, const float* bias, float* y, int N, int H,
                          int W, int Cin, int Cout, int dtype, void* stream);
+/* Pair-forward forms of the "never stored" edge kernels (mixed mode; gs_stem_fwd_bn / gs_head1x1_bn_fwd of the default engine):
+ * gs_head1x1_bn_fwd_split: OutConv on act(scale * (y_hi + y_lo) + shift) of the last stage's conv-output pair.
+ * gs_stem_fwd_bn_pair: the one-channel stem conv + BatchNorm + activation in one pass -> z_hi / z_lo (pixel stride
+ *   z_pix_stride, z_lo may be NULL).   gs_stem_bwd_onepass_strided: gs_stem_bwd_onepass with z at a pixel stride.
+ * gs_bn_act_apply_split accepts z_lo == NULL / zp_lo == NULL when no consumer reads the lo plane. */
+int gs_head1x1_bn_fwd_split(const void* y_hi, const void* y_lo, const float* scale, const float* shift, int act, const float* w,
+                            const float* bias, float* logits, int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
+int gs_stem_fwd_bn_pair(const float* x, const float* w, const float* bn_scale, const float* bn_shift, int act, void* z_hi,
+                        void* z_lo, int z_pix_stride, int N, int H, int W, int dtype, void* stream);
+int gs_stem_bwd_onepass_strided(const float* x, const void* z, int z_pix_stride, const void* dz, int dz_stride, int dz_coff,
+                                int act, float* s1_partials, float* ws, int N, int H, int W, int dtype, void* stream);
 
 /* Deterministic weight gradient of the 3x3 conv without atomics: gs_conv3x3_wgrad_slabs stores every split-K part's
  * tile into its own slab ws[part][9][Cout][Cin] (fp32, gs_conv3x3_wgrad_ws_floats() elements, no zero fill needed,

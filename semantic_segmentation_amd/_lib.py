@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 GS_F16, GS_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH = 0, 1, 2, 3
 GS_MAX_TAPS = 64
-ABI_VERSION = 39
+ABI_VERSION = 40
 
 
 class GsConvGeom(ctypes.Structure):
@@ -150,6 +150,9 @@ PROTOTYPES = {
     "gs_conv_smallcin_fwd_split": (c_int, [_F, _F, _P, _P, _F] + [c_int] * 8 + [c_void_p]),
     "gs_bn_act_apply_split": (c_int, [_P, _P, _F, _F, c_int, _P, _P, c_int, c_int, _P, _P] + [c_int] * 6 + [c_void_p]),
     "gs_head1x1_fwd_split": (c_int, [_P, _P, _F, _F, _F] + [c_int] * 6 + [c_void_p]),
+    "gs_head1x1_bn_fwd_split": (c_int, [_P, _P, _F, _F, c_int, _F, _F, _F] + [c_int] * 6 + [c_void_p]),
+    "gs_stem_fwd_bn_pair": (c_int, [_F, _F, _F, _F, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "gs_stem_bwd_onepass_strided": (c_int, [_F, _P, c_int, _P, c_int, c_int, c_int, _F, _F, c_int, c_int, c_int, c_int, c_void_p]),
     "gs_mean_loss_bwd": (c_int, [_F, _F, c_float, c_int, c_int64, _F, c_float, _F, c_void_p]),
 }
 

@@ -20,6 +20,8 @@ struct SCArgs {
     int N, Cin, IH, IW, Cout, OH, OW, k, stride, pad, act;
     const float* bn_scale; const float* bn_shift;      // smallcin_fwd64_line_kernel MODE 2
     float* sg;                                         // MODE 1: per-block tap sums + Gram entries [block][54] (may be null)
+    unsigned short* y_lo = nullptr;                    // MODE 2: lo half of the output pair (pair forward), same stride
+    int ys = 64;                                       // MODE 2: pixel stride of y / y_lo
 };
 
 template <int DT>
@@ -255,7 +257,8 @@ __global__ __launch_bounds__(256) void smallcin_fwd64_line_kernel(const SCArgs a
                 for (int u = t; u < TT; ++u) G[t * TT - t * (t - 1) / 2 + (u - t)] += xv[t] * xv[u];      // upper triangle, row-major
             }
         }
-        unsigned short* dst = a.y + (int64_t)mm * 64;
+        unsigned short* dst = a.y + (int64_t)mm * (MODE == 2 ? a.ys : 64);
+        unsigned short* dst_lo = (MODE == 2 && a.y_lo) ? a.y_lo + (int64_t)mm * a.ys : nullptr;
 #pragma unroll 1
         for (int g = 0; g < (MODE == 1 ? 0 : 4); ++g) {     // 16 channels at a time, a runtime loop: unrolled, the compiler hoists all
             const float* wk = wl + sc_opaque(g * 16);       // 144 weight reads above the FMAs and spills the accumulators
@@ -296,7 +299,15 @@ __global__ __launch_bounds__(256) void smallcin_fwd64_line_kernel(const SCArgs a
                         const float v = acc[8 * i + c];
                         o[c] = v > 0.f ? v : v * slope;
                     }
-                    *reinterpret_cast<uint4*>(dst + g * 16 + 8 * i) = pack8<DT>(o);
+                    const uint4 hi = pack8<DT>(o);
+                    *reinterpret_cast<uint4*>(dst + g * 16 + 8 * i) = hi;
+                    if (MODE == 2 && dst_lo) {               // pair forward: lo = 16-bit(value - hi)
+                        float hf[8];
+                        unpack8<DT>(hi, hf);
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) o[c] -= hf[c];
+                        *reinterpret_cast<uint4*>(dst_lo + g * 16 + 8 * i) = pack8<DT>(o);
+                    }
                 }
             }
         }
@@ -540,6 +551,7 @@ struct SBWArgs {
     int dz_stride, dz_coff, N, H, W, act;
     int64_t pix_per_block;
     float* partials;         // stem_bwd_onepass_kernel: s1 [block][64]
+    int zs = 64;             // stem_bwd_onepass_kernel: pixel stride of the stored activation (128: the hi plane of a pair)
 };
 
 // ONE backward pass for the y-free stem.  With g = dz * act'(.), A[c][t] = sum_p g[p][c] x_t(p) and s1_c = sum_p g[p][c]:
@@ -581,7 +593,7 @@ __global__ __launch_bounds__(256) void stem_bwd_onepass_kernel(const SBWArgs a) 
         for (int k = 0; k < UNR; ++k) {
             const int m = mb + 32 * k;
             const int64_t mm = m < m1 ? m : mb;
-            rz[k] = *reinterpret_cast<const uint4*>(a.y + mm * 64 + c0);          // a.y: the stored activation z here
+            rz[k] = *reinterpret_cast<const uint4*>(a.y + mm * a.zs + c0);          // a.y: the stored activation z here
             rg[k] = *reinterpret_cast<const uint4*>(a.dz + mm * a.dz_stride + a.dz_coff + c0);
         }
 #pragma unroll
@@ -1411,14 +1423,43 @@ extern "C" int gs_stem_fwd_bn(const float* x, const float* w, const float* bn_sc
     return GS_OK;
 }
 
+// Pair form (UNet(precise=...)): z_hi / z_lo with pixel stride z_pix_stride (e.g. the two planes of a [hi | lo] buffer); z_lo may be NULL.
+extern "C" int gs_stem_fwd_bn_pair(const float* x, const float* w, const float* bn_scale, const float* bn_shift, int act,
+                                   void* z_hi, void* z_lo, int z_pix_stride, int N, int H, int W, int dtype, void* stream) {
+    int rc = stem_check("gs_stem_fwd_bn_pair", x, w, N, H, W, dtype);
+    if (rc) return rc;
+    GS_CHECK_ARG(bn_scale && bn_shift && z_hi && z_pix_stride >= 64 && z_pix_stride % 8 == 0, "gs_stem_fwd_bn_pair: bad arguments");
+    GS_CHECK_ARG(act == GS_ACT_NONE || act == GS_ACT_RELU || act == GS_ACT_LEAKY02, "gs_stem_fwd_bn_pair: activation %d not supported", act);
+    SCArgs a{x, w, nullptr, (unsigned short*)z_hi, nullptr, N, 1, H, W, 64, H, W, 3, 1, 1, act};
+    a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.y_lo = (unsigned short*)z_lo; a.ys = z_pix_stride;
+    const int nb = gs_conv_smallcin_mtiles(N, H, W);
+    if (dtype == GS_F16) smallcin_fwd64_line_kernel<GS_F16, 2><<<nb, 256, 0, (hipStream_t)stream>>>(a);
+    else smallcin_fwd64_line_kernel<GS_BF16, 2><<<nb, 256, 0, (hipStream_t)stream>>>(a);
+    GS_CHECK_LAUNCH("gs_stem_fwd_bn_pair");
+    return GS_OK;
+}
+
 extern "C" int gs_stem_bwd_tiles(int N, int H, int W) {
     const int64_t M = (int64_t)N * H * W;
     return (N > 0 && H > 0 && W > 0) ? (int)cdiv64(M, stem_bwd_ppb(M)) : 0;
 }
 
+static int stem_bwd_onepass_impl(const float* x, const void* z, int z_stride, const void* dz, int dz_stride, int dz_coff, int act,
+                                 float* s1_partials, float* ws, int N, int H, int W, int dtype, void* stream);
 extern "C" int gs_stem_bwd_onepass(const float* x, const void* z, const void* dz, int dz_stride, int dz_coff, int act,
                                    float* s1_partials, float* ws, int N, int H, int W, int dtype, void* stream) {
-    GS_CHECK_ARG(x && z && dz && s1_partials && ws && N > 0 && H > 0 && W > 0 && (int64_t)N * H * W < 2147483647LL / 64,
+    return stem_bwd_onepass_impl(x, z, 64, dz, dz_stride, dz_coff, act, s1_partials, ws, N, H, W, dtype, stream);
+}
+// the same with the stored activation at a pixel stride (the hi plane of a [hi | lo] pair buffer)
+extern "C" int gs_stem_bwd_onepass_strided(const float* x, const void* z, int z_pix_stride, const void* dz, int dz_stride,
+                                           int dz_coff, int act, float* s1_partials, float* ws, int N, int H, int W, int dtype,
+                                           void* stream) {
+    GS_CHECK_ARG(z_pix_stride >= 64 && z_pix_stride % 8 == 0, "gs_stem_bwd_onepass_strided: bad z stride");
+    return stem_bwd_onepass_impl(x, z, z_pix_stride, dz, dz_stride, dz_coff, act, s1_partials, ws, N, H, W, dtype, stream);
+}
+static int stem_bwd_onepass_impl(const float* x, const void* z, int z_stride, const void* dz, int dz_stride, int dz_coff, int act,
+                                 float* s1_partials, float* ws, int N, int H, int W, int dtype, void* stream) {
+    GS_CHECK_ARG(x && z && dz && s1_partials && ws && N > 0 && H > 0 && W > 0 && (int64_t)N * H * W < 2147483647LL / z_stride,
                  "gs_stem_bwd_onepass: bad arguments");
     GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_stem_bwd_onepass: bad dtype");
     GS_CHECK_ARG(dz_stride % 8 == 0 && dz_coff % 8 == 0 && dz_stride >= dz_coff + 64, "gs_stem_bwd_onepass: bad gradient layout");
@@ -1430,6 +1471,7 @@ extern "C" int gs_stem_bwd_onepass(const float* x, const void* z, const void* dz
     SBWArgs a{};
     a.y = (const unsigned short*)z; a.dz = (const unsigned short*)dz; a.x = x; a.slabs = ws; a.partials = s1_partials;
     a.dz_stride = dz_stride; a.dz_coff = dz_coff; a.N = N; a.H = H; a.W = W; a.act = act; a.pix_per_block = ppb;
+    a.zs = z_stride;
     const int nb = (int)cdiv64(M, ppb);
     if (dtype == GS_F16) stem_bwd_onepass_kernel<GS_F16><<<nb, 256, lds, (hipStream_t)stream>>>(a);
     else stem_bwd_onepass_kernel<GS_BF16><<<nb, 256, lds, (hipStream_t)stream>>>(a);

@@ -179,58 +179,123 @@ struct ApplySArgs {
     int act, N, H, W, C, zs, zc, zps;
 };
 
-template <int DT, bool POOL>
+// Plain form: a thread owns ONE 8-channel chunk for the whole launch (scale / shift live in registers, no index divisions:
+// pixels are a flat range, y dense with stride C, z with stride zs) and keeps UNR pixels in flight -- 2 x UNR 16-byte loads
+// issued before the first use.  The first version (one element per grid-stride iteration, 64-bit div / mod per element,
+// coefficients re-loaded) ran the level-0 tensors at 3.1 TB/s of its four streams.  z_lo may be NULL (no consumer reads it).
+template <int DT, bool LO>
 __global__ __launch_bounds__(256) void bn_act_apply_split_kernel(const ApplySArgs a) {
+    constexpr int UNR = 4;
+    const float slope = a.act == GS_ACT_RELU ? 0.f : (a.act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
+    const int nch = a.C >> 3;                              // a power-of-two-free divisor of the thread count (host-checked)
+    const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int ch = (int)(gt % nch);
+    const int64_t pl = gt / nch, npl = ((int64_t)gridDim.x * 256) / nch;
+    const int c0 = ch * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sc[i] = a.scale ? a.scale[c0 + i] : 1.f; sh[i] = a.shift ? a.shift[c0 + i] : 0.f; }
+    const int64_t P = (int64_t)a.N * a.H * a.W;
+    const unsigned short* yh = a.y_hi + c0;
+    const unsigned short* yl = a.y_lo + c0;
+    unsigned short* zh = a.z_hi + a.zc + c0;
+    unsigned short* zl = LO ? a.z_lo + a.zc + c0 : nullptr;
+    for (int64_t p0 = pl; p0 < P; p0 += npl * UNR) {
+        uint4 vh[UNR], vl[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t p = p0 + u * npl;
+            if (p < P) {
+                vh[u] = *reinterpret_cast<const uint4*>(yh + p * a.C);
+                vl[u] = *reinterpret_cast<const uint4*>(yl + p * a.C);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t p = p0 + u * npl;
+            if (p < P) {
+                float v[8];
+                join8<DT>(vh[u], vl[u], v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float t = v[i] * sc[i] + sh[i];
+                    v[i] = t > 0.f ? t : t * slope;
+                }
+                if (LO) {
+                    uint4 hi, lo;
+                    split8<DT>(v, hi, lo);
+                    *reinterpret_cast<uint4*>(zh + p * a.zs) = hi;
+                    *reinterpret_cast<uint4*>(zl + p * a.zs) = lo;
+                } else {
+                    *reinterpret_cast<uint4*>(zh + p * a.zs) = pack8<DT>(v);
+                }
+            }
+        }
+    }
+}
+
+// Pooled form: a thread owns one chunk; units are 2x2 windows (32-bit index arithmetic), the four pixels of a window are
+// loaded before the first use.  The pooled pair is the maximum of the STORED pair values.
+template <int DT, bool LO>
+__global__ __launch_bounds__(256) void bn_act_apply_split_pool_kernel(const ApplySArgs a) {
     const float slope = a.act == GS_ACT_RELU ? 0.f : (a.act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
     const int nch = a.C >> 3;
-    const int PH = POOL ? (a.H + 1) / 2 : a.H, PW = POOL ? (a.W + 1) / 2 : a.W;
-    const int64_t total = (int64_t)a.N * PH * PW * nch;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(idx % nch);
-        int64_t pidx = idx / nch;
-        const int px = (int)(pidx % PW); pidx /= PW;
-        const int py = (int)(pidx % PH);
-        const int n = (int)(pidx / PH);
-        const int c0 = ch * 8;
-        float sc[8], sh[8];
+    const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int ch = (int)(gt % nch);
+    const int pl = (int)(gt / nch), npl = (int)(((int64_t)gridDim.x * 256) / nch);
+    const int c0 = ch * 8;
+    float sc[8], sh[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { sc[i] = a.scale ? a.scale[c0 + i] : 1.f; sh[i] = a.shift ? a.shift[c0 + i] : 0.f; }
+    for (int i = 0; i < 8; ++i) { sc[i] = a.scale ? a.scale[c0 + i] : 1.f; sh[i] = a.shift ? a.shift[c0 + i] : 0.f; }
+    const int PH = (a.H + 1) / 2, PW = (a.W + 1) / 2;
+    const int units = a.N * PH * PW;                       // host guarantees < 2^31
+    for (int u = pl; u < units; u += npl) {
+        const int px = u % PW;
+        const int r = u / PW;
+        const int py = r % PH, n = r / PH;
+        uint4 vh[4], vl[4];
+        bool ok[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int yy = 2 * py + (q >> 1), xx = 2 * px + (q & 1);
+            ok[q] = yy < a.H && xx < a.W;
+            if (ok[q]) {
+                const int64_t pix = ((int64_t)n * a.H + yy) * a.W + xx;
+                vh[q] = *reinterpret_cast<const uint4*>(a.y_hi + pix * a.C + c0);
+                vl[q] = *reinterpret_cast<const uint4*>(a.y_lo + pix * a.C + c0);
+            }
+        }
         float mx[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) mx[i] = -INFINITY;
 #pragma unroll
-        for (int dy = 0; dy < (POOL ? 2 : 1); ++dy)
+        for (int q = 0; q < 4; ++q) {
+            if (!ok[q]) continue;
+            const int yy = 2 * py + (q >> 1), xx = 2 * px + (q & 1);
+            const int64_t pix = ((int64_t)n * a.H + yy) * a.W + xx;
+            float v[8];
+            join8<DT>(vh[q], vl[q], v);
 #pragma unroll
-            for (int dx = 0; dx < (POOL ? 2 : 1); ++dx) {
-                const int yy = POOL ? 2 * py + dy : py, xx = POOL ? 2 * px + dx : px;
-                if (yy < a.H && xx < a.W) {
-                    const int64_t pix = ((int64_t)n * a.H + yy) * a.W + xx;
-                    float v[8];
-                    join8<DT>(*reinterpret_cast<const uint4*>(a.y_hi + pix * a.C + c0),
-                              *reinterpret_cast<const uint4*>(a.y_lo + pix * a.C + c0), v);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const float u = v[i] * sc[i] + sh[i];
-                        v[i] = u > 0.f ? u : u * slope;
-                    }
-                    uint4 hi, lo;
-                    split8<DT>(v, hi, lo);
-                    *reinterpret_cast<uint4*>(a.z_hi + pix * a.zs + a.zc + c0) = hi;
-                    *reinterpret_cast<uint4*>(a.z_lo + pix * a.zs + a.zc + c0) = lo;
-                    if (POOL) {
-                        float r[8];                          // pool the STORED pair values
-                        join8<DT>(hi, lo, r);
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) mx[i] = fmaxf(mx[i], r[i]);
-                    }
-                }
+            for (int i = 0; i < 8; ++i) {
+                const float t = v[i] * sc[i] + sh[i];
+                v[i] = t > 0.f ? t : t * slope;
             }
-        if (POOL && py < a.H / 2 && px < a.W / 2) {
+            uint4 hi, lo;
+            split8<DT>(v, hi, lo);
+            *reinterpret_cast<uint4*>(a.z_hi + pix * a.zs + a.zc + c0) = hi;
+            if (LO) *reinterpret_cast<uint4*>(a.z_lo + pix * a.zs + a.zc + c0) = lo;
+            float rr[8];
+            if (LO) join8<DT>(hi, lo, rr);
+            else unpack8<DT>(hi, rr);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mx[i] = fmaxf(mx[i], rr[i]);
+        }
+        if (py < a.H / 2 && px < a.W / 2) {
             const int64_t pp = ((int64_t)n * (a.H / 2) + py) * (a.W / 2) + px;
             uint4 hi, lo;
             split8<DT>(mx, hi, lo);
             *reinterpret_cast<uint4*>(a.zp_hi + pp * a.zps + c0) = hi;
-            *reinterpret_cast<uint4*>(a.zp_lo + pp * a.zps + c0) = lo;
+            if (a.zp_lo) *reinterpret_cast<uint4*>(a.zp_lo + pp * a.zps + c0) = lo;
         }
     }
 }
@@ -239,6 +304,8 @@ __global__ __launch_bounds__(256) void bn_act_apply_split_kernel(const ApplySArg
 struct HeadSArgs {
     const unsigned short* x_hi; const unsigned short* x_lo; const float* w; const float* bias; float* y;
     int N, HW, Cout;
+    const float* scale = nullptr; const float* shift = nullptr;      // BatchNorm + activation on the load path (x = a conv output pair)
+    int act = GS_ACT_NONE;
 };
 
 __device__ __forceinline__ float sum8_dpp_p(float v) {
@@ -259,10 +326,21 @@ __global__ __launch_bounds__(256) void head1x1_split_kernel(const HeadSArgs a) {
         for (int i = 0; i < 8; ++i) w[c][i] = c < a.Cout ? a.w[c * 64 + ch * 8 + i] : 0.f;
     }
     const int M = a.N * a.HW;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sc[i] = a.scale ? a.scale[ch * 8 + i] : 1.f; sh[i] = a.scale ? a.shift[ch * 8 + i] : 0.f; }
+    const float slope = a.act == GS_ACT_RELU ? 0.f : (a.act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
     for (int m = blockIdx.x * 32 + pl; m < M; m += gridDim.x * 32) {
         float v[8], s[4];
         join8<DT>(*reinterpret_cast<const uint4*>(a.x_hi + (int64_t)m * 64 + ch * 8),
                   *reinterpret_cast<const uint4*>(a.x_lo + (int64_t)m * 64 + ch * 8), v);
+        if (a.scale) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float t = v[i] * sc[i] + sh[i];
+                v[i] = t > 0.f ? t : t * slope;
+            }
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float t = 0.f;
@@ -350,39 +428,68 @@ extern "C" int gs_conv_smallcin_fwd_split(const float* x, const float* w, void* 
 extern "C" int gs_bn_act_apply_split(const void* y_hi, const void* y_lo, const float* scale, const float* shift, int act,
                                      void* z_hi, void* z_lo, int z_pix_stride, int z_coff, void* zp_hi, void* zp_lo,
                                      int zp_pix_stride, int N, int H, int W, int C, int dtype, void* stream) {
-    GS_CHECK_ARG(y_hi && y_lo && z_hi && z_lo && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "gs_bn_act_apply_split: bad arguments");
+    GS_CHECK_ARG(y_hi && y_lo && z_hi && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "gs_bn_act_apply_split: bad arguments");
     GS_CHECK_ARG(z_pix_stride >= z_coff + C && z_pix_stride % 8 == 0 && z_coff % 8 == 0, "gs_bn_act_apply_split: bad z stride");
     GS_CHECK_ARG((scale == nullptr) == (shift == nullptr), "gs_bn_act_apply_split: scale/shift must both be given or NULL");
-    GS_CHECK_ARG((zp_hi == nullptr) == (zp_lo == nullptr) && (zp_hi == nullptr || (zp_pix_stride >= C && zp_pix_stride % 8 == 0)),
+    GS_CHECK_ARG((zp_hi != nullptr || zp_lo == nullptr) && (zp_hi == nullptr || (zp_pix_stride >= C && zp_pix_stride % 8 == 0)),
                  "gs_bn_act_apply_split: bad pooled output");
     GS_CHECK_ARG(act == GS_ACT_NONE || act == GS_ACT_RELU || act == GS_ACT_LEAKY02, "gs_bn_act_apply_split: activation %d", act);
     GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_bn_act_apply_split: bad dtype");
+    GS_CHECK_ARG((int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) < 2147483000LL, "gs_bn_act_apply_split: too many pixels");
     ApplySArgs a{(const unsigned short*)y_hi, (const unsigned short*)y_lo, scale, shift, (unsigned short*)z_hi,
                  (unsigned short*)z_lo, (unsigned short*)zp_hi, (unsigned short*)zp_lo, act, N, H, W, C, z_pix_stride, z_coff,
                  zp_pix_stride};
-    const bool pool = zp_hi != nullptr;
+    const bool pool = zp_hi != nullptr, lo = z_lo != nullptr;
+    const int nch = C / 8;
+    // the grid's thread count must be a multiple of the chunk count (a thread keeps its chunk): blocks of 256 threads,
+    // nch | 256 * blocks
     const int PH = pool ? (H + 1) / 2 : H, PW = pool ? (W + 1) / 2 : W;
-    int64_t blocks = cdiv64((int64_t)N * PH * PW * (C / 8), 256);
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    const int64_t work = (int64_t)N * PH * PW * nch / (pool ? 1 : 4);
+    int64_t blocks = cdiv64(work, 256);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    int bq = 1;                                            // smallest block multiple with nch | 256 * bq
+    while ((256 * bq) % nch != 0) ++bq;
+    blocks = cdiv64(blocks, bq) * bq;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GS_F16) {
-        if (pool) bn_act_apply_split_kernel<GS_F16, true><<<(int)blocks, 256, 0, s>>>(a);
-        else bn_act_apply_split_kernel<GS_F16, false><<<(int)blocks, 256, 0, s>>>(a);
-    } else {
-        if (pool) bn_act_apply_split_kernel<GS_BF16, true><<<(int)blocks, 256, 0, s>>>(a);
-        else bn_act_apply_split_kernel<GS_BF16, false><<<(int)blocks, 256, 0, s>>>(a);
-    }
+#define GS_APPLY_SPLIT(DT)                                                                         \
+    do {                                                                                           \
+        if (pool) {                                                                                \
+            if (lo) bn_act_apply_split_pool_kernel<DT, true><<<(int)blocks, 256, 0, s>>>(a);       \
+            else bn_act_apply_split_pool_kernel<DT, false><<<(int)blocks, 256, 0, s>>>(a);         \
+        } else {                                                                                   \
+            if (lo) bn_act_apply_split_kernel<DT, true><<<(int)blocks, 256, 0, s>>>(a);            \
+            else bn_act_apply_split_kernel<DT, false><<<(int)blocks, 256, 0, s>>>(a);              \
+        }                                                                                          \
+    } while (0)
+    if (dtype == GS_F16) GS_APPLY_SPLIT(GS_F16);
+    else GS_APPLY_SPLIT(GS_BF16);
+#undef GS_APPLY_SPLIT
     GS_CHECK_LAUNCH("gs_bn_act_apply_split");
     return GS_OK;
 }
 
+static int head1x1_split_impl(const void* x_hi, const void* x_lo, const float* scale, const float* shift, int act, const float* w,
+                              const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
+// the head on a CONV OUTPUT pair with BatchNorm + activation on the load path: the last activation pair is never stored
+extern "C" int gs_head1x1_bn_fwd_split(const void* y_hi, const void* y_lo, const float* scale, const float* shift, int act,
+                                       const float* w, const float* bias, float* logits, int N, int H, int W, int Cin, int Cout,
+                                       int dtype, void* stream) {
+    GS_CHECK_ARG(scale && shift, "gs_head1x1_bn_fwd_split: scale / shift are NULL");
+    GS_CHECK_ARG(act == GS_ACT_NONE || act == GS_ACT_RELU || act == GS_ACT_LEAKY02, "gs_head1x1_bn_fwd_split: activation %d", act);
+    return head1x1_split_impl(y_hi, y_lo, scale, shift, act, w, bias, logits, N, H, W, Cin, Cout, dtype, stream);
+}
 extern "C" int gs_head1x1_fwd_split(const void* x_hi, const void* x_lo, const float* w, const float* bias, float* y, int N,
                                     int H, int W, int Cin, int Cout, int dtype, void* stream) {
+    return head1x1_split_impl(x_hi, x_lo, nullptr, nullptr, GS_ACT_NONE, w, bias, y, N, H, W, Cin, Cout, dtype, stream);
+}
+static int head1x1_split_impl(const void* x_hi, const void* x_lo, const float* scale, const float* shift, int act, const float* w,
+                              const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int dtype, void* stream) {
     GS_CHECK_ARG(x_hi && x_lo && w && y && N > 0 && H > 0 && W > 0, "gs_head1x1_fwd_split: bad arguments");
     GS_CHECK_ARG(Cin == 64 && Cout >= 1 && Cout <= 4, "gs_head1x1_fwd_split: Cin must be 64 and Cout 1..4");
     GS_CHECK_ARG((int64_t)N * H * W + 256 < 2147483647LL, "gs_head1x1_fwd_split: too many pixels");
     GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_head1x1_fwd_split: bad dtype");
     HeadSArgs a{(const unsigned short*)x_hi, (const unsigned short*)x_lo, w, bias, y, N, H * W, Cout};
+    a.scale = scale; a.shift = shift; a.act = act;
     int64_t hb = cdiv64((int64_t)N * H * W, 32);
     if (hb > 8192) hb = 8192;
     hipStream_t s = (hipStream_t)stream;

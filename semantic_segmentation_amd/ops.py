@@ -602,18 +602,19 @@ def stem_stats(x, w, bn_partials, tap_sums=None):
     _lib.call("gs_stem_stats", _p(x), _p(w), _p(bn_partials), _p(tap_sums), N, H, W, _stream())
 
 
-def stem_bwd_onepass(x, z, dz, dz_stride, dz_coff, act, s1_partials, ws) -> bool:
+def stem_bwd_onepass(x, z, dz, dz_stride, dz_coff, act, s1_partials, ws, z_stride=64) -> bool:
     """One pass over z (its sign = the activation's mask) and dz: s1_partials [stem_bwd_tiles][64] (sum g) and the slabs of
-    A = sum g x_tap in ws [stem_bwd_tiles][576].  False: image too wide for the LDS strip."""
+    A = sum g x_tap in ws [stem_bwd_tiles][576].  False: image too wide for the LDS strip.  z: dense [N,H,W,64], or (z_stride
+    > 64) the first 64 channels of a wider buffer, e.g. the hi plane of a pair."""
     _dev(x)
     _f32(x, "x"); _f32(s1_partials, "s1_partials"); _f32(ws, "ws")
     N, H, W = x.shape[0], x.shape[2], x.shape[3]
     nt = stem_bwd_tiles(N, H, W)
     if (x.shape[1] != 1 or not x.is_contiguous() or s1_partials.numel() < nt * 64 or ws.numel() < nt * 576
-            or tuple(z.shape) != (N, H, W, 64) or not z.is_contiguous() or z.dtype != dz.dtype):
-        raise ValueError("stem_bwd_onepass: x [N,1,H,W], z dense [N,H,W,64], buffers of stem_bwd_tiles * 64 / 576 floats")
-    rc = _lib.load().gs_stem_bwd_onepass(_p(x), _p(z), _p(dz), dz_stride, dz_coff, act, _p(s1_partials), _p(ws), N, H, W,
-                                         dt_code(z), _stream())
+            or tuple(z.shape) != (N, H, W, z_stride) or not z.is_contiguous() or z.dtype != dz.dtype or z_stride % 8 or z_stride < 64):
+        raise ValueError("stem_bwd_onepass: x [N,1,H,W], z dense [N,H,W,z_stride], buffers of stem_bwd_tiles * 64 / 576 floats")
+    rc = _lib.load().gs_stem_bwd_onepass_strided(_p(x), _p(z), z_stride, _p(dz), dz_stride, dz_coff, act, _p(s1_partials), _p(ws),
+                                                 N, H, W, dt_code(z), _stream())
     if rc == _lib.GS_EUNSUPPORTED:
         return False
     if rc != 0:
@@ -640,6 +641,16 @@ def stem_fwd_bn(x, w, scale, shift, act, z):
     if tuple(z.shape) != (N, H, W, 64) or not z.is_contiguous():
         raise ValueError("stem_fwd_bn: z must be dense [N,H,W,64]")
     _lib.call("gs_stem_fwd_bn", _p(x), _p(w), _p(scale), _p(shift), act, _p(z), N, H, W, dt_code(z), _stream())
+
+
+def stem_fwd_bn_pair(x, w, scale, shift, act, zpair, write_lo=True):
+    """The stem in one pass into a pair buffer zpair [N,H,W,128] = [hi (64) | lo (64)]; write_lo=False leaves the lo plane alone."""
+    N, H, W = _stem_check(x, w, "stem_fwd_bn_pair")
+    _f32(scale, "scale"); _f32(shift, "shift")
+    if tuple(zpair.shape) != (N, H, W, 128) or not zpair.is_contiguous():
+        raise ValueError("stem_fwd_bn_pair: zpair must be dense [N,H,W,128]")
+    lo = zpair.data_ptr() + 64 * zpair.element_size() if write_lo else None
+    _lib.call("gs_stem_fwd_bn_pair", _p(x), _p(w), _p(scale), _p(shift), act, _p(zpair), lo, 128, N, H, W, dt_code(zpair), _stream())
 
 
 def stem_bwd_tiles(N, H, W) -> int:
@@ -1176,6 +1187,19 @@ def bn_act_apply_split(y_hi, y_lo, scale, shift, act, z_hi, z_lo, z_stride, z_co
     _f32(scale, "scale"); _f32(shift, "shift")
     _lib.call("gs_bn_act_apply_split", _p(y_hi), _p(y_lo), _p(scale), _p(shift), act, _p(z_hi), _p(z_lo), z_stride, z_coff,
               _p(zp_hi), _p(zp_lo), zp_stride, N, H, W, C, dt_code(y_hi), _stream())
+
+
+def head1x1_bn_fwd_split(y_hi, y_lo, scale, shift, act, w, bias, logits):
+    """OutConv 1x1 on act(scale * (y_hi + y_lo) + shift) of a dense conv-output pair [N,H,W,64] -> fp32 NCHW logits."""
+    _dev(y_hi)
+    _f32(scale, "scale"); _f32(shift, "shift"); _f32(w, "w"); _f32(bias, "bias"); _f32(logits, "logits")
+    N, H, W, C = y_hi.shape
+    ncls = logits.shape[1]
+    if (C != 64 or y_lo.shape != y_hi.shape or tuple(logits.shape) != (N, ncls, H, W) or w.numel() != ncls * 64
+            or not (y_hi.is_contiguous() and y_lo.is_contiguous() and logits.is_contiguous())):
+        raise ValueError("head1x1_bn_fwd_split: y pair [N,H,W,64] dense, logits [N,ncls,H,W], w [ncls,64]")
+    _lib.call("gs_head1x1_bn_fwd_split", _p(y_hi), _p(y_lo), _p(scale), _p(shift), act, _p(w), _p(bias), _p(logits), N, H, W, 64,
+              ncls, dt_code(y_hi), _stream())
 
 
 def head1x1_fwd_split(x_hi, x_lo, w, bias, y):

@@ -115,15 +115,18 @@ def resolve_plan(precise, dtype: str):
     raise ValueError("precise must be False, True, 'mixed' or a {stage: mode} dict")
 
 
-def _segs(mode: str, cin: int):
-    """(segment list for pack_weight_segs, K extent, input wrap) of a stage reading a [hi | lo] pair of cin channels"""
+def _segs(mode: str, cin: int, lo_len=None):
+    """(segment list for pack_weight_segs, K extent, input wrap) of a stage reading a [hi | lo] pair of cin channels.  lo_len:
+    only the first lo_len channels of the lo plane are valid (a concat buffer whose up half was written hi-only): the x_lo
+    segment then covers those alone -- the input is read as [hi (cin) | lo (lo_len)] and wraps to the hi plane for w_lo."""
+    ll = cin if lo_len is None else lo_len
     if mode == "1":
         return [(0, 0, cin)], cin, cin
     if mode == "x":
-        return [(0, 0, cin), (0, 0, cin)], 2 * cin, 2 * cin
+        return [(0, 0, cin), (0, 0, ll)], cin + ll, cin + ll
     if mode == "w":
         return [(0, 0, cin), (1, 0, cin)], 2 * cin, cin
-    return [(0, 0, cin), (0, 0, cin), (1, 0, cin)], 3 * cin, 2 * cin
+    return [(0, 0, cin), (0, 0, ll), (1, 0, cin)], 2 * cin + ll, cin + ll
 
 
 class UNetEngine:
@@ -475,6 +478,7 @@ class UNetEngine:
         """Segment packs of the pair forward ([taps][Cout][K], K = the stage's concatenation of hi / lo segments), every
         stale one re-packed in ONE launch; cached until the Parameter is modified."""
         items, fresh = [], []
+        full = all(v == "xw" for v in self.plan.values())
         for st in STAGES:
             mode = self.plan[st]
             if st.endswith(".up"):
@@ -489,11 +493,17 @@ class UNetEngine:
             cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
             if cin % 8 != 0:                               # the image-end layer is not packed
                 continue
-            key = (_pack_key(w), mode)
+            lo_len = None
+            if not full:
+                if transposed and mode == "1":
+                    continue                               # runs on the default LDS-DMA GEMM with the ordinary pack
+                if st.endswith(".conv.0") and self.plan[st[:-len(".conv.0")] + ".up"] == "1":
+                    lo_len = cin // 2                      # the up half of the concat buffer carries no lo plane
+            key = (_pack_key(w), mode, lo_len)
             ent = self._packs.get(wkey + "|segs")
             if ent is not None and ent[0] == key:
                 continue
-            segs, K, _ = _segs(mode, cin)
+            segs, K, _ = _segs(mode, cin, lo_len)
             pack = torch.empty((w.shape[2] * w.shape[3], cout, K), dtype=self.tdt, device=w.device)
             items.append((w.detach().contiguous(), pack, transposed, segs))
             fresh.append((wkey, key, pack))
@@ -506,12 +516,17 @@ class UNetEngine:
         return self._packs[wkey + "|segs"][1]
 
     def forward_precise(self, x: torch.Tensor, params: Dict[str, torch.Tensor], training: bool, need_grad: bool):
-        """The same network with every activation and weight carried as a PAIR of 16-bit values v = hi + lo
-        (hi = 16-bit(v), lo = 16-bit(v - hi): ~22 significand bits in fp16).  The MFMA contractions run over the K
-        concatenation [x_hi | x_lo | x_hi] . [w_hi | w_hi | w_lo] -- exact products, one fp32 accumulator, 3x the MFMA work
-        of the forward convolutions -- and BatchNorm / ReLU / max-pool / the head read and write pairs.  Measured against
-        the fp32 reference (unet/unet_model.py:26-37): max |dlogit| ~1e-5 instead of ~4e-3 (tools/parity_attribution.py
-        shows that the 16-bit error comes from the full-resolution stages, so a precise *tail* alone buys nothing).
+        """The pair forward: every activation and conv output travels as a PAIR of 16-bit values v = hi + lo (hi = 16-bit(v),
+        lo = 16-bit(v - hi): ~22 significand bits in fp16); BatchNorm / ReLU / max-pool / the head read and write pairs.  The
+        MFMA contraction of a stage runs over a K concatenation of SEGMENTS chosen by `self.plan` (exact products, one fp32
+        accumulator): "xw" = [x_hi | x_lo | x_hi] . [w_hi | w_hi | w_lo] (3x the MFMA work), "x" / "w" two of them, "1" = x_hi . w_hi.
+          precise=True    every stage "xw": max |dlogit| ~1e-5 against the fp32 reference (unet/unet_model.py:26-37).
+          precise="mixed" "xw" on the nine stages that make the 16-bit error (MIXED_XW; tools/parity_attribution.py), "1"
+                          elsewhere: max |dlogit| 5e-4 .. 7e-4 -- the north star's 1e-3 -- for half the extra MFMA work.
+        In a plan that is not all-"xw": the one-channel stem runs as in the default engine (statistics from the image, conv +
+        BatchNorm + ReLU in one pass -> z pair, conv output never stored); a "1" transposed conv runs on the LDS-DMA GEMM
+        and writes the hi plane only (the consumer's x_lo segment then covers the skip half alone); the head reads the last
+        stage's conv-output pair with BatchNorm + ReLU on its load path; lo planes nobody reads are not written.
 
         HBM layout: a pair buffer is [N,h,w,2*Ct] = [hi plane (Ct) | lo plane (Ct)]; for the concat levels Ct = 2C with
         skip in channels [0,C) and the up-sampled tensor in [C,2C) of EACH plane.  Raw conv outputs are two dense tensors.
@@ -531,10 +546,11 @@ class UNetEngine:
         ws_ = [W >> i for i in range(5)]
         C = [64, 128, 256, 512, 1024]
         plan = self.plan
+        full = all(v == "xw" for v in plan.values())
         if not pack_reuse_allowed(need_grad, self.trust_versions):
             self._packs.clear()                            # `.data` writes are invisible to the version keys
-        if need_grad:
-            self._prepack(params, True)                    # the backward's data-gradient packs, one launch
+        if need_grad or not full:
+            self._prepack(params, need_grad)               # the backward's data-gradient packs / the "1" up-convs' packs, one launch
         self._prepack_segs(params)                         # the forward's segment packs, one launch
 
         def empty(*shape, dtype=tdt):
@@ -543,25 +559,11 @@ class UNetEngine:
         recs: List[_ConvRec] = []
         ups: List[_UpRec] = []
 
-        def stage(prefix, idx, inp, cin, cout, h, w, z_hi, z_lo, z_stride, zp_hi=None, zp_lo=None, zp_stride=0,
-                  image=False):
-            """prefix.double_conv.{idx} conv + BN + ReLU on pairs; inp: fp32 image or a pair buffer [N,h,w,2*cin]."""
-            wkey, bnkey = f"{prefix}.double_conv.{idx}.weight", f"{prefix}.double_conv.{idx + 1}"
-            wparam = params[wkey]
-            y_hi, y_lo = empty(N, h, w, cout), empty(N, h, w, cout)
-            rm = bufs.get(bnkey + ".running_mean")
-            batch_stats = training or rm is None
-            ntiles = ops.conv_smallcin_mtiles(N, h, w) if image else ops.conv3x3_mtiles(N, h, w, cout)
-            partials = empty(ops.bn_partials_numel(ntiles, cout), dtype=torch.float32) if batch_stats else None
-            if image:
-                ops.conv_smallcin_fwd_split(inp, wparam.detach().contiguous(), y_hi, y_lo, partials, 3, 1)
-            else:
-                _, K, wrap = _segs(plan[prefix.replace(".maxpool_conv.1", "") + f".{idx}"], cin)
-                ops.conv3x3_segs(inp, self._seg_pack(wkey), y_hi, y_lo, N, h, w, K, wrap, cin, cout, in_stride=2 * cin,
-                                 bn_partials=partials)
+        def bn_coef(bnkey, partials, ntiles, cout, count, batch_stats):
             coef = empty(4, cout, dtype=torch.float32)
             gamma, beta = params[bnkey + ".weight"], params[bnkey + ".bias"]
             bn_mod = self.submodule(bnkey)
+            rm = bufs.get(bnkey + ".running_mean")
             if batch_stats:
                 nbt = bufs.get(bnkey + ".num_batches_tracked")
                 mom = bn_mod.momentum
@@ -573,22 +575,70 @@ class UNetEngine:
                 if mom is None:
                     mom = 1.0 / float(nbt.item()) if nbt is not None else 0.0
                 upd = training and rm is not None
-                ops.bn_finalize(partials, ntiles, cout, N * h * w, gamma.detach(), beta.detach(), rm if upd else None,
+                ops.bn_finalize(partials, ntiles, cout, count, gamma.detach(), beta.detach(), rm if upd else None,
                                 bufs.get(bnkey + ".running_var") if upd else None, mom, bn_mod.eps,
                                 coef[0], coef[1], coef[2], coef[3])
             else:
                 ops.bn_eval_coeffs(cout, gamma.detach(), beta.detach(), rm, bufs[bnkey + ".running_var"], bn_mod.eps,
                                    coef[0], coef[1], coef[2], coef[3])
-            ops.bn_act_apply_split(y_hi, y_lo, coef[0], coef[1], ACT_RELU, z_hi, z_lo, z_stride, 0, zp_hi, zp_lo, zp_stride)
+            return coef
+
+        def stage(prefix, idx, inp, cin, cout, h, w, zbuf, z_stride, want_lo, zp=None, zp_want_lo=False, image=False,
+                  lo_len=None, to_head=False):
+            """prefix.double_conv.{idx} conv + BN + ReLU on pairs.  inp: fp32 image or a pair buffer [N,h,w,2*cin]; the z pair
+            goes to channels [0,cout) / [z_stride/2, z_stride/2 + cout) of zbuf (pixel stride z_stride), the lo plane only when
+            a consumer reads it; zp: pooled pair buffer [.., 2*cout].  to_head: BatchNorm + ReLU are left to the head's load
+            path (returns the record; nothing stored).  lo_len: leading channels of the input's lo plane that are valid."""
+            short = prefix.replace(".maxpool_conv.1", "") + f".{idx}"
+            wkey, bnkey = f"{prefix}.double_conv.{idx}.weight", f"{prefix}.double_conv.{idx + 1}"
+            wparam = params[wkey]
+            rm = bufs.get(bnkey + ".running_mean")
+            batch_stats = training or rm is None
+            rec = _ConvRec()
+            rec.name, rec.wkey, rec.bnkey = f"{prefix}.{idx}", wkey, bnkey
+            rec.cin, rec.cout, rec.h, rec.w, rec.inp_is_image = cin, cout, h, w, image
+            rec.inp, rec.train_stats, rec.geom, rec.z, rec.tap_sums = inp, batch_stats, None, None, None
+            rec.inp_stride = None if image else 2 * cin
+            ntiles = ops.conv_smallcin_mtiles(N, h, w) if image else ops.conv3x3_mtiles(N, h, w, cout)
+            partials = empty(ops.bn_partials_numel(ntiles, cout), dtype=torch.float32) if batch_stats else None
+            z_lo = zbuf[..., z_stride // 2:] if (zbuf is not None and want_lo) else None
+            if (image and not full and FUSED_STEM_FWD and cin == 1 and cout == 64 and zp is None and z_stride == 2 * cout
+                    and inp.is_contiguous()):
+                # one-channel stem as in the default engine: statistics from the image, one pass writes the z pair
+                wst = wparam.detach().contiguous()
+                if need_grad:
+                    rec.tap_sums = (empty(ntiles * 54, dtype=torch.float32) if batch_stats
+                                    else torch.zeros(ntiles * 54, dtype=torch.float32, device=dev))
+                if batch_stats:
+                    ops.stem_stats(inp, wst, partials, rec.tap_sums)
+                coef = bn_coef(bnkey, partials, ntiles, cout, N * h * w, batch_stats)
+                ops.stem_fwd_bn_pair(inp, wst, coef[0], coef[1], ACT_RELU, zbuf, write_lo=want_lo)
+                rec.y, rec.coef, rec.z, rec.wd = None, coef, zbuf, None
+                if need_grad:
+                    recs.append(rec)
+                return rec
+            y_hi, y_lo = empty(N, h, w, cout), empty(N, h, w, cout)
+            if image:
+                ops.conv_smallcin_fwd_split(inp, wparam.detach().contiguous(), y_hi, y_lo, partials, 3, 1)
+            else:
+                _, K, wrap = _segs(plan[short], cin, lo_len)
+                ops.conv3x3_segs(inp, self._seg_pack(wkey), y_hi, y_lo, N, h, w, K, wrap, cin, cout, in_stride=2 * cin,
+                                 bn_partials=partials)
+            coef = bn_coef(bnkey, partials, ntiles, cout, N * h * w, batch_stats)
+            rec.y, rec.coef = y_hi, coef
+            rec.wd = None if image else (self._packed(wkey, wparam, False, True)[1] if need_grad else None)
             if need_grad:
-                rec = _ConvRec()
-                rec.name, rec.wkey, rec.bnkey = f"{prefix}.{idx}", wkey, bnkey
-                rec.cin, rec.cout, rec.h, rec.w, rec.inp_is_image = cin, cout, h, w, image
-                rec.inp, rec.y, rec.coef, rec.train_stats = inp, y_hi, coef, batch_stats
-                rec.inp_stride = None if image else 2 * cin
-                rec.geom = None
-                rec.wd = None if image else self._packed(wkey, wparam, False, True)[1]
                 recs.append(rec)
+            if to_head:
+                return rec, y_lo
+            zp_hi = zp if zp is not None else None
+            zp_lo = zp[..., zp.shape[3] // 2:] if (zp is not None and zp_want_lo) else None
+            ops.bn_act_apply_split(y_hi, y_lo, coef[0], coef[1], ACT_RELU, zbuf, z_lo, z_stride, 0, zp_hi, zp_lo,
+                                   0 if zp is None else zp.shape[3])
+            return rec
+
+        def reads_lo(st):                                   # does stage `st` run an x_lo segment?
+            return "x" in plan[st]
 
         # ---- encoder ----
         cats = [None] * 4
@@ -599,18 +649,18 @@ class UNetEngine:
         inp, cin = x, net.n_channels
         for i in range(5):
             prefix = "inc" if i == 0 else f"down{i}.maxpool_conv.1"
+            blk = "inc" if i == 0 else f"down{i}"
             h, w = hs[i], ws_[i]
             zmid = empty(N, h, w, 2 * C[i])
-            stage(prefix, 0, inp, cin, C[i], h, w, zmid, zmid[..., C[i]:], 2 * C[i], image=(i == 0))
+            stage(prefix, 0, inp, cin, C[i], h, w, zmid, 2 * C[i], reads_lo(blk + ".3"), image=(i == 0))
             if i < 4:
                 pooled = empty(N, hs[i + 1], ws_[i + 1], 2 * C[i])
-                cat = cats[i]
-                stage(prefix, 3, zmid, C[i], C[i], h, w, cat, cat[..., 2 * C[i]:], 4 * C[i],
-                      pooled, pooled[..., C[i]:], 2 * C[i])
+                stage(prefix, 3, zmid, C[i], C[i], h, w, cats[i], 4 * C[i], reads_lo(f"up{4 - i}.conv.0"),
+                      zp=pooled, zp_want_lo=reads_lo(f"down{i + 1}.0"))
                 inp, cin = pooled, C[i]
             else:
                 x5 = empty(N, h, w, 2 * C[i])
-                stage(prefix, 3, zmid, C[i], C[i], h, w, x5, x5[..., C[i]:], 2 * C[i])
+                stage(prefix, 3, zmid, C[i], C[i], h, w, x5, 2 * C[i], reads_lo("up1.up"))
                 inp = x5
 
         # ---- decoder ----
@@ -624,10 +674,19 @@ class UNetEngine:
             pt, pl = (H2 - 2 * h) // 2, (W2 - 2 * w) // 2
             cat = cats[lvl]
             wkey = prefix + ".up.weight"
-            _, K, wrap = _segs(plan[prefix + ".up"], cin_t)
-            ops.upconv2x2_fwd_segs(inp, self._seg_pack(wkey), params[prefix + ".up.bias"].detach(),
-                                   cat[..., cout_t:], cat[..., 3 * cout_t:], N, h, w, K, wrap, cin_t, cout_t, H2, W2,
-                                   in_stride=2 * cin_t, out_stride=4 * cout_t, ooy=pt, oox=pl)
+            up_mode = plan[prefix + ".up"]
+            up_lo_valid = True
+            if up_mode == "1" and not full:
+                # x_hi . w_hi on the LDS-DMA pointwise GEMM, hi plane only: the consumer's x_lo segment skips the up half
+                wf, _ = self._packed(wkey, params[wkey], True, need_grad)
+                ops.upconv2x2_fwd(inp, wf, params[prefix + ".up.bias"].detach(), cat, N, 1, h, w, cin_t, cout_t, 1, H2, W2,
+                                  in_stride=2 * cin_t, out_stride=4 * cout_t, out_coff=cout_t, ooy=pt, oox=pl)
+                up_lo_valid = False
+            else:
+                _, K, wrap = _segs(up_mode, cin_t)
+                ops.upconv2x2_fwd_segs(inp, self._seg_pack(wkey), params[prefix + ".up.bias"].detach(),
+                                       cat[..., cout_t:], cat[..., 3 * cout_t:], N, h, w, K, wrap, cin_t, cout_t, H2, W2,
+                                       in_stride=2 * cin_t, out_stride=4 * cout_t, ooy=pt, oox=pl)
             if need_grad:
                 u = _UpRec()
                 u.name, u.zin, u.cat = prefix, inp, cat
@@ -642,19 +701,31 @@ class UNetEngine:
                                           in_stride=2 * cout_t, in_coff=cout_t, out_stride=2 * cin_t)
                 ups.append(u)
             zmid = empty(N, H2, W2, 2 * cout_t)
-            stage(prefix + ".conv", 0, cat, 2 * cout_t, cout_t, H2, W2, zmid, zmid[..., cout_t:], 2 * cout_t)
+            stage(prefix + ".conv", 0, cat, 2 * cout_t, cout_t, H2, W2, zmid, 2 * cout_t, reads_lo(prefix + ".conv.3"),
+                  lo_len=None if up_lo_valid else cout_t)
             if j < 4:
                 zout = empty(N, H2, W2, 2 * cout_t)
-                stage(prefix + ".conv", 3, zmid, cout_t, cout_t, H2, W2, zout, zout[..., cout_t:], 2 * cout_t)
+                stage(prefix + ".conv", 3, zmid, cout_t, cout_t, H2, W2, zout, 2 * cout_t, reads_lo(f"up{j + 1}.up"))
                 inp = zout
+            elif not full and FUSED_HEAD_FWD and cout_t == 64 and net.n_classes <= 4:
+                # last stage: its activation has one reader, the head, which applies BatchNorm + ReLU on its own load path
+                last_rec, y_lo_last = stage(prefix + ".conv", 3, zmid, cout_t, cout_t, H2, W2, None, 0, False, to_head=True)
             else:                                  # last stage: two dense planes (the head and its backward read dense tensors)
-                zl_hi, zl_lo = empty(N, H2, W2, cout_t), empty(N, H2, W2, cout_t)
-                stage(prefix + ".conv", 3, zmid, cout_t, cout_t, H2, W2, zl_hi, zl_lo, cout_t)
+                zl = empty(2, N, H2, W2, cout_t)
+                zl_hi, zl_lo = zl[0], zl[1]
+                last_rec = None
+                st_rec = stage(prefix + ".conv", 3, zmid, cout_t, cout_t, H2, W2, None, 0, False, to_head=True)
+                ops.bn_act_apply_split(st_rec[0].y, st_rec[1], st_rec[0].coef[0], st_rec[0].coef[1], ACT_RELU, zl_hi, zl_lo,
+                                       cout_t, 0)
                 z_last = zl_hi
 
         logits = empty(N, net.n_classes, H, W, dtype=torch.float32)
-        ops.head1x1_fwd_split(zl_hi, zl_lo, params["outc.conv.weight"].detach().contiguous(),
-                              params["outc.conv.bias"].detach(), logits)
+        if z_last is None:
+            ops.head1x1_bn_fwd_split(last_rec.y, y_lo_last, last_rec.coef[0], last_rec.coef[1], ACT_RELU,
+                                     params["outc.conv.weight"].detach().contiguous(), params["outc.conv.bias"].detach(), logits)
+        else:
+            ops.head1x1_fwd_split(zl_hi, zl_lo, params["outc.conv.weight"].detach().contiguous(),
+                                  params["outc.conv.bias"].detach(), logits)
         if nbt_pending:
             torch._foreach_add_(nbt_pending, 1)
         ctx = None
@@ -824,7 +895,7 @@ class UNetEngine:
                     nts = ops.stem_bwd_tiles(N, h, w)
                     sws = empty(nts * 576, dtype=torch.float32)
                     s1p = empty(nts * 64, dtype=torch.float32)
-                    if ops.stem_bwd_onepass(rec.inp, rec.z, dz_a, sa, ca, ACT_RELU, s1p, sws):
+                    if ops.stem_bwd_onepass(rec.inp, rec.z, dz_a, sa, ca, ACT_RELU, s1p, sws, z_stride=rec.z.shape[3]):
                         dgamma = galloc(rec.bnkey + ".weight", params[rec.bnkey + ".weight"])
                         dbeta = galloc(rec.bnkey + ".bias", params[rec.bnkey + ".bias"])
                         dw = galloc(rec.wkey, params[rec.wkey], zero=True)
