@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 40
+#define GS_ABI_VERSION 41
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -107,13 +107,22 @@ int gs_upconv2x2_dgrad(const void* dy, const void* wd, void* dx, int N, int IH, 
 /* ---- 3x3 / stride 1 / pad 1 convolution with LDS halo reuse (the U-Net DoubleConv hot loop,
  * unet_parts.py:16,19) and its data gradient (pass flipped taps and the [9][Cin][Cout] pack).
  * Same operands as gs_conv_igemm; tap t reads input pixel (y + tap_dy[t], x + tap_dx[t]), offsets in [-1,1];
- * bn_partials is [gs_conv3x3_mtiles][2][Cout] (one tile per spatial patch). */
+ * bn_partials: a buffer of gs_conv3x3_mtiles() rows of [2][Cout] fp32 always suffices; the launch WRITES
+ * gs_conv3x3_stat_rows() rows -- one per block and cout-tile group on the LDS-DMA kernel (which keeps its sums in registers
+ * across the items of a block), one per spatial patch on the others and in the pair forward -- and that is the row count
+ * gs_bn_finalize / gs_bn_partials_colsum must be given.  (gs_conv3x3_stat_rows assumes the forward or flipped tap table and
+ * channel strides / offsets that are multiples of 8; a launch with partials outside that fails with GS_EINVAL.) */
 int gs_conv3x3_mtiles(int N, int H, int W, int Cout);
-/* Diagnostics (process-wide, not part of the data path): which form of the 2-D kernel gs_conv3x3 launches where several
- * apply: -1 chosen by CU fill (default), 0 the register-staged big-K-step kernel, 4 / 8 the LDS-DMA kernel with that many
- * waves per block, 2 two 4-wave LDS-DMA blocks per CU, 16 / 32 the 8-wave form with 128 couts per item and 16- / 32-channel
- * stages (layers with Cout % 128 == 0, others fall to 8).  Every form computes the same sums in a form-specific order. */
+int gs_conv3x3_stat_rows(int N, int H, int W, int Cin, int Cout, int pair);
+/* Diagnostics (process-wide, not part of the data path): which form of the kernel gs_conv3x3 launches where several apply:
+ * -1 chosen by CU fill (default), 0 the register-staged big-K-step kernel, 4 / 8 the LDS-DMA kernel with that many waves per
+ * block.  Every form computes the same sums in a form-specific order. */
 int gs_conv3x3_set_kernel_form(int form);
+/* Persistent-kernel grids (conv3x3, and the kernels that read gs_get_persistent_grid): at most `blocks` workgroups instead of
+ * one per CU (256) -- data-parallel runs leave CUs to RCCL's kernels, which otherwise wait for a 152 KB-LDS block to retire.
+ * 0 restores the default (GSSEG_C3_GRID or 256).  Changes gs_conv3x3_stat_rows(): set it before planning buffers. */
+int gs_set_persistent_grid(int blocks);
+int gs_get_persistent_grid(void);
 int gs_conv3x3(const void* x, const void* w, void* y, const float* bias, float* bn_partials, int N, int H, int W,
                int Cin, int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff,
                const int32_t* tap_dy, const int32_t* tap_dx, int act, int dtype, void* stream);

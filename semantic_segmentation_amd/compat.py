@@ -25,8 +25,10 @@ def _callers_package(name):
     mod = sys.modules.get(name)
     if mod is not None and not _is_ours(mod) and getattr(mod, "__path__", None):
         return mod
-    if mod is not None and (_is_ours(mod) or not getattr(mod, "__path__", None)):
-        del sys.modules[name]              # an earlier stub / our namesake: look at sys.path again
+    if mod is not None and not _is_ours(mod) and not getattr(mod, "__is_gsseg_stub__", False):
+        return None                        # the caller's own single-file module of that name: never evict it
+    if mod is not None:
+        del sys.modules[name]              # an earlier stub of ours / our namesake: look at sys.path again
     try:
         spec = importlib.util.find_spec(name)
     except (ImportError, ValueError):
@@ -54,10 +56,16 @@ def install(force: bool = True) -> None:
     put("unet.evaluate", _evaluate)
 
     util = _callers_package("util")
-    if util is None:
+    foreign_file = sys.modules.get("util")
+    if util is None and foreign_file is not None and not _is_ours(foreign_file):
+        # the caller has a single-file `util.py`: it stays what `import util` gives; only `util.dice_score` is added
+        # (as a sys.modules entry and as an attribute), `from util import X` keeps working
+        util = foreign_file
+    elif util is None:
         # no `util` package anywhere on sys.path: provide a bare one so `import util.dice_score` resolves
         util = types.ModuleType("util")
         util.__path__ = []
+        util.__is_gsseg_stub__ = True
         sys.modules["util"] = util
     if force or "util.dice_score" not in sys.modules:
         sys.modules["util.dice_score"] = _dice

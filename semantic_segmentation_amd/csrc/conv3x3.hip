@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "conv3x3_args.hpp"
 
 // K loop of the big kernel: one LDS fragment read in the shadow of every MFMA (sched_group_barrier pattern) instead of the
 // four reads + prefetch load as a block in front of four MFMAs: +1.3 % over the 13 layer shapes (5.23 -> 5.16 ms), same
@@ -28,34 +29,12 @@
 
 namespace {
 
-struct C3Args {
-    const unsigned short* x;
-    const unsigned short* w;      // [9][Cout][Cin]
-    unsigned short* y;
-    const float* bias;
-    float* bnp;                   // [npatches][2][Cout]
-    int act;
-    int N, H, W, Cin, in_stride, in_coff, Cout, out_stride, out_coff;
-    int tiles_x, tiles_y, ntn, nblocks;
-    int tap_dy[9], tap_dx[9];
-    // 3-D (3x3x3) convolution: images are the N = volumes*D depth slices; stage (dz index, channel chunk) reads slice
-    // n + tap_dz and the weight slots [dzi*9 .. dzi*9+8].  2-D: D = 1, ndz = 1, tap_dz = {0}.
-    int D, ndz, tap_dz[3];
-    // precise mode (conv3x3_big_kernel<.., PREC>): the K extent Cin is a concatenation of segments over the same input
-    // channels -- K chunk c reads input chunk (c >= in_wrap ? c - in_wrap : c) -- and the result is stored as a 16-bit
-    // hi/lo pair: hi at y, lo = 16-bit(value - hi) at y_lo (same stride / offset).
-    unsigned short* y_lo;
-    int in_wrap;                  // in 64-channel chunks; 0 = no wrap
-    int xcd_order;                // big kernel: XCD-aware item order (grid must be a multiple of 8)
-};
-
 __device__ __forceinline__ int xcd_remap3(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + (bid >> 3);
 }
 
-constexpr int C3_LDR = 72;
 
 template <int DT, int BN, int TW>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const C3Args a) {
@@ -254,9 +233,6 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const C3Args a) {
 // tile through a small LDS staging area (packed pairs via DPP + v_perm, ds_write_b32 / ds_read_b128) and
 // writes whole 128-byte channel rows with 16-byte stores instead of 64 two-byte stores per lane.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned int dpp_xor1(unsigned int v) {
-    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false);
-}
 
 template <int DT, int BN, int TW>
 __global__ __launch_bounds__(256, 2) void conv3x3_persist_kernel(const C3Args a) {
@@ -1015,555 +991,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
 #undef PH
 }
 
-// ---------------------------------------------------------------------------------------------------
-// v4 "LDS-DMA": the same (patch x 64 couts) items as the big K-step kernel, but the operands never pass through
-// registers: every K stage (32 input channels: the halo + the nine 64x32 weight slabs) is written into LDS by
-// `buffer_load_dwordx4 ... lds` (1 KiB = 16 rows x 64 B per wave-instruction) into the buffer the previous stage has just
-// left, while the current stage's 72 MFMAs per wave run -- no staging registers, no ds_write phase, one barrier per stage.
-//   LDS image : rows of 64 B (32 channels), no padding (the DMA destination is lane-linear); the 16-byte slot s of row r
-//               lives at slot s ^ ((r >> 2) & 3): any 16 rows {b..b+3, b+12..b+15, b+20..b+27} (one ds_read_b128 lane
-//               group of a 32-row fragment) hit 16 distinct 16-byte bank groups for every base b.  The swizzle is
-//               applied on the SOURCE side: lane l of a piece fetches logical slot (l & 3) ^ ((l >> 4) & 3).
-//   zero pad  : out-of-image halo pixels / couts >= Cout carry an out-of-range buffer offset: the DMA writes zeros.
-//   stage s   : wait vmcnt(0) + barrier (stage s landed everywhere, stage s-1 fully read) -> issue the pieces of stage
-//               s+1 interleaved with the first MFMA steps -> 18 steps of 4 MFMAs (fragment reads one step ahead).
-//   NWV       : 4 waves = 8x32 pixels (one wave per SIMD) or 8 waves = 16x32 pixels (two per SIMD, weights fetched
-//               once per 512 pixels); BatchNorm partials are always written per 8x32 half (gs_conv3x3_mtiles()).
-// Requires Cin % 64 == 0 (an even number of stages keeps the buffer parity fixed per item), W >= 24, the forward or the
-// data-gradient (flipped) tap table.  Conv3d 3x3x3: the stages run over (depth tap, channel chunk) -- stage (dz, c) fetches the
-// halo of slice n + dz (empty pieces outside the volume) and the nine weight slots of that depth tap.  Everything else (the
-// 16x16 level, the precise mode, Cin % 64 != 0) stays on conv3x3_big_kernel.
-// ---------------------------------------------------------------------------------------------------
-// (a "v" constraint inside the kernel body itself would make the host-side instantiation of the launch stub invalid)
-__device__ __forceinline__ void opaque_vgpr(unsigned& x) { asm volatile("" : "+v"(x)); }
-// one LDS-DMA piece: lane l's 16 bytes at buffer offset voff + soff land at dst + 16 l (dst wave-uniform).  A device
-// function of its own: the address-space cast inside the kernel body invalidates the host-side launch stub.
-__device__ __forceinline__ void dma_piece16(const __amdgpu_buffer_rsrc_t& rs, unsigned char* dst, unsigned voff, unsigned soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)dst, 16, voff, soff, 0, 0);
-}
-
-// NB = 2 (8 waves, 16-channel stages): 128 couts per item, every wave 64 pixels x 128 couts -- 8 MFMAs per six fragment reads
-// instead of 4 per four, and the weights are fetched once per 512 pixels x 128 couts: 97 B of DMA and 0.75 KB of LDS reads per
-// MFMA instead of 133 B and 1 KB.  Built because the ablation (tools/ablate_conv_dma.py) shows the deep layers 28-31 % faster
-// with the DMA pieces switched off; measured 2-3 % SLOWER than NB = 1 (245-256 VGPRs, a few spills with the statistics
-// epilogue, one step of fragment prefetch = 8 MFMAs): kept selectable, not the default.
-template <int DT, int NWV, int KC, bool STATS, bool PREC = false, int NB = 1>
-__global__ __launch_bounds__(64 * NWV, (KC == 16 && NB == 1) ? 2 : 1) void conv3x3_dma_kernel(const C3Args a) {
-    typedef typename Elem<DT>::V8 V8;
-    constexpr int BN = 64 * NB, TW = 32, TH = 2 * NWV, TWS = 5;
-    static_assert(NB == 1 || (NWV == 8 && !PREC), "the 128-cout forms: 8 waves");
-    // WS (NB = 2 with 32-channel stages): the nine 128-cout weight slabs of a stage (72 KB) are SINGLE-buffered in two halves
-    // -- taps 0..4 and taps 5..8 -- with a second hand-over in the middle of the stage: while taps 0..4 are multiplied the
-    // slabs of taps 5..8 of the SAME stage land, while taps 5..8 are multiplied the slabs of taps 0..4 and the halo of the
-    // NEXT stage land.  Two barriers per 144 MFMAs per wave (the same density as the 64-cout form), 97 B of DMA per MFMA in
-    // 64-byte segments instead of 133 B, 0.75 KB of fragment reads per MFMA instead of 1 KB.
-    constexpr bool WS = (NB == 2 && KC == 32);
-    constexpr int HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;
-    constexpr int ROWB = KC * 2;                           // bytes per LDS row (one pixel / one cout, KC channels)
-    constexpr int SPR = ROWB / 16, RPP = 64 / SPR;         // 16-byte slots per row, rows per 1-KiB piece
-    constexpr int KSTEPS = KC / 16, NSTEP = 9 * KSTEPS;    // MFMA steps (tap, k half) per stage
-    constexpr int HI = (HP + RPP - 1) / RPP;               // halo pieces that hold real rows
-    constexpr int HJ = (HI + NWV - 1) / NWV;               // halo pieces per wave (the tail ones are spare)
-    constexpr int WG = BN / RPP;                           // weight pieces (row groups) per tap
-    constexpr int WP = 9 * WG;                             // weight pieces per stage
-    constexpr int NWP = (WP + NWV - 1) / NWV;              // ... per wave
-    constexpr int HALO_B = HJ * NWV * 1024, W_B = 9 * BN * ROWB, STAGE_B = HALO_B + W_B;
-    constexpr int STG_EL = 32 * C3_LDR;
-    constexpr unsigned VOOB = 0x80000000u;
-    // LDS: [weights 0 | halo 0 | halo 1 | weights 1]; the epilogue staging overlays halo 1 + weights 1 (the last stage of an
-    // item always sits in buffer 1, the next item's first stage is on its way into buffer 0)
-    constexpr int H0_OFF = W_B, W1_OFF = W_B + 2 * HALO_B;
-    constexpr int NSTEP_A = WS ? 5 * KSTEPS : NSTEP;       // WS: steps of the first weight half (taps 0..4)
-    constexpr int WB_OFF = 5 * BN * ROWB;                  // WS: [weights taps 0..4 | weights taps 5..8 | halo 0 | halo 1]
-    constexpr int LDS_B = WS ? W_B + 2 * HALO_B : 2 * STAGE_B;
-    static_assert(LDS_B * ((KC == 16 && NB == 1) ? 2 : 1) <= 160 * 1024, "the stage buffers (per resident block) must fit in LDS");
-    static_assert(!WS || (WP == 9 * NWV && NWV * STG_EL * 2 <= HALO_B && NWV * 2 * BN * 4 <= W_B - WB_OFF),
-                  "WS: one weight piece per wave and tap; staging in halo 1, partial sums in the second weight half");
-    // PREC (precise mode): K is a concatenation of segments over the same input channels (stage c reads
-    // input chunk c mod wrap) and the result leaves as a hi / lo pair (a second staging area and store stream)
-    static_assert(WS || (PREC ? 2 : 1) * NWV * STG_EL * 2 + NWV * 2 * BN * 4 <= HALO_B + W_B, "epilogue staging overlays the second stage buffer");
-    static_assert(NWP + HJ <= NSTEP && HJ + 1 <= NSTEP, "one DMA piece / one next-item offset per MFMA step");
-    static_assert(NWV % WG == 0, "a wave's weight pieces all belong to one row group");
-    static_assert(WP % NWV == 0 || HI < HJ * NWV, "a surplus weight slot parks its (empty) piece in the spare halo piece");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_B];
-
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int l31 = lane & 31, h = lane >> 5;
-    const int nitems = a.nblocks;
-    const int act = a.act & 0xff;
-    const int dbg = a.act >> 8;                            // ablation bits (GSSEG_C3_DEBUG=1): 2 no MFMAs, 4 no epilogue
-    const int nstage = a.ndz * (a.Cin / KC);               // even: Cin % 64 == 0
-    const unsigned img_bytes = (unsigned)a.H * a.W * a.in_stride * 2u;
-    const unsigned tap_stride = (unsigned)a.Cout * a.Cin * 2u;
-    const bool flip = a.tap_dy[0] > 0;                     // data-gradient table: geometric tap g uses weight slot 8 - g
-    const int tiles_y8 = (a.H + 7) >> 3;                   // BatchNorm partial rows are numbered in 8x32 patches
-
-#ifdef GS_C3_PHASE_TIMING
-    long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tq = clock64();
-#define PH(i) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = clock64(); ph[i] += t_ - tq; tq = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define PH(i) do {} while (0)
-#endif
-    struct Item { int n, y0, x0, n0, mt; };
-    const __amdgpu_buffer_rsrc_t w_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)(9u * a.ndz * a.Cout * a.Cin * 2u), 0x00020000);
-
-    // ---- DMA side: lane l of a piece fills physical slot l % SPR of row l / SPR; the logical slot (8 channels) that belongs
-    // there is the physical one xor-ed with the row's swizzle key ((row >> 2) & 3 for 64-byte rows, (row >> 3) & 1 for 32) ----
-    const int drow = lane / SPR;
-    const int dls = (lane % SPR) ^ ((lane >> 4) & (SPR - 1));
-    unsigned hv[HJ], wv;         // this item's buffer offsets per piece slot
-    unsigned hvn[HJ], wvn;       // the next item's: computed one slot per MFMA step of every even stage (nearly free
-                                 // there; at the item boundary the same ~70 instructions ran with nothing to hide behind)
-    auto halo_voff = [&](int y0, int x0, int j) __attribute__((always_inline)) {      // j compile-time
-        const int r = (wave + j * NWV) * RPP + drow;
-        const int hy = r / HWD, hx = r - hy * HWD;
-        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-        const bool ok = r < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        return ok ? (unsigned)(((gy * a.W + gx) * a.in_stride + a.in_coff + dls * 8) * 2) : VOOB;
-    };
-    auto weight_voff = [&](int n0) __attribute__((always_inline)) {
-        const int co = n0 + (wave % WG) * RPP + drow;
-        return co < a.Cout ? (unsigned)((co * a.Cin + dls * 8) * 2) : VOOB;
-    };
-    auto setup_item = [&](const Item& itn) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < HJ; ++j) hv[j] = halo_voff(itn.y0, itn.x0, j);
-        wv = weight_voff(itn.n0);
-    };
-    // LDS: [halo 0 | halo 1 | weights 0 | weights 1] -- every fragment read is (per-lane base register) + (16-bit immediate)
-    // piece k (compile-time) of stage (image rx, channel byte offset sc) into buffer bb
-    // (sc / wsc: scalar byte offsets of the stage's channel chunk in the image / of its chunk and depth-tap group in the pack;
-    // hkill: the depth tap points outside the volume -- the halo pieces carry zeros)
-    // (issuing the halo pieces before the weight pieces measured the same)
-    auto issue_piece = [&](int k, const __amdgpu_buffer_rsrc_t& rx, unsigned sc, unsigned wsc, unsigned bb, unsigned hkill,
-                           unsigned kill) __attribute__((always_inline)) {
-        if (k < NWP) {
-            const int pc = wave + NWV * k;                 // piece = tap * WG + row group; the group is wave % WG for every k
-            const int tap = pc / WG;
-            const bool real = pc < WP;                     // surplus slots of the last round carry an empty piece
-            const int slot = flip ? 8 - tap : tap;
-            const unsigned dst = real ? (unsigned)(pc * 1024) + bb * W1_OFF
-                                      : (unsigned)(H0_OFF + HALO_B - 1024) + bb * HALO_B;
-            dma_piece16(w_rsrc, smem + dst, (real && !(dbg & 8)) ? (wv | kill) : VOOB, (unsigned)(real ? slot : 0) * tap_stride + wsc);   // dbg 8: ablation, no weight traffic
-        } else if (k - NWP < HJ) {
-            const int j = k - NWP < HJ ? k - NWP : 0;
-            const unsigned dst = H0_OFF + bb * HALO_B + (unsigned)(wave + j * NWV) * 1024u;
-            dma_piece16(rx, smem + dst, (dbg & 16) ? VOOB : (hv[j] | kill | hkill), sc);                 // dbg 16: no halo traffic
-        }
-    };
-    // stage c of an item in slice n: 2-D: channel chunk c; Conv3d: (depth tap c / nchunk, chunk c % nchunk) reads slice n + dz
-    // and the nine weight slots of that depth tap
-    struct Src { int n; unsigned sc, wsc, hkill; };
-    const int nchunk = a.Cin / KC;
-    auto stage_src = [&](int n, int c) __attribute__((always_inline)) {
-        Src r;
-        r.n = n; r.sc = (unsigned)c * ROWB; r.wsc = r.sc; r.hkill = 0u;
-        if (PREC && a.in_wrap > 0 && c >= 2 * a.in_wrap) r.sc = (unsigned)(c - 2 * a.in_wrap) * ROWB;    // in_wrap counts 64-channel chunks
-        if (a.ndz > 1) {
-            const int dzi = c / nchunk, cc = c - dzi * nchunk;
-            const int dz = a.tap_dz[dzi];
-            const int d = n % a.D;
-            const bool inside = (unsigned)(d + dz) < (unsigned)a.D;
-            r.n = inside ? n + dz : n;
-            r.hkill = inside ? 0u : VOOB;
-            r.sc = (unsigned)cc * ROWB;
-            r.wsc = (unsigned)(dzi * 9) * tap_stride + r.sc;
-        }
-        return r;
-    };
-
-    // ---- MFMA side: fragment byte addresses inside a stage buffer (item independent) ----
-    // (kept opaque: hipcc otherwise materialises every base + constant combination of both buffers in its own register)
-    unsigned aaddr[KSTEPS][4][3];                          // [k half][halo row 2*wave + e, e = i + dy + 1][column l31 + dx + 1]
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int r = (2 * wave + e) * HWD + l31 + d;
-            const int key = (KC == 32) ? ((r >> 2) & 3) : ((r >> 3) & 1);
-            aaddr[0][e][d] = (unsigned)(H0_OFF + r * ROWB + ((h ^ key) << 4));
-            opaque_vgpr(aaddr[0][e][d]);
-            if (KSTEPS == 2 && NB == 1) {                 // (NB = 2 is short of registers: the second k half is formed at the read)
-                aaddr[KSTEPS - 1][e][d] = aaddr[0][e][d] ^ 32u;
-                opaque_vgpr(aaddr[KSTEPS - 1][e][d]);
-            }
-        }
-    unsigned baddr[2][KSTEPS];                             // [buffer][k half]
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int key = (KC == 32) ? ((l31 >> 2) & 3) : ((l31 >> 3) & 1);
-        baddr[b][0] = (unsigned)(b * (WS ? WB_OFF : W1_OFF) + l31 * ROWB + ((h ^ key) << 4));      // WS: b = weight half
-        opaque_vgpr(baddr[b][0]);
-        if (KSTEPS == 2) {
-            baddr[b][KSTEPS - 1] = baddr[b][0] ^ 32u;
-            opaque_vgpr(baddr[b][KSTEPS - 1]);
-        }
-    }
-
-    f32x16 acc[2][2 * NB];
-    auto zero_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2 * NB; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    };
-
-    // one stage: NSTEP steps (tap, k half) of 4 MFMAs out of buffer BUF; the pieces of the next stage (image rx_n, channel
-    // offset sc_n) go into the other buffer, one per step
-    // FIRST: the first stage of an item starts its accumulators from the MFMA's zero C operand (no clearing pass)
-    // WS: piece slot k of a half -- first half (k < 4): weight taps 5..8 of the CURRENT stage (scalar offset wsc_cur); second half
-    // (k < 10): weight taps 0..4 and the halo of the NEXT stage
-    auto issue_ws = [&](bool second, int k, const __amdgpu_buffer_rsrc_t& rx, unsigned sc, unsigned wsc, unsigned bb, unsigned hkill,
-                        unsigned kill) __attribute__((always_inline)) {
-        if (!second) {
-            const int tap = 5 + k, slot = flip ? 8 - tap : tap;
-            dma_piece16(w_rsrc, smem + WB_OFF + (unsigned)(k * NWV + wave) * 1024u, wv, (unsigned)slot * tap_stride + wsc);
-        } else if (k < 5) {
-            const int slot = flip ? 8 - k : k;
-            dma_piece16(w_rsrc, smem + (unsigned)(k * NWV + wave) * 1024u, wv | kill, (unsigned)slot * tap_stride + wsc);
-        } else {
-            const int j = k - 5 < HJ ? k - 5 : 0;
-            dma_piece16(rx, smem + H0_OFF + bb * HALO_B + (unsigned)(wave + j * NWV) * 1024u, hv[j] | kill | hkill, sc);
-        }
-    };
-    auto run_stage = [&](auto buf_tag, auto first_tag, const __amdgpu_buffer_rsrc_t& rx_n, const Src& sn, unsigned kill, const Item& itn,
-                         unsigned wsc_cur = 0u, bool swap_mid = false) __attribute__((always_inline)) {
-        const unsigned sc_n = sn.sc, wsc_n = sn.wsc, hkill_n = sn.hkill;
-        constexpr int BUF = decltype(buf_tag)::value;
-        constexpr bool FIRST = decltype(first_tag)::value;
-        constexpr unsigned OBUF = 1 - BUF;           // the buffer the next stage is fetched into
-        if (dbg & 2) {                                     // ablation: DMA traffic only
-#pragma unroll
-            for (int k = 0; k < NWP + HJ; ++k) issue_piece(k, rx_n, sc_n, wsc_n, OBUF, hkill_n, kill);
-            if (BUF == 0) {
-#pragma unroll
-                for (int j = 0; j < HJ; ++j) hvn[j] = halo_voff(itn.y0, itn.x0, j);
-                wvn = weight_voff(itn.n0);
-            }
-            if (FIRST) zero_acc();
-            return;
-        }
-        V8 af[2][2], bf[2][2 * NB];
-        auto frag_load = [&](int step, V8 (&fa)[2], V8 (&fb)[2 * NB]) __attribute__((always_inline)) {
-            const int tap = step / KSTEPS, kh = step % KSTEPS;
-            const int dyi = tap / 3, dxi = tap - 3 * dyi;
-            const int wsel = WS ? (tap >= 5 ? 1 : 0) : BUF;              // weight buffer (WS: weight half)
-            const int wtap = WS ? tap - 5 * wsel : tap;
-            const unsigned a0 = (NB == 2 && kh == 1) ? (aaddr[0][dyi][dxi] ^ 32u) : aaddr[NB == 2 ? 0 : kh][dyi][dxi];
-            const unsigned a1 = (NB == 2 && kh == 1) ? (aaddr[0][dyi + 1][dxi] ^ 32u) : aaddr[NB == 2 ? 0 : kh][dyi + 1][dxi];
-            fa[0] = *reinterpret_cast<const V8*>(smem + a0 + BUF * HALO_B);
-            fb[0] = *reinterpret_cast<const V8*>(smem + baddr[wsel][kh] + wtap * (BN * ROWB));
-            fa[1] = *reinterpret_cast<const V8*>(smem + a1 + BUF * HALO_B);
-            fb[1] = *reinterpret_cast<const V8*>(smem + baddr[wsel][kh] + wtap * (BN * ROWB) + 32 * ROWB);
-            if (NB == 2) {
-                fb[2 * NB - 2] = *reinterpret_cast<const V8*>(smem + baddr[wsel][kh] + wtap * (BN * ROWB) + 64 * ROWB);
-                fb[2 * NB - 1] = *reinterpret_cast<const V8*>(smem + baddr[wsel][kh] + wtap * (BN * ROWB) + 96 * ROWB);
-            }
-        };
-        frag_load(0, af[0], bf[0]);
-#pragma unroll
-        for (int step = 0; step < NSTEP; ++step) {
-            const int cur = step & 1;
-            if (WS && step == NSTEP_A) {
-                // second hand-over: the weight slabs of taps 5..8 have landed everywhere, nobody reads taps 0..4 any more
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                if (swap_mid) {                            // last stage of the item: the pieces from here on belong to the next item
-#pragma unroll
-                    for (int j = 0; j < HJ; ++j) hv[j] = hvn[j];
-                    wv = wvn;
-                }
-                frag_load(step, af[cur], bf[cur]);         // (not prefetched across the hand-over)
-            }
-            if (step + 1 < NSTEP && !(WS && step + 1 == NSTEP_A)) frag_load(step + 1, af[cur ^ 1], bf[cur ^ 1]);
-            // (two pieces per step, i.e. everything issued in the first half of the stage, measured the same or 1 % slower
-            // on the deep layers: the pieces are not late)
-            if (WS) {
-                if (step < 4) issue_ws(false, step, rx_n, sc_n, wsc_cur, OBUF, hkill_n, kill);
-                else if (step == NSTEP_A || step == NSTEP_A + 1) {
-                    issue_ws(true, 2 * (step - NSTEP_A), rx_n, sc_n, wsc_n, OBUF, hkill_n, kill);
-                    issue_ws(true, 2 * (step - NSTEP_A) + 1, rx_n, sc_n, wsc_n, OBUF, hkill_n, kill);
-                } else if (step > NSTEP_A + 1 && step - NSTEP_A + 2 < 5 + HJ) {
-                    issue_ws(true, step - NSTEP_A + 2, rx_n, sc_n, wsc_n, OBUF, hkill_n, kill);
-                }
-            } else {
-                issue_piece(step, rx_n, sc_n, wsc_n, OBUF, hkill_n, kill);
-            }
-            if (BUF == 0 && step <= HJ) {                  // the next item's piece offsets, one slot per step
-                int py0 = itn.y0, px0 = itn.x0, pn0 = itn.n0;
-                asm volatile("" : "+s"(py0), "+s"(px0), "+s"(pn0));      // keeps this arithmetic in the step (else hoisted to the item boundary)
-                if (step < HJ) hvn[step < HJ ? step : 0] = halo_voff(py0, px0, step < HJ ? step : 0);
-                else wvn = weight_voff(pn0);
-            }
-#pragma unroll
-            for (int j = 0; j < 2 * NB; ++j)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    if (FIRST && step == 0) {
-                        f32x16 z;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                        acc[i][j] = Elem<DT>::mfma32(af[cur][i], bf[cur][j], z);
-                    } else {
-                        acc[i][j] = Elem<DT>::mfma32(af[cur][i], bf[cur][j], acc[i][j]);
-                    }
-                }
-#pragma unroll
-            for (int q = 0; q < 2 + 2 * NB; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // one LDS fragment read in its shadow
-            }
-            if (NB == 2) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);           // the DMA piece of this step
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    // stage hand-over: this wave's pieces have landed; after the barrier everybody's have, and nobody reads the other
-    // buffer any more.  (Stores count in vmcnt too: the epilogue's are drained here as well.)
-    auto stage_sync = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
-    // (A counted wait at the item boundary -- vmcnt(8) = "all but the eight output stores issued behind the last piece" --
-    // instead of draining the stores measured the same: 4.36 / 4.32 vs 4.35 / 4.31 ms over the 13 layer shapes.)
-
-    // ---- epilogue: as conv3x3_big_kernel (staging overlays the second stage buffer, which the last stage has just left) ----
-    unsigned short* stg = reinterpret_cast<unsigned short*>(smem + H0_OFF + HALO_B) + wave * STG_EL;
-    unsigned short* stg_lo = stg + NWV * STG_EL;                                        // PREC: the lo halves
-    float* red = reinterpret_cast<float*>(smem + (WS ? WB_OFF : H0_OFF + HALO_B + (PREC ? 2 : 1) * NWV * STG_EL * 2));  // [NWV][2][BN]
-    const bool odd = lane & 1;
-    const unsigned int psel = odd ? 0x03020706u : 0x05040100u;
-    const float neg_slope = act == GS_ACT_RELU ? 0.f : (act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
-    auto epilogue_t = [&](const Item& itc, auto plain_tag, auto full_tag) __attribute__((always_inline)) {
-        constexpr bool PLAIN = decltype(plain_tag)::value;
-        constexpr bool FULL = decltype(full_tag)::value;
-        int e_y0 = itc.y0, e_x0 = itc.x0, e_n = itc.n, e_n0 = itc.n0;
-        asm volatile("" : "+s"(e_y0), "+s"(e_x0), "+s"(e_n), "+s"(e_n0));
-        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(a.y + (int64_t)e_n * a.H * a.W * a.out_stride), 0, (unsigned)a.H * a.W * a.out_stride * 2u, 0x00020000);
-        const __amdgpu_buffer_rsrc_t ry_lo = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)((PREC ? a.y_lo : a.y) + (int64_t)e_n * a.H * a.W * a.out_stride), 0, (unsigned)a.H * a.W * a.out_stride * 2u, 0x00020000);
-        constexpr bool want_stats = STATS;              // BatchNorm partial sums: a template flag (no per-element selects)
-#pragma unroll
-      for (int jj = 0; jj < NB; ++jj) {                  // one 64-cout half of the item at a time
-        const int e_nj = e_n0 + jj * 64;
-        float bv[2] = {0.f, 0.f};
-        if (!PLAIN) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int co = e_nj + j * 32 + l31;
-                bv[j] = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
-            }
-        }
-        // (even row, odd row) sums in packed fp32 math: the statistics cost +7..8 % on the 64-channel layers with four scalar
-        // operations per pair, +5 % with two packed ones; the rest is the reduction / hand-over behind the epilogue
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        f32x2 s1v[2] = {{0.f, 0.f}, {0.f, 0.f}}, s2v[2] = {{0.f, 0.f}, {0.f, 0.f}};
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int prow0 = (wave * 2 + i) * 32;
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const int r0 = 2 * m;
-                const int rowa = (r0 & 3) + 8 * (r0 >> 2) + 4 * h;
-                float w0 = 1.f, w1 = 1.f;
-                if (!FULL && want_stats) {
-                    const int p0 = prow0 + rowa;
-                    const int gy0 = e_y0 + (p0 >> TWS), gx0 = e_x0 + (p0 & (TW - 1));
-                    const int gy1 = e_y0 + ((p0 + 1) >> TWS), gx1 = e_x0 + ((p0 + 1) & (TW - 1));
-                    w0 = (float)((unsigned)((gy0 - a.H) & (gx0 - a.W)) >> 31);
-                    w1 = (float)((unsigned)((gy1 - a.H) & (gx1 - a.W)) >> 31);
-                }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    float v0 = acc[i][2 * jj + j][r0], v1 = acc[i][2 * jj + j][r0 + 1];
-                    if (want_stats) {
-                        f32x2 vv = {v0, v1};
-                        if (!FULL) vv *= f32x2{w0, w1};
-                        s1v[j] += vv;
-                        s2v[j] += vv * vv;
-                    }
-                    if (!PLAIN) {
-                        v0 += bv[j];
-                        v1 += bv[j];
-                        v0 = v0 > 0.f ? v0 : v0 * neg_slope;
-                        v1 = v1 > 0.f ? v1 : v1 * neg_slope;
-                    }
-                    const unsigned int own = Elem<DT>::pack2(v0, v1);
-                    const unsigned int oth = dpp_xor1(own);
-                    const unsigned int pk = __builtin_amdgcn_perm(oth, own, psel);
-                    const int row = rowa + (odd ? 1 : 0);
-                    *reinterpret_cast<unsigned int*>(stg + row * C3_LDR + j * 32 + (l31 & ~1)) = pk;
-                    if (PREC) {                               // lo = 16-bit(value - hi): the pair carries ~22 bits
-                        const float l0 = v0 - Elem<DT>::to_f((unsigned short)(own & 0xffffu));
-                        const float l1 = v1 - Elem<DT>::to_f((unsigned short)(own >> 16));
-                        const unsigned int own_l = Elem<DT>::pack2(l0, l1);
-                        const unsigned int oth_l = dpp_xor1(own_l);
-                        const unsigned int pk_l = __builtin_amdgcn_perm(oth_l, own_l, psel);
-                        *reinterpret_cast<unsigned int*>(stg_lo + row * C3_LDR + j * 32 + (l31 & ~1)) = pk_l;
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            uint4 sv[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                sv[q] = *reinterpret_cast<const uint4*>(stg + (q * 8 + (lane >> 3)) * C3_LDR + (lane & 7) * 8);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int p = prow0 + q * 8 + (lane >> 3);
-                const int gy = e_y0 + (p >> TWS), gx = e_x0 + (p & (TW - 1));
-                const int co = e_nj + (lane & 7) * 8;
-                const bool ok = (FULL || (gy < a.H && gx < a.W)) && co < a.Cout;
-                const unsigned off = ok ? (unsigned)(((gy * a.W + gx) * a.out_stride + a.out_coff + co) * 2) : VOOB;
-                u32x4 d;
-                d[0] = sv[q].x; d[1] = sv[q].y; d[2] = sv[q].z; d[3] = sv[q].w;
-                __builtin_amdgcn_raw_buffer_store_b128(d, ry, off, 0, 0);
-                if (PREC) {
-                    const uint4 lv = *reinterpret_cast<const uint4*>(stg_lo + (q * 8 + (lane >> 3)) * C3_LDR + (lane & 7) * 8);
-                    u32x4 dl;
-                    dl[0] = lv.x; dl[1] = lv.y; dl[2] = lv.z; dl[3] = lv.w;
-                    __builtin_amdgcn_raw_buffer_store_b128(dl, ry_lo, off, 0, 0);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (want_stats) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float t1 = s1v[j].x + s1v[j].y, t2 = s2v[j].x + s2v[j].y;
-                t1 += __shfl_xor(t1, 32, 64);
-                t2 += __shfl_xor(t2, 32, 64);
-                if (h == 0) {
-                    red[(wave * 2 + 0) * BN + jj * 64 + j * 32 + l31] = t1;
-                    red[(wave * 2 + 1) * BN + jj * 64 + j * 32 + l31] = t2;
-                }
-            }
-        }
-      }
-    };
-    const bool plain = (a.bias == nullptr && act == GS_ACT_NONE);
-    auto epilogue = [&](const Item& itc) __attribute__((always_inline)) {
-        const bool full = (itc.y0 + TH <= a.H) && (itc.x0 + TW <= a.W);
-        if (plain && full) epilogue_t(itc, std::true_type{}, std::true_type{});
-        else epilogue_t(itc, std::false_type{}, std::false_type{});
-    };
-    // partial sums of the 8x32 halves: waves 4*half .. 4*half+3
-    auto finish_stats = [&](const Item& itc) __attribute__((always_inline)) {
-        constexpr int NH = NWV / 4;
-        if (STATS && t < NH * BN) {
-            const int half = t / BN, c = t % BN;
-            if (itc.n0 + c < a.Cout && (itc.y0 >> 3) + half < tiles_y8) {
-                float v1 = 0.f, v2 = 0.f;
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    v1 += red[((half * 4 + m) * 2 + 0) * BN + c];
-                    v2 += red[((half * 4 + m) * 2 + 1) * BN + c];
-                }
-                float* dst = a.bnp + (int64_t)(itc.mt + half * a.tiles_x) * 2 * a.Cout + itc.n0 + c;
-                dst[0] = v1;
-                dst[a.Cout] = v2;
-            }
-        }
-    };
-
-    // ---- items: same numbering and XCD-aware start as conv3x3_big_kernel ----
-    int it = a.xcd_order ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
-    if (it >= nitems) return;
-    int dg0 = it % a.ntn, dg1, dg2, dg3;
-    {
-        int r = it / a.ntn;
-        dg1 = r % a.tiles_x; r /= a.tiles_x;
-        dg2 = r % a.tiles_y; dg3 = r / a.tiles_y;
-    }
-    int st0, st1, st2, st3;
-    {
-        int r = gridDim.x;
-        st0 = r % a.ntn; r /= a.ntn;
-        st1 = r % a.tiles_x; r /= a.tiles_x;
-        st2 = r % a.tiles_y; st3 = r / a.tiles_y;
-    }
-    auto make_item = [&]() __attribute__((always_inline)) {
-        Item r;
-        r.n = dg3; r.y0 = dg2 * TH; r.x0 = dg1 * TW; r.n0 = dg0 * BN;
-        r.mt = (dg3 * tiles_y8 + (r.y0 >> 3)) * a.tiles_x + dg1;
-        return r;
-    };
-    auto advance_item = [&]() __attribute__((always_inline)) {
-        dg0 += st0; int c = dg0 >= a.ntn ? 1 : 0; dg0 -= c * a.ntn;
-        dg1 += st1 + c; c = dg1 >= a.tiles_x ? 1 : 0; dg1 -= c * a.tiles_x;
-        dg2 += st2 + c; c = dg2 >= a.tiles_y ? 1 : 0; dg2 -= c * a.tiles_y;
-        dg3 += st3 + c;
-        return make_item();
-    };
-    auto image_rsrc = [&](int n) __attribute__((always_inline)) {
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)n * a.H * a.W * a.in_stride), 0, img_bytes, 0x00020000);
-    };
-    Item cur = make_item();
-    setup_item(cur);
-    {
-        const Src s0 = stage_src(cur.n, 0);
-        const __amdgpu_buffer_rsrc_t rx0 = image_rsrc(s0.n);
-        if (WS) {
-#pragma unroll
-            for (int k = 0; k < 5 + HJ; ++k) issue_ws(true, k, rx0, s0.sc, s0.wsc, 0u, s0.hkill, 0u);   // taps 0..4 + halo of stage 0
-        } else {
-#pragma unroll
-            for (int k = 0; k < NWP + HJ; ++k) issue_piece(k, rx0, s0.sc, s0.wsc, 0u, s0.hkill, 0u);   // stage 0 -> buffer 0
-        }
-    }
-    for (;;) {
-        const int nit = it + gridDim.x;
-        const bool more_items = nit < nitems;
-        Item nxt = cur;
-        if (more_items) nxt = advance_item();
-        for (int sp = 0; sp < nstage; sp += 2) {
-            const bool last = sp + 2 >= nstage;
-            PH(7);
-            stage_sync();
-            PH(0);
-            const Src s1 = stage_src(cur.n, sp + 1);
-            const unsigned wsc0 = WS ? stage_src(cur.n, sp).wsc : 0u;
-            if (sp == 0) run_stage(std::integral_constant<int, 0>{}, std::true_type{}, image_rsrc(s1.n), s1, 0u, nxt, wsc0, false);
-            else run_stage(std::integral_constant<int, 0>{}, std::false_type{}, image_rsrc(s1.n), s1, 0u, nxt, wsc0, false);
-            PH(1);
-            stage_sync();
-            PH(2);
-            if (last && !WS) {                             // from here on the pieces belong to the next item (WS: from mid-stage on)
-#pragma unroll
-                for (int j = 0; j < HJ; ++j) hv[j] = hvn[j];
-                wv = wvn;
-            }
-            const Src s2 = stage_src(last ? nxt.n : cur.n, last ? 0 : sp + 2);
-            run_stage(std::integral_constant<int, 1>{}, std::false_type{}, image_rsrc(s2.n), s2, (last && !more_items) ? VOOB : 0u, nxt,
-                      WS ? stage_src(cur.n, sp + 1).wsc : 0u, WS && last);
-            PH(3);
-        }
-        __builtin_amdgcn_s_barrier();              // every wave has left the second buffer: staging may overlay it
-        asm volatile("" ::: "memory");
-        PH(4);
-        if (!(dbg & 4)) epilogue(cur);
-        PH(5);
-        __syncthreads();
-        PH(6);
-        finish_stats(cur);
-        if (!more_items) break;
-        it = nit;
-        cur = nxt;
-    }
-#ifdef GS_C3_PHASE_TIMING
-    if (blockIdx.x == 0 && lane == 0 && a.bnp != nullptr)           // debug build only: the partials double as sink
-        for (int i = 0; i < 8; ++i) a.bnp[wave * 8 + i] = (float)ph[i];
-#endif
-#undef PH
-}
-
 struct C3Plan { int bn, tw, th, tiles_x, tiles_y; };
 
 int c3_variant_get();
@@ -1583,23 +1010,17 @@ C3Plan c3_plan(int H, int W, int Cout) {
 
 }  // namespace
 
-// form of the LDS-DMA kernel: -1 = by CU fill (default), 0 = off (big K-step kernel), 4 / 8 = waves per block, 2 = two 4-wave
-// blocks per CU with 16-channel stages (measured slower; kept for the record).  GSSEG_C3_DMA presets it; tests and tools
-// switch it through gs_conv3x3_set_kernel_form() to compare the forms on the same operands.
+// form of the LDS-DMA kernel (conv3x3_dma.hip): -1 = by CU fill (default), 0 = off (big K-step kernel), 4 / 8 = waves per block.
+// GSSEG_C3_DMA presets it; tests and tools switch it through gs_conv3x3_set_kernel_form() to compare the forms on the same
+// operands.  (Round 2 also carried a two-blocks-per-CU form and two 128-cout forms; all three measured slower -- numbers in
+// DESIGN.md section 4 -- and were removed in round 3.)
 static std::atomic<int> c3_dma_form{getenv("GSSEG_C3_DMA") ? atoi(getenv("GSSEG_C3_DMA")) : -1};
 
 extern "C" int gs_conv3x3_set_kernel_form(int form) {
-    GS_CHECK_ARG(form == -1 || form == 0 || form == 2 || form == 4 || form == 8 || form == 16 || form == 32,
-                 "gs_conv3x3_set_kernel_form: form must be -1, 0, 2, 4, 8, 16 or 32");
+    GS_CHECK_ARG(form == -1 || form == 0 || form == 4 || form == 8,
+                 "gs_conv3x3_set_kernel_form: form must be -1 (automatic), 0 (big K-step kernel), 4 or 8 (waves of the LDS-DMA kernel)");
     c3_dma_form.store(form, std::memory_order_relaxed);
     return GS_OK;
-}
-
-// the 128-cout form (16) is not chosen automatically: measured 4.55-4.57 ms against 4.43-4.47 for the 64-cout 8-wave form over
-// the 13 layer shapes (GSSEG_C3_WIDE=1 or gs_conv3x3_set_kernel_form(16) select it)
-static bool c3_wide_auto() {
-    static const int v = getenv("GSSEG_C3_WIDE") ? atoi(getenv("GSSEG_C3_WIDE")) : 0;
-    return v != 0;
 }
 
 static int c3_variant() {          // 0 = v1 one patch per block, 1 = persistent (v2), 2 = big K-step (v3)
@@ -1620,6 +1041,61 @@ static bool c3_big_ok(int H, int W, int Cin, int in_pix_stride, int Cout, int ou
 extern "C" int gs_conv3x3_mtiles(int N, int H, int W, int Cout) {
     const C3Plan p = c3_plan(H, W, Cout);
     return N * p.tiles_x * p.tiles_y;
+}
+
+// ---- the LDS-DMA kernel's launch plan: shared by the launch and by gs_conv3x3_stat_rows() ----
+static int c3_max_blocks() {
+    static const int v = getenv("GSSEG_C3_GRID") ? atoi(getenv("GSSEG_C3_GRID")) : 256;
+    return v;
+}
+// persistent-grid cap at run time (parallel.py leaves CUs to RCCL when world > 1): 0 = the default above
+static std::atomic<int> c3_grid_cap{0};
+static int c3_blocks_now() {
+    const int cap = c3_grid_cap.load(std::memory_order_relaxed);
+    return cap > 0 ? cap : c3_max_blocks();
+}
+extern "C" int gs_set_persistent_grid(int blocks) {
+    GS_CHECK_ARG(blocks == 0 || (blocks >= 8 && blocks <= 1024), "gs_set_persistent_grid: 0 (default) or 8..1024 blocks");
+    c3_grid_cap.store(blocks, std::memory_order_relaxed);
+    return GS_OK;
+}
+extern "C" int gs_get_persistent_grid(void) { return c3_blocks_now(); }
+
+struct C3DmaPlan { int waves, tiles_x, tiles_y, ntn, nitems, grid; };
+// shape part of the eligibility (the launch also needs the standard / flipped tap table and 16-byte aligned strides)
+static bool c3_dma_shape_ok(int W, int Cin, int Cout) {
+    return c3_variant() == 2 && c3_dma_form.load(std::memory_order_relaxed) != 0 && W >= 24 && Cin % 64 == 0 && Cout % 8 == 0;
+}
+static C3DmaPlan c3_dma_plan(int N, int H, int W, int Cout, bool per_block_rows) {
+    C3DmaPlan p;
+    const int blocks = c3_blocks_now();
+    p.tiles_x = cdiv(W, 32);
+    p.ntn = cdiv(Cout, 64);
+    // the 8-wave form (16x32-pixel items, -11..13 % against the big K-step kernel over the U-Net layer shapes) unless its
+    // items -- twice the work each -- fill the CUs worse than the 4-wave form's (-2 %) do
+    const int64_t items4 = (int64_t)N * p.tiles_x * cdiv(H, 8) * p.ntn, items8 = (int64_t)N * p.tiles_x * cdiv(H, 16) * p.ntn;
+    const double cost4 = 0.98 * (double)((items4 + blocks - 1) / blocks);
+    const double cost8 = 0.87 * 2.0 * (double)((items8 + blocks - 1) / blocks);
+    const int forced = c3_dma_form.load(std::memory_order_relaxed);
+    p.waves = (forced == 4 || forced == 8) ? forced : (cost8 <= cost4 ? 8 : 4);
+    p.tiles_y = cdiv(H, p.waves == 8 ? 16 : 8);
+    p.nitems = N * p.tiles_x * p.tiles_y * p.ntn;
+    p.grid = per_block_rows ? c3_dma_grid(p.nitems, p.ntn, blocks) : (p.nitems < blocks ? p.nitems : blocks);
+    return p;
+}
+
+// Rows of BatchNorm partial sums ([rows][2][Cout] fp32) a gs_conv3x3 / gs_conv3d_3x3x3 / gs_conv3x3_precise launch with these
+// dimensions writes -- what gs_bn_finalize / gs_bn_partials_colsum must be told.  The LDS-DMA kernel keeps its sums in
+// registers across the items of a block and writes ONE row per block and cout-tile group; the pair forward (pair != 0) and the
+// other kernels write one row per 8x32 / 16x16 patch (= gs_conv3x3_mtiles).  Never more than gs_conv3x3_mtiles(): a buffer of
+// that many rows always suffices.  Assumes what every caller in this package does: the forward or the flipped tap table and
+// channel strides / offsets that are multiples of 8 (a launch that would fall off that path with statistics fails loudly).
+extern "C" int gs_conv3x3_stat_rows(int N, int H, int W, int Cin, int Cout, int pair) {
+    if (!pair && c3_dma_shape_ok(W, Cin, Cout)) {
+        const C3DmaPlan p = c3_dma_plan(N, H, W, Cout, true);
+        return p.grid / p.ntn;
+    }
+    return gs_conv3x3_mtiles(N, H, W, Cout);
 }
 
 static int conv3x3_launch(const void* x, const void* w, void* y, const float* bias, float* bn_partials, int N, int H,
@@ -1669,7 +1145,7 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
         a.tiles_x = cdiv(W, tw); a.tiles_y = cdiv(H, th);
         a.ntn = cdiv(Cout, 64);
         a.nblocks = N * a.tiles_x * a.tiles_y * a.ntn;
-        static const int big_blocks = getenv("GSSEG_C3_GRID") ? atoi(getenv("GSSEG_C3_GRID")) : 256;
+        const int big_blocks = c3_blocks_now();
         dim3 bgrid(a.nblocks < big_blocks ? a.nblocks : big_blocks);
         static const int xcd_env = getenv("GSSEG_C3_XCD") ? atoi(getenv("GSSEG_C3_XCD")) : 1;
         // activation-heavy launches only: where the weights outweigh the input (the 16x16 level at batch 32: 18.9 MB of
@@ -1678,40 +1154,26 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
         a.xcd_order = (xcd_env && (bgrid.x % 8) == 0 && a.ntn > 1 && (int64_t)N * H * W > (int64_t)18 * Cout) ? 1 : 0;
         hipStream_t bs = (hipStream_t)stream;
         const bool wres = (Cin <= 64 && a.ntn == 1 && ndz == 1);   // one stage, one N tile: weights stay resident in LDS
-        static const int prec_dma_env = getenv("GSSEG_C3_PREC_DMA") ? atoi(getenv("GSSEG_C3_PREC_DMA")) : 1;
-        if (prec && prec_dma_env != 0 && c3_dma_form.load(std::memory_order_relaxed) != 0 && tw == 32 && Cin % 64 == 0) {
-            bool std_taps = true;
-            for (int i = 0; i < 9; ++i) std_taps = std_taps && tap_dy[i] == i / 3 - 1 && tap_dx[i] == i % 3 - 1;
-            if (std_taps) {
-                // the precise forward on the LDS-DMA kernel: same form choice as the default mode
-                const int64_t items4 = (int64_t)N * a.tiles_x * cdiv(H, 8) * a.ntn, items8 = (int64_t)N * a.tiles_x * cdiv(H, 16) * a.ntn;
-                const double cost4 = 0.98 * (double)((items4 + big_blocks - 1) / big_blocks);
-                const double cost8 = 0.87 * 2.0 * (double)((items8 + big_blocks - 1) / big_blocks);
-                const int forced = c3_dma_form.load(std::memory_order_relaxed);
-                const int waves = (forced == 4 || forced == 8) ? forced : (cost8 <= cost4 ? 8 : 4);
-                if (waves == 8) {
-                    a.tiles_y = cdiv(H, 16);
-                    a.nblocks = N * a.tiles_x * a.tiles_y * a.ntn;
-                }
-                dim3 dgrid(a.nblocks < big_blocks ? a.nblocks : big_blocks);
-                a.xcd_order = (xcd_env && (dgrid.x % 8) == 0 && a.ntn > 1 && (int64_t)N * H * W > (int64_t)18 * Cout) ? 1 : 0;
-#define C3_DMA_PREC(DT)                                                                                      \
-    do {                                                                                                     \
-        if (bn_partials != nullptr) {                                                                        \
-            if (waves == 8) conv3x3_dma_kernel<DT, 8, 32, true, true><<<dgrid, 512, 0, bs>>>(a);             \
-            else conv3x3_dma_kernel<DT, 4, 32, true, true><<<dgrid, 256, 0, bs>>>(a);                        \
-        } else {                                                                                             \
-            if (waves == 8) conv3x3_dma_kernel<DT, 8, 32, false, true><<<dgrid, 512, 0, bs>>>(a);            \
-            else conv3x3_dma_kernel<DT, 4, 32, false, true><<<dgrid, 256, 0, bs>>>(a);                       \
-        }                                                                                                    \
-    } while (0)
-                if (dtype == GS_F16) C3_DMA_PREC(GS_F16);
-                else C3_DMA_PREC(GS_BF16);
-#undef C3_DMA_PREC
-                GS_CHECK_LAUNCH("gs_conv3x3_precise");
-                return GS_OK;
-            }
+        // LDS-DMA kernel (conv3x3_dma.hip) for the layers it covers (2-D and Conv3d: depth taps = stages); GSSEG_C3_DMA = 0
+        // (off) / 4 / 8 forces a form.  The pair forward (prec) keeps the forward tap table and per-patch statistics rows.
+        bool std_taps = true, flip_taps = true;
+        for (int i = 0; i < 9; ++i) {
+            std_taps = std_taps && tap_dy[i] == i / 3 - 1 && tap_dx[i] == i % 3 - 1;
+            flip_taps = flip_taps && tap_dy[i] == 1 - i / 3 && tap_dx[i] == 1 - i % 3;
         }
+        static const int prec_dma_env = getenv("GSSEG_C3_PREC_DMA") ? atoi(getenv("GSSEG_C3_PREC_DMA")) : 1;
+        const bool dma = c3_dma_shape_ok(W, Cin, Cout) && (prec ? (std_taps && prec_dma_env != 0) : (std_taps || flip_taps));
+        if (dma) {
+            const C3DmaPlan dp = c3_dma_plan(N, H, W, Cout, !prec);
+            a.tiles_x = dp.tiles_x; a.tiles_y = dp.tiles_y; a.ntn = dp.ntn; a.nblocks = dp.nitems;
+            a.xcd_order = (xcd_env && (dp.grid % 8) == 0 && a.ntn > 1 && (int64_t)N * H * W > (int64_t)18 * Cout) ? 1 : 0;
+            c3_dma_launch(a, dp.waves, prec, dtype, dp.grid, bs);
+            GS_CHECK_LAUNCH(prec ? "gs_conv3x3_precise" : "gs_conv3x3");
+            return GS_OK;
+        }
+        // statistics rows: gs_conv3x3_stat_rows() promised the per-block rows of the LDS-DMA kernel for this shape
+        GS_CHECK_ARG(bn_partials == nullptr || prec || !c3_dma_shape_ok(W, Cin, Cout),
+                     "gs_conv3x3: BatchNorm partials with a tap table / layout outside the LDS-DMA kernel (gs_conv3x3_stat_rows would be wrong)");
         if (prec) {
             if (dtype == GS_F16) {
                 if (tw == 32) conv3x3_big_kernel<GS_F16, 32, false, true><<<bgrid, 256, 0, bs>>>(a);
@@ -1721,65 +1183,6 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
                 else conv3x3_big_kernel<GS_BF16, 16, false, true><<<bgrid, 256, 0, bs>>>(a);
             }
             GS_CHECK_LAUNCH("gs_conv3x3_precise");
-            return GS_OK;
-        }
-        // LDS-DMA kernel (conv3x3_dma_kernel) for the 2-D layers it covers; GSSEG_C3_DMA = 0 (off) / 4 / 8 forces a form.
-        // Default: the 8-wave form (16x32-pixel items, -11..13 % against the big K-step kernel over the U-Net layer shapes)
-        // unless its items -- twice the work each -- fill the 256 CUs worse than the 4-wave form's (-2 %) do.
-        const int dma_env = c3_dma_form.load(std::memory_order_relaxed);
-        bool std_taps = true, flip_taps = true;
-        for (int i = 0; i < 9; ++i) {
-            std_taps = std_taps && tap_dy[i] == i / 3 - 1 && tap_dx[i] == i % 3 - 1;
-            flip_taps = flip_taps && tap_dy[i] == 1 - i / 3 && tap_dx[i] == 1 - i % 3;
-        }
-        int dma_waves = 0;
-        if (dma_env != 0 && tw == 32 && Cin % 64 == 0 && (std_taps || flip_taps)) {      // 2-D and Conv3d (depth taps = stages)
-            const int64_t items4 = (int64_t)N * a.tiles_x * cdiv(H, 8) * a.ntn, items8 = (int64_t)N * a.tiles_x * cdiv(H, 16) * a.ntn;
-            const double cost4 = 0.98 * (double)((items4 + big_blocks - 1) / big_blocks);
-            const double cost8 = 0.87 * 2.0 * (double)((items8 + big_blocks - 1) / big_blocks);
-            dma_waves = (dma_env == 4 || dma_env == 8 || dma_env == 2) ? dma_env : (cost8 <= cost4 ? 8 : 4);   // 2: two 4-wave blocks per CU
-            // 16: the 8-wave form with 128 couts per item (16-channel stages) where the layer has them
-            // 32: the same 128-cout items with 32-channel stages and split single-buffered weights (WS)
-            if ((dma_env == 16 || dma_env == 32 || (dma_env == -1 && dma_waves == 8 && c3_wide_auto())) && Cout % 128 == 0) {
-                const int64_t items16 = (int64_t)N * a.tiles_x * cdiv(H, 16) * (Cout / 128);
-                if (dma_env == 16) dma_waves = 16;
-                else if (dma_env == 32 || items16 >= big_blocks) dma_waves = 32;
-            } else if (dma_env == 16 || dma_env == 32) {
-                dma_waves = 8;
-            }
-        }
-        if (dma_waves != 0) {
-            if (dma_waves == 16 || dma_waves == 32) a.ntn = Cout / 128;
-            if (dma_waves == 8 || dma_waves == 16 || dma_waves == 32) {
-                a.tiles_y = cdiv(H, 16);
-                a.nblocks = N * a.tiles_x * a.tiles_y * a.ntn;
-            }
-            const int dblocks = dma_waves == 2 ? 2 * big_blocks : big_blocks;
-            dim3 dgrid(a.nblocks < dblocks ? a.nblocks : dblocks);
-            a.xcd_order = (xcd_env && (dgrid.x % 8) == 0 && a.ntn > 1 && (int64_t)N * H * W > (int64_t)18 * Cout) ? 1 : 0;
-#define C3_DMA_LAUNCH(DT)                                                                          \
-    do {                                                                                           \
-        if (bn_partials != nullptr) {                                                              \
-            if (dma_waves == 32) conv3x3_dma_kernel<DT, 8, 32, true, false, 2><<<dgrid, 512, 0, bs>>>(a); \
-            else if (dma_waves == 16) conv3x3_dma_kernel<DT, 8, 16, true, false, 2><<<dgrid, 512, 0, bs>>>(a); \
-            else if (dma_waves == 8) conv3x3_dma_kernel<DT, 8, 32, true><<<dgrid, 512, 0, bs>>>(a); \
-            else if (dma_waves == 2) conv3x3_dma_kernel<DT, 4, 16, true><<<dgrid, 256, 0, bs>>>(a); \
-            else conv3x3_dma_kernel<DT, 4, 32, true><<<dgrid, 256, 0, bs>>>(a);                    \
-        } else {                                                                                   \
-            if (dma_waves == 32) conv3x3_dma_kernel<DT, 8, 32, false, false, 2><<<dgrid, 512, 0, bs>>>(a); \
-            else if (dma_waves == 16) conv3x3_dma_kernel<DT, 8, 16, false, false, 2><<<dgrid, 512, 0, bs>>>(a); \
-            else if (dma_waves == 8) conv3x3_dma_kernel<DT, 8, 32, false><<<dgrid, 512, 0, bs>>>(a); \
-            else if (dma_waves == 2) conv3x3_dma_kernel<DT, 4, 16, false><<<dgrid, 256, 0, bs>>>(a); \
-            else conv3x3_dma_kernel<DT, 4, 32, false><<<dgrid, 256, 0, bs>>>(a);                   \
-        }                                                                                          \
-    } while (0)
-            if (dtype == GS_F16) {
-                C3_DMA_LAUNCH(GS_F16);
-            } else {
-                C3_DMA_LAUNCH(GS_BF16);
-            }
-#undef C3_DMA_LAUNCH
-            GS_CHECK_LAUNCH("gs_conv3x3");
             return GS_OK;
         }
         if (dtype == GS_F16) {
@@ -1802,6 +1205,8 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
         GS_CHECK_LAUNCH("gs_conv3x3");
         return GS_OK;
     }
+    GS_CHECK_ARG(bn_partials == nullptr || !c3_dma_shape_ok(W, Cin, Cout),
+                 "gs_conv3x3: BatchNorm partials with channel strides / offsets that are not multiples of 8 (gs_conv3x3_stat_rows would be wrong)");
     GS_CHECK_ARG(!prec, "gs_conv3x3_precise: needs the big-K-step kernel (GSSEG_C3=2, Cout %% 8 == 0, 16-byte aligned output channels)");
     static const bool force_v1 = c3_variant() == 0;
     // the persistent kernel stores whole 16-byte channel groups; odd shapes go to the one-patch-per-block kernel

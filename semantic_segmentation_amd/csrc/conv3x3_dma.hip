@@ -1,0 +1,681 @@
+// 3x3 / stride-1 / pad-1 convolution (forward and data gradient, Conv3d 3x3x3 through depth-tap stages) on the LDS-DMA
+// kernel: the same (patch x 64 couts) items as the big K-step kernel of conv3x3.hip, but the operands never pass through
+// registers: every K stage (32 input channels: the halo + the nine 64x32 weight slabs) is written into LDS by
+// `buffer_load_dwordx4 ... lds` (1 KiB = 16 rows x 64 B per wave-instruction) into the buffer the previous stage has just
+// left, while the current stage's 72 MFMAs per wave run -- no staging registers, no ds_write phase, one barrier per stage.
+//   LDS image : rows of 64 B (32 channels), no padding (the DMA destination is lane-linear); the 16-byte slot s of row r
+//               lives at slot s ^ ((r >> 2) & 3): any 16 rows {b..b+3, b+12..b+15, b+20..b+27} (one ds_read_b128 lane
+//               group of a 32-row fragment) hit 16 distinct 16-byte bank groups for every base b.  The swizzle is
+//               applied on the SOURCE side: lane l of a piece fetches logical slot (l & 3) ^ ((l >> 4) & 3).
+//   zero pad  : out-of-image halo pixels / couts >= Cout carry an out-of-range buffer offset: the DMA writes zeros.
+//   stage s   : wait vmcnt(0) + barrier (stage s landed everywhere, stage s-1 fully read) -> issue the pieces of stage
+//               s+1 interleaved with the first MFMA steps -> 18 steps of 4 MFMAs (fragment reads one step ahead).
+//   NWV       : 4 waves = 8x32 pixels (one wave per SIMD) or 8 waves = 16x32 pixels (two per SIMD, weights fetched
+//               once per 512 pixels).
+// Requires Cin % 64 == 0 (an even number of stages keeps the buffer parity fixed per item), W >= 24, the forward or the
+// data-gradient (flipped) tap table.  Conv3d 3x3x3: the stages run over (depth tap, channel chunk) -- stage (dz, c) fetches the
+// halo of slice n + dz (empty pieces outside the volume) and the nine weight slots of that depth tap.  Everything else (the
+// 16x16 level, Cin % 64 != 0) stays on conv3x3_big_kernel.
+//
+// Two epilogue forms (template flag DEFER):
+//   DEFER = false (the pair / precise forward, PREC): as conv3x3_big_kernel -- at the end of an item every wave packs its
+//     64 x 64 tile, transposes it through an LDS staging area that overlays the second stage buffer and stores 128-byte
+//     rows; BatchNorm partial sums per 8x32 half-item, handed over through LDS (one row per half-item).
+//   DEFER = true (everything else): the epilogue of item k runs UNDER THE MFMAs OF ITEM k+1.  Measured on the round-2
+//     kernel (tools/ablate_conv_epilogue.py): without its epilogue the 64->64 layer at 256^2 runs 28 % faster (128->64:
+//     19 %, 128->128 @128^2: 12 %), while the global stores themselves cost 2-3 % -- the time is the pack / DPP / LDS
+//     transposition work with no MFMA in flight, because the two waves of a SIMD reach it together.  Now, at the item
+//     boundary a wave only converts its fp32 accumulators to 32 registers of packed 16-bit pairs (and adds them to its
+//     running statistics); the transposition (8 passes of 8 pixel rows through a PRIVATE 1 KB LDS buffer per wave: 4
+//     ds_write_b32, one ds_read_b128, one 16-byte store each) is spread over the steps of the next item's first stage, two
+//     steps per pass.  BatchNorm partial sums are kept in registers across ALL items of the block (a block keeps its cout
+//     tile: the grid is a multiple of the tile count) and written once at the end: one row per block instead of one per
+//     half-item (c3_dma_grid() rows; no LDS hand-over and barrier per item, no first-stage reduction launch afterwards).
+//     Items with a bias / activation (inference) or a partial patch take the immediate path.
+#include <stdlib.h>
+#include <type_traits>
+
+#include "conv3x3_args.hpp"
+
+namespace {
+
+// (a "v" constraint inside the kernel body itself would make the host-side instantiation of the launch stub invalid)
+__device__ __forceinline__ void opaque_vgpr(unsigned& x) { asm volatile("" : "+v"(x)); }
+// one LDS-DMA piece: lane l's 16 bytes at buffer offset voff + soff land at dst + 16 l (dst wave-uniform).  A device
+// function of its own: the address-space cast inside the kernel body invalidates the host-side launch stub.
+__device__ __forceinline__ void dma_piece16(const __amdgpu_buffer_rsrc_t& rs, unsigned char* dst, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)dst, 16, voff, soff, 0, 0);
+}
+
+template <int DT, int NWV, bool STATS, bool PREC, bool DEFER>
+__global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a) {
+    typedef typename Elem<DT>::V8 V8;
+    static_assert(!(PREC && DEFER), "the pair epilogue is the immediate one");
+    constexpr int BN = 64, TW = 32, TH = 2 * NWV, TWS = 5, KC = 32;
+    constexpr int HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;
+    constexpr int ROWB = KC * 2;                           // bytes per LDS row (one pixel / one cout, KC channels)
+    constexpr int SPR = ROWB / 16, RPP = 64 / SPR;         // 16-byte slots per row, rows per 1-KiB piece
+    constexpr int KSTEPS = KC / 16, NSTEP = 9 * KSTEPS;    // MFMA steps (tap, k half) per stage
+    constexpr int HI = (HP + RPP - 1) / RPP;               // halo pieces that hold real rows
+    constexpr int HJ = (HI + NWV - 1) / NWV;               // halo pieces per wave (the tail ones are spare)
+    constexpr int WG = BN / RPP;                           // weight pieces (row groups) per tap
+    constexpr int WP = 9 * WG;                             // weight pieces per stage
+    constexpr int NWP = (WP + NWV - 1) / NWV;              // ... per wave
+    constexpr int HALO_B = HJ * NWV * 1024, W_B = 9 * BN * ROWB, STAGE_B = HALO_B + W_B;
+    constexpr int STG_EL = 32 * C3_LDR;
+    constexpr unsigned VOOB = 0x80000000u;
+    // LDS: [weights 0 | halo 0 | halo 1 | weights 1 | private transposition buffers (DEFER)]; the immediate epilogue's
+    // staging overlays halo 1 + weights 1 (the last stage of an item always sits in buffer 1, the next item's first stage
+    // is on its way into buffer 0)
+    constexpr int H0_OFF = W_B, W1_OFF = W_B + 2 * HALO_B;
+    constexpr int PRIV_OFF = 2 * STAGE_B, PRIV_B = DEFER ? NWV * 1024 : 0;
+    constexpr int LDS_B = 2 * STAGE_B + PRIV_B;
+    static_assert(LDS_B <= 160 * 1024, "the stage buffers must fit in LDS");
+    // PREC (precise mode): K is a concatenation of segments over the same input channels (stage c reads
+    // input chunk c mod wrap) and the result leaves as a hi / lo pair (a second staging area and store stream)
+    static_assert((PREC ? 2 : 1) * NWV * STG_EL * 2 + NWV * 2 * BN * 4 <= HALO_B + W_B, "epilogue staging overlays the second stage buffer");
+    static_assert(NWP + HJ <= NSTEP && HJ + 1 <= NSTEP, "one DMA piece / one next-item offset per MFMA step");
+    static_assert(NWV % WG == 0, "a wave's weight pieces all belong to one row group");
+    static_assert(WP % NWV == 0 || HI < HJ * NWV, "a surplus weight slot parks its (empty) piece in the spare halo piece");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_B];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nitems = a.nblocks;
+    const int act = a.act & 0xff;
+    const int dbg = a.act >> 8;                            // ablation bits (GSSEG_C3_DEBUG=1): 2 no MFMAs, 4 no epilogue, 8 / 16 no
+                                                           // weight / halo traffic, 64 no global stores (immediate epilogue only)
+    const int nstage = a.ndz * (a.Cin / KC);               // even: Cin % 64 == 0
+    const unsigned img_bytes = (unsigned)a.H * a.W * a.in_stride * 2u;
+    const unsigned tap_stride = (unsigned)a.Cout * a.Cin * 2u;
+    const bool flip = a.tap_dy[0] > 0;                     // data-gradient table: geometric tap g uses weight slot 8 - g
+    const int tiles_y8 = (a.H + 7) >> 3;                   // immediate form: BatchNorm partial rows are numbered in 8x32 patches
+
+    struct Item { int n, y0, x0, n0, mt; };
+    const __amdgpu_buffer_rsrc_t w_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)(9u * a.ndz * a.Cout * a.Cin * 2u), 0x00020000);
+
+    // ---- DMA side: lane l of a piece fills physical slot l % SPR of row l / SPR; the logical slot (8 channels) that belongs
+    // there is the physical one xor-ed with the row's swizzle key (row >> 2) & 3 ----
+    const int drow = lane / SPR;
+    const int dls = (lane % SPR) ^ ((lane >> 4) & (SPR - 1));
+    unsigned hv[HJ], wv;         // this item's buffer offsets per piece slot
+    unsigned hvn[HJ], wvn;       // the next item's: computed one slot per MFMA step of every even stage (nearly free
+                                 // there; at the item boundary the same ~70 instructions ran with nothing to hide behind)
+    auto halo_voff = [&](int y0, int x0, int j) __attribute__((always_inline)) {      // j compile-time
+        const int r = (wave + j * NWV) * RPP + drow;
+        const int hy = r / HWD, hx = r - hy * HWD;
+        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool ok = r < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        return ok ? (unsigned)(((gy * a.W + gx) * a.in_stride + a.in_coff + dls * 8) * 2) : VOOB;
+    };
+    auto weight_voff = [&](int n0) __attribute__((always_inline)) {
+        const int co = n0 + (wave % WG) * RPP + drow;
+        return co < a.Cout ? (unsigned)((co * a.Cin + dls * 8) * 2) : VOOB;
+    };
+    auto setup_item = [&](const Item& itn) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < HJ; ++j) hv[j] = halo_voff(itn.y0, itn.x0, j);
+        wv = weight_voff(itn.n0);
+    };
+    // piece k (compile-time) of stage (image rx, channel byte offset sc) into buffer bb
+    // (sc / wsc: scalar byte offsets of the stage's channel chunk in the image / of its chunk and depth-tap group in the pack;
+    // hkill: the depth tap points outside the volume -- the halo pieces carry zeros)
+    // (issuing the halo pieces before the weight pieces measured the same)
+    auto issue_piece = [&](int k, const __amdgpu_buffer_rsrc_t& rx, unsigned sc, unsigned wsc, unsigned bb, unsigned hkill,
+                           unsigned kill, bool wskip = false) __attribute__((always_inline)) {
+        if (k < NWP) {
+            if (wskip) return;                             // resident weights (WRES below): the slabs are already there
+            const int pc = wave + NWV * k;                 // piece = tap * WG + row group; the group is wave % WG for every k
+            const int tap = pc / WG;
+            const bool real = pc < WP;                     // surplus slots of the last round carry an empty piece
+            const int slot = flip ? 8 - tap : tap;
+            const unsigned dst = real ? (unsigned)(pc * 1024) + bb * W1_OFF
+                                      : (unsigned)(H0_OFF + HALO_B - 1024) + bb * HALO_B;
+            dma_piece16(w_rsrc, smem + dst, (real && !(dbg & 8)) ? (wv | kill) : VOOB, (unsigned)(real ? slot : 0) * tap_stride + wsc);
+        } else if (k - NWP < HJ) {
+            const int j = k - NWP < HJ ? k - NWP : 0;
+            const unsigned dst = H0_OFF + bb * HALO_B + (unsigned)(wave + j * NWV) * 1024u;
+            dma_piece16(rx, smem + dst, (dbg & 16) ? VOOB : (hv[j] | kill | hkill), sc);
+        }
+    };
+    // stage c of an item in slice n: 2-D: channel chunk c; Conv3d: (depth tap c / nchunk, chunk c % nchunk) reads slice n + dz
+    // and the nine weight slots of that depth tap
+    struct Src { int n; unsigned sc, wsc, hkill; };
+    const int nchunk = a.Cin / KC;
+    auto stage_src = [&](int n, int c) __attribute__((always_inline)) {
+        Src r;
+        r.n = n; r.sc = (unsigned)c * ROWB; r.wsc = r.sc; r.hkill = 0u;
+        if (PREC && a.in_wrap > 0 && c >= 2 * a.in_wrap) r.sc = (unsigned)(c - 2 * a.in_wrap) * ROWB;    // in_wrap counts 64-channel chunks
+        if (a.ndz > 1) {
+            const int dzi = c / nchunk, cc = c - dzi * nchunk;
+            const int dz = a.tap_dz[dzi];
+            const int d = n % a.D;
+            const bool inside = (unsigned)(d + dz) < (unsigned)a.D;
+            r.n = inside ? n + dz : n;
+            r.hkill = inside ? 0u : VOOB;
+            r.sc = (unsigned)cc * ROWB;
+            r.wsc = (unsigned)(dzi * 9) * tap_stride + r.sc;
+        }
+        return r;
+    };
+
+    // ---- MFMA side: fragment byte addresses inside a stage buffer (item independent) ----
+    // (kept opaque: hipcc otherwise materialises every base + constant combination of both buffers in its own register)
+    // (DEFER is short of registers -- 32 of packed results ride through the next item's first stage: the second k half's
+    // address is formed at the read, one v_xor each)
+    constexpr int AK = DEFER ? 1 : KSTEPS;
+    unsigned aaddr[AK][4][3];                              // [k half][halo row 2*wave + e, e = i + dy + 1][column l31 + dx + 1]
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int r = (2 * wave + e) * HWD + l31 + d;
+            const int key = (r >> 2) & 3;
+            aaddr[0][e][d] = (unsigned)(H0_OFF + r * ROWB + ((h ^ key) << 4));
+            opaque_vgpr(aaddr[0][e][d]);
+            if (AK == 2) {
+                aaddr[AK - 1][e][d] = aaddr[0][e][d] ^ 32u;
+                opaque_vgpr(aaddr[AK - 1][e][d]);
+            }
+        }
+    unsigned baddr[2][KSTEPS];                             // [buffer][k half]
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int key = (l31 >> 2) & 3;
+        baddr[b][0] = (unsigned)(b * W1_OFF + l31 * ROWB + ((h ^ key) << 4));
+        opaque_vgpr(baddr[b][0]);
+        baddr[b][1] = baddr[b][0] ^ 32u;
+        opaque_vgpr(baddr[b][1]);
+    }
+
+    f32x16 acc[2][2];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+
+    // ---- deferred epilogue state (DEFER): the previous item's tile as packed 16-bit pairs, its store base, its image ----
+    constexpr int NPK = DEFER ? 8 : 1;
+    unsigned pk[2][2][NPK];                                // [i][j][m]: rows 2m, 2m+1 of the lane's cout in tile (i, j)
+    unsigned pend_voff = 0u;                               // lane part of the store offset of the pending tile
+    int pend_n = 0;                                        // its image
+    bool pend = false;
+    const bool odd = lane & 1;
+    const unsigned int psel = odd ? 0x03020706u : 0x05040100u;
+    // private transposition buffer of the wave: 8 pixel rows x 128 B (64 couts), 16-byte slot s of row r at s ^ r
+    unsigned char* const priv = smem + PRIV_OFF + wave * 1024;
+    const unsigned row_stride_b = (unsigned)a.W * a.out_stride * 2u;          // one image row of the output, bytes
+    // pass p (0..7) of the pending tile, three phases: W (4 ds_write_b32), R (ds_read_b128), S (the 16-byte store)
+    u32x4 dsv;                                             // the read-back value in flight
+    auto defer_write = [&](int p) __attribute__((always_inline)) {          // p compile-time
+        const int i = p >> 2, m0 = (p & 3) * 2;
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) {
+            const int m = m0 + mm;                         // rows 2m, 2m+1 (+4h) of the 32-row tile: local rows 2*mm + odd + 4h
+            const int lr = 2 * mm + (odd ? 1 : 0) + 4 * h;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned own = pk[i][j][DEFER ? m : 0];
+                const unsigned oth = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
+                const unsigned v = __builtin_amdgcn_perm(oth, own, psel);
+                const int slot = (j * 4 + (l31 >> 3)) ^ lr;                  // 16-byte slot (8 couts) of cout pair l31 & ~1
+                *reinterpret_cast<unsigned*>(priv + lr * 128 + slot * 16 + (l31 & 6) * 2) = v;
+            }
+        }
+    };
+    // The read-back is inline assembly: hipcc cannot tell a plain LDS read from the destination of the LDS-DMA pieces in flight
+    // and puts `s_waitcnt vmcnt(0)` in front of it -- every pass then waited for the whole next stage to land.  The wait for
+    // the value (defer_wait) sits at the top of the following step, where the step's own fragment reads are due anyway.
+    const unsigned priv_rd = (unsigned)(PRIV_OFF + wave * 1024 + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4));
+    auto defer_read = [&](int p) __attribute__((always_inline)) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(dsv) : "v"(priv_rd) : "memory");
+    };
+    auto defer_wait = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto defer_store = [&](int p) __attribute__((always_inline)) {
+        const int i = p >> 2;
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.y + (int64_t)pend_n * a.H * a.W * a.out_stride), 0, (unsigned)a.H * a.W * a.out_stride * 2u, 0x00020000);
+        const unsigned soff = (unsigned)i * row_stride_b + (unsigned)((p & 3) * 8) * (unsigned)a.out_stride * 2u;
+        __builtin_amdgcn_raw_buffer_store_b128(dsv, ry, pend_voff, soff, 0);
+    };
+    // the deferred work of MFMA step `step` of the first stage: pass p = step / 2 writes at step 2p, reads at 2p + 1, stores at 2p + 2
+    // (in front of the writes of pass p + 1; LDS operations of a wave execute in order)
+    auto defer_step = [&](int step) __attribute__((always_inline)) {
+        if (step >= 2 && step % 2 == 0 && (step - 2) / 2 < 8) defer_store((step - 2) / 2);
+        if (step % 2 == 0 && step / 2 < 8) defer_write(step / 2);
+        if (step % 2 == 1 && step / 2 < 8) defer_read(step / 2);
+    };
+    auto defer_step_head = [&](int step) __attribute__((always_inline)) {     // top of a step that stores: the read-back has landed
+        if (step >= 2 && step % 2 == 0 && (step - 2) / 2 < 8) defer_wait();
+    };
+    static_assert(NSTEP >= 17, "eight passes need steps 0..16 of one stage");
+    auto defer_flush = [&]() __attribute__((always_inline)) {               // everything at once (after the last item)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            defer_write(p);
+            defer_read(p);
+            defer_wait();
+            defer_store(p);
+        }
+    };
+
+    // one stage: NSTEP steps (tap, k half) of 4 MFMAs out of buffer BUF; the pieces of the next stage (image rx_n, channel
+    // offset sc_n) go into the other buffer, one per step
+    // FIRST: the first stage of an item starts its accumulators from the MFMA's zero C operand (no clearing pass)
+    // PEND : the previous item's deferred epilogue passes ride on this stage's steps
+    auto run_stage = [&](auto buf_tag, auto first_tag, auto pend_tag, const __amdgpu_buffer_rsrc_t& rx_n, const Src& sn, unsigned kill,
+                         const Item& itn, bool wskip = false) __attribute__((always_inline)) {
+        const unsigned sc_n = sn.sc, wsc_n = sn.wsc, hkill_n = sn.hkill;
+        constexpr int BUF = decltype(buf_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr bool PEND = decltype(pend_tag)::value;
+        constexpr unsigned OBUF = 1 - BUF;           // the buffer the next stage is fetched into
+        if (dbg & 2) {                                     // ablation: DMA traffic only
+#pragma unroll
+            for (int k = 0; k < NWP + HJ; ++k) issue_piece(k, rx_n, sc_n, wsc_n, OBUF, hkill_n, kill, wskip);
+            if (BUF == 0) {
+#pragma unroll
+                for (int j = 0; j < HJ; ++j) hvn[j] = halo_voff(itn.y0, itn.x0, j);
+                wvn = weight_voff(itn.n0);
+            }
+            if (FIRST) zero_acc();
+            if (PEND) defer_flush();
+            return;
+        }
+        V8 af[2][2], bf[2][2];
+        auto frag_load = [&](int step, V8 (&fa)[2], V8 (&fb)[2]) __attribute__((always_inline)) {
+            const int tap = step / KSTEPS, kh = step % KSTEPS;
+            const int dyi = tap / 3, dxi = tap - 3 * dyi;
+            const unsigned a0 = (AK == 1 && kh == 1) ? (aaddr[0][dyi][dxi] ^ 32u) : aaddr[AK == 1 ? 0 : kh][dyi][dxi];
+            const unsigned a1 = (AK == 1 && kh == 1) ? (aaddr[0][dyi + 1][dxi] ^ 32u) : aaddr[AK == 1 ? 0 : kh][dyi + 1][dxi];
+            fa[0] = *reinterpret_cast<const V8*>(smem + a0 + BUF * HALO_B);
+            fb[0] = *reinterpret_cast<const V8*>(smem + baddr[BUF][kh] + tap * (BN * ROWB));
+            fa[1] = *reinterpret_cast<const V8*>(smem + a1 + BUF * HALO_B);
+            fb[1] = *reinterpret_cast<const V8*>(smem + baddr[BUF][kh] + tap * (BN * ROWB) + 32 * ROWB);
+        };
+        frag_load(0, af[0], bf[0]);
+#pragma unroll
+        for (int step = 0; step < NSTEP; ++step) {
+            const int cur = step & 1;
+            if (PEND) defer_step_head(step);
+            if (step + 1 < NSTEP) frag_load(step + 1, af[cur ^ 1], bf[cur ^ 1]);
+            // (two pieces per step, i.e. everything issued in the first half of the stage, measured the same or 1 % slower
+            // on the deep layers: the pieces are not late)
+            issue_piece(step, rx_n, sc_n, wsc_n, OBUF, hkill_n, kill, wskip);
+            if (BUF == 0 && step <= HJ) {                  // the next item's piece offsets, one slot per step
+                int py0 = itn.y0, px0 = itn.x0, pn0 = itn.n0;
+                asm volatile("" : "+s"(py0), "+s"(px0), "+s"(pn0));      // keeps this arithmetic in the step (else hoisted to the item boundary)
+                if (step < HJ) hvn[step < HJ ? step : 0] = halo_voff(py0, px0, step < HJ ? step : 0);
+                else wvn = weight_voff(pn0);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (FIRST && step == 0) {
+                        f32x16 z;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                        acc[i][j] = Elem<DT>::mfma32(af[cur][i], bf[cur][j], z);
+                    } else {
+                        acc[i][j] = Elem<DT>::mfma32(af[cur][i], bf[cur][j], acc[i][j]);
+                    }
+                }
+            if (PEND) defer_step(step);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // one LDS fragment read in its shadow
+            }
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);           // the DMA piece of this step
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // stage hand-over: this wave's pieces have landed; after the barrier everybody's have, and nobody reads the other
+    // buffer any more.  (Stores count in vmcnt too: the epilogue's are drained here as well.)
+    auto stage_sync = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    // ---- BatchNorm partial sums: (even row, odd row) sums in packed fp32 math.  DEFER: kept across the items of the block ----
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 s1v[2] = {{0.f, 0.f}, {0.f, 0.f}}, s2v[2] = {{0.f, 0.f}, {0.f, 0.f}};
+
+    // ---- immediate epilogue: as conv3x3_big_kernel (staging overlays the second stage buffer, which the last stage has just left) ----
+    unsigned short* stg = reinterpret_cast<unsigned short*>(smem + H0_OFF + HALO_B) + wave * STG_EL;
+    unsigned short* stg_lo = stg + NWV * STG_EL;                                        // PREC: the lo halves
+    float* red = reinterpret_cast<float*>(smem + H0_OFF + HALO_B + (PREC ? 2 : 1) * NWV * STG_EL * 2);  // [NWV][2][BN]
+    const float neg_slope = act == GS_ACT_RELU ? 0.f : (act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
+    auto epilogue_t = [&](const Item& itc, auto plain_tag, auto full_tag) __attribute__((always_inline)) {
+        constexpr bool PLAIN = decltype(plain_tag)::value;
+        constexpr bool FULL = decltype(full_tag)::value;
+        int e_y0 = itc.y0, e_x0 = itc.x0, e_n = itc.n, e_n0 = itc.n0;
+        asm volatile("" : "+s"(e_y0), "+s"(e_x0), "+s"(e_n), "+s"(e_n0));
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.y + (int64_t)e_n * a.H * a.W * a.out_stride), 0, (unsigned)a.H * a.W * a.out_stride * 2u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ry_lo = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((PREC ? a.y_lo : a.y) + (int64_t)e_n * a.H * a.W * a.out_stride), 0, (unsigned)a.H * a.W * a.out_stride * 2u, 0x00020000);
+        constexpr bool want_stats = STATS;              // BatchNorm partial sums: a template flag (no per-element selects)
+        float bv[2] = {0.f, 0.f};
+        if (!PLAIN) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int co = e_n0 + j * 32 + l31;
+                bv[j] = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
+            }
+        }
+        if (!DEFER) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { s1v[j] = f32x2{0.f, 0.f}; s2v[j] = f32x2{0.f, 0.f}; }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int prow0 = (wave * 2 + i) * 32;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int r0 = 2 * m;
+                const int rowa = (r0 & 3) + 8 * (r0 >> 2) + 4 * h;
+                float w0 = 1.f, w1 = 1.f;
+                if (!FULL && want_stats) {
+                    const int p0 = prow0 + rowa;
+                    const int gy0 = e_y0 + (p0 >> TWS), gx0 = e_x0 + (p0 & (TW - 1));
+                    const int gy1 = e_y0 + ((p0 + 1) >> TWS), gx1 = e_x0 + ((p0 + 1) & (TW - 1));
+                    w0 = (float)((unsigned)((gy0 - a.H) & (gx0 - a.W)) >> 31);
+                    w1 = (float)((unsigned)((gy1 - a.H) & (gx1 - a.W)) >> 31);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v0 = acc[i][j][r0], v1 = acc[i][j][r0 + 1];
+                    if (want_stats) {
+                        f32x2 vv = {v0, v1};
+                        if (!FULL) vv *= f32x2{w0, w1};
+                        s1v[j] += vv;
+                        s2v[j] += vv * vv;
+                    }
+                    if (!PLAIN) {
+                        v0 += bv[j];
+                        v1 += bv[j];
+                        v0 = v0 > 0.f ? v0 : v0 * neg_slope;
+                        v1 = v1 > 0.f ? v1 : v1 * neg_slope;
+                    }
+                    const unsigned int own = Elem<DT>::pack2(v0, v1);
+                    const unsigned int oth = dpp_xor1(own);
+                    const unsigned int pkv = __builtin_amdgcn_perm(oth, own, psel);
+                    const int row = rowa + (odd ? 1 : 0);
+                    *reinterpret_cast<unsigned int*>(stg + row * C3_LDR + j * 32 + (l31 & ~1)) = pkv;
+                    if (PREC) {                               // lo = 16-bit(value - hi): the pair carries ~22 bits
+                        const float l0 = v0 - Elem<DT>::to_f((unsigned short)(own & 0xffffu));
+                        const float l1 = v1 - Elem<DT>::to_f((unsigned short)(own >> 16));
+                        const unsigned int own_l = Elem<DT>::pack2(l0, l1);
+                        const unsigned int oth_l = dpp_xor1(own_l);
+                        const unsigned int pk_l = __builtin_amdgcn_perm(oth_l, own_l, psel);
+                        *reinterpret_cast<unsigned int*>(stg_lo + row * C3_LDR + j * 32 + (l31 & ~1)) = pk_l;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint4 sv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                sv[q] = *reinterpret_cast<const uint4*>(stg + (q * 8 + (lane >> 3)) * C3_LDR + (lane & 7) * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int p = prow0 + q * 8 + (lane >> 3);
+                const int gy = e_y0 + (p >> TWS), gx = e_x0 + (p & (TW - 1));
+                const int co = e_n0 + (lane & 7) * 8;
+                const bool ok = (FULL || (gy < a.H && gx < a.W)) && co < a.Cout;
+                const unsigned off = ok ? (unsigned)(((gy * a.W + gx) * a.out_stride + a.out_coff + co) * 2) : VOOB;
+                u32x4 d;
+                d[0] = sv[q].x; d[1] = sv[q].y; d[2] = sv[q].z; d[3] = sv[q].w;
+                if (dbg & 64) asm volatile("" :: "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(off));      // ablation: no global stores
+                else __builtin_amdgcn_raw_buffer_store_b128(d, ry, off, 0, 0);
+                if (PREC) {
+                    const uint4 lv = *reinterpret_cast<const uint4*>(stg_lo + (q * 8 + (lane >> 3)) * C3_LDR + (lane & 7) * 8);
+                    u32x4 dl;
+                    dl[0] = lv.x; dl[1] = lv.y; dl[2] = lv.z; dl[3] = lv.w;
+                    __builtin_amdgcn_raw_buffer_store_b128(dl, ry_lo, off, 0, 0);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (want_stats && !DEFER) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float t1 = s1v[j].x + s1v[j].y, t2 = s2v[j].x + s2v[j].y;
+                t1 += __shfl_xor(t1, 32, 64);
+                t2 += __shfl_xor(t2, 32, 64);
+                if (h == 0) {
+                    red[(wave * 2 + 0) * BN + j * 32 + l31] = t1;
+                    red[(wave * 2 + 1) * BN + j * 32 + l31] = t2;
+                }
+            }
+        }
+    };
+    const bool plain = (a.bias == nullptr && act == GS_ACT_NONE);
+    // immediate form, per-item partial rows (!DEFER): partial sums of the 8x32 halves: waves 4*half .. 4*half+3
+    auto finish_stats = [&](const Item& itc) __attribute__((always_inline)) {
+        constexpr int NH = NWV / 4;
+        if (STATS && t < NH * BN) {
+            const int half = t / BN, c = t % BN;
+            if (itc.n0 + c < a.Cout && (itc.y0 >> 3) + half < tiles_y8) {
+                float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    v1 += red[((half * 4 + m) * 2 + 0) * BN + c];
+                    v2 += red[((half * 4 + m) * 2 + 1) * BN + c];
+                }
+                float* dst = a.bnp + (int64_t)(itc.mt + half * a.tiles_x) * 2 * a.Cout + itc.n0 + c;
+                dst[0] = v1;
+                dst[a.Cout] = v2;
+            }
+        }
+    };
+    // deferred form, item boundary: accumulators -> packed pairs + running statistics (nothing leaves the registers)
+    auto convert_item = [&](const Item& itc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float v0 = acc[i][j][2 * m], v1 = acc[i][j][2 * m + 1];
+                    if (STATS) {
+                        const f32x2 vv = {v0, v1};
+                        s1v[j] += vv;
+                        s2v[j] += vv * vv;
+                    }
+                    pk[i][j][DEFER ? m : 0] = Elem<DT>::pack2(v0, v1);
+                }
+        int e_y0 = itc.y0, e_x0 = itc.x0;
+        asm volatile("" : "+s"(e_y0), "+s"(e_x0));
+        // pixel (patch row 2*wave + i, column 8*(p & 3) + lane / 8), couts n0 + 8*(lane & 7): i and p ride in the scalar offset
+        // (a partial cout tile: the lanes beyond Cout carry the out-of-range offset, their stores are dropped)
+        pend_voff = (itc.n0 + (lane & 7) * 8 < a.Cout)
+                        ? (unsigned)((((e_y0 + 2 * wave) * a.W + e_x0 + (lane >> 3)) * a.out_stride + a.out_coff + itc.n0 + (lane & 7) * 8) * 2)
+                        : VOOB;
+        pend_n = itc.n;
+        pend = true;
+    };
+
+    // ---- items: same numbering and XCD-aware start as conv3x3_big_kernel ----
+    int it = a.xcd_order ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+    if (it >= nitems) return;
+    const int it_first = it;
+    int dg0 = it % a.ntn, dg1, dg2, dg3;
+    {
+        int r = it / a.ntn;
+        dg1 = r % a.tiles_x; r /= a.tiles_x;
+        dg2 = r % a.tiles_y; dg3 = r / a.tiles_y;
+    }
+    int st0, st1, st2, st3;
+    {
+        int r = gridDim.x;
+        st0 = r % a.ntn; r /= a.ntn;
+        st1 = r % a.tiles_x; r /= a.tiles_x;
+        st2 = r % a.tiles_y; st3 = r / a.tiles_y;
+    }
+    auto make_item = [&]() __attribute__((always_inline)) {
+        Item r;
+        r.n = dg3; r.y0 = dg2 * TH; r.x0 = dg1 * TW; r.n0 = dg0 * BN;
+        r.mt = (dg3 * tiles_y8 + (r.y0 >> 3)) * a.tiles_x + dg1;
+        return r;
+    };
+    auto advance_item = [&]() __attribute__((always_inline)) {
+        dg0 += st0; int c = dg0 >= a.ntn ? 1 : 0; dg0 -= c * a.ntn;
+        dg1 += st1 + c; c = dg1 >= a.tiles_x ? 1 : 0; dg1 -= c * a.tiles_x;
+        dg2 += st2 + c; c = dg2 >= a.tiles_y ? 1 : 0; dg2 -= c * a.tiles_y;
+        dg3 += st3 + c;
+        return make_item();
+    };
+    auto image_rsrc = [&](int n) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)n * a.H * a.W * a.in_stride), 0, img_bytes, 0x00020000);
+    };
+    Item cur = make_item();
+    const int block_n0 = cur.n0;                           // DEFER: the block's cout tile (st0 == 0: host-guaranteed)
+    // WRES: a 64-channel input is two stages -- the weight slabs of stage 0 / stage 1 of the block's cout tile sit in buffer 0 /
+    // buffer 1, and every item would fetch the same 2 x 36 KB again.  The block keeps its cout tile, so they are fetched ONCE:
+    // 73 of the 215 KB an item moves through the CU's memory pipe (halo 78 KB in, 64 KB out).  With the immediate epilogue this
+    // measured +-2 % (the epilogue was the longer pole: 194 vs 198 us on 64->64 @256^2); with the epilogue out of the way the
+    // weight traffic is what these layers wait for (without epilogue: 171 us -> 138 us with resident weights).
+    // (The immediate epilogue's staging overlays halo 1 exactly -- 8 x 4.5 KB + 4 KB of partial sums = 40 KB -- so a partial
+    // patch on that path does not disturb the slabs; the pair form overlays weights 1 and never takes this path.)
+    const bool wres = DEFER && nstage == 2 && a.ndz == 1 && st0 == 0 && !(dbg & 32);
+    bool first_item = true;
+    setup_item(cur);
+    {
+        const Src s0 = stage_src(cur.n, 0);
+        const __amdgpu_buffer_rsrc_t rx0 = image_rsrc(s0.n);
+#pragma unroll
+        for (int k = 0; k < NWP + HJ; ++k) issue_piece(k, rx0, s0.sc, s0.wsc, 0u, s0.hkill, 0u);   // stage 0 -> buffer 0
+    }
+    for (;;) {
+        const int nit = it + gridDim.x;
+        const bool more_items = nit < nitems;
+        Item nxt = cur;
+        if (more_items) nxt = advance_item();
+        for (int sp = 0; sp < nstage; sp += 2) {
+            const bool last = sp + 2 >= nstage;
+            stage_sync();
+            const Src s1 = stage_src(cur.n, sp + 1);
+            if (sp == 0) {
+                const bool ws0 = wres && !first_item;      // stage 1's slabs are in buffer 1 since the first item
+                if (DEFER && pend) {
+                    run_stage(std::integral_constant<int, 0>{}, std::true_type{}, std::true_type{}, image_rsrc(s1.n), s1, 0u, nxt, ws0);
+                    pend = false;
+                } else {
+                    run_stage(std::integral_constant<int, 0>{}, std::true_type{}, std::false_type{}, image_rsrc(s1.n), s1, 0u, nxt, ws0);
+                }
+            } else {
+                run_stage(std::integral_constant<int, 0>{}, std::false_type{}, std::false_type{}, image_rsrc(s1.n), s1, 0u, nxt);
+            }
+            stage_sync();
+            if (last) {                                    // from here on the pieces belong to the next item
+#pragma unroll
+                for (int j = 0; j < HJ; ++j) hv[j] = hvn[j];
+                wv = wvn;
+            }
+            const Src s2 = stage_src(last ? nxt.n : cur.n, last ? 0 : sp + 2);
+            run_stage(std::integral_constant<int, 1>{}, std::false_type{}, std::false_type{}, image_rsrc(s2.n), s2,
+                      (last && !more_items) ? VOOB : 0u, nxt, wres && last);      // the next item's stage-0 slabs are in buffer 0
+        }
+        const bool full = (cur.y0 + TH <= a.H) && (cur.x0 + TW <= a.W);
+        if (DEFER && plain && full && !(dbg & 4)) {
+            convert_item(cur);                             // registers only: no barrier, no LDS
+        } else {
+            if (DEFER) {                                   // (nothing is pending here; tells the register allocator so)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int m = 0; m < NPK; ++m) pk[i][j][m] = 0u;
+            }
+            __builtin_amdgcn_s_barrier();              // every wave has left the second buffer: staging may overlay it
+            asm volatile("" ::: "memory");
+            if (!(dbg & 4)) {
+                if (plain && full) epilogue_t(cur, std::true_type{}, std::true_type{});
+                else epilogue_t(cur, std::false_type{}, std::false_type{});
+            }
+            __syncthreads();
+            if (!DEFER) finish_stats(cur);
+        }
+        if (!more_items) break;
+        it = nit;
+        cur = nxt;
+        first_item = false;
+    }
+    if (DEFER) {
+        if (pend) defer_flush();
+        if (STATS) {
+            // the block's partial sums: one row per block, written once (rows = grid / ntn; block b with cout tile b % ntn
+            // writes columns n0 .. n0 + 63 of row it_first / ntn)
+            __syncthreads();                               // the stage buffers are free: every wave has left the K loop
+            float* redb = reinterpret_cast<float*>(smem);  // [NWV][2][BN]
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float t1 = s1v[j].x + s1v[j].y, t2 = s2v[j].x + s2v[j].y;
+                t1 += __shfl_xor(t1, 32, 64);
+                t2 += __shfl_xor(t2, 32, 64);
+                if (h == 0) {
+                    redb[(wave * 2 + 0) * BN + j * 32 + l31] = t1;
+                    redb[(wave * 2 + 1) * BN + j * 32 + l31] = t2;
+                }
+            }
+            __syncthreads();
+            if (t < 2 * BN) {
+                const int stat = t / BN, c = t % BN;
+                if (block_n0 + c < a.Cout) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int m = 0; m < NWV; ++m) v += redb[(m * 2 + stat) * BN + c];     // wave order: deterministic
+                    a.bnp[(int64_t)(it_first / a.ntn) * 2 * a.Cout + stat * a.Cout + block_n0 + c] = v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// grid of the deferred form: at most max_blocks, a multiple of the cout-tile count (a block keeps its tile), at least one
+// item per block.  It is also the number of BatchNorm partial rows times ntn.
+int c3_dma_grid(int nitems, int ntn, int max_blocks) {
+    int g = nitems < max_blocks ? nitems : max_blocks;
+    g -= g % ntn;
+    return g < ntn ? ntn : g;
+}
+
+int c3_dma_launch(C3Args& a, int waves, bool prec, int dtype, int grid_blocks, hipStream_t s) {
+    dim3 grid(grid_blocks);
+    const bool stats = a.bnp != nullptr;
+#define C3_DMA_GO(DT, NWV)                                                                                    \
+    do {                                                                                                      \
+        if (prec) {                                                                                           \
+            if (stats) conv3x3_dma_kernel<DT, NWV, true, true, false><<<grid, 64 * NWV, 0, s>>>(a);           \
+            else conv3x3_dma_kernel<DT, NWV, false, true, false><<<grid, 64 * NWV, 0, s>>>(a);                \
+        } else {                                                                                              \
+            if (stats) conv3x3_dma_kernel<DT, NWV, true, false, true><<<grid, 64 * NWV, 0, s>>>(a);           \
+            else conv3x3_dma_kernel<DT, NWV, false, false, true><<<grid, 64 * NWV, 0, s>>>(a);                \
+        }                                                                                                     \
+    } while (0)
+    if (dtype == GS_F16) {
+        if (waves == 8) C3_DMA_GO(GS_F16, 8);
+        else C3_DMA_GO(GS_F16, 4);
+    } else {
+        if (waves == 8) C3_DMA_GO(GS_BF16, 8);
+        else C3_DMA_GO(GS_BF16, 4);
+    }
+#undef C3_DMA_GO
+    return 0;
+}

@@ -3,6 +3,7 @@ any launch, so failures are synchronous Python exceptions.  torch supplies devic
 current HIP stream only; all arithmetic happens in libgsseg_hip.so."""
 from __future__ import annotations
 
+import collections
 import ctypes
 import os
 from typing import List, Optional, Sequence, Tuple
@@ -172,13 +173,16 @@ def geom_conv_s2_dgrad_class(N, IH, IW, Cin, Cout, k, pad, py, px, **kw) -> GsCo
 
 
 # ---------------------------------------------------------------------------- MFMA engine
-_SPLITK_WS = {}      # (device index, stream handle) -> zeroed fp32 workspace (the library itself holds no state)
+_SPLITK_WS = collections.OrderedDict()      # (device index, stream handle) -> zeroed fp32 workspace, least recently used first
+_SPLITK_WS_MAX = int(os.environ.get("GSSEG_SPLITK_WS_MAX", "3"))
 
 
 def _splitk_workspace(device: torch.device, stream) -> Optional[torch.Tensor]:
-    """gs_conv_igemm's split-K workspace, passed with every call: one per (device, stream), because launches that
+    """gs_conv_igemm's split-K workspace (134 MB), passed with every call: one per (device, stream), because launches that
     share one must be ordered on one stream (ticket counters and slabs are reused); allocated zeroed once, the kernels
-    leave the counters zeroed.  Streams of a process are few (compute + side streams), so nothing is ever evicted."""
+    leave the counters zeroed.  At most GSSEG_SPLITK_WS_MAX (3) are kept: a process that runs the engine on many streams
+    (or whose stream handles torch recycles) evicts the least recently used one -- it was allocated and used on its own
+    stream only, so handing it back to torch's stream-ordered allocator is safe -- instead of pinning 134 MB per handle."""
     if os.environ.get("GSSEG_SPLITK", "1") == "0":
         return None
     key = (device.index, int(stream or 0))
@@ -187,6 +191,10 @@ def _splitk_workspace(device: torch.device, stream) -> Optional[torch.Tensor]:
         n = int(_lib.load().gs_conv_igemm_workspace_floats())
         ws = torch.zeros(n, dtype=torch.float32, device=device)     # zero fill runs on this same (current) stream
         _SPLITK_WS[key] = ws
+        while len(_SPLITK_WS) > max(1, _SPLITK_WS_MAX):
+            _SPLITK_WS.popitem(last=False)
+    else:
+        _SPLITK_WS.move_to_end(key)
     return ws
 
 
@@ -246,9 +254,29 @@ def conv3x3_mtiles(N, H, W, Cout) -> int:
     return _lib.load().gs_conv3x3_mtiles(N, H, W, Cout)
 
 
+def conv3x3_stat_rows(N, H, W, Cin, Cout, pair: bool = False) -> int:
+    """Rows of BatchNorm partial sums a conv3x3 launch of these dimensions WRITES (what bn_finalize / bn_partials_colsum must
+    be told): one per block and cout-tile group on the LDS-DMA kernel, one per patch otherwise and in the pair forward.  A
+    buffer of conv3x3_mtiles() rows always suffices."""
+    return int(_lib.load().gs_conv3x3_stat_rows(N, H, W, Cin, Cout, 1 if pair else 0))
+
+
+def conv3d3_stat_rows(NB, D, H, W, Cin, Cout) -> int:
+    return conv3x3_stat_rows(NB * D, H, W, Cin, Cout)
+
+
+def set_persistent_grid(blocks: int = 0) -> None:
+    """At most `blocks` workgroups for the persistent conv kernels (0: the default, one per CU); parallel.py leaves CUs to RCCL."""
+    _lib.call("gs_set_persistent_grid", int(blocks))
+
+
+def get_persistent_grid() -> int:
+    return int(_lib.load().gs_get_persistent_grid())
+
+
 def conv3x3_set_kernel_form(form: int = -1) -> None:
-    """Diagnostics: pin the form of the 2-D conv3x3 kernel (-1 auto, 0 register-staged, 4 / 8 LDS-DMA waves per block, 2 two
-    LDS-DMA blocks per CU).  Process-wide; tests compare the forms on the same operands and restore -1."""
+    """Diagnostics: pin the form of the conv3x3 kernel (-1 auto, 0 register-staged, 4 / 8 LDS-DMA waves per block).
+    Process-wide; tests compare the forms on the same operands and restore -1."""
     _lib.call("gs_conv3x3_set_kernel_form", int(form))
 
 
@@ -260,8 +288,8 @@ def conv3x3(x, w, y, N, H, W, Cin, Cout, taps=TAPS3_FWD, bias=None, bn_partials=
     _f32(bias, "bias"); _f32(bn_partials, "bn_partials")
     if not (x.dtype == w.dtype == y.dtype):
         raise TypeError("conv3x3: x, w, y must share one 16-bit dtype")
-    if bn_partials is not None and bn_partials.numel() < bn_partials_numel(conv3x3_mtiles(N, H, W, Cout), Cout):
-        raise ValueError("conv3x3: bn_partials too small")
+    if bn_partials is not None and bn_partials.numel() < bn_partials_numel(conv3x3_stat_rows(N, H, W, Cin, Cout), Cout):
+        raise ValueError("conv3x3: bn_partials too small (conv3x3_stat_rows rows of [2][Cout])")
     dy = (ctypes.c_int32 * 9)(*[t[0] for t in taps])
     dx = (ctypes.c_int32 * 9)(*[t[1] for t in taps])
     ev = TIMER.start() if TIMER is not None else None
@@ -346,7 +374,7 @@ def conv3d3(x, w, y, NB, D, H, W, Cin, Cout, dgrad=False, bias=None, bn_partials
         raise TypeError("conv3d3: x, w, y must share one 16-bit dtype")
     if w.numel() != 27 * Cout * Cin:
         raise ValueError("conv3d3: packed weight has the wrong size")
-    if bn_partials is not None and bn_partials.numel() < bn_partials_numel(conv3d3_mtiles(NB, D, H, W, Cout), Cout):
+    if bn_partials is not None and bn_partials.numel() < bn_partials_numel(conv3d3_stat_rows(NB, D, H, W, Cin, Cout), Cout):
         raise ValueError("conv3d3: bn_partials too small")
     sgn = -1 if dgrad else 1
     dz = (ctypes.c_int32 * 3)(*[sgn * (k - 1) for k in range(3)])

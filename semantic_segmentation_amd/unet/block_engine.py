@@ -58,7 +58,7 @@ class _Stage:
         dev, tdt = inp.device, _tdt()
         y = torch.empty((N, h, w, cout), dtype=tdt, device=dev)
         batch_stats = training or bn.running_mean is None
-        ntiles = ops.conv_smallcin_mtiles(N, h, w) if image else ops.conv3x3_mtiles(N, h, w, cout)
+        ntiles = ops.conv_smallcin_mtiles(N, h, w) if image else ops.conv3x3_stat_rows(N, h, w, cin, cout)
         part = torch.empty(ops.bn_partials_numel(ntiles, cout), dtype=torch.float32, device=dev) if batch_stats else None
         self.wd = None
         if image:

@@ -348,7 +348,7 @@ class UNetEngine:
             if image:
                 ntiles = ops.conv_smallcin_mtiles(N, h, w)
             elif ops.USE_HALO_CONV:
-                ntiles = ops.conv3x3_mtiles(N, h, w, cout)
+                ntiles = ops.conv3x3_stat_rows(N, h, w, cin, cout)
             else:
                 ntiles = ops.conv_igemm_mtiles(g)
             partials = empty(ops.bn_partials_numel(ntiles, cout), dtype=torch.float32) if batch_stats else None
@@ -599,7 +599,7 @@ class UNetEngine:
             rec.cin, rec.cout, rec.h, rec.w, rec.inp_is_image = cin, cout, h, w, image
             rec.inp, rec.train_stats, rec.geom, rec.z, rec.tap_sums = inp, batch_stats, None, None, None
             rec.inp_stride = None if image else 2 * cin
-            ntiles = ops.conv_smallcin_mtiles(N, h, w) if image else ops.conv3x3_mtiles(N, h, w, cout)
+            ntiles = ops.conv_smallcin_mtiles(N, h, w) if image else ops.conv3x3_stat_rows(N, h, w, cin, cout, pair=True)
             partials = empty(ops.bn_partials_numel(ntiles, cout), dtype=torch.float32) if batch_stats else None
             z_lo = zbuf[..., z_stride // 2:] if (zbuf is not None and want_lo) else None
             if (image and not full and FUSED_STEM_FWD and cin == 1 and cout == 64 and zp is None and z_stride == 2 * cout
@@ -738,6 +738,10 @@ class UNetEngine:
         net, tdt = self.net, self.tdt
         N, H, W, hs, ws_, C = ctx["N"], ctx["H"], ctx["W"], ctx["hs"], ctx["ws"], ctx["C"]
         dev = dlogits.device
+        if self.dynamic_loss_scale and self.grad_ready_hook is not None:
+            # (before any kernel or collective: the bucket all-reduces would be issued on gradients renormalised by THIS rank's
+            # factor, and raising later would leave the reducer's asynchronous work un-waited)
+            raise RuntimeError("dynamic_loss_scale is not supported together with the bucketed GradReducer")
         recs: Dict[str, _ConvRec] = {r.name: r for r in ctx["recs"]}
         ups: Dict[str, _UpRec] = {u.name: u for u in ctx["ups"]}
         # Gradients travel in 16 bits multiplied by a power-of-two scale S so that fp16 neither underflows nor overflows.
@@ -966,7 +970,7 @@ class UNetEngine:
                     dinp = empty(N, h, w, cin)
                     if ops.USE_HALO_CONV and colsum is not None:
                         ops.conv3x3(dy, rec.wd, dinp, N, h, w, cout, cin, ops.TAPS3_DGRAD, bn_partials=partials)
-                        ops.bn_partials_colsum(partials, ops.conv3x3_mtiles(N, h, w, cin), cin, colsum[0], colsum[1], inv_s, colsum[2])
+                        ops.bn_partials_colsum(partials, ops.conv3x3_stat_rows(N, h, w, cout, cin), cin, colsum[0], colsum[1], inv_s, colsum[2])
                     elif ops.USE_HALO_CONV:
                         ops.conv3x3(dy, rec.wd, dinp, N, h, w, cout, cin, ops.TAPS3_DGRAD)
                     else:
@@ -1035,10 +1039,6 @@ class UNetEngine:
             flush_deferred(True)
             main_stream.wait_stream(side)          # every weight gradient is complete before anything downstream reads it
         if renorm is not None:
-            # data-parallel note: the bucket all-reduces were issued on the renormalised gradients of THIS rank; with the
-            # dynamic scale every rank must use the same factor, so it is only supported without a reducer
-            if self.grad_ready_hook is not None:
-                raise RuntimeError("dynamic_loss_scale is not supported together with the bucketed GradReducer")
             inv_r = torch.reciprocal(renorm)
             torch._foreach_mul_(list(grads.values()), inv_r)
             if dx is not None:

@@ -107,7 +107,7 @@ class UNet3DEngine:
                 st.halo = ops.conv3d3_eligible(cin, cout)
                 if st.halo:                      # halo-reuse kernel: (depth tap, channel chunk) K stages
                     g = None
-                    nt = ops.conv3d3_mtiles(NB, D, H, W, cout)
+                    nt = ops.conv3d3_stat_rows(NB, D, H, W, cin, cout)
                     part = empty(ops.bn_partials_numel(nt, cout), dtype=torch.float32) if batch else None
                     ops.conv3d3(inp, wf, y, NB, D, H, W, cin, cout, bn_partials=part, in_stride=in_stride, in_coff=in_coff)
                 else:

@@ -132,7 +132,7 @@ def test_dgrad_partials_give_upconv_bias_gradient(dtn, dt, N, H, W, Cin, Cout):
     ref = F.conv_transpose2d(dy.float(), w.float(), None, padding=1)            # = data gradient of conv2d(pad 1)
     wd = torch.empty(9, Cin, Cout, dtype=dt, device=dev())
     ops.pack_weight(w.to(dev()), None, wd, False)
-    mt = ops.conv3x3_mtiles(N, H, W, Cin)
+    mt = ops.conv3x3_stat_rows(N, H, W, Cout, Cin)              # rows the data-gradient launch (Cout -> Cin) writes
     part = torch.full((ops.bn_partials_numel(mt, Cin),), float("nan"), dtype=torch.float32, device=dev())
     dx = torch.empty(N, H, W, Cin, dtype=dt, device=dev())
     ops.conv3x3(nhwc(dy, dt), wd, dx, N, H, W, Cout, Cin, ops.TAPS3_DGRAD, bn_partials=part)
@@ -390,15 +390,23 @@ def test_smallcin(dtn, dt, Cin, k, s, p, bias, H, W):
 
 
 @pytest.mark.parametrize("dtn,dt", DTS)
+@pytest.mark.parametrize("image", ["noise", "smooth"])
 @pytest.mark.parametrize("N,H,W", [(2, 18, 22), (3, 45, 53), (2, 64, 96)])
-def test_stem_without_conv_output_in_memory(dtn, dt, N, H, W):
+def test_stem_without_conv_output_in_memory(dtn, dt, N, H, W, image):
     """Conv2d(1,64,3,p1) -> BatchNorm2d(train) -> ReLU (unet_parts.py:16-18) with the convolution output never stored:
-    statistics from the image alone, fused forward, and the two backward passes re-forming y -- against torch fp32 autograd."""
+    statistics from the image alone, fused forward, and the two backward passes re-forming y -- against torch autograd
+    (fp64 for the statistics).  image = "smooth": 0.9 + 0.1 * low-pass noise -- positive, with a DC offset and strongly
+    correlated taps like the real JSRT / ISIC inputs in [0,1]: the hard case for the closed-form w^T G w - mean^2 statistics
+    (white noise has a tap Gram matrix close to n * I and never exercises the cancellation)."""
     from semantic_segmentation_amd import ops
     from semantic_segmentation_amd._lib import ACT_RELU
     g = torch.Generator().manual_seed(53)
     C = 64
     x = torch.randn(N, 1, H, W, generator=g)
+    smooth = image == "smooth"
+    if smooth:
+        lp = F.avg_pool2d(F.pad(x, (4, 4, 4, 4), mode="reflect"), 9, stride=1)
+        x = (0.9 + 0.1 * lp / lp.abs().max()).contiguous()
     w = (0.3 * torch.randn(C, 1, 3, 3, generator=g)).requires_grad_(True)
     gamma = (1 + 0.2 * torch.randn(C, generator=g)).requires_grad_(True)
     beta = (0.2 * torch.randn(C, generator=g)).requires_grad_(True)
@@ -416,25 +424,47 @@ def test_stem_without_conv_output_in_memory(dtn, dt, N, H, W):
     rm, rv = torch.zeros(C, device=dev()), torch.ones(C, device=dev())
     ops.bn_finalize(part, mt, C, N * H * W, gamma.detach().to(dev()), beta.detach().to(dev()), rm, rv, 0.1, 1e-5,
                     coef[0], coef[1], coef[2], coef[3])
-    yd_ = y.detach().double()
-    assert rel_err(coef[2], yd_.mean((0, 2, 3))) < 1e-4 + 1e-5 and rel_err(coef[3], 1 / torch.sqrt(yd_.var((0, 2, 3), unbiased=False) + 1e-5)) < 1e-4
+    yd_ = F.conv2d(x.double(), w.detach().double(), None, padding=1)
+    # (smooth: per-channel variance down to ~1e-4 of mean^2 -- fp32 sums of squares leave ~1e-4 relative on invstd)
+    assert rel_err(coef[2], yd_.mean((0, 2, 3))) < 1e-4 + 1e-5
+    assert rel_err(coef[3], 1 / torch.sqrt(yd_.var((0, 2, 3), unbiased=False) + 1e-5)) < (5e-4 if smooth else 1e-4)
     # forward
     zd = torch.full((N, H, W, C), float("nan"), dtype=dt, device=dev())
     ops.stem_fwd_bn(xd, wd_, coef[0], coef[1], ACT_RELU, zd)
     torch.cuda.synchronize()
-    assert (from_nhwc(zd) - z.detach()).abs().max() < (4e-3 if dt == torch.float16 else 3e-2)
+    ztol = (4e-3 if dt == torch.float16 else 3e-2) * (3.0 if smooth else 1.0)
+    assert (from_nhwc(zd) - z.detach()).abs().max() < ztol
+    # pair form (mixed / precise plans): hi + lo carries the fp32 value, into a [hi | lo] buffer; the hi plane is what the
+    # single-output form stores
+    zpair = torch.full((N, H, W, 2 * C), float("nan"), dtype=dt, device=dev())
+    ops.stem_fwd_bn_pair(xd, wd_, coef[0], coef[1], ACT_RELU, zpair)
+    torch.cuda.synchronize()
+    assert torch.equal(zpair[..., :C], zd)
+    zsum = (zpair[..., :C].double() + zpair[..., C:].double()).permute(0, 3, 1, 2).cpu()
+    zown = F.relu(yd_ * coef[0].double().cpu().view(1, C, 1, 1) + coef[1].double().cpu().view(1, C, 1, 1))    # with OUR coefficients
+    assert (zsum - zown).abs().max() < (2e-5 if dt == torch.float16 else 3e-4) * max(1.0, float(zown.abs().max()))
     dzd = nhwc(dz, dt)
     nt = ops.stem_bwd_tiles(N, H, W)
     # ONE pass over z (its sign) and dz + closed-form BatchNorm / weight gradients (tap sums / Gram matrix of the image)
     s1p = torch.full((nt * 64,), float("nan"), dtype=torch.float32, device=dev())
     sws = torch.full((nt * 576,), float("nan"), dtype=torch.float32, device=dev())
     assert ops.stem_bwd_onepass(xd, zd, dzd, C, 0, ACT_RELU, s1p, sws)
+    # the same pass reading z as the hi plane of the pair buffer (pixel stride 2C): identical sums
+    s1q, swq = torch.full_like(s1p, float("nan")), torch.full_like(sws, float("nan"))
+    assert ops.stem_bwd_onepass(xd, zpair, dzd, C, 0, ACT_RELU, s1q, swq, z_stride=2 * C)
+    torch.cuda.synchronize()
+    assert torch.equal(s1q, s1p) and torch.equal(swq, sws)
     dgamma3 = torch.full((C,), float("nan"), device=dev()); dbeta3 = torch.full((C,), float("nan"), device=dev())
     dw3 = torch.zeros(C, 1, 3, 3, device=dev())
     ops.stem_bwd_finalize(sws, s1p, taps, wd_, coef[0], coef[2], coef[3], True, 0.5, dw3, dgamma3, dbeta3, N, H, W)
     torch.cuda.synchronize()
-    assert rel_err(dbeta3 * 2, beta.grad) < 2e-3 and rel_err(dgamma3 * 2, gamma.grad) < 2e-3, (rel_err(dbeta3 * 2, beta.grad), rel_err(dgamma3 * 2, gamma.grad))
-    assert rel_err(dw3.cpu() * 2, w.grad) < (2e-3 if dt == torch.float16 else 1e-2), rel_err(dw3.cpu() * 2, w.grad)
+    # references in fp64 on the same dz (the fp32 autograd reference itself is ~1e-3 off on the smooth images)
+    xw, ww = x.double(), w.detach().double().requires_grad_(True)
+    g64, b64 = gamma.detach().double().requires_grad_(True), beta.detach().double().requires_grad_(True)
+    F.relu(F.batch_norm(F.conv2d(xw, ww, None, padding=1), None, None, g64, b64, True, 0.1, 1e-5)).backward(dz.double())
+    gtol = 2e-2 if smooth else 2e-3
+    assert rel_err(dbeta3 * 2, b64.grad) < gtol and rel_err(dgamma3 * 2, g64.grad) < gtol, (rel_err(dbeta3 * 2, b64.grad), rel_err(dgamma3 * 2, g64.grad))
+    assert rel_err(dw3.cpu() * 2, ww.grad) < (gtol if dt == torch.float16 else 5 * gtol), rel_err(dw3.cpu() * 2, ww.grad)
     # eval-mode statistics (constants): c1 = c2 = 0, the tap sums are not read
     dw4 = torch.zeros(C, 1, 3, 3, device=dev())
     ops.stem_bwd_finalize(sws, s1p, None, wd_, coef[0], coef[2], coef[3], False, 1.0, dw4, dgamma3, dbeta3, N, H, W)
@@ -1052,11 +1082,15 @@ def _unpack_merged(pf, cin, cout):
 
 
 @pytest.mark.parametrize("dtn,dt", DTS)
-@pytest.mark.parametrize("form", [0, 4, 8, 2, 16, 32])
+@pytest.mark.parametrize("form", [0, 4, 8])
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 37, 41, 64, 64), (1, 17, 33, 128, 72), (3, 9, 100, 64, 128), (2, 48, 32, 192, 64),
-                                            (2, 33, 40, 128, 256)])
+                                            (2, 33, 40, 128, 256),
+                                            # several items per block (the persistent grid is 256 blocks): the deferred epilogue's
+                                            # hand-over between items, running statistics across items, resident weights (Cin = 64),
+                                            # a ragged last row of patches in between
+                                            (24, 96, 128, 64, 64), (10, 104, 96, 64, 128), (20, 64, 96, 128, 64)])
 def test_conv3x3_kernel_forms(dtn, dt, form, N, H, W, Cin, Cout):
-    """every form of the 2-D kernel (register-staged big-K-step, LDS-DMA with 4 / 8 waves, two LDS-DMA blocks per CU) on the
+    """every form of the 2-D kernel (register-staged big-K-step, LDS-DMA with 4 / 8 waves) on the
     same operands: forward with BatchNorm partials into a strided slice (ragged patches, a partial cout tile, an odd
     number of 8-row halves), bias + ReLU epilogue, and the data gradient (flipped tap table)"""
     from semantic_segmentation_amd import ops
@@ -1116,7 +1150,7 @@ def test_dma_kernels_repeatable_under_memory_noise():
         mt = ops.conv3x3_mtiles(N, H, W, Cout)
         ws = torch.empty(ops.conv3x3_wgrad_ws_floats(N, H, W, Cin, Cout), dtype=torch.float32, device=dev())
         try:
-            for form in (8, 4, 2, 16, 32):
+            for form in (8, 4):
                 ops.conv3x3_set_kernel_form(form)
                 ref = None
                 for it in range(30):

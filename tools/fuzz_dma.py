@@ -42,7 +42,7 @@ def main():
     for case in range(a.cases):
         dt = rng.choice([torch.float16, torch.bfloat16])
         tol = 3e-3 if dt == torch.float16 else 1.5e-2
-        form = rng.choice([-1, 4, 8, 2, 16, 32])
+        form = rng.choice([-1, 4, 8])
         N, H, W = rng.randint(1, 6), rng.randint(1, 72), rng.randint(24, 80)
         Cin, Cout = 64 * rng.randint(1, 5), rng.choice([64, 128, 256, 8 * rng.randint(1, 30)])
         x = torch.randn(N, Cin, H, W, generator=g).to(dt).float().requires_grad_(True)
