@@ -307,7 +307,8 @@ int pw_upconv2x2_fwd_fast(const void* x, const void* w, const float* bias, void*
     a.out_stride = out_pix_stride; a.out_coff = out_coff; a.ooy = ooy; a.oox = oox;
     a.ntn = 4 * Cout / 256;
     a.nitems = (int)(M / 256) * a.ntn;
-    const int blocks = a.nitems < 256 ? a.nitems : 256;
+    const int pg = gs_get_persistent_grid();              // 256, or fewer when CUs are left to RCCL
+    const int blocks = a.nitems < pg ? a.nitems : pg;
     a.xcd_order = (blocks % 8 == 0 && a.ntn > 1) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == GS_F16) upconv2x2_dma_kernel<GS_F16, false><<<blocks, 512, 0, s>>>(a);
@@ -345,7 +346,8 @@ extern "C" int gs_upconv2x2_dgrad(const void* dy, const void* wd, void* dx, int 
     a.out_stride = dx_pix_stride; a.out_coff = dx_coff; a.ooy = ooy; a.oox = oox;
     a.ntn = cdiv(Cin, 256);
     a.nitems = (int)(M / 256) * a.ntn;
-    const int blocks = a.nitems < 256 ? a.nitems : 256;
+    const int pg = gs_get_persistent_grid();              // 256, or fewer when CUs are left to RCCL
+    const int blocks = a.nitems < pg ? a.nitems : pg;
     a.xcd_order = (blocks % 8 == 0 && a.ntn > 1) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == GS_F16) upconv2x2_dma_kernel<GS_F16, true><<<blocks, 512, 0, s>>>(a);

@@ -410,7 +410,8 @@ static int w3_ksplit(int N, int H, int W, int Cin, int Cout, int* pps_out, int* 
     const int npatches = N * cdiv(W, tw) * cdiv(H, th);
     const int pairs = cdiv(Cout, 64) * cdiv(Cin, 64);
     static const int target_env = getenv("GSSEG_W3_GRID") ? atoi(getenv("GSSEG_W3_GRID")) : 0;
-    const int target = target_env > 0 ? target_env : (dma ? 256 : 512);     // one 8-wave / two 4-wave blocks per CU
+    // one 8-wave / two 4-wave blocks per CU (fewer when gs_set_persistent_grid() leaves CUs to RCCL)
+    const int target = target_env > 0 ? target_env : (dma ? gs_get_persistent_grid() : 2 * gs_get_persistent_grid());
     // every part writes a 9 x 64 x 64 fp32 tile per (co, ci) pair (147 KB) that the ordered reduction reads back: a part
     // must cover a few patches for that to be worth it (batch 2: 512 one-patch parts cost more than the MFMAs)
     static const int min_pps_env = getenv("GSSEG_W3_MINPPS") ? atoi(getenv("GSSEG_W3_MINPPS")) : 4;

@@ -27,7 +27,10 @@ def generator_backward(engine, ctx, arch, dout, need_dx):
     H, W = hs[0], ws[0]
     S = float(2 ** round(math.log2(N * H * W)))
     inv_s = 1.0 / S
-    grads: Dict[str, torch.Tensor] = {}
+    # (data parallel: every parameter gradient is announced to the reducer as soon as it is final -- parallel.GradEmitter)
+    from ..parallel import GradEmitter
+    emitter = GradEmitter(getattr(engine, "grad_ready_hook", None))
+    grads = emitter.grads
     names = {id(p): n for n, p in engine.net.named_parameters()}
     darch = torch.zeros(arch.shape, dtype=torch.float32, device=dev)
 
@@ -35,7 +38,7 @@ def generator_backward(engine, ctx, arch, dout, need_dx):
         return torch.empty(shape, dtype=dtype, device=dev)
 
     def emit(p, g):
-        grads[names[id(p)]] = g
+        emitter.emit(names[id(p)], g)
 
     def bn_bwd(y, coef, stats, bnmod, dz_a, sa, ca, act, dz_b=None, act_b=ACT_NONE, keep=None, kscale=1.0):
         """gradient w.r.t. the raw conv output y of  act(bn(y)) [two consumers / dropout]; emits dgamma/dbeta."""
@@ -156,4 +159,6 @@ def generator_backward(engine, ctx, arch, dout, need_dx):
             dL = empty(N, hs[k - 1], ws[k - 1], cin)
             gds = [ops.geom_conv_s2_dgrad_class(N, hs[k - 1], ws[k - 1], cin, cout, 4, 1, cls >> 1, cls & 1) for cls in range(4)]
             ops.conv_igemm_batch(gds, dy, [lv["wd"]] * 4, dL)
+    if getattr(engine, "after_backward", None) is not None:
+        engine.after_backward()
     return grads, darch.to(arch.device), dx

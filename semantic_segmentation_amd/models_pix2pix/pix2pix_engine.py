@@ -90,6 +90,16 @@ def _ver(*ts):
     return tuple((t.data_ptr(), t._version) for t in ts)
 
 
+class _EmitDict:
+    """`grads[name] = g` of a backward pass routed through parallel.GradEmitter (each name is assigned once)"""
+
+    def __init__(self, emitter):
+        self._e = emitter
+
+    def __setitem__(self, name, g):
+        self._e.emit(name, g)
+
+
 # =====================================================================================================
 # Generator
 # =====================================================================================================
@@ -99,6 +109,7 @@ class GeneratorEngine:
         self.dtype, self.tdt = _dtype_of(dtype)
         self.packs = _PackCache()
         self.trust_versions = False      # see unet_engine.pack_reuse_allowed
+        self.grad_ready_hook = self.after_backward = self.grad_fetch = None      # parallel.GradReducer.attach
 
     def blocks(self):
         """UnetSkipConnectionBlocks from the outermost (depth 0) to the innermost."""
@@ -330,7 +341,9 @@ class _GeneratorFunction(torch.autograd.Function):
         from .pix2pix_backward import generator_backward
         grads, darch, dx = generator_backward(ctx.engine, ctx.ectx, ctx.arch, dout, ctx.x_needs_grad)
         names = [n for n, _ in ctx.engine.net.named_parameters()]
-        out = [grads.get(n) if p.requires_grad else None for n, p in zip(names, ctx.plist)]
+        fetch = ctx.engine.grad_fetch               # data parallel: the reduced gradients
+        out = [(fetch(n) if (fetch is not None and n in grads) else grads.get(n)) if p.requires_grad else None
+               for n, p in zip(names, ctx.plist)]
         return (None, None, None, None, dx, darch, *out)
 
 
@@ -343,6 +356,7 @@ class DiscriminatorEngine:
         self.dtype, self.tdt = _dtype_of(dtype)
         self.packs = _PackCache()
         self.trust_versions = False      # see unet_engine.pack_reuse_allowed
+        self.grad_ready_hook = self.after_backward = self.grad_fetch = None      # parallel.GradReducer.attach
 
     def run(self, x):
         params = [p for p in self.net.parameters()]
@@ -424,7 +438,9 @@ class DiscriminatorEngine:
         dev = dlogits.device
         S = float(2 ** round(math.log2(max(dlogits.numel(), 1))))
         inv_s = 1.0 / S
-        grads: Dict[str, torch.Tensor] = {}
+        from ..parallel import GradEmitter
+        emitter = GradEmitter(self.grad_ready_hook)          # data parallel: announced as soon as final
+        grads = _EmitDict(emitter)
 
         def empty(*shape, dtype=tdt):
             return torch.empty(shape, dtype=dtype, device=dev)
@@ -489,7 +505,9 @@ class DiscriminatorEngine:
         if need_dx:
             dx = torch.empty_like(first["x"])
             ops.conv_smallcin_dgrad(dy, conv.weight.detach().contiguous(), dx, first["k"], first["s"], first["p"], inv_s)
-        return grads, dx
+        if self.after_backward is not None:
+            self.after_backward()
+        return emitter.grads, dx
 
 
 class _DiscriminatorFunction(torch.autograd.Function):
@@ -506,5 +524,7 @@ class _DiscriminatorFunction(torch.autograd.Function):
             raise RuntimeError("NLayerDiscriminator forward ran without gradient tracking")
         grads, dx = ctx.engine.backward(ctx.ectx, dlogits, ctx.x_needs_grad)
         names = [n for n, _ in ctx.engine.net.named_parameters()]
-        out = [grads.get(n) if p.requires_grad else None for n, p in zip(names, ctx.plist)]
+        fetch = ctx.engine.grad_fetch               # data parallel: the reduced gradients
+        out = [(fetch(n) if (fetch is not None and n in grads) else grads.get(n)) if p.requires_grad else None
+               for n, p in zip(names, ctx.plist)]
         return (None, None, None, dx, *out)

@@ -11,10 +11,39 @@ reduce-scatter+all-gather but ~1.4 ms through a single-link ring, so buckets are
 32 MB) and always overlapped with the remaining backward kernels."""
 from __future__ import annotations
 
-from typing import Dict, List, Optional
+import os
+from typing import Callable, Dict, List, Optional
 
 import torch
 import torch.distributed as dist
+
+# CUs left to RCCL's kernels while the persistent conv / weight-gradient / up-conv grids run: one 160 KB-LDS block per CU holds
+# every CU until its items are done, so a bucket's all-reduce kernel starts at the next kernel boundary (every ~150 us in the
+# U-Net backward) rather than immediately.  GSSEG_RCCL_CUS=n makes GradReducer.attach() cap those grids at 256 - n blocks when
+# world > 1.  DEFAULT 0 (no cap): measured on one GPU (tools/bench_grid_cap.py, profiles/r03_grid_cap.txt) a cap of 248 / 240 /
+# 224 blocks costs +8.2 / +8.4 / +8.5 % of the bs=32 step -- the layers' item counts are multiples of 256, so ANY smaller grid
+# adds a whole round of items (and doubles the launches that have exactly 256) -- which is more than the 124 MB exchange can
+# cost un-overlapped over xGMI (0.2 ms direct, 1.4 ms ring = 1.6..11 %).  The knob is there for the 8-GPU measurement.
+RCCL_CUS = int(os.environ.get("GSSEG_RCCL_CUS", "0"))
+
+
+class GradEmitter:
+    """What an engine's backward uses to hand out parameter gradients: `emit(name, g)` accumulates (a module used twice --
+    the shared BatchNorm3d of the 3-D decoder blocks -- emits twice) and, once a parameter has received all `expected[name]`
+    contributions, announces it to `hook` (GradReducer.ready) so that the bucket all-reduce overlaps the rest of backward."""
+
+    def __init__(self, hook: Optional[Callable[[str, torch.Tensor], None]] = None, expected: Optional[Dict[str, int]] = None):
+        self.grads: Dict[str, torch.Tensor] = {}
+        self.hook = hook
+        self.expected = expected or {}
+        self._count: Dict[str, int] = {}
+
+    def emit(self, name: str, g: torch.Tensor):
+        c = self._count.get(name, 0) + 1
+        self._count[name] = c
+        self.grads[name] = g if c == 1 else self.grads[name] + g
+        if self.hook is not None and c == self.expected.get(name, 1):
+            self.hook(name, self.grads[name])
 
 
 class GradReducer:
@@ -25,7 +54,12 @@ class GradReducer:
     asynchronously; `finish()` makes the current stream wait for all of them."""
 
     def __init__(self, named_params, bucket_bytes: int = 32 << 20, group=None, average: bool = True,
-                 force_collective: bool = False):
+                 force_collective: bool = False, dtype: torch.dtype = torch.float32):
+        """dtype=torch.bfloat16: the buckets (and the exchange) are bf16 -- half the xGMI bytes for the generator's 1.09 GB
+        of fp32 gradients; gradients are then produced in the engine's own fp32 tensors and cast into the bucket."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("bucket dtype must be float32 or bfloat16")
+        self.dtype = dtype
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # force_collective: issue the all-reduces even in a 1-rank group (exercises the RCCL path on one GPU)
@@ -35,7 +69,7 @@ class GradReducer:
             raise ValueError("no trainable parameters")
         dev = items[0][1].device
         total = sum(p.numel() for _, p in items)
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat = torch.zeros(total, dtype=dtype, device=dev)
         self.views: Dict[str, torch.Tensor] = {}
         self.bucket_of: Dict[str, int] = {}
         self.buckets: List[dict] = []
@@ -44,7 +78,7 @@ class GradReducer:
             self.views[n] = self.flat[off:off + p.numel()].view(p.shape)
             names.append(n)
             off += p.numel()
-            if (off - start) * 4 >= bucket_bytes:
+            if (off - start) * self.flat.element_size() >= bucket_bytes:
                 self._close(start, off, names)
                 start, names = off, []
         if names:
@@ -88,10 +122,21 @@ class GradReducer:
         self._works = []
         self._pending = []
 
+    def fetch(self, name: str) -> torch.Tensor:
+        """the reduced gradient as a fresh fp32 tensor (the bucket is overwritten by the next backward)"""
+        return self.views[name].to(torch.float32, copy=True)
+
     def attach(self, engine):
-        engine.grad_alloc = self.alloc
+        """UNetEngine / UNet3DEngine / GeneratorEngine / DiscriminatorEngine: gradients are announced as they become final,
+        `after_backward` waits for the collectives, autograd receives `fetch(name)`."""
+        if hasattr(engine, "grad_alloc"):
+            engine.grad_alloc = self.alloc if self.dtype == torch.float32 else None      # fp32 buckets: produced in place
         engine.grad_ready_hook = self.ready
         engine.after_backward = self.finish
+        engine.grad_fetch = self.fetch
+        if self.world > 1 and RCCL_CUS > 0 and self.flat.is_cuda:
+            from . import ops
+            ops.set_persistent_grid(max(8, 256 - RCCL_CUS))
         return self
 
 

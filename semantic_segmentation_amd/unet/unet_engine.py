@@ -152,6 +152,7 @@ class UNetEngine:
         self.grad_ready_hook: Optional[Callable[[str, torch.Tensor], None]] = None
         self.grad_alloc: Optional[Callable[[str, torch.Tensor], torch.Tensor]] = None
         self.after_backward: Optional[Callable[[], None]] = None
+        self.grad_fetch: Optional[Callable[[str], torch.Tensor]] = None      # reduced gradient handed to autograd
 
     # ------------------------------------------------------------------ parameters
     def _index(self):
@@ -1065,11 +1066,11 @@ class _UNetFunction(torch.autograd.Function):
             raise RuntimeError("UNet forward ran without gradient tracking")
         params = dict(zip(ctx.names, ctx.plist))
         grads, dx = ctx.engine.backward(ctx.ectx, params, dlogits, ctx.x_needs_grad)
-        # gradients living in a GradReducer bucket are handed to autograd as copies: a stolen bucket view
-        # would be overwritten (not accumulated) by the next backward
-        alias = ctx.engine.grad_alloc is not None
-        out = [(grads[n].clone() if alias else grads[n]) if (p.requires_grad and n in grads) else None
-               for n, p in zip(ctx.names, ctx.plist)]
+        # with a GradReducer attached autograd receives the REDUCED gradients, as copies (fetch): a stolen bucket view would
+        # be overwritten (not accumulated) by the next backward
+        fetch, alias = ctx.engine.grad_fetch, ctx.engine.grad_alloc is not None
+        out = [(fetch(n) if fetch is not None else (grads[n].clone() if alias else grads[n])) if (p.requires_grad and n in grads)
+               else None for n, p in zip(ctx.names, ctx.plist)]
         return (None, None, None, None, dx if ctx.x_needs_grad else None, *out)
 
 

@@ -42,6 +42,11 @@ class UNet3DEngine:
         if dtype not in _TORCH_DT:
             raise ValueError("dtype must be 'f16' or 'bf16'")
         self.net, self.dtype, self.tdt = net, dtype, _TORCH_DT[dtype]
+        # data-parallel hooks (parallel.GradReducer.attach): gradients announced as they become final, the compute stream
+        # waits for the collectives at the end of backward, autograd receives the reduced gradients
+        self.grad_ready_hook = None
+        self.after_backward = None
+        self.grad_fetch = None
 
     # ------------------------------------------------------------------------------------------------
     def forward(self, x, training, need_grad):
@@ -204,14 +209,21 @@ class UNet3DEngine:
         S = float(2 ** round(math.log2(NB * D0 * H0 * W0)))
         inv_s = 1.0 / S
         names = {id(p): n for n, p in net.named_parameters()}
-        grads: Dict[str, torch.Tensor] = {}
+        # a gradient is announced to the reducer (bucketed all-reduce overlapped with the rest of backward) once ALL its
+        # contributions are in: the decoder blocks' shared BatchNorm3d is used by two stages
+        from ..parallel import GradEmitter
+        expected: Dict[str, int] = {}
+        for st_ in ctx["stages"]:
+            for p_ in (st_.bn.weight, st_.bn.bias):
+                expected[names[id(p_)]] = expected.get(names[id(p_)], 0) + 1
+        emitter = GradEmitter(self.grad_ready_hook, expected)
+        grads = emitter.grads
 
         def empty(*shape, dtype=tdt):
             return torch.empty(shape, dtype=dtype, device=dev)
 
         def emit(p, g):
-            n = names[id(p)]
-            grads[n] = g if n not in grads else grads[n] + g       # the decoder's shared bn is used twice
+            emitter.emit(names[id(p)], g)
 
         col_ws = empty(1024 * 1024, dtype=torch.float32)
 
@@ -307,6 +319,8 @@ class UNet3DEngine:
             ops.maxpool3d_bwd(cats[k], dpool, dres[k], dz2, NB, D, H, W, s2.cout, ctot, cup[k], ctot, cup[k])
             dmid = stage_bwd(s2, dz2, s2.cout, 0, True)
             dpool = stage_bwd(s1, dmid, s1.cout, 0, k > 1)
+        if self.after_backward is not None:
+            self.after_backward()
         return grads
 
 
@@ -323,7 +337,9 @@ class _UNet3DFunction(torch.autograd.Function):
             raise RuntimeError("UNet3D forward ran without gradient tracking")
         grads = ctx.engine.backward(ctx.ectx, dlogits)
         names = [n for n, _ in ctx.engine.net.named_parameters()]
-        out = [grads.get(n) if p.requires_grad else None for n, p in zip(names, ctx.plist)]
+        fetch = ctx.engine.grad_fetch               # data parallel: the reduced gradients (parallel.GradReducer.fetch)
+        out = [(fetch(n) if (fetch is not None and n in grads) else grads.get(n)) if p.requires_grad else None
+               for n, p in zip(names, ctx.plist)]
         return (None, None, None, None, *out)
 
 

@@ -68,6 +68,32 @@ def _worker(rank, world, port, q):
                 assert p.grad is None
             else:
                 assert torch.allclose(p.grad, torch.full_like(p, (i + 1) * (world + 1) / 2)), i
+        # ---- the hooked-engine protocol of UNet3D / Pix2Pix G / D (parallel.GradEmitter + GradReducer.fetch): a parameter that
+        # receives TWO contributions (the shared BatchNorm3d of the 3-D decoder blocks) is announced after the second one;
+        # what autograd would receive (fetch) is the rank average; bf16 buckets exchange half the bytes
+        from semantic_segmentation_amd.parallel import GradEmitter
+        for bdt, tol in ((torch.float32, 0.0), (torch.bfloat16, 8e-3)):
+            red2 = GradReducer(net.named_parameters(), bucket_bytes=64, dtype=bdt)
+            announced = []
+            def hook(n, g, red2=red2):
+                announced.append(n)
+                red2.ready(n, g)
+            shared = names[1]                                # pretend this parameter is used by two stages
+            em = GradEmitter(hook, expected={shared: 2})
+            red2.begin()
+            for n in names:
+                em.emit(n, torch.full_like(params[n], float(rank + 1)))
+                if n == shared:
+                    assert shared not in announced           # one contribution still missing
+            em.emit(shared, torch.full_like(params[shared], 10.0 * (rank + 1)))
+            assert announced.count(shared) == 1 and sorted(announced) == sorted(names)
+            red2.finish()
+            for n in names:
+                want = (11.0 if n == shared else 1.0) * (world + 1) / 2
+                got = red2.fetch(n)
+                assert got.dtype == torch.float32 and got.data_ptr() != red2.views[n].data_ptr()
+                assert torch.allclose(got, torch.full_like(params[n], want), rtol=tol, atol=tol), (bdt, n)
+            assert red2.flat.dtype == bdt
         q.put((rank, "ok"))
     except Exception as e:      # noqa: BLE001
         q.put((rank, repr(e)))

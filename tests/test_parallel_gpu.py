@@ -63,6 +63,60 @@ def test_grad_reducer_on_unet_engine_rccl_single_rank():
             for k in g0[step]:
                 a, b = g0[step][k], g1[step][k]
                 assert float((a - b).abs().max()) <= 1e-6 * (float(a.abs().max()) + 1e-12) + 1e-12, (step, k)
+        # ---- UNet3D / Pix2Pix generator / discriminator with the reducer attached: gradients announced from
+        # inside their backward passes, bucket all-reduces through RCCL, autograd receives the fetched (reduced) gradients --
+        # equal to the plain gradients in a 1-rank group; bf16 buckets within bf16 rounding
+        from semantic_segmentation_amd.models_pix2pix import networks as nw
+        from semantic_segmentation_amd.unet3d import UNet3D
+
+        def grads_of(make, loss_of, dtype=None):
+            outs = []
+            for attach in (False, True):
+                torch.manual_seed(3)
+                net = make().to(dev).train()
+                red = None
+                if attach:
+                    red = GradReducer(net.named_parameters(), bucket_bytes=4 << 20, force_collective=True,
+                                      dtype=dtype or torch.float32).attach(net.engine)
+                loss_of(net).backward()
+                torch.cuda.synchronize()
+                outs.append({k: p.grad.detach().clone() for k, p in net.named_parameters()})
+                if red is not None:
+                    assert not red._works and not red._pending          # finish() ran at the end of backward
+            return outs
+
+        def check(outs, rtol):
+            for k in outs[0]:
+                a, b = outs[0][k], outs[1][k]
+                assert float((a - b).abs().max()) <= rtol * (float(a.abs().max()) + 1e-12) + 1e-12, k
+
+        g3 = torch.Generator().manual_seed(2)
+        vol = torch.randn(1, 1, 32, 32, 32, generator=g3).to(dev)
+        vmask = (torch.rand(1, 32, 32, 32, generator=g3) > 0.5).long().to(dev)
+
+        def loss3d(net):
+            lg = net(vol)
+            n, c, d, h, w = lg.shape
+            return seg_loss(lg.reshape(n, c, d * h, w), vmask.reshape(n, d * h, w))
+        sd3 = oracle.unet3d_state_dict(1, 2, seed=4)
+
+        def make3d():
+            m = UNet3D(1, 2)
+            m.load_state_dict(sd3, strict=True)
+            return m
+        check(grads_of(make3d, loss3d), 1e-6)
+        check(grads_of(make3d, loss3d, torch.bfloat16), 1e-2)
+        gm = torch.Generator().manual_seed(6)
+        gmask = (torch.rand(2, 1, 256, 256, generator=gm) > 0.5).float().to(dev)
+        real = torch.rand(2, 1, 256, 256, generator=gm).to(dev)
+        nw.upconv_arch.data.zero_()
+        makeG = lambda: nw.define_G(1, 1, 64, "unet_256", "batch", True, "normal", 0.02, [0])
+        makeD = lambda: nw.define_D(2, 64, "basic", 3, "batch", "normal", 0.02, [0])
+        def lossG(G):
+            G.eval()                                             # no dropout noise between the two runs
+            return (G(gmask) - real).abs().mean()
+        check(grads_of(makeG, lossG), 1e-6)
+        check(grads_of(makeD, lambda D: D(torch.cat((gmask, real), 1)).square().mean()), 1e-6)
         # the generic post-backward exchange on HIP tensors (1-rank group: early return)
         net = UNet(1, 2).to(dev)
         assert all_reduce_gradients(net.parameters()) == 0

@@ -73,6 +73,52 @@ def test_unet3d_step_vs_golden(golden_dir, name):
     assert de.max() < 2e-2 * max(1.0, np.abs(z["logits_eval"]).max())
 
 
+def test_unet3d_128_vs_reference_fixture(golden_dir):
+    """BASELINE config 5 at its per-GPU size -- UNet3D(1,2), one 128^3 volume, train mode -- against the compact fixture from
+    the imported reference (tests/golden/make_golden.py --only unet3d_128: logits sub-sampled 8x8x8 + the 64 largest-|logit|
+    positions, the loss, every gradient summary, the BatchNorm buffers).  Inputs are regenerated from the seed."""
+    from golden_util import tensor_checksum
+    from semantic_segmentation_amd.unet3d import UNet3D
+    z = np.load(os.path.join(golden_dir, "unet3d_c2_128.npz"))
+    n_classes, seed, size = int(z["n_classes"]), int(z["seed"]), int(z["size"])
+    g = torch.Generator().manual_seed(int(z["data_seed"]))
+    x = torch.randn(1, 1, size, size, size, generator=g)
+    mask = (torch.rand(1, size, size, size, generator=g) > 0.6).long()
+    assert np.allclose(tensor_checksum(x), z["xsum"], rtol=1e-6, atol=1e-6), "the synthetic input stream drifted"
+    assert np.allclose(tensor_checksum(mask.float()), z["masksum"], rtol=0, atol=0)
+    sd = oracle.unet3d_state_dict(1, n_classes, seed=seed)
+    net = UNet3D(1, n_classes)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    logits = net(x.cuda())
+    loss = vol_loss(logits, mask.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    lg = logits.detach().cpu()
+    d_sub = (lg[:, :, ::8, ::8, ::8] - torch.from_numpy(z["logits_sub"])).abs()
+    d_top = (lg.flatten()[torch.from_numpy(z["top_idx"])] - torch.from_numpy(z["top_val"])).abs()
+    errs = {}
+    for k, p in net.named_parameters():
+        ref = z["gsum/" + k]
+        errs[k] = abs(grad_summary(p.grad.cpu())[1] - ref[1]) / max(ref[1], 1e-12)
+    bworst = 0.0
+    for k, b in net.named_buffers():
+        ref = z["buf/" + k]
+        if "num_batches" in k:
+            assert int(b) == int(ref), k
+        else:
+            bworst = max(bworst, float(np.abs(b.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-6)))
+    rep = {"logit_sub_max_abs": float(d_sub.max()), "logit_sub_mean_abs": float(d_sub.mean()), "logit_top64_max_abs": float(d_top.max()),
+           "loss": float(loss.item()), "loss_ref": float(z["loss"]), "grad_norm_rel_err_median": float(np.median(list(errs.values()))),
+           "grad_norm_rel_err_worst": float(max(errs.values())), "worst_key": max(errs, key=errs.get), "bn_buffer_rel_err_worst": bworst}
+    REPORT["unet3d_c2_128"] = rep
+    _dump()
+    assert abs(rep["loss"] - rep["loss_ref"]) < 1e-3, rep
+    assert rep["logit_sub_mean_abs"] < 2e-3 and rep["logit_sub_max_abs"] < 2e-2 and rep["logit_top64_max_abs"] < 2e-2, rep
+    assert rep["grad_norm_rel_err_median"] < 0.05, rep
+    assert bworst < 1e-2, rep
+
+
 def test_unet3d_descent_direction():
     from semantic_segmentation_amd.unet3d import UNet3D
     sd = oracle.unet3d_state_dict(1, 2, seed=61)
