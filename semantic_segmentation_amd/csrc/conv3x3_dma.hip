@@ -463,6 +463,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
         }
     };
     const bool plain = (a.bias == nullptr && act == GS_ACT_NONE);
+    const bool deferable = DEFER && act == GS_ACT_NONE;    // a bias rides along (bvb), an activation takes the immediate path
     // immediate form, per-item partial rows (!DEFER): partial sums of the 8x32 halves: waves 4*half .. 4*half+3
     auto finish_stats = [&](const Item& itc) __attribute__((always_inline)) {
         constexpr int NH = NWV / 4;
@@ -481,7 +482,10 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
             }
         }
     };
-    // deferred form, item boundary: accumulators -> packed pairs + running statistics (nothing leaves the registers)
+    // deferred form, item boundary: accumulators -> packed pairs + running statistics (nothing leaves the registers).  A bias
+    // (Conv3d of the 3-D U-Net, unet3d.py:28-31) is added after the statistics, as on the immediate path; the block keeps its
+    // cout tile, so the lane's two bias values are loaded once.
+    float bvb[2] = {0.f, 0.f};
     auto convert_item = [&](const Item& itc) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -489,12 +493,14 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
             for (int m = 0; m < 8; ++m)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const float v0 = acc[i][j][2 * m], v1 = acc[i][j][2 * m + 1];
+                    float v0 = acc[i][j][2 * m], v1 = acc[i][j][2 * m + 1];
                     if (STATS) {
                         const f32x2 vv = {v0, v1};
                         s1v[j] += vv;
                         s2v[j] += vv * vv;
                     }
+                    v0 += bvb[j];
+                    v1 += bvb[j];
                     pk[i][j][DEFER ? m : 0] = Elem<DT>::pack2(v0, v1);
                 }
         int e_y0 = itc.y0, e_x0 = itc.x0;
@@ -543,6 +549,13 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
     };
     Item cur = make_item();
     const int block_n0 = cur.n0;                           // DEFER: the block's cout tile (st0 == 0: host-guaranteed)
+    if (DEFER && a.bias != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int co = block_n0 + j * 32 + l31;
+            bvb[j] = co < a.Cout ? a.bias[co] : 0.f;
+        }
+    }
     // WRES: a 64-channel input is two stages -- the weight slabs of stage 0 / stage 1 of the block's cout tile sit in buffer 0 /
     // buffer 1, and every item would fetch the same 2 x 36 KB again.  The block keeps its cout tile, so they are fetched ONCE:
     // 73 of the 215 KB an item moves through the CU's memory pipe (halo 78 KB in, 64 KB out).  With the immediate epilogue this
@@ -590,7 +603,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
                       (last && !more_items) ? VOOB : 0u, nxt, wres && last);      // the next item's stage-0 slabs are in buffer 0
         }
         const bool full = (cur.y0 + TH <= a.H) && (cur.x0 + TW <= a.W);
-        if (DEFER && plain && full && !(dbg & 4)) {
+        if (deferable && full && !(dbg & 4)) {
             convert_item(cur);                             // registers only: no barrier, no LDS
         } else {
             if (DEFER) {                                   // (nothing is pending here; tells the register allocator so)

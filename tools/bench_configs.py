@@ -42,6 +42,13 @@ def main():
     U = UNet(1, 1).to(dev).train()
     networks.upconv_arch = (1e-3 * torch.randn(8, 3)).to(dev).requires_grad_(True)
     crit = networks.GANLoss("vanilla").to(dev)
+    # pack reuse between the training forwards of one iteration: harness.EndToEndTrainer owns every update and sets
+    # engine.trust_versions (version-keyed reuse); a foreign loop (Betty: `.data` writes) gets the safe default, where every
+    # training forward re-packs (GSSEG_TRUST=0 times that)
+    trust = os.environ.get("GSSEG_TRUST", "1") != "0"
+    for m in (G, D, U):
+        m.engine.trust_versions = trust
+    print("pack reuse between training forwards:", "version-keyed (harness)" if trust else "none (safe default)")
     for B in (2, 32):
         x, mask = synthetic_batch(B, 256, seed=3)
         x, mask = x.to(dev), mask.to(dev)
