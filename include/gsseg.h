@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 41
+#define GS_ABI_VERSION 42
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -493,6 +493,18 @@ int gs_stem_fwd_bn_pair(const float* x, const float* w, const float* bn_scale, c
                         void* z_lo, int z_pix_stride, int N, int H, int W, int dtype, void* stream);
 int gs_stem_bwd_onepass_strided(const float* x, const void* z, int z_pix_stride, const void* dz, int dz_stride, int dz_coff,
                                 int act, float* s1_partials, float* ws, int N, int H, int W, int dtype, void* stream);
+
+/* Weight gradient of ConvTranspose2d(kernel 2, stride 2) (unet/unet_parts.py:51,57) as a pointwise GEMM with K = pixels and
+ * LDS-DMA operands (csrc/upwgrad.hip): x = the layer's input [N][IH][IW][x_pix_stride], dy = the gradient of its output
+ * inside [N][OH][OW][dy_pix_stride] (output pixel (2y + a + ooy, 2x + b + oox)).  gs_upconv2x2_wgrad_parts() slabs
+ * [4][Cin][Cout] (class = 2a + b) go to ws (gs_upconv2x2_wgrad_ws_floats() floats) and are summed in order by
+ * gs_wgrad_reduce_unpack(ws, parts, grad, Cin, Cout, 4, 0, gscale) into the reference layout [Cin][Cout][2][2].  parts == 0 /
+ * GS_EUNSUPPORTED: shape outside the kernel (power-of-two maps, IW >= 16, Cin % 128 == 0, Cout % 64 == 0): use gs_conv_wgrad_slabs. */
+int gs_upconv2x2_wgrad_parts(int N, int IH, int IW, int Cin, int Cout);
+int64_t gs_upconv2x2_wgrad_ws_floats(int N, int IH, int IW, int Cin, int Cout);
+int gs_upconv2x2_wgrad_slabs(const void* x, const void* dy, float* ws, int N, int IH, int IW, int Cin, int x_pix_stride,
+                             int x_coff, int Cout, int OH, int OW, int dy_pix_stride, int dy_coff, int ooy, int oox, int dtype,
+                             void* stream);
 
 /* Deterministic weight gradient of the 3x3 conv without atomics: gs_conv3x3_wgrad_slabs stores every split-K part's
  * tile into its own slab ws[part][9][Cout][Cin] (fp32, gs_conv3x3_wgrad_ws_floats() elements, no zero fill needed,

@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 GS_F16, GS_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH = 0, 1, 2, 3
 GS_MAX_TAPS = 64
-ABI_VERSION = 41
+ABI_VERSION = 42
 
 
 class GsConvGeom(ctypes.Structure):
@@ -49,6 +49,9 @@ PROTOTYPES = {
     "gs_abi_version": (c_int, []),
     "gs_conv_igemm_mtiles": (c_int, [POINTER(GsConvGeom)]),
     "gs_conv3x3_stat_rows": (c_int, [c_int] * 6),
+    "gs_upconv2x2_wgrad_parts": (c_int, [c_int] * 5),
+    "gs_upconv2x2_wgrad_ws_floats": (c_int64, [c_int] * 5),
+    "gs_upconv2x2_wgrad_slabs": (c_int, [_P, _P, _F] + [c_int] * 14 + [c_void_p]),
     "gs_set_persistent_grid": (c_int, [c_int]),
     "gs_get_persistent_grid": (c_int, []),
     "gs_conv_igemm": (c_int, [POINTER(GsConvGeom), _P, _P, _P, _F, _F, c_int, c_int, _F, c_int64, c_void_p]),

@@ -525,6 +525,35 @@ def conv_wgrad_det(g: GsConvGeom, x, dy, ws, grad, A, B, taps, gscale, transpose
     _lib.call("gs_wgrad_reduce_unpack", _p(ws), parts, _p(grad), A, B, taps, 1 if transposed else 0, float(gscale), _stream())
 
 
+def upconv2x2_wgrad_ws_floats(N, IH, IW, Cin, Cout) -> int:
+    """workspace floats of upconv2x2_wgrad_det's LDS-DMA path (0: shape not covered, the generic engine is used)"""
+    return int(_lib.load().gs_upconv2x2_wgrad_ws_floats(N, IH, IW, Cin, Cout))
+
+
+def upconv2x2_wgrad_det(geom, x, dy, ws, grad, N, IH, IW, Cin, Cout, OH, OW, x_stride, dy_stride, dy_coff, ooy, oox, gscale):
+    """Deterministic weight gradient of ConvTranspose2d(k 2, s 2) into grad [Cin][Cout][2][2]: x = the layer's input (pixel
+    stride x_stride), dy = d(output) inside a [N,OH,OW,dy_stride] buffer at channel dy_coff.  The LDS-DMA pointwise GEMM
+    (csrc/upwgrad.hip) where it covers the shape, else the generic engine on `geom` (the layer seen from its output side)."""
+    _dev(x)
+    _f32(ws, "ws"); _f32(grad, "grad")
+    if x.dtype != dy.dtype:
+        raise TypeError("upconv2x2_wgrad_det: x and dy must share one 16-bit dtype")
+    lib = _lib.load()
+    parts = int(lib.gs_upconv2x2_wgrad_parts(N, IH, IW, Cin, Cout))
+    if parts > 0 and grad.numel() == 4 * Cin * Cout and ws.numel() >= parts * 4 * Cin * Cout:
+        ev = TIMER.start() if TIMER is not None else None
+        rc = lib.gs_upconv2x2_wgrad_slabs(_p(x), _p(dy), _p(ws), N, IH, IW, Cin, x_stride, 0, Cout, OH, OW, dy_stride, dy_coff,
+                                          ooy, oox, dt_code(x), _stream())
+        if rc == 0:
+            if ev is not None:
+                TIMER.stop("igemm_wgrad", ev, 2.0 * N * IH * IW * Cin * 4 * Cout)
+            _lib.call("gs_wgrad_reduce_unpack", _p(ws), parts, _p(grad), Cin, Cout, 4, 0, float(gscale), _stream())
+            return
+        if rc != _lib.GS_EUNSUPPORTED:
+            _lib.check(rc, "gs_upconv2x2_wgrad_slabs")
+    conv_wgrad_det(geom, dy, x, ws, grad, Cin, Cout, 4, gscale)
+
+
 def conv_wgrad_det_batch(geoms, x, dy, ws, grad, gscale=1.0):
     """Deterministic weight gradients of up to four GEMMs (the sub-pixel classes of one merged transposed conv) in ONE
     launch, in the kernel layout grad[n][taps][Cout][Cin]: K parts in fp32 slabs (ws) + one ordered reduction over all

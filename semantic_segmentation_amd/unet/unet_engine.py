@@ -836,7 +836,8 @@ class UNetEngine:
                 tot_w += wnum
         for u in ctx["ups"]:
             if u.geom_bwd is not None:                   # ConvTranspose2d weight gradient: slabs too (deterministic)
-                wg_need = max(wg_need, ops.conv_wgrad_ws_floats(u.geom_wg if u.geom_wg is not None else u.geom_bwd))
+                wg_need = max(wg_need, ops.conv_wgrad_ws_floats(u.geom_wg if u.geom_wg is not None else u.geom_bwd),
+                              ops.upconv2x2_wgrad_ws_floats(N, u.h, u.w, u.cin, u.cout))
         dw_arena = torch.zeros(max(tot_w, 1), dtype=torch.float32, device=dev)
         wg_ws = empty(wg_need, dtype=torch.float32)
         arena_off = [0]
@@ -1013,9 +1014,12 @@ class UNetEngine:
                 db = galloc(prefix + ".up.bias", params[prefix + ".up.bias"])
                 ops.colsum(dcat, 2 * cout_t, cout_t, N, u.H2, u.W2, u.pt, u.pl, 2 * u.h, 2 * u.w, cout_t, inv_s, col_ws, db)
             dw = galloc(wkey, wparam)
+            # K = pixels pointwise GEMM on LDS-DMA operands (csrc/upwgrad.hip); the generic engine for shapes outside it.
+            # u.zin: the layer's input -- dense, or the hi plane of a pair buffer (pixel stride = its last dimension)
             on_side((dcat, u.zin, wg_ws, dw),
-                    lambda u=u, dcat=dcat, dw=dw: ops.conv_wgrad_det(u.geom_wg if u.geom_wg is not None else u.geom_bwd, dcat, u.zin,
-                                                                     wg_ws, dw, u.cin, u.cout, 4, inv_s),
+                    lambda u=u, dcat=dcat, dw=dw: ops.upconv2x2_wgrad_det(
+                        u.geom_wg if u.geom_wg is not None else u.geom_bwd, u.zin, dcat, wg_ws, dw, N, u.h, u.w, u.cin, u.cout,
+                        u.H2, u.W2, u.zin.shape[3], 2 * u.cout, u.cout, u.pt, u.pl, inv_s),
                     wkey, dw)
             dz = empty(N, u.h, u.w, u.cin)
             ops.upconv2x2_dgrad(u.geom_bwd, dcat, u.wd, dz, N, u.h, u.w, u.cin, u.cout, u.H2, u.W2, 2 * cout_t, cout_t, u.pt, u.pl)

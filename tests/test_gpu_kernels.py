@@ -1242,6 +1242,45 @@ def test_upconv2x2_dgrad(dtn, dt, N, h, w, Cin, Cout, pad):
 
 
 @pytest.mark.parametrize("dtn,dt", DTS)
+@pytest.mark.parametrize("N,h,w,Cin,Cout,pad,pair", [(2, 16, 16, 128, 64, (0, 0), False), (4, 32, 64, 256, 128, (0, 0), True),
+                                                      (3, 64, 32, 128, 64, (2, 2), False), (8, 16, 16, 1024, 512, (0, 0), False),
+                                                      (1, 8, 16, 256, 192, (1, 1), False), (2, 5, 6, 128, 64, (0, 0), False)])
+def test_upconv2x2_wgrad(dtn, dt, N, h, w, Cin, Cout, pad, pair):
+    """weight gradient of ConvTranspose2d(k2, s2) (unet_parts.py:51,57) out of the up half of a concat-gradient buffer: the
+    K = pixels LDS-DMA GEMM (csrc/upwgrad.hip: several K parts, several (ci, co) tile pairs, padded output, the layer input as
+    the hi plane of a pair buffer) on the shapes it covers, the generic engine on the rest (Cout = 192 and the odd map) -- both
+    through ops.upconv2x2_wgrad_det, against torch fp32 autograd; bit-reproducible."""
+    from semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(19)
+    H2, W2 = 2 * h + pad[0], 2 * w + pad[1]
+    pt, pl = pad[0] // 2, pad[1] // 2
+    x = rnd(g, N, Cin, h, w, dt=dt)
+    wt = rnd(g, Cin, Cout, 2, 2, dt=dt, scale=0.05).requires_grad_(True)
+    dyf = rnd(g, N, Cout, H2, W2, dt=dt)
+    out = F.pad(F.conv_transpose2d(x, wt, None, stride=2), [pl, pad[1] - pl, pt, pad[0] - pt])
+    out.backward(dyf)
+    dcat = torch.full((N, H2, W2, 2 * Cout), 3.0, dtype=dt, device=dev())          # the skip half must not be read
+    dcat[..., Cout:] = nhwc(dyf, dt)
+    xs = 2 * Cin if pair else Cin
+    xin = torch.full((N, h, w, xs), 5.0, dtype=dt, device=dev())                    # pair: the lo plane must not be read
+    xin[..., :Cin] = nhwc(x, dt)
+    taps = [(py + pt, px + pl) for py in range(2) for px in range(2)]
+    geom = ops.make_geom(N, H2, W2, Cout, h, w, Cin, h, w, taps, isy=2, isx=2, in_stride=2 * Cout, in_coff=Cout, out_stride=xs)
+    need = max(ops.conv_wgrad_ws_floats(geom), ops.upconv2x2_wgrad_ws_floats(N, h, w, Cin, Cout), 1)
+    fast = ops.upconv2x2_wgrad_ws_floats(N, h, w, Cin, Cout) > 0
+    assert fast == (Cout % 64 == 0 and h & (h - 1) == 0 and w & (w - 1) == 0 and w >= 16 and Cin % 128 == 0)
+    res = []
+    for rep in range(2):
+        ws = torch.full((need,), float("nan"), dtype=torch.float32, device=dev())
+        dw = torch.full((Cin, Cout, 2, 2), float("nan"), dtype=torch.float32, device=dev())
+        ops.upconv2x2_wgrad_det(geom, xin, dcat, ws, dw, N, h, w, Cin, Cout, H2, W2, xs, 2 * Cout, Cout, pt, pl, 0.5)
+        torch.cuda.synchronize()
+        res.append(dw.clone())
+    assert torch.equal(res[0], res[1])
+    assert rel_err(res[0].cpu() * 2, wt.grad) < 2e-3 * (1 if dt == torch.float16 else 4), rel_err(res[0].cpu() * 2, wt.grad)
+
+
+@pytest.mark.parametrize("dtn,dt", DTS)
 def test_pack_weight_multi_matches_single(dtn, dt):
     """gs_pack_weight_multi (all stale conv weights of a network in one launch) == gs_pack_weight per tensor, bit for bit:
     3x3 convs and k2/s2 transposed convs of mixed sizes, with and without the data-gradient pack"""
