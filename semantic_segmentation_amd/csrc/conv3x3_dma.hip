@@ -547,6 +547,8 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
     auto image_rsrc = [&](int n) __attribute__((always_inline)) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)n * a.H * a.W * a.in_stride), 0, img_bytes, 0x00020000);
     };
+    // (a static s_setprio 1 for waves 4..7 -- the arbitration losers of an 8-wave block -- measured -0.5 .. +2.1 %, +0.5 % over
+    // six layer shapes: profiles/r03_ab_setprio.txt; not kept)
     Item cur = make_item();
     const int block_n0 = cur.n0;                           // DEFER: the block's cout tile (st0 == 0: host-guaranteed)
     if (DEFER && a.bias != nullptr) {

@@ -397,6 +397,199 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_dma_kernel(const W3Args a) {
             }
         }
 }
+
+// ---------------------------------------------------------------------------------------------------
+// 128-cout form of the LDS-DMA kernel (layers with Cout % 128 == 0): a block owns (128 co x 64 ci) and walks 128-pixel patches
+// (4 x 32).  The 256-pixel / 64-cout form above moves 75 KB through the CU's DMA path per 576 block-MFMAs (130 B per MFMA) and
+// is bound by that stream and its overlap with the matrix pipe (ablation in DESIGN.md: MFMAs alone 1.87 ms, DMA alone 1.55 ms,
+// both 2.45 ms per step); here a patch is 32 KB of dY (two 64-cout images) + 26 KB of X halo = 58 KB for the same 576 MFMAs
+// (101 B per MFMA), the X halo is read once per 128 couts instead of once per 64, and there is no K split inside the block
+// (waves = 4 cout tiles x 2 ci halves, every wave sees all 128 pixels: 4 rows x 2 column halves x 9 taps = 72 MFMAs per
+// patch), so the final in-block reduction through LDS is gone as well.
+// ---------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(512, 1) void wgrad3x3_dma128_kernel(const W3Args a) {
+    typedef typename Elem<DT>::V8 V8;
+    constexpr int TW = 32, TH = 4, TWS = 5, BM = 128;
+    constexpr int HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;       // 204 halo pixels
+    constexpr int DJ = 4;                                            // dY piece slots per wave: 2 images x 16 pieces = 32
+    constexpr int HPC = (HP + 7) / 8;                                // 26 halo pieces
+    constexpr int HJ = 4;                                            // halo piece slots per wave: 32 slots, 26 real + spare
+    constexpr int IMG_B = BM * 128;                                  // one 64-cout dY image: 16 KB
+    constexpr int DY_B = 2 * IMG_B, HALO_B = (HPC + 1) * 1024;       // one spare piece takes the surplus slots
+    constexpr int HALO_OFF = 2 * DY_B;
+    constexpr unsigned VOOB = 0x80000000u;
+    static_assert(HPC + 1 <= HJ * 8 && 2 * (DY_B + HALO_B) <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (DY_B + HALO_B)];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wmm = wave >> 1, wn = wave & 1;  // cout tile of 32 (0..3), ci half of 32
+    int bid;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int cob = bid % a.ncob; bid /= a.ncob;
+    const int cib = bid % a.ncib; bid /= a.ncib;
+    const int ks = bid;
+    const int co0 = cob * 128, ci0 = cib * 64;
+    const int p_begin = ks * a.pps;
+    const int p_end = min(a.npatches, p_begin + a.pps);
+    if (p_begin >= p_end) return;
+
+    const unsigned x_img_bytes = (unsigned)a.H * a.W * a.in_stride * 2u;
+    const unsigned dy_img_bytes = (unsigned)a.H * a.W * a.out_stride * 2u;
+    // DMA side: lane l fills physical 16-byte slot l & 7 of row l >> 3 of its piece
+    const int drow = lane >> 3;
+    const int dls = (lane & 7) ^ (((lane >> 4) & 1) << 2);
+    const bool ci_ok = ci0 + dls * 8 < a.Cin;
+    unsigned dv[DJ], hv[HJ];
+    unsigned rel_d[DJ], rel_h[HJ];
+    bool d_ok[DJ];
+#pragma unroll
+    for (int j = 0; j < DJ; ++j) {
+        const int q = wave + 8 * j;                                  // piece: image q >> 4, rows 8 * (q & 15) ..
+        const int p = (q & 15) * 8 + drow;
+        const int co = co0 + (q >> 4) * 64 + dls * 8;
+        d_ok[j] = co < a.Cout;
+        rel_d[j] = (unsigned)((((p >> TWS) * a.W + (p & (TW - 1))) * a.out_stride + a.out_coff + co) * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < HJ; ++j) {
+        const int hp = (wave + 8 * j) * 8 + drow;
+        const int hy = hp / HWD, hx = hp - hy * HWD;
+        rel_h[j] = (unsigned)((((hy - 1) * a.W + (hx - 1)) * a.in_stride + a.in_coff + ci0 + dls * 8) * 2);   // may wrap: added mod 2^32
+    }
+    struct Pf { __amdgpu_buffer_rsrc_t rx, rdy; };
+    int pt_x, pt_y, pt_n;
+    {
+        pt_x = p_begin % a.tiles_x;
+        const int r = p_begin / a.tiles_x;
+        pt_y = r % a.tiles_y; pt_n = r / a.tiles_y;
+    }
+    auto prep_patch = [&](bool live) __attribute__((always_inline)) {      // prepares (pt_x, pt_y, pt_n), then steps to the next patch
+        Pf f;
+        const int n = pt_n, y0 = pt_y * TH, x0 = pt_x * TW;
+        const int d = a.D > 1 ? n % a.D : 0;                       // Conv3d: X comes from slice n + dz (zeros outside the volume)
+        const bool xin = (unsigned)(d + a.dz) < (unsigned)a.D;
+        f.rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)(xin ? n + a.dz : n) * a.H * a.W * a.in_stride), 0, x_img_bytes, 0x00020000);
+        f.rdy = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + (int64_t)n * a.H * a.W * a.out_stride), 0, dy_img_bytes, 0x00020000);
+        const unsigned base_d = (unsigned)((y0 * a.W + x0) * a.out_stride * 2), base_h = (unsigned)((y0 * a.W + x0) * a.in_stride * 2);
+        const int ylim = a.H - y0, xlim = a.W - x0;                 // rows / columns of the patch inside the image
+        const bool hlive = live && xin && ci_ok;
+#pragma unroll
+        for (int j = 0; j < DJ; ++j) {
+            const int p = ((wave + 8 * j) & 15) * 8 + drow;
+            const bool ok = live && d_ok[j] && (p >> TWS) < ylim && (p & (TW - 1)) < xlim;
+            const unsigned v = base_d + rel_d[j];
+            dv[j] = ok ? v : VOOB;
+        }
+#pragma unroll
+        for (int j = 0; j < HJ; ++j) {
+            const int hp = (wave + 8 * j) * 8 + drow;
+            const int hy = hp / HWD, hx = hp - hy * HWD;
+            const bool ok = hlive && hp < HP && (unsigned)(hy + y0 - 1) < (unsigned)a.H && (unsigned)(hx + x0 - 1) < (unsigned)a.W;
+            const unsigned v = base_h + rel_h[j];
+            hv[j] = ok ? v : VOOB;
+        }
+        int c = ++pt_x == a.tiles_x ? 1 : 0;
+        pt_x -= c * a.tiles_x;
+        pt_y += c; c = pt_y == a.tiles_y ? 1 : 0;
+        pt_y -= c * a.tiles_y;
+        pt_n += c;
+        return f;
+    };
+    // piece slot k (compile-time, 0 .. DJ+HJ-1) of the prepared patch into buffer nb
+    auto issue_piece = [&](const Pf& f, int k, unsigned nb) __attribute__((always_inline)) {
+        if (k < DJ) {
+            w3_dma_piece16(f.rdy, smem + nb * DY_B + (unsigned)(wave + 8 * k) * 1024u, dv[k < DJ ? k : 0]);
+        } else if (k - DJ < HJ) {
+            const int j = k - DJ < HJ ? k - DJ : 0;
+            const int q = wave + 8 * j;
+            w3_dma_piece16(f.rx, smem + HALO_OFF + nb * HALO_B + (unsigned)(q < HPC ? q : HPC) * 1024u, hv[j]);
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // transposed-read lane addressing on the swizzled images, in bytes
+    const int G = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int krow = 8 * (G >> 1) + q;
+    const int chn = 16 * (G & 1) + 4 * pp;
+    unsigned a_base0 = (unsigned)((wmm >> 1) * IMG_B + krow * 128 + ((((wmm & 1) ^ ((q >> 1) & 1)) * 32 + chn) * 2));
+    unsigned b_base0[4];                       // by (constant row offset & 3)
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4)
+        b_base0[c4] = (unsigned)(HALO_OFF + krow * 128 + (((wn ^ (((c4 + q) >> 1) & 1)) * 32 + chn) * 2));
+
+    {
+        const Pf f0 = prep_patch(true);
+#pragma unroll
+        for (int k = 0; k < DJ + HJ; ++k) issue_piece(f0, k, 0u);
+    }
+    for (int patch = p_begin; patch < p_end; ++patch) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of the patch have landed
+        __builtin_amdgcn_s_barrier();                              // ... everybody's; the other buffer is free
+        asm volatile("" ::: "memory");
+        const unsigned buf = (unsigned)(patch - p_begin) & 1u;
+        const bool more = patch + 1 < p_end;
+        const Pf pf = prep_patch(more);        // (behind the range: empty pieces, the position is not used again)
+        unsigned ab = a_base0 + buf * DY_B, bb[4];
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) { bb[c4] = b_base0[c4] + buf * HALO_B; w3_opaque(bb[c4]); }
+        w3_opaque(ab);
+        const LDS_AS unsigned char* lds = (const LDS_AS unsigned char*)smem;
+        // 72 steps: (patch row s, column half g, tap); the X fragment of step i+PD (and the dY fragment of the next (s, g)) is
+        // read while the MFMA of step i runs
+        constexpr int PD = 3;
+        V8 afr[2], bfr[PD + 1];
+        auto load_a = [&](int sg, V8& dst) __attribute__((always_inline)) {       // sg = 2 * s + g: pixels 32 s + 16 g ..
+            dst = tr_read8<DT>((const LDS_AS unsigned short*)(lds + ab + sg * 16 * 128),
+                               (const LDS_AS unsigned short*)(lds + ab + (sg * 16 + 4) * 128));
+        };
+        auto load_b = [&](int step, V8& dst) __attribute__((always_inline)) {
+            const int sg = step / 9, tap = step - 9 * sg;
+            const int s = sg >> 1, g = sg & 1;
+            const int C = (s + tap / 3) * HWD + tap % 3 + 16 * g;   // halo row of this step's pixel column 0
+            dst = tr_read8<DT>((const LDS_AS unsigned short*)(lds + bb[C & 3] + C * 128),
+                               (const LDS_AS unsigned short*)(lds + bb[C & 3] + (C + 4) * 128));
+        };
+        load_a(0, afr[0]);
+#pragma unroll
+        for (int i = 0; i < PD; ++i) load_b(i, bfr[i]);
+#pragma unroll
+        for (int step = 0; step < 72; ++step) {
+            const int sg = step / 9, tap = step - 9 * sg;
+            if (step + PD < 72) load_b(step + PD, bfr[(step + PD) % (PD + 1)]);
+            if (tap == 4 && sg + 1 < 8) load_a(sg + 1, afr[(sg + 1) & 1]);
+            // the eight pieces of the next patch go out in the first steps
+            if (sg < 3 && (tap == 1 || tap == 4 || tap == 7) && 3 * sg + tap / 3 < DJ + HJ) issue_piece(pf, 3 * sg + tap / 3, buf ^ 1u);
+            acc[tap] = Elem<DT>::mfma32(afr[sg & 1], bfr[step % (PD + 1)], acc[tap]);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // the MFMA, then the reads of the next step in its shadow
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the (empty) pieces behind the last patch
+    const int l31 = lane & 31, h = lane >> 5;
+    const int ci = ci0 + wn * 32 + l31;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wmm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (ci < a.Cin && co < a.Cout) {
+                float* qd = a.dw + ((int64_t)tap * a.Cout + co) * a.Cin + ci;
+                if (a.slab_stride > 0) qd[(int64_t)ks * a.slab_stride] = acc[tap][r];
+                else atomicAdd(qd, acc[tap][r]);
+            }
+        }
+}
 }  // namespace
 
 // the LDS-DMA kernel covers the layers with 32-wide patches, 2-D and Conv3d (GSSEG_W3_DMA=0 switches it off)
@@ -405,17 +598,24 @@ static bool w3_use_dma(int W) {
     return env != 0 && W >= 24;
 }
 
+// the 128-cout form of the LDS-DMA kernel (GSSEG_W3_CO128=0 switches it off)
+static bool w3_use_co128(int W, int Cout) {
+    static const int env = getenv("GSSEG_W3_CO128") ? atoi(getenv("GSSEG_W3_CO128")) : 1;
+    return env != 0 && w3_use_dma(W) && Cout % 128 == 0;
+}
+
 static int w3_ksplit(int N, int H, int W, int Cin, int Cout, int* pps_out, int* npatches_out, bool dma) {
-    const int tw = (W >= 24) ? 32 : 16, th = dma ? 8 : W3_BM / tw;
+    const bool co128 = dma && w3_use_co128(W, Cout);
+    const int tw = (W >= 24) ? 32 : 16, th = co128 ? 4 : (dma ? 8 : W3_BM / tw);
     const int npatches = N * cdiv(W, tw) * cdiv(H, th);
-    const int pairs = cdiv(Cout, 64) * cdiv(Cin, 64);
+    const int pairs = cdiv(Cout, co128 ? 128 : 64) * cdiv(Cin, 64);
     static const int target_env = getenv("GSSEG_W3_GRID") ? atoi(getenv("GSSEG_W3_GRID")) : 0;
     // one 8-wave / two 4-wave blocks per CU (fewer when gs_set_persistent_grid() leaves CUs to RCCL)
     const int target = target_env > 0 ? target_env : (dma ? gs_get_persistent_grid() : 2 * gs_get_persistent_grid());
     // every part writes a 9 x 64 x 64 fp32 tile per (co, ci) pair (147 KB) that the ordered reduction reads back: a part
     // must cover a few patches for that to be worth it (batch 2: 512 one-patch parts cost more than the MFMAs)
     static const int min_pps_env = getenv("GSSEG_W3_MINPPS") ? atoi(getenv("GSSEG_W3_MINPPS")) : 4;
-    const int min_pps = dma ? (min_pps_env + 1) / 2 : min_pps_env;            // in patches of this kernel (256 / 128 pixels)
+    const int min_pps = (dma && !co128) ? (min_pps_env + 1) / 2 : min_pps_env;            // in patches of this kernel (256 / 128 pixels)
     int ksplit = cdiv(target, pairs);
     if (ksplit > npatches / min_pps) ksplit = npatches / min_pps;
     if (ksplit < 1) ksplit = 1;
@@ -441,10 +641,11 @@ static int wgrad3x3_launch(const void* x, const void* dy, float* dw, int N, int 
     a.Cout = Cout; a.out_stride = out_pix_stride; a.out_coff = out_coff;
     a.D = D; a.dz = dz; a.slab_stride = slab_stride;
     const bool dma = w3_use_dma(W);
-    const int tw = (W >= 24) ? 32 : 16, th = dma ? 8 : W3_BM / tw;
+    const bool co128 = dma && w3_use_co128(W, Cout);
+    const int tw = (W >= 24) ? 32 : 16, th = co128 ? 4 : (dma ? 8 : W3_BM / tw);
     a.tiles_x = cdiv(W, tw); a.tiles_y = cdiv(H, th);
     a.npatches = N * a.tiles_x * a.tiles_y;
-    a.ncob = cdiv(Cout, 64); a.ncib = cdiv(Cin, 64);
+    a.ncob = cdiv(Cout, co128 ? 128 : 64); a.ncib = cdiv(Cin, 64);
     const int pairs = a.ncob * a.ncib;
     {
         int pps = 0, np = 0;
@@ -454,7 +655,10 @@ static int wgrad3x3_launch(const void* x, const void* dy, float* dw, int N, int 
     hipStream_t s = (hipStream_t)stream;
     if (dma) {
         dim3 dgrid(pairs * a.ksplit);
-        if (dtype == GS_F16) wgrad3x3_dma_kernel<GS_F16><<<dgrid, 512, 0, s>>>(a);
+        if (co128) {
+            if (dtype == GS_F16) wgrad3x3_dma128_kernel<GS_F16><<<dgrid, 512, 0, s>>>(a);
+            else wgrad3x3_dma128_kernel<GS_BF16><<<dgrid, 512, 0, s>>>(a);
+        } else if (dtype == GS_F16) wgrad3x3_dma_kernel<GS_F16><<<dgrid, 512, 0, s>>>(a);
         else wgrad3x3_dma_kernel<GS_BF16><<<dgrid, 512, 0, s>>>(a);
         GS_CHECK_LAUNCH("gs_conv3x3_wgrad");
         return GS_OK;
