@@ -92,6 +92,18 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
     const bool flip = a.tap_dy[0] > 0;                     // data-gradient table: geometric tap g uses weight slot 8 - g
     const int tiles_y8 = (a.H + 7) >> 3;                   // immediate form: BatchNorm partial rows are numbered in 8x32 patches
 
+#ifdef GS_C3_PHASE_TIMING          // diagnostic build (tools/conv_dma_phase.py): cycles per phase of this wave, summed over its items
+    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = clock64();
+#define PH(i) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = clock64(); ph[i] += t_ - tq; tq = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PH(i) do {} while (0)
+#endif
+    // (Two waves share a SIMD's matrix pipe and the OLDER one wins every arbitration: in-kernel stamps (tools/conv_dma_phase.py,
+    // profiles/r03_conv_phase_stamps.txt) show wave 0 finishing a stage after ~60 % of the stage time and waiting at the barrier
+    // while its partner, wave 5, spends 91 % of its time inside stage bodies.  Evening them out does not help: a static
+    // s_setprio for waves 4..7 (+0.5 %) and a priority hand-over inside every stage at step 7 / 9 / 11 / 13 (+1.2 / +0.4 / +0.2 /
+    // +0.2 %, profiles/r03_ab_setprio.txt) both measured no gain -- the kernel delivers what the chip grants this instruction
+    // mix at the 1.8 GHz it holds under it, however the two waves split the pipe.)
     struct Item { int n, y0, x0, n0, mt; };
     const __amdgpu_buffer_rsrc_t w_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)(9u * a.ndz * a.Cout * a.Cin * 2u), 0x00020000);
@@ -547,8 +559,6 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
     auto image_rsrc = [&](int n) __attribute__((always_inline)) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)n * a.H * a.W * a.in_stride), 0, img_bytes, 0x00020000);
     };
-    // (a static s_setprio 1 for waves 4..7 -- the arbitration losers of an 8-wave block -- measured -0.5 .. +2.1 %, +0.5 % over
-    // six layer shapes: profiles/r03_ab_setprio.txt; not kept)
     Item cur = make_item();
     const int block_n0 = cur.n0;                           // DEFER: the block's cout tile (st0 == 0: host-guaranteed)
     if (DEFER && a.bias != nullptr) {
@@ -579,9 +589,11 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
         const bool more_items = nit < nitems;
         Item nxt = cur;
         if (more_items) nxt = advance_item();
+        PH(5);
         for (int sp = 0; sp < nstage; sp += 2) {
             const bool last = sp + 2 >= nstage;
             stage_sync();
+            PH(0);
             const Src s1 = stage_src(cur.n, sp + 1);
             if (sp == 0) {
                 const bool ws0 = wres && !first_item;      // stage 1's slabs are in buffer 1 since the first item
@@ -594,7 +606,9 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
             } else {
                 run_stage(std::integral_constant<int, 0>{}, std::false_type{}, std::false_type{}, image_rsrc(s1.n), s1, 0u, nxt);
             }
+            PH(1);
             stage_sync();
+            PH(2);
             if (last) {                                    // from here on the pieces belong to the next item
 #pragma unroll
                 for (int j = 0; j < HJ; ++j) hv[j] = hvn[j];
@@ -603,6 +617,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
             const Src s2 = stage_src(last ? nxt.n : cur.n, last ? 0 : sp + 2);
             run_stage(std::integral_constant<int, 1>{}, std::false_type{}, std::false_type{}, image_rsrc(s2.n), s2,
                       (last && !more_items) ? VOOB : 0u, nxt, wres && last);      // the next item's stage-0 slabs are in buffer 0
+            PH(3);
         }
         const bool full = (cur.y0 + TH <= a.H) && (cur.x0 + TW <= a.W);
         if (deferable && full && !(dbg & 4)) {
@@ -625,11 +640,18 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
             __syncthreads();
             if (!DEFER) finish_stats(cur);
         }
+        PH(4);
         if (!more_items) break;
         it = nit;
         cur = nxt;
         first_item = false;
     }
+#ifdef GS_C3_PHASE_TIMING
+    if (blockIdx.x == 0 && lane == 0 && a.bnp != nullptr) {          // the partials buffer doubles as sink (rows 300..)
+        for (int i = 0; i < 8; ++i) a.bnp[300 * 2 * a.Cout + wave * 8 + i] = (float)ph[i];
+    }
+#endif
+#undef PH
     if (DEFER) {
         if (pend) defer_flush();
         if (STATS) {
