@@ -28,6 +28,8 @@ if kind in "gdu":
     U = UNet(1, 1).to(dev).train()
     networks.upconv_arch = (1e-3 * torch.randn(8, 3)).to(dev).requires_grad_(True)
     crit = networks.GANLoss("vanilla").to(dev)
+    for m_ in (G, D, U):
+        m_.engine.trust_versions = True          # as harness.EndToEndTrainer (it owns every update): version-keyed pack reuse
     x, mask = synthetic_batch(B, 256, seed=3)
     x, mask = x.to(dev), mask.to(dev)
     maskf, real = mask.float(), torch.rand(B, 1, 256, 256, device=dev)
