@@ -1088,7 +1088,9 @@ def _unpack_merged(pf, cin, cout):
                                             # several items per block (the persistent grid is 256 blocks): the deferred epilogue's
                                             # hand-over between items, running statistics across items, resident weights (Cin = 64),
                                             # a ragged last row of patches in between
-                                            (24, 96, 128, 64, 64), (10, 104, 96, 64, 128), (20, 64, 96, 128, 64)])
+                                            (24, 96, 128, 64, 64), (10, 104, 96, 64, 128), (20, 64, 96, 128, 64),
+                                            # ... with ragged patches on both edges (immediate epilogue between deferred ones, resident weights kept)
+                                            (20, 100, 70, 64, 64), (12, 100, 70, 64, 136)])
 def test_conv3x3_kernel_forms(dtn, dt, form, N, H, W, Cin, Cout):
     """every form of the 2-D kernel (register-staged big-K-step, LDS-DMA with 4 / 8 waves) on the
     same operands: forward with BatchNorm partials into a strided slice (ragged patches, a partial cout tile, an odd
