@@ -1086,12 +1086,13 @@ static C3DmaPlan c3_dma_plan(int N, int H, int W, int Cout, bool per_block_rows)
 
 // Rows of BatchNorm partial sums ([rows][2][Cout] fp32) a gs_conv3x3 / gs_conv3d_3x3x3 / gs_conv3x3_precise launch with these
 // dimensions writes -- what gs_bn_finalize / gs_bn_partials_colsum must be told.  The LDS-DMA kernel keeps its sums in
-// registers across the items of a block and writes ONE row per block and cout-tile group; the pair forward (pair != 0) and the
-// other kernels write one row per 8x32 / 16x16 patch (= gs_conv3x3_mtiles).  Never more than gs_conv3x3_mtiles(): a buffer of
+// registers across the items of a block and writes ONE row per block and cout-tile group (the pair forward too: `pair` tells
+// which K extent the shape test sees); the other kernels write one row per 8x32 / 16x16 patch (= gs_conv3x3_mtiles).  Never more than gs_conv3x3_mtiles(): a buffer of
 // that many rows always suffices.  Assumes what every caller in this package does: the forward or the flipped tap table and
 // channel strides / offsets that are multiples of 8 (a launch that would fall off that path with statistics fails loudly).
 extern "C" int gs_conv3x3_stat_rows(int N, int H, int W, int Cin, int Cout, int pair) {
-    if (!pair && c3_dma_shape_ok(W, Cin, Cout)) {
+    static const int prec_dma = getenv("GSSEG_C3_PREC_DMA") ? atoi(getenv("GSSEG_C3_PREC_DMA")) : 1;
+    if ((!pair || prec_dma != 0) && c3_dma_shape_ok(W, Cin, Cout)) {
         const C3DmaPlan p = c3_dma_plan(N, H, W, Cout, true);
         return p.grid / p.ntn;
     }
@@ -1164,7 +1165,7 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
         static const int prec_dma_env = getenv("GSSEG_C3_PREC_DMA") ? atoi(getenv("GSSEG_C3_PREC_DMA")) : 1;
         const bool dma = c3_dma_shape_ok(W, Cin, Cout) && (prec ? (std_taps && prec_dma_env != 0) : (std_taps || flip_taps));
         if (dma) {
-            const C3DmaPlan dp = c3_dma_plan(N, H, W, Cout, !prec);
+            const C3DmaPlan dp = c3_dma_plan(N, H, W, Cout, true);
             a.tiles_x = dp.tiles_x; a.tiles_y = dp.tiles_y; a.ntn = dp.ntn; a.nblocks = dp.nitems;
             a.xcd_order = (xcd_env && (dp.grid % 8) == 0 && a.ntn > 1 && (int64_t)N * H * W > (int64_t)18 * Cout) ? 1 : 0;
             c3_dma_launch(a, dp.waves, prec, dtype, dp.grid, bs);
@@ -1172,7 +1173,7 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
             return GS_OK;
         }
         // statistics rows: gs_conv3x3_stat_rows() promised the per-block rows of the LDS-DMA kernel for this shape
-        GS_CHECK_ARG(bn_partials == nullptr || prec || !c3_dma_shape_ok(W, Cin, Cout),
+        GS_CHECK_ARG(bn_partials == nullptr || !c3_dma_shape_ok(W, Cin, Cout) || (prec && prec_dma_env == 0),
                      "gs_conv3x3: BatchNorm partials with a tap table / layout outside the LDS-DMA kernel (gs_conv3x3_stat_rows would be wrong)");
         if (prec) {
             if (dtype == GS_F16) {

@@ -19,8 +19,8 @@
 //
 // Two epilogue forms (template flag DEFER):
 //   DEFER = false (the pair / precise forward, PREC): as conv3x3_big_kernel -- at the end of an item every wave packs its
-//     64 x 64 tile, transposes it through an LDS staging area that overlays the second stage buffer and stores 128-byte
-//     rows; BatchNorm partial sums per 8x32 half-item, handed over through LDS (one row per half-item).
+//     64 x 64 tile (hi and lo), transposes it through an LDS staging area that overlays the second stage buffer and stores
+//     128-byte rows.
 //   DEFER = true (everything else): the epilogue of item k runs UNDER THE MFMAs OF ITEM k+1.  Measured on the round-2
 //     kernel (tools/ablate_conv_epilogue.py): without its epilogue the 64->64 layer at 256^2 runs 28 % faster (128->64:
 //     19 %, 128->128 @128^2: 12 %), while the global stores themselves cost 2-3 % -- the time is the pack / DPP / LDS
@@ -28,10 +28,10 @@
 //     boundary a wave only converts its fp32 accumulators to 32 registers of packed 16-bit pairs (and adds them to its
 //     running statistics); the transposition (8 passes of 8 pixel rows through a PRIVATE 1 KB LDS buffer per wave: 4
 //     ds_write_b32, one ds_read_b128, one 16-byte store each) is spread over the steps of the next item's first stage, two
-//     steps per pass.  BatchNorm partial sums are kept in registers across ALL items of the block (a block keeps its cout
-//     tile: the grid is a multiple of the tile count) and written once at the end: one row per block instead of one per
-//     half-item (c3_dma_grid() rows; no LDS hand-over and barrier per item, no first-stage reduction launch afterwards).
-//     Items with a bias / activation (inference) or a partial patch take the immediate path.
+//     steps per pass.  Items with an activation (inference) or a partial patch take the immediate path.
+// Both forms keep the BatchNorm partial sums in registers across ALL items of the block (a block keeps its cout tile: the grid
+// is a multiple of the tile count) and write them once at the end: one row per block instead of one per half-item
+// (c3_dma_grid() rows; no LDS hand-over and barrier per item, no first-stage reduction launch afterwards).
 #include <stdlib.h>
 #include <type_traits>
 
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
     const unsigned img_bytes = (unsigned)a.H * a.W * a.in_stride * 2u;
     const unsigned tap_stride = (unsigned)a.Cout * a.Cin * 2u;
     const bool flip = a.tap_dy[0] > 0;                     // data-gradient table: geometric tap g uses weight slot 8 - g
-    const int tiles_y8 = (a.H + 7) >> 3;                   // immediate form: BatchNorm partial rows are numbered in 8x32 patches
+    const int tiles_y8 = (a.H + 7) >> 3;
 
 #ifdef GS_C3_PHASE_TIMING          // diagnostic build (tools/conv_dma_phase.py): cycles per phase of this wave, summed over its items
     long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = clock64();
@@ -367,7 +367,6 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
     // ---- immediate epilogue: as conv3x3_big_kernel (staging overlays the second stage buffer, which the last stage has just left) ----
     unsigned short* stg = reinterpret_cast<unsigned short*>(smem + H0_OFF + HALO_B) + wave * STG_EL;
     unsigned short* stg_lo = stg + NWV * STG_EL;                                        // PREC: the lo halves
-    float* red = reinterpret_cast<float*>(smem + H0_OFF + HALO_B + (PREC ? 2 : 1) * NWV * STG_EL * 2);  // [NWV][2][BN]
     const float neg_slope = act == GS_ACT_RELU ? 0.f : (act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
     auto epilogue_t = [&](const Item& itc, auto plain_tag, auto full_tag) __attribute__((always_inline)) {
         constexpr bool PLAIN = decltype(plain_tag)::value;
@@ -386,10 +385,6 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
                 const int co = e_n0 + j * 32 + l31;
                 bv[j] = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
             }
-        }
-        if (!DEFER) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) { s1v[j] = f32x2{0.f, 0.f}; s2v[j] = f32x2{0.f, 0.f}; }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -461,39 +456,9 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if (want_stats && !DEFER) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float t1 = s1v[j].x + s1v[j].y, t2 = s2v[j].x + s2v[j].y;
-                t1 += __shfl_xor(t1, 32, 64);
-                t2 += __shfl_xor(t2, 32, 64);
-                if (h == 0) {
-                    red[(wave * 2 + 0) * BN + j * 32 + l31] = t1;
-                    red[(wave * 2 + 1) * BN + j * 32 + l31] = t2;
-                }
-            }
-        }
     };
     const bool plain = (a.bias == nullptr && act == GS_ACT_NONE);
     const bool deferable = DEFER && act == GS_ACT_NONE;    // a bias rides along (bvb), an activation takes the immediate path
-    // immediate form, per-item partial rows (!DEFER): partial sums of the 8x32 halves: waves 4*half .. 4*half+3
-    auto finish_stats = [&](const Item& itc) __attribute__((always_inline)) {
-        constexpr int NH = NWV / 4;
-        if (STATS && t < NH * BN) {
-            const int half = t / BN, c = t % BN;
-            if (itc.n0 + c < a.Cout && (itc.y0 >> 3) + half < tiles_y8) {
-                float v1 = 0.f, v2 = 0.f;
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    v1 += red[((half * 4 + m) * 2 + 0) * BN + c];
-                    v2 += red[((half * 4 + m) * 2 + 1) * BN + c];
-                }
-                float* dst = a.bnp + (int64_t)(itc.mt + half * a.tiles_x) * 2 * a.Cout + itc.n0 + c;
-                dst[0] = v1;
-                dst[a.Cout] = v2;
-            }
-        }
-    };
     // deferred form, item boundary: accumulators -> packed pairs + running statistics (nothing leaves the registers).  A bias
     // (Conv3d of the 3-D U-Net, unet3d.py:28-31) is added after the statistics, as on the immediate path; the block keeps its
     // cout tile, so the lane's two bias values are loaded once.
@@ -637,8 +602,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
                 if (plain && full) epilogue_t(cur, std::true_type{}, std::true_type{});
                 else epilogue_t(cur, std::false_type{}, std::false_type{});
             }
-            __syncthreads();
-            if (!DEFER) finish_stats(cur);
+            // (no barrier behind it: the staging area is overwritten by DMA pieces only after the next stage hand-over)
         }
         PH(4);
         if (!more_items) break;
@@ -652,8 +616,8 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
     }
 #endif
 #undef PH
-    if (DEFER) {
-        if (pend) defer_flush();
+    {
+        if (DEFER && pend) defer_flush();
         if (STATS) {
             // the block's partial sums: one row per block, written once (rows = grid / ntn; block b with cout tile b % ntn
             // writes columns n0 .. n0 + 63 of row it_first / ntn)
