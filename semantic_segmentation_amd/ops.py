@@ -1125,7 +1125,7 @@ def conv3x3_precise(x, w, y_hi, y_lo, N, H, W, Cin, Cout, in_stride, in_coff=0, 
         raise TypeError("conv3x3_precise: x, w, y must share one 16-bit dtype")
     if Cin % 64 != 0 or w.numel() != 9 * Cout * 3 * Cin:
         raise ValueError("conv3x3_precise: Cin must be a multiple of 64 and w the [9][Cout][3*Cin] split pack")
-    if bn_partials is not None and bn_partials.numel() < bn_partials_numel(conv3x3_mtiles(N, H, W, Cout), Cout):
+    if bn_partials is not None and bn_partials.numel() < bn_partials_numel(conv3x3_stat_rows(N, H, W, Cin, Cout, pair=True), Cout):
         raise ValueError("conv3x3_precise: bn_partials too small")
     dy = (ctypes.c_int32 * 9)(*[t[0] for t in taps])
     dx = (ctypes.c_int32 * 9)(*[t[1] for t in taps])
@@ -1194,8 +1194,8 @@ def conv3x3_segs(x, w, y_hi, y_lo, N, H, W, K, wrap, Cin, Cout, in_stride, in_co
         raise TypeError("conv3x3_segs: x, w, y must share one 16-bit dtype")
     if K % 64 != 0 or wrap % 64 != 0 or not (wrap <= K <= 2 * wrap) or w.numel() != 9 * Cout * K:
         raise ValueError("conv3x3_segs: K / wrap must be multiples of 64 with wrap <= K <= 2*wrap and w the [9][Cout][K] pack")
-    if bn_partials is not None and bn_partials.numel() < bn_partials_numel(conv3x3_mtiles(N, H, W, Cout), Cout):
-        raise ValueError("conv3x3_segs: bn_partials too small")
+    if bn_partials is not None and bn_partials.numel() < bn_partials_numel(conv3x3_stat_rows(N, H, W, Cin, Cout, pair=True), Cout):
+        raise ValueError("conv3x3_segs: bn_partials too small (conv3x3_stat_rows(pair=True) rows of [2][Cout])")
     dy = (ctypes.c_int32 * 9)(*[t[0] for t in taps])
     dx = (ctypes.c_int32 * 9)(*[t[1] for t in taps])
     ev = TIMER.start() if TIMER is not None else None
