@@ -49,7 +49,7 @@ FUSED_UP_BIAS_GRAD = os.environ.get("GSSEG_UP_BIAS_FUSED", "1") != "0"
 class _ConvRec:
     """Saved state of one conv -> BN -> ReLU stage."""
     __slots__ = ("name", "wkey", "bnkey", "inp", "inp_is_image", "y", "coef", "geom", "cin", "cout", "h", "w",
-                 "wd", "train_stats", "inp_stride", "z", "tap_sums")
+                 "wd", "train_stats", "inp_stride", "z", "tap_sums", "wide")
 
 
 class _UpRec:
@@ -239,6 +239,22 @@ class UNetEngine:
         self._packs[name] = (key, wf, wd)
         return wf, wd
 
+    def _packed_padded(self, name: str, w: torch.Tensor, cpad: int, need_dgrad: bool):
+        """packs of a 3x3 conv weight whose input channels are zero-padded to cpad (an image of more than 4 channels enters
+        the MFMA path as a 16-bit NHWC tensor with a multiple of 8 channels)"""
+        key = (_pack_key(w), cpad)
+        ent = self._packs.get(name + "|padded")
+        if ent is not None and ent[0] == key and (ent[2] is not None or not need_dgrad):
+            return ent[1], ent[2]
+        cout, cin = w.shape[0], w.shape[1]
+        wp = torch.zeros((cout, cpad, 3, 3), dtype=torch.float32, device=w.device)
+        wp[:, :cin] = w.detach()
+        wf = torch.empty((9, cout, cpad), dtype=self.tdt, device=w.device)
+        wd = torch.empty((9, cpad, cout), dtype=self.tdt, device=w.device) if need_dgrad else None
+        ops.pack_weight(wp, wf, wd, False)
+        self._packs[name + "|padded"] = (key, wf, wd)
+        return wf, wd
+
     def _folded(self, wkey: str, bnkey: str, w, gamma, beta, rm, rv, eps: float, image: bool):
         """Inference: BatchNorm(eval) folded into the conv -- w' = w * gamma/sqrt(var+eps) per output channel and a bias
         beta - mean*gamma/sqrt(var+eps).  Cached until a Parameter or running statistic changes."""
@@ -269,9 +285,9 @@ class UNetEngine:
         N, _, H, W = x.shape
         if H < 16 or W < 16:
             raise ValueError("input must be at least 16x16 (four 2x2 poolings)")
-        if net.n_channels > 4 or net.n_classes > 4:
-            raise NotImplementedError("n_channels / n_classes above 4 are not supported by the direct end kernels")
         if self.precise:
+            if net.n_channels > 4 or net.n_classes > 4:
+                raise NotImplementedError("the pair forward supports n_channels / n_classes up to 4 (the direct end kernels)")
             return self.forward_precise(x, params, training, need_grad)
         dev, tdt = x.device, self.tdt
         x = x.contiguous().float()
@@ -319,13 +335,14 @@ class UNetEngine:
                                    coef[0], coef[1], coef[2], coef[3])
             return coef, batch_stats
 
-        def conv_bn_relu(prefix, idx, inp, cin, cout, h, w, z, z_stride, z_coff, zp, image=False):
-            """prefix.double_conv.{idx} conv + .{idx+1} BN + ReLU."""
+        def conv_bn_relu(prefix, idx, inp, cin, cout, h, w, z, z_stride, z_coff, zp, image=False, wide=0):
+            """prefix.double_conv.{idx} conv + .{idx+1} BN + ReLU.  wide = C0 > 4: `inp` is the image already converted to a
+            16-bit NHWC tensor of cin = ceil8(C0) channels (zero padded); the weight's input channels are padded alike."""
             wkey, bnkey = f"{prefix}.double_conv.{idx}.weight", f"{prefix}.double_conv.{idx + 1}"
             wparam = params[wkey]
             rm = bufs.get(bnkey + ".running_mean")
             batch_stats = training or rm is None
-            if FOLD_BN_INFERENCE and not batch_stats and not need_grad and ops.USE_HALO_CONV:
+            if FOLD_BN_INFERENCE and not batch_stats and not need_grad and ops.USE_HALO_CONV and not wide:
                 # inference: one kernel per conv block (folded BN as bias, ReLU in the epilogue, written where the
                 # consumer reads it); the 2x2 pool of the Down blocks is a read-only pass over the skip tensor
                 wf, bias = self._folded(wkey, bnkey, wparam, params[bnkey + ".weight"], params[bnkey + ".bias"], rm,
@@ -344,6 +361,7 @@ class UNetEngine:
             rec.name, rec.wkey, rec.bnkey = f"{prefix}.{idx}", wkey, bnkey
             rec.cin, rec.cout, rec.h, rec.w, rec.inp_is_image = cin, cout, h, w, image
             rec.inp_stride = None
+            rec.wide = wide
             nonlocal partials
             g = None if image else ops.geom_conv(N, h, w, cin, cout, 3, 1, 1)
             if image:
@@ -377,7 +395,8 @@ class UNetEngine:
                 ops.conv_smallcin_fwd(inp, wparam.detach().contiguous(), None, y, partials, 3, 1, 1)
                 rec.geom, rec.wd = None, None
             else:
-                wf, wd = self._packed(wkey, wparam, False, need_grad)
+                wf, wd = (self._packed_padded(wkey, wparam, cin, need_grad) if wide
+                          else self._packed(wkey, wparam, False, need_grad))
                 if ops.USE_HALO_CONV:
                     ops.conv3x3(inp, wf, y, N, h, w, cin, cout, ops.TAPS3_FWD, None, partials)
                 else:
@@ -400,12 +419,23 @@ class UNetEngine:
             cats[i] = alloc((N, hs[i], ws_[i], 2 * C[i]), dtype=tdt, device=dev)
         inp = x
         cin = net.n_channels
+        wide = 0
+        if cin > 4:
+            # more than four input channels (the reference takes any, unet_model.py:8-12): the image enters the MFMA path as a
+            # 16-bit NHWC tensor zero-padded to a multiple of 8 channels (the direct first-layer kernels read 1..4 fp32 channels)
+            if not ops.USE_HALO_CONV:
+                raise NotImplementedError("n_channels above 4 needs the halo-reuse conv kernel")
+            wide, cpad = cin, (cin + 7) // 8 * 8
+            xin = (torch.zeros if cpad != cin else torch.empty)((N, H, W, cpad), dtype=tdt, device=dev)
+            ops.nchw_to_nhwc(x, xin, dst_stride=cpad)
+            inp, cin = xin, cpad
         pooled = None
         for i in range(5):
             prefix = "inc" if i == 0 else f"down{i}.maxpool_conv.1"
             h, w = hs[i], ws_[i]
             zmid = empty(N, h, w, C[i])
-            conv_bn_relu(prefix, 0, inp, cin, C[i], h, w, zmid, C[i], 0, None, image=(i == 0))
+            conv_bn_relu(prefix, 0, inp, cin, C[i], h, w, zmid, C[i], 0, None, image=(i == 0 and not wide),
+                         wide=wide if i == 0 else 0)
             if i < 4:
                 pooled = empty(N, hs[i + 1], ws_[i + 1], C[i])
                 conv_bn_relu(prefix, 3, zmid, C[i], C[i], h, w, cats[i], 2 * C[i], 0, pooled)
@@ -464,9 +494,17 @@ class UNetEngine:
         if inp is None:
             ops.head1x1_bn_fwd(last_rec.y, last_rec.coef[0], last_rec.coef[1], ACT_RELU,
                                params["outc.conv.weight"].detach().contiguous(), params["outc.conv.bias"].detach(), logits)
-        else:
+        elif net.n_classes <= 4:
             ops.conv_smallcout_fwd(inp, params["outc.conv.weight"].detach().contiguous(),
                                    params["outc.conv.bias"].detach(), logits)
+        else:
+            # more than four classes (the reference takes any): the pointwise head kernel in groups of four output channels
+            wo, bo = params["outc.conv.weight"].detach(), params["outc.conv.bias"].detach()
+            for g0 in range(0, net.n_classes, 4):
+                g1 = min(g0 + 4, net.n_classes)
+                tmp = empty(N, g1 - g0, H, W, dtype=torch.float32)
+                ops.conv_smallcout_fwd(inp, wo[g0:g1].contiguous(), bo[g0:g1].contiguous(), tmp)
+                logits[:, g0:g1] = tmp
         if nbt_pending:
             torch._foreach_add_(nbt_pending, 1)
         ctx = None
@@ -874,6 +912,16 @@ class UNetEngine:
             dz = None
             if z_last is not None:
                 ops.conv_smallcout_bwd(z_last, wout_c, dl, None, dwo, dbo, gscale=inv_s)
+        elif wout.shape[0] > 4:
+            # more than four classes: the head's backward in groups of four output channels, data gradients summed in fp32
+            dzs = torch.zeros((N, H, W, 64), dtype=torch.float32, device=dev)
+            for g0 in range(0, wout.shape[0], 4):
+                g1 = min(g0 + 4, wout.shape[0])
+                dzg = empty(N, H, W, 64)
+                ops.conv_smallcout_bwd(z_last, wout_c[g0:g1].contiguous(), dl[:, g0:g1].contiguous(), dzg, dwo[g0:g1], dbo[g0:g1],
+                                       gscale=inv_s)
+                dzs += dzg
+            dz = dzs.to(tdt)
         else:
             dz = empty(N, H, W, 64)
             if z_last is not None:
@@ -953,6 +1001,19 @@ class UNetEngine:
                 if need_dinp:
                     dinp = torch.empty_like(rec.inp)
                     ops.conv_smallcin_dgrad(dy, wparam.detach().contiguous(), dinp, 3, 1, 1, inv_s)
+            elif getattr(rec, "wide", 0):
+                # the image stage of a wide input: the weight gradient over the zero-padded channels, then the real ones
+                dwp = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dev)
+                ops.conv3x3_wgrad_det(rec.inp, dy, wg_ws, dwp, N, h, w, cin, cout, inv_s)
+                dw = galloc(rec.wkey, wparam)
+                dw.copy_(dwp[:, :rec.wide])
+                wgrad_on_side = False
+                if need_dinp:
+                    dxp = empty(N, h, w, cin)
+                    ops.conv3x3(dy, rec.wd, dxp, N, h, w, cout, cin, ops.TAPS3_DGRAD)
+                    dfull = torch.empty((N, cin, h, w), dtype=torch.float32, device=dev)
+                    ops.nhwc_to_nchw(dxp, dfull, gscale=inv_s)
+                    dinp = dfull[:, :rec.wide].contiguous()
             else:
                 dw = galloc(rec.wkey, wparam)
                 wgrad_on_side = rec.name in det_recs

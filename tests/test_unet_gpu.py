@@ -519,6 +519,48 @@ def test_data_writes_between_training_forwards_are_seen_by_default():
     assert not torch.equal(l3, l1)
 
 
+@pytest.mark.parametrize("n_channels,n_classes,need_dx", [(6, 7, False), (8, 2, True), (3, 9, False)])
+def test_unet_wide_ends_vs_oracle(n_channels, n_classes, need_dx):
+    """`UNet(n_channels, n_classes)` takes ANY channel / class count in the reference (unet/unet_model.py:8-12); the direct end
+    kernels cover 1..4.  More input channels enter the MFMA path as a zero-padded 16-bit NHWC image, more classes run the
+    pointwise head in groups of four: forward, loss and every gradient (incl. the image gradient) against the oracle."""
+    from semantic_segmentation_amd.losses import seg_loss
+    from semantic_segmentation_amd.unet import UNet
+    sd = oracle.unet_state_dict(n_channels, n_classes, seed=41)
+    net = UNet(n_channels, n_classes)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, n_channels, 48, 64, generator=g)
+    mask = torch.randint(0, n_classes, (2, 1, 48, 64), generator=g)
+    xr = x.clone().requires_grad_(need_dx)
+    params = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    ref_logits = oracle.unet_forward(params, xr, True, {})
+    ref_loss = oracle.seg_loss(ref_logits, mask)
+    leaves = {k: v for k, v in params.items() if v.requires_grad}
+    ref_g = torch.autograd.grad(ref_loss, list(leaves.values()) + ([xr] if need_dx else []))
+    ref_grads = dict(zip(leaves.keys(), ref_g))
+    xd = x.cuda().requires_grad_(need_dx)
+    logits = net(xd)
+    loss = seg_loss(logits, mask.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    d = (logits.detach().cpu() - ref_logits.detach()).abs()
+    rel = {k: float((p.grad.cpu().double() - ref_grads[k].double()).norm() / max(ref_grads[k].double().norm().item(), 1e-20))
+           for k, p in net.named_parameters()}
+    REPORT[f"wide_{n_channels}_{n_classes}"] = {"logit_max_abs": float(d.max()), "logit_mean_abs": float(d.mean()),
+                                                "loss_abs_err": abs(loss.item() - ref_loss.item()),
+                                                "grad_rel_l2_worst": max(rel.values()), "worst_key": max(rel, key=rel.get)}
+    _dump()
+    assert tuple(logits.shape) == (2, n_classes, 48, 64)
+    assert abs(loss.item() - ref_loss.item()) < 1e-3
+    assert d.mean() < 1.2e-3 and d.max() < 1e-2, REPORT[f"wide_{n_channels}_{n_classes}"]
+    assert max(rel.values()) < 0.35, (max(rel, key=rel.get), max(rel.values()))
+    if need_dx:
+        gx, rx = xd.grad.cpu().double(), ref_g[-1].double()
+        assert float((gx - rx).norm() / rx.norm()) < 0.35
+
+
 # ------------------------------------------------------------------------------------------------ mixed mode: 1e-3 on logits
 def build_mode(n_classes, seed, mode, dtype="f16"):
     from semantic_segmentation_amd.unet import UNet
