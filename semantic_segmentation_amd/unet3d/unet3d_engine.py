@@ -34,7 +34,7 @@ def geom_conv3d(NB, D, H, W, Cin, Cout, dgrad=False, **kw):
 
 class _Stage:
     __slots__ = ("conv", "bn", "inp", "in_stride", "in_coff", "y", "coef", "stats", "geom", "wd", "cin", "cout",
-                 "D", "H", "W", "first", "x3", "halo")
+                 "D", "H", "W", "first", "x3", "halo", "wide")
 
 
 class UNet3DEngine:
@@ -55,8 +55,6 @@ class UNet3DEngine:
             raise RuntimeError("UNet3D (semantic_segmentation_amd) runs on the MI355X only (no CPU / ATen fallback)")
         if x.dim() != 5 or x.shape[1] != net.in_channels:
             raise ValueError(f"expected input [N,{net.in_channels},D,H,W], got {tuple(x.shape)}")
-        if net.in_channels != 1:
-            raise NotImplementedError("UNet3D on the HIP engine supports in_channels == 1 (BASELINE config 5)")
         NB, _, D0, H0, W0 = x.shape
         if D0 % 8 or H0 % 8 or W0 % 8:
             raise ValueError("volume dims must be multiples of 8 (three 2x2x2 poolings, no padding in the reference)")
@@ -91,7 +89,7 @@ class UNet3DEngine:
             cout = conv.out_channels
             st = _Stage()
             st.conv, st.bn, st.cin, st.cout, st.D, st.H, st.W, st.first = conv, bn, cin, cout, D, H, W, first
-            st.inp, st.in_stride, st.in_coff = inp, in_stride, in_coff
+            st.inp, st.in_stride, st.in_coff, st.wide = inp, in_stride, in_coff, 0
             y = empty(NB * D, H, W, cout)
             batch = training or bn.running_mean is None
             if first:
@@ -105,7 +103,12 @@ class UNet3DEngine:
                 st.geom = st.wd = None
                 st.halo = False
             else:
-                w4 = conv.weight.detach().reshape(cout, cin, 27, 1)
+                w4 = conv.weight.detach().reshape(cout, conv.weight.shape[1], 27, 1)
+                if w4.shape[1] != cin:             # a multi-channel input volume: input channels zero-padded to cin = ceil8(C)
+                    st.wide = w4.shape[1]
+                    wp = torch.zeros((cout, cin, 27, 1), dtype=torch.float32, device=dev)
+                    wp[:, :st.wide] = w4
+                    w4 = wp
                 wf = empty(27, cout, cin)
                 wd = empty(27, cin, cout) if need_grad else None
                 ops.pack_weight(w4, wf, wd, False)
@@ -142,11 +145,23 @@ class UNet3DEngine:
         # ---- analysis path ----
         enc = []
         inp, in_stride, cin = x, None, net.in_channels
+        wide_in = cin != 1
+        if wide_in:
+            # more than one input channel (the reference takes any, unet3d.py:103-106): the volume enters the MFMA path as a
+            # 16-bit NDHWC tensor zero-padded to a multiple of 8 channels (the direct first-layer kernel folds the three depth
+            # taps of a ONE-channel volume into its 1..4 input channels)
+            if not ops.USE_HALO_CONV:
+                raise NotImplementedError("UNet3D with in_channels != 1 needs the halo-reuse conv kernel")
+            cpad = (cin + 7) // 8 * 8
+            xin = (torch.zeros if cpad != cin else torch.empty)((NB * D0, H0, W0, cpad), dtype=tdt, device=dev)
+            ops.nchw_to_nhwc(x.permute(0, 2, 1, 3, 4).reshape(NB * D0, cin, H0, W0).contiguous(), xin, dst_stride=cpad)
+            inp, cin = xin, cpad
         for k, blk in enumerate(a_blocks, 1):
             D, H, W = dims[k - 1]
             cmid, cout = blk.conv1.out_channels, blk.conv2.out_channels
             z1 = empty(NB * D, H, W, cmid)
-            s1 = conv_bn_relu(blk.conv1, blk.bn1, inp, cin if k > 1 else None, 0, cin, D, H, W, z1, cmid, 0, first=(k == 1))
+            s1 = conv_bn_relu(blk.conv1, blk.bn1, inp, cin if (k > 1 or wide_in) else None, 0, cin, D, H, W, z1, cmid, 0,
+                              first=(k == 1 and not wide_in))
             ctot = cats[k].shape[3]
             s2 = conv_bn_relu(blk.conv2, blk.bn2, z1, cmid, 0, cmid, D, H, W, cats[k], ctot, cup[k])
             pooled = empty(NB * (D // 2), H // 2, W // 2, cout)
@@ -264,6 +279,8 @@ class UNet3DEngine:
                 else:
                     wsl = empty(ops.conv_wgrad_ws_floats(st.geom), dtype=torch.float32)
                     ops.conv_wgrad_det(st.geom, st.inp, dy, wsl, dw, cout, cin, 27, inv_s)
+                if st.wide:                          # the padded input channels carry no parameter
+                    dw = dw.view(cout, cin, 27)[:, :st.wide].contiguous()
                 emit(wparam, dw.view(wparam.shape))
                 if need_dinp:
                     dinp = empty(n2, H, W, cin)

@@ -119,6 +119,47 @@ def test_unet3d_128_vs_reference_fixture(golden_dir):
     assert bworst < 1e-2, rep
 
 
+@pytest.mark.parametrize("cin,ncls", [(3, 2), (8, 3), (4, 1)])
+def test_unet3d_multi_channel_input_vs_oracle(cin, ncls):
+    """The reference's UNet3D takes any in_channels (unet3d.py:103-106): a multi-channel volume goes through the MFMA conv path
+    with zero-padded input channels; logits, loss and every parameter gradient against the fp32 oracle."""
+    from semantic_segmentation_amd.unet3d import UNet3D
+    sd = oracle.unet3d_state_dict(cin, ncls, seed=23 + cin)
+    g = torch.Generator().manual_seed(cin)
+    x = torch.randn(1, cin, 16, 16, 16, generator=g)
+    mask = (torch.rand(1, 16, 16, 16, generator=g) > 0.5).long() if ncls > 1 else \
+        (torch.rand(1, 16, 16, 16, generator=g) > 0.5).float()
+    ref_p = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
+    ref_logits = oracle.unet3d_forward(ref_p, x, train=True)
+    n, c, dd, hh, ww = ref_logits.shape
+    ref_loss = oracle.seg_loss(ref_logits.reshape(n, c, dd * hh, ww), mask.reshape(n, dd * hh, ww))
+    ref_loss.backward()
+    net = UNet3D(cin, ncls)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    logits = net(x.cuda())
+    loss = vol_loss(logits, mask.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    d = (logits.detach().cpu() - ref_logits.detach()).abs()
+    assert abs(float(loss) - float(ref_loss)) < 1e-3, (float(loss), float(ref_loss))
+    assert float(d.mean()) < 2e-3 and float(d.max()) < 2e-2, (float(d.mean()), float(d.max()))
+    errs = {}
+    for k, p in net.named_parameters():
+        r = ref_p[k].grad
+        assert p.grad.shape == r.shape, k
+        if k.endswith("conv1.bias") or k.endswith("conv2.bias"):
+            continue                                # a bias in front of a batch-statistics BatchNorm: true gradient 0
+        errs[k] = float((p.grad.cpu() - r).norm() / (r.norm() + 1e-12))
+    REPORT["multi_channel_%d_%d" % (cin, ncls)] = {"logit_max_abs": float(d.max()), "grad_rel_err_median":
+                                                  float(np.median(list(errs.values()))), "first_conv_grad_rel_err":
+                                                  errs["a_block1.conv1.weight"]}
+    _dump()
+    # elementwise relative error of 16-bit-storage gradients on a 16^3 volume at batch 1 (the 1-channel net sits at the same level)
+    assert errs["a_block1.conv1.weight"] < 0.15, errs["a_block1.conv1.weight"]
+    assert float(np.median(list(errs.values()))) < 0.15 and max(errs.values()) < 0.3, errs
+
+
 def test_unet3d_descent_direction():
     from semantic_segmentation_amd.unet3d import UNet3D
     sd = oracle.unet3d_state_dict(1, 2, seed=61)
