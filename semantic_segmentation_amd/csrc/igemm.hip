@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "common.hpp"
+#include "skinny.hpp"
 
 namespace {
 
@@ -778,9 +779,24 @@ static int launch_igemm(IgemmArgs& a, int dtype, hipStream_t s, const char* who,
     return GS_OK;
 }
 
+// rows of BatchNorm partial sums a launch of this geometry writes: one per 128-row tile, or -- for the geometries the
+// weight-streaming form (skinny.hip) covers -- one per 16 output rows
 extern "C" int gs_conv_igemm_mtiles(const GsConvGeom* g) {
     if (!g) return GS_EINVAL;
+    const int sk = gs_skinny_stat_rows(g);
+    if (sk > 0) return sk;
     return (int)cdiv64((int64_t)g->N * (g->Dg > 0 ? g->Dg : 1) * g->OHg * g->OWg, FW_BM);
+}
+
+// a covered geometry that ran on the register-staged engine after all (no workspace, mismatched batch): it wrote one row per
+// 128-row tile; the rows gs_conv_igemm_mtiles() promised beyond those carry zeros
+static int pad_stat_rows(const GsConvGeom* g, float* bnp, hipStream_t s) {
+    const int sk = gs_skinny_stat_rows(g);
+    if (sk <= 0 || bnp == nullptr) return GS_OK;
+    const int wrote = (int)cdiv64((int64_t)g->N * g->OHg * g->OWg, FW_BM);
+    if (sk > wrote && hipMemsetAsync(bnp + (int64_t)wrote * 2 * g->Cout, 0, (size_t)(sk - wrote) * 2 * g->Cout * 4, s) != hipSuccess)
+        return GS_ELAUNCH;
+    return GS_OK;
 }
 
 extern "C" int gs_conv_igemm(const GsConvGeom* g, const void* x, const void* w, void* y, const float* bias,
@@ -800,7 +816,14 @@ extern "C" int gs_conv_igemm(const GsConvGeom* g, const void* x, const void* w, 
     a.shuffle_cout = 0; a.shuffle_cls = 0;
     GS_CHECK_ARG(splitk_ws == nullptr || splitk_ws_floats >= IGEMM_BATCH_MAX * (SPLITK_CNT_SLOTS + SPLITK_TILE_FLOATS),
                  "gs_conv_igemm: split-K workspace too small (gs_conv_igemm_workspace_floats())");
-    return launch_igemm(a, dtype, (hipStream_t)stream, "gs_conv_igemm", splitk_ws, splitk_ws ? splitk_ws_floats : 0);
+    if (a.vec_store && !(g->Cin == 8 && g->ntaps >= 8)) {        // <= 128 output pixels under a long K: the weight-streaming form
+        float* const bnp1[1] = {bn_partials};
+        rc = gs_skinny_try(1, &g, x, &w, y, bias, bn_partials ? bnp1 : nullptr, act, dtype, splitk_ws, splitk_ws_floats,
+                           (hipStream_t)stream);
+        if (rc != GS_EUNSUPPORTED) return rc;
+    }
+    rc = launch_igemm(a, dtype, (hipStream_t)stream, "gs_conv_igemm", splitk_ws, splitk_ws ? splitk_ws_floats : 0);
+    return rc ? rc : pad_stat_rows(g, bn_partials, (hipStream_t)stream);
 }
 
 // Split-K workspace of gs_conv_igemm (skinny GEMMs: the 1x1 .. 16x16 levels of the Pix2Pix generator at the script's
@@ -822,6 +845,20 @@ extern "C" int gs_conv_igemm_batch(int n, const GsConvGeom* const* g, const void
     GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_conv_igemm_batch: bad dtype %d", dtype);
     GS_CHECK_ARG(splitk_ws == nullptr || splitk_ws_floats >= IGEMM_BATCH_MAX * (SPLITK_CNT_SLOTS + SPLITK_TILE_FLOATS),
                  "gs_conv_igemm_batch: split-K workspace too small (gs_conv_igemm_workspace_floats())");
+    {
+        bool vec = true;
+        for (int i = 0; i < n && vec; ++i)
+            vec = g[i] && g[i]->Cout % 8 == 0 && g[i]->out_pix_stride % 8 == 0 && g[i]->out_coff % 8 == 0 && g[i]->Cin % 64 == 0;
+        if (vec) {
+            for (int i = 0; i < n; ++i) {
+                int rc = check_geom(g[i], "gs_conv_igemm_batch");
+                if (rc) return rc;
+                GS_CHECK_ARG(w[i] != nullptr, "gs_conv_igemm_batch: null weight pointer");
+            }
+            const int rc = gs_skinny_try(n, g, x, w, y, bias, bn_partials, act, dtype, splitk_ws, splitk_ws_floats, (hipStream_t)stream);
+            if (rc != GS_EUNSUPPORTED) return rc;
+        }
+    }
     IgemmBatchArgs b;
     b.n = n;
     int bn0 = 0, total = 0;
@@ -884,6 +921,10 @@ extern "C" int gs_conv_igemm_batch(int n, const GsConvGeom* const* g, const void
     if (total2 > 0) {
         run(b, total2);
         GS_CHECK_LAUNCH("gs_conv_igemm_batch");
+    }
+    for (int i = 0; i < n && bn_partials; ++i) {
+        const int rc = pad_stat_rows(g[i], bn_partials[i], s);
+        if (rc) return rc;
     }
     return GS_OK;
 }

@@ -42,12 +42,18 @@ class EndToEndTrainer:
     def __init__(self, net, netG, netD, criterionGAN, train_loader, val_loader, device, *, unet_lr=1e-5, gan_lr=2e-4,
                  beta1=0.5, arch_lr=3e-4, lambda_L1=100.0, loss_lambda=1.0, unroll_steps=1, valid_every=10,
                  mask_augment: Optional[Callable] = None, save_dir: Optional[str] = None,
-                 arch_through_generator: bool = False, train_gan: bool = True, data_parallel: bool = False):
+                 arch_through_generator: bool = False, train_gan: bool = True, data_parallel: bool = False,
+                 hip_graphs: bool = False, graph_warmup: int = 2):
         self.net, self.netG, self.netD, self.criterionGAN = net, netG, netD, criterionGAN
         self.device, self.train_loader, self.val_loader = device, train_loader, val_loader
         self.lambda_L1, self.loss_lambda, self.unroll_steps, self.valid_every = lambda_L1, loss_lambda, unroll_steps, valid_every
         self.mask_augment, self.save_dir, self.train_gan = mask_augment, save_dir, train_gan
         self.arch_through_generator = arch_through_generator
+        # the architecture tensors live on the device (the reference creates them with .cuda(); a host-resident one costs a
+        # host-to-device copy per generator forward and cannot be read inside a captured graph)
+        for a in networks.arch_parameters():
+            if a.device != torch.device(device):
+                a.data = a.data.to(device)
         # optimisers of the reference, fused
         self.optimizer_unet = gs_optim.RMSprop(net.parameters(), lr=unet_lr, weight_decay=1e-8, momentum=0.9)
         self.scheduler_unet = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer_unet, "max", patience=5)
@@ -65,6 +71,18 @@ class EndToEndTrainer:
             if eng is not None and hasattr(eng, "trust_versions"):
                 eng.trust_versions = True
         self._train_iter, self._val_iter = _cycle(train_loader), _cycle(val_loader)
+        # HIP graphs (hip_graphs=True): at the script's batch size (2) an iteration is ~1,300 kernel launches of 2-100 us and the
+        # Python / ctypes launch path (~16 us per launch) is what bounds it, not the GPU (tools/probe_graph_step.py: 105 -> 160
+        # img/s).  After `graph_warmup` eager iterations the forward + backward of each of the three lower problems is captured
+        # ONCE into a hipGraph (torch.cuda.CUDAGraph) and replayed; batches are copied into static input tensors, the mask
+        # augmentation is drawn on the host outside the graph, optimiser steps / gradient exchange / arch step / validation stay
+        # eager.  Every graph is self-contained: the engines' weight-pack caches are dropped before a capture, so each replay
+        # re-packs the current weights inside the graph, and nothing a graph reads is owned by eager code that could free it.
+        self.hip_graphs, self.graph_warmup = bool(hip_graphs), int(graph_warmup)
+        self._graphs: Dict[str, tuple] = {}
+        self._static: Dict[str, torch.Tensor] = {}
+        self._gpool, self._gkeep = None, []
+        self._gstream = torch.cuda.Stream(device) if self.hip_graphs else None
         # data parallel (one process per GPU, torch.distributed initialised by the caller, every rank feeds its own shard
         # of the loaders): replicas start from rank 0's parameters / buffers; after every backward the gradients of the
         # problem that is about to step are averaged over the ranks in flat fp32 buckets (parallel.all_reduce_gradients: the
@@ -96,35 +114,95 @@ class EndToEndTrainer:
         for p in module.parameters():
             p.requires_grad = flag
 
+    # ---- HIP-graph plumbing ------------------------------------------------------------------------
+    def _static_copy(self, name: str, t: torch.Tensor) -> torch.Tensor:
+        """the graphs read their inputs from fixed tensors: copy the batch in (allocated at first use, shapes must not change)"""
+        if not self.hip_graphs:
+            return t
+        st = self._static.get(name)
+        if st is None:
+            st = self._static[name] = t.detach().clone()
+        else:
+            if st.shape != t.shape or st.dtype != t.dtype:
+                raise RuntimeError(f"hip_graphs: the shape of '{name}' changed ({tuple(st.shape)} -> {tuple(t.shape)}); use drop_last loaders")
+            st.copy_(t, non_blocking=True)
+        return st
+
+    def _problem(self, name: str, loss_fn: Callable[[], torch.Tensor], optimizer, extra_none=()) -> torch.Tensor:
+        """zero_grad + forward + backward of one problem: eager, or (hip_graphs, after the warm-up iterations) captured once into
+        a hipGraph and replayed.  Returns the detached loss."""
+        if not self.hip_graphs or self.global_step < self.graph_warmup:
+            optimizer.zero_grad(set_to_none=True)
+            loss = loss_fn()
+            loss.backward()
+            return loss.detach()
+        ent = self._graphs.get(name)
+        if ent is None:
+            from . import ops
+            optimizer.zero_grad(set_to_none=True)              # the captured backward allocates the gradients in the graph's pool
+            for a in extra_none:
+                a.grad = None
+            for m in (self.net, self.netG, self.netD):          # self-contained graph: every pack it uses is rebuilt inside it
+                eng = getattr(m, "engine", None)
+                if eng is not None and hasattr(eng, "invalidate_packs"):
+                    eng.invalidate_packs()
+            self._gkeep.append(ops._splitk_workspace(self.device, torch.cuda.current_stream().cuda_stream))   # pinned: the LRU must not free it
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, pool=self._gpool, stream=self._gstream):
+                loss = loss_fn()
+                loss.backward()
+            if self._gpool is None:
+                self._gpool = graph.pool()
+            grads = [(p, p.grad) for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
+            ent = self._graphs[name] = (graph, loss.detach(), grads)
+        graph, loss, grads = ent
+        graph.replay()
+        for p, g in grads:                                      # (eager code in between -- the arch step -- may have dropped them)
+            p.grad = g
+        return loss.clone()
+
     def train_iteration(self) -> Dict[str, "float | torch.Tensor"]:
         """One lower-level iteration.  Losses come back as 0-dim device tensors (convert with float() when they are needed:
         a conversion per step would make the host wait for the GPU four times per iteration)."""
+        if not self.hip_graphs:
+            return self._train_iteration()
+        self._gstream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._gstream):
+            out = self._train_iteration()
+        torch.cuda.current_stream().wait_stream(self._gstream)
+        return out
+
+    def _train_iteration(self) -> Dict[str, "float | torch.Tensor"]:
         image, mask = self._batch(next(self._train_iter))
-        real_mask, real_image = mask.float(), image
+        aug = None
+        if self.hip_graphs:                                     # static inputs; the host-side augmentation stays outside the graphs
+            if self.mask_augment is not None:
+                aug = self._static_copy("aug", self.mask_augment(mask.float()))
+            image, mask = self._static_copy("image", image), self._static_copy("mask", mask)
+        real_mask, real_image = (self._static_copy("real_mask", mask.float()) if self.hip_graphs else mask.float()), image
         out: Dict[str, float] = {}
         if self.train_gan:
             # Generator problem (:141-154): D frozen, GAN + lambda*L1
             self._set_requires_grad(self.netD, False)
-            self.optimizer_G.zero_grad(set_to_none=True)
-            loss_g = steps.generator_step_loss(self.netG, self.netD, self.criterionGAN, real_mask, real_image, self.lambda_L1)
-            loss_g.backward()
+            loss_g = self._problem("G", lambda: steps.generator_step_loss(self.netG, self.netD, self.criterionGAN, real_mask,
+                                                                           real_image, self.lambda_L1),
+                                   self.optimizer_G, extra_none=networks.arch_parameters())
             self._exchange(self.netG.parameters())
             self.optimizer_G.step()
             # Discriminator problem (:157-172)
             self._set_requires_grad(self.netD, True)
-            self.optimizer_D.zero_grad(set_to_none=True)
-            loss_d = steps.discriminator_step_loss(self.netG, self.netD, self.criterionGAN, real_mask, real_image)
-            loss_d.backward()
+            loss_d = self._problem("D", lambda: steps.discriminator_step_loss(self.netG, self.netD, self.criterionGAN, real_mask,
+                                                                               real_image), self.optimizer_D)
             self._exchange(self.netD.parameters())
             self.optimizer_D.step()
-            out.update(loss_G=loss_g.detach(), loss_D=loss_d.detach())      # 0-dim device tensors: no host sync per step
+            out.update(loss_G=loss_g, loss_D=loss_d)            # 0-dim device tensors: no host sync per step
         # Unet problem (:176-226): real pair + generated pair from the (augmented) masks
-        self.optimizer_unet.zero_grad(set_to_none=True)
-        loss_u = steps.unet_step_loss(self.net, self.netG, image, mask, self.loss_lambda, self.mask_augment)
-        loss_u.backward()
+        loss_u = self._problem("U", lambda: steps.unet_step_loss(self.net, self.netG, image, mask, self.loss_lambda,
+                                                                  None if self.hip_graphs else self.mask_augment, aug),
+                               self.optimizer_unet)
         self._exchange(self.net.parameters())
         self.optimizer_unet.step()
-        out["loss_unet"] = loss_u.detach()
+        out["loss_unet"] = loss_u
         self.global_step += 1
         # Arch problem (:229-236) on validation data, every unroll_steps lower iterations
         if self.global_step % self.unroll_steps == 0:
@@ -235,6 +313,7 @@ def main(argv=None):
     ap.add_argument("--save-dir", default=None)
     ap.add_argument("--no-augment", action="store_true", help="do not augment the masks that feed the generator")
     ap.add_argument("--no-gan", action="store_true", help="freeze the Pix2Pix pair (only the Unet / Arch problems step)")
+    ap.add_argument("--hip-graphs", action="store_true", help="capture forward + backward of the three lower problems into hipGraphs")
     args = ap.parse_args(argv)
     if not args.synthetic:
         raise SystemExit("only --synthetic data ships with this repository; build the loaders of your dataset and use EndToEndTrainer")
@@ -247,7 +326,7 @@ def main(argv=None):
                                                      shuffle=True, drop_last=True)
     trainer = EndToEndTrainer(net, netG, netD, crit, mk(8 * args.batch_size, 1), mk(2 * args.batch_size, 2), dev,
                               unet_lr=args.unet_lr, save_dir=args.save_dir, train_gan=not args.no_gan,
-                              mask_augment=None if args.no_augment else MaskAugmenter(seed=0))
+                              mask_augment=None if args.no_augment else MaskAugmenter(seed=0), hip_graphs=args.hip_graphs)
     trainer.run(args.iters, log_every=5)
 
 

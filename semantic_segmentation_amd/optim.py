@@ -18,6 +18,14 @@ from . import _lib
 from .ops import _stream
 
 
+def _h2d(values, dtype, dev):
+    """small host table -> device without draining the stream: a pageable-memory `.to(device)` waits for everything queued on the
+    stream (one full pipeline drain per optimiser step); pinned + non_blocking is an ordinary stream-ordered copy.  Returns
+    (device tensor, pinned source): the caller keeps BOTH alive until the next step."""
+    host = torch.tensor(values, dtype=dtype).pin_memory()
+    return host.to(dev, non_blocking=True), host
+
+
 class _FusedMixin:
     """Builds (and caches while the pointers stay the same) the device tables of one parameter group."""
 
@@ -54,7 +62,7 @@ class _FusedMixin:
             tuple(0 if t is None else t.data_ptr() for t in s1) + tuple(0 if t is None else t.data_ptr() for t in s2)
         if cache.get("key") != key:
             T = len(params)
-            cache["ptrs"] = torch.tensor(list(key), dtype=torch.int64).to(dev)      # [4][T]: p, g, s1, s2
+            cache["ptrs"], cache["ptrs_host"] = _h2d(list(key), torch.int64, dev)   # [4][T]: p, g, s1, s2
             cache["key"] = key
             cache["T"] = T
         cache["keep"] = (params, grads, s1, s2)         # the launch is asynchronous: keep every operand alive
@@ -154,12 +162,12 @@ class Adam(_FusedMixin, torch.optim.Adam):
             if not params:
                 continue
             tb = self._tables(group, params, grads, m, v)
-            sc = torch.tensor(scal, dtype=torch.float32).to(params[0].device, non_blocking=True)
+            sc, sc_host = _h2d(scal, torch.float32, params[0].device)
             _lib.call("gs_optim_adam", tb["p"], tb["g"], tb["s1"], tb["s2"], tb["n"], tb["ct"], tb["cs"],
                       tb["nchunks"], sc.data_ptr(),
                       float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), float(self.grad_scale),
                       _stream())
-            group["_gs_keepalive"] = sc          # the launch is asynchronous: keep the scalars alive until the next step
+            group["_gs_keepalive"] = (sc, sc_host)      # the copy and the launch are asynchronous: alive until the next step
             self._mark_updated(params)
         return loss
 

@@ -105,11 +105,14 @@ def unet_step_loss_isic(net, netG, images, true_masks, loss_lambda: float = 1.0,
 
 
 def unet_step_loss(net, netG, images, true_masks, loss_lambda: float = 1.0,
-                   mask_augment: Optional[Callable[[torch.Tensor], torch.Tensor]] = None):
-    """loss(net(images), masks) + loss_lambda * loss(net(G(aug(masks))), aug(masks)); G is cut by the detach."""
+                   mask_augment: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
+                   augmented_masks: Optional[torch.Tensor] = None):
+    """loss(net(images), masks) + loss_lambda * loss(net(G(aug(masks))), aug(masks)); G is cut by the detach.
+    `augmented_masks`: aug(masks) computed by the caller (the HIP-graph form of the harness draws the augmentation on the host
+    outside the captured step); `mask_augment` is not applied then."""
     loss = seg_loss(net(images), true_masks)
-    fake_mask = true_masks.float()
-    if mask_augment is not None:
+    fake_mask = true_masks.float() if augmented_masks is None else augmented_masks.float()
+    if mask_augment is not None and augmented_masks is None:
         fake_mask = mask_augment(fake_mask)
     fake_mask = torch.where(fake_mask > 0.1, torch.ones_like(fake_mask), torch.zeros_like(fake_mask))
     with torch.no_grad():

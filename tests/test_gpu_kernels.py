@@ -865,11 +865,14 @@ def test_conv3d_3x3x3_halo_fwd_dgrad_wgrad(dtn, dt, NB, D, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("dtn,dt", DTS)
-@pytest.mark.parametrize("N,h,Cin,Cout,k,s,p", [(2, 2, 512, 512, 4, 2, 1), (2, 4, 512, 256, 4, 2, 1), (1, 8, 1024, 128, 3, 1, 1)])
+@pytest.mark.parametrize("N,h,Cin,Cout,k,s,p", [(2, 2, 512, 512, 4, 2, 1), (2, 4, 512, 256, 4, 2, 1), (1, 8, 1024, 128, 3, 1, 1),
+                                                 (2, 16, 512, 512, 4, 2, 1), (2, 12, 256, 384, 4, 2, 1), (3, 5, 192, 256, 3, 1, 1),
+                                                 (2, 16, 320, 192, 4, 2, 1)])
 def test_igemm_split_k_skinny(dtn, dt, N, h, Cin, Cout, k, s, p):
     """Skinny GEMMs (a few output pixels, K = taps x 512..1024 channels: the bottom of the Pix2Pix generator at batch 2,
-    networks.py:582-602) go through the split-K path of gs_conv_igemm: partial tiles in the fp32 workspace, the last
-    part runs bias / activation / BatchNorm partial sums; the workspace must come back zeroed (two calls agree)."""
+    networks.py:582-602) go through the weight-streaming form (<= 128 output pixels, Cin % 64 == 0, Cout % 128 == 0:
+    csrc/skinny.hip) or the split-K path of gs_conv_igemm: fp32 partial rows / tiles in the workspace, summed in part order
+    before bias / activation / BatchNorm partial sums; the workspace needs no initialisation (NaN-filled between two calls)."""
     from semantic_segmentation_amd import ops
     g = torch.Generator().manual_seed(13)
     x = rnd(g, N, Cin, h, h, dt=dt)
@@ -888,8 +891,10 @@ def test_igemm_split_k_skinny(dtn, dt, N, h, Cin, Cout, k, s, p):
         ops.conv_igemm(geom, nhwc(x, dt), wf, y, b.to(dev()), None, ACT_LEAKY02)
         torch.cuda.synchronize()
         outs.append(from_nhwc(y))
+        for ws in ops._SPLITK_WS.values():
+            ws.fill_(float("nan"))
     assert rel_err(outs[0], ref) < tol(dt)
-    assert rel_err(outs[1], ref) < tol(dt)
+    assert torch.equal(outs[0], outs[1])
     # BatchNorm partial sums come from the full (summed) accumulators
     nt = ops.conv_igemm_mtiles(geom)
     part = torch.empty(ops.bn_partials_numel(nt, Cout), dtype=torch.float32, device=dev())
@@ -899,11 +904,11 @@ def test_igemm_split_k_skinny(dtn, dt, N, h, Cin, Cout, k, s, p):
     ps = part[: nt * 2 * Cout].view(nt, 2, Cout).double().sum(0).cpu()
     r1 = ref_raw.double().sum(dim=(0, 2, 3))
     assert float((ps[0] - r1).abs().max() / (r1.abs().max() + 1e-6)) < 3e-3
+    p2 = part[nt * 2 * Cout - Cout: nt * 2 * Cout].double().cpu() if nt == 1 else None
+    if p2 is not None:
+        r2 = (ref_raw.double() ** 2).sum(dim=(0, 2, 3))
+        assert float((p2 - r2).abs().max() / (r2.abs().max() + 1e-6)) < 3e-3
     assert ops._SPLITK_WS                                            # one workspace per (device, stream), passed per call
-    for ws in ops._SPLITK_WS.values():
-        q = ws.numel() // 4                                          # one quarter per GEMM of a batched launch
-        for i in range(4):
-            assert int(ws[i * q:i * q + 1024].view(torch.int32).abs().max()) == 0    # tile ticket counters back to zero
 
 
 @pytest.mark.parametrize("C", [1, 2])
@@ -1037,10 +1042,12 @@ def test_jaccard_seg_loss_matches_golden_and_oracle(golden_dir):
     assert (xd.grad.cpu() - 3.0 * xr.grad).abs().max() < 1e-8 + 2e-6 * xr.grad.abs().max()
 
 
-@pytest.mark.parametrize("N,h,cin,cout", [(2, 4, 1024, 512), (2, 16, 512, 256), (8, 32, 256, 128)])
+@pytest.mark.parametrize("N,h,cin,cout", [(2, 4, 1024, 512), (2, 16, 512, 256), (8, 32, 256, 128), (2, 1, 512, 512),
+                                          (2, 2, 1024, 512), (2, 8, 1024, 512)])
 def test_igemm_batch_equals_per_class_launches(N, h, cin, cout):
     """gs_conv_igemm_batch (four sub-pixel classes of a merged k8/s2 transposed conv in one grid, incl. split-K through the
-    per-GEMM workspace quarters and BatchNorm partials) is bit-identical to four gs_conv_igemm launches."""
+    workspace and BatchNorm partials) against four gs_conv_igemm launches (bit-identical on the register-staged engine) and
+    against F.conv_transpose2d."""
     from semantic_segmentation_amd import ops
     g = torch.Generator().manual_seed(h)
     dt = torch.float16
@@ -1063,8 +1070,17 @@ def test_igemm_batch_equals_per_class_launches(N, h, cin, cout):
     p2 = torch.zeros(npart, device=dev())
     ops.conv_igemm_batch(geoms, x, [pf[c] for c in range(4)], y2, bias, [p2[c * mt * 2 * cout:] for c in range(4)])
     torch.cuda.synchronize()
-    assert torch.equal(y1, y2)
-    assert torch.equal(p1[:4 * mt * 2 * cout], p2[:4 * mt * 2 * cout])
+    if mt == (N * h * h + 127) // 128 and N * h * h > 16:
+        assert torch.equal(y1, y2)
+        assert torch.equal(p1[:4 * mt * 2 * cout], p2[:4 * mt * 2 * cout])
+    else:
+        # the weight-streaming form (csrc/skinny.hip) cuts K by the launch's block budget (one GEMM vs four): the same sums in
+        # a different split
+        assert float((y1.float() - y2.float()).abs().max()) <= 2e-3 * float(y1.float().abs().max())
+        assert float((p1 - p2)[:4 * mt * 2 * cout].abs().max()) <= 1e-4 * float(p1.abs().max())
+        y3 = torch.zeros_like(y1)
+        ops.conv_igemm_batch(geoms, x, [pf[c] for c in range(4)], y3, bias, [p2[c * mt * 2 * cout:] for c in range(4)])
+        assert torch.equal(y2, y3)                                   # run-to-run identical
     ref = torch.nn.functional.conv_transpose2d(x.float().permute(0, 3, 1, 2).cpu(),
                                                _unpack_merged(pf.float().cpu(), cin, cout), bias.cpu(), stride=2, padding=3)
     assert rel_err(from_nhwc(y2), ref) < tol(dt)

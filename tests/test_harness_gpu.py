@@ -38,6 +38,46 @@ def test_end_to_end_iterations(tmp_path):
     UNet(1, 1).load_state_dict(torch.load(tmp_path / "final.pkl", map_location="cpu"), strict=True)
 
 
+def test_hip_graph_iterations_match_eager():
+    """hip_graphs=True: forward + backward of the Generator / Discriminator / Unet problems captured into hipGraphs after two eager
+    iterations and replayed (static inputs, eager optimiser / arch steps in between, one validation) -- the same losses and the
+    same weights as the eager loop on the same data (no dropout in G, so the two runs draw no random numbers)."""
+    from semantic_segmentation_amd.harness import EndToEndTrainer, SyntheticLungDataset
+    from semantic_segmentation_amd.models_pix2pix import networks
+    from semantic_segmentation_amd.unet import UNet
+    dev = torch.device("cuda:0")
+    mk = lambda n, seed: torch.utils.data.DataLoader(SyntheticLungDataset(n, 256, seed), batch_size=2, shuffle=False, drop_last=True)
+
+    def run(graphs):
+        torch.manual_seed(0)
+        networks.upconv_arch.data.zero_()
+        net = UNet(1, 1).to(dev)
+        netG = networks.define_G(1, 1, 64, "unet_256", "batch", False, "normal", 0.02, [0])
+        netD = networks.define_D(2, 64, "basic", 3, "batch", "normal", 0.02, [0])
+        crit = networks.GANLoss("vanilla").to(dev)
+        tr = EndToEndTrainer(net, netG, netD, crit, mk(6, 1), mk(2, 2), dev, unet_lr=1e-4, unroll_steps=3, valid_every=5,
+                             arch_through_generator=True, hip_graphs=graphs)
+        tr.run(7, log_every=0)
+        torch.cuda.synchronize()
+        if graphs:
+            assert set(tr._graphs) == {"G", "D", "U"}
+        hist = [{k: float(v) for k, v in rec.items()} for rec in tr.history]
+        return hist, [p.detach().clone() for m in (net, netG, netD) for p in m.parameters()], \
+            [b.detach().clone() for m in (net, netG, netD) for b in m.buffers()]
+
+    h0, p0, b0 = run(False)
+    h1, p1, b1 = run(True)
+    assert len(h0) == len(h1) == 7
+    for r0, r1 in zip(h0, h1):
+        assert r0.keys() == r1.keys()
+        for k in r0:
+            assert abs(r0[k] - r1[k]) <= 1e-5 * max(1.0, abs(r0[k])), (k, r0[k], r1[k])
+    worst = max(float((a - b).abs().max() / (a.abs().max() + 1e-12)) for a, b in zip(p0, p1))
+    assert worst < 1e-4, worst
+    for a, b in zip(b0, b1):
+        assert torch.allclose(a.float(), b.float(), rtol=1e-4, atol=1e-6)
+
+
 def test_unet_only_loss_decreases():
     """over-fit 2 synthetic batches with the fused RMSprop: the segmentation loss must drop"""
     from semantic_segmentation_amd.harness import SyntheticLungDataset

@@ -49,7 +49,8 @@ def main():
     for m in (G, D, U):
         m.engine.trust_versions = trust
     print("pack reuse between training forwards:", "version-keyed (harness)" if trust else "none (safe default)")
-    for B in (2, 32):
+    only3 = os.environ.get("GSSEG_BENCH_ONLY", "") == "config3"        # GSSEG_BENCH_ONLY=config3 [GSSEG_BENCH_B=2]: just the trio
+    for B in ([int(os.environ["GSSEG_BENCH_B"])] if "GSSEG_BENCH_B" in os.environ else (2, 32)):
         x, mask = synthetic_batch(B, 256, seed=3)
         x, mask = x.to(dev), mask.to(dev)
         maskf = mask.float()
@@ -73,9 +74,28 @@ def main():
         def u_step():
             zero(U); steps.unet_step_loss(U, G, x, mask, 1.0).backward()
 
-        tg, td, tu = timeit(g_step), timeit(d_step), timeit(u_step)
+        tg, td, tu = timeit(g_step, 10, 3), timeit(d_step, 10, 3), timeit(u_step, 10, 3)
         print(f"config3 B={B:3d}: generator step {tg * 1e3:8.2f} ms | discriminator step {td * 1e3:8.2f} ms | "
               f"unet step (2 U-Net fwd+bwd + G fwd + post-proc) {tu * 1e3:8.2f} ms | trio {B / (tg + td + tu):8.1f} img/s")
+    # the whole iteration through harness.EndToEndTrainer (three problems + their fused optimiser steps; no arch step, no
+    # validation, no augmentation): the eager loop against forward + backward captured into hipGraphs
+    from semantic_segmentation_amd.harness import EndToEndTrainer, SyntheticLungDataset
+    for B in ([int(os.environ["GSSEG_BENCH_B"])] if "GSSEG_BENCH_B" in os.environ else (2,)):
+        def mk(n, seed):                                 # batches resident on the device: the input pipeline is not what is timed
+            ds = SyntheticLungDataset(n, 256, seed)
+            return [{k: torch.stack([ds[i + j][k] for j in range(B)]).to(dev) for k in ("image", "mask")} for i in range(0, n, B)]
+        for graphs in (False, True):
+            tr = EndToEndTrainer(U, G, D, crit, mk(4 * B, 1), mk(B, 2), dev, unroll_steps=10 ** 9, valid_every=0, hip_graphs=graphs)
+            tr.run(6, log_every=0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tr.run(20, log_every=0)
+            torch.cuda.synchronize()
+            t = (time.perf_counter() - t0) / 20
+            print(f"config3 B={B:3d}: EndToEndTrainer iteration ({'hipGraphs' if graphs else 'eager    '}) {t * 1e3:8.2f} ms = {B / t:8.1f} img/s", flush=True)
+            del tr
+    if only3:
+        return
     # inference: eval-mode U-Net forward, BatchNorm folded into the convs vs the two-pass form
     from semantic_segmentation_amd.unet import unet_engine
     U2 = UNet(1, 2).to(dev).eval()

@@ -119,8 +119,31 @@ def mfma(d, nsteps, out):
         json.dump(res, f, indent=1)
 
 
+def timeline(d, nsteps, out):
+    """every launch of the LAST step in stream order: start offset, duration, gap to the previous kernel, grid, kernel"""
+    with open(find(d, "*kernel_trace.csv")) as f:
+        rows = sorted(csv.DictReader(f), key=lambda r: int(r["Start_Timestamp"]))
+    per = len(rows) // nsteps
+    last = rows[len(rows) - per:]
+    # align on the first stem kernel of the step if the split is off by the probe step's extra launches
+    t0 = int(last[0]["Start_Timestamp"])
+    prev_end = t0
+    with open(out, "w") as f:
+        f.write("# launches of the last step (rocprofv3 --kernel-trace): start_us dur_us gap_us grid kernel\n")
+        for r in last:
+            s_, e_ = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            grid = r.get("Grid_Size_X", r.get("Grid_Size", "?"))
+            f.write("%9.1f %8.1f %6.1f %8s  %s\n" % ((s_ - t0) / 1e3, (e_ - s_) / 1e3, (s_ - prev_end) / 1e3, grid,
+                                                  short(r["Kernel_Name"])[:110]))
+            prev_end = e_
+        f.write("# span %.1f us, kernel time %.1f us\n" % ((prev_end - t0) / 1e3,
+                                                           sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in last) / 1e3))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "timeline":
+        timeline(sys.argv[2], int(sys.argv[3]), sys.argv[4])
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], int(sys.argv[3]), sys.argv[4])
     elif sys.argv[1] == "mfma":
         mfma(sys.argv[2], int(sys.argv[3]), sys.argv[4])

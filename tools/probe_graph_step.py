@@ -1,0 +1,69 @@
+"""Feasibility probe: the three config-3 training steps (forward + backward) captured into HIP graphs (torch.cuda.CUDAGraph) and
+replayed, against the eager loop.  Weights are not updated (timing only); gradients of eager and replay are compared."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from semantic_segmentation_amd import steps
+from semantic_segmentation_amd.harness import synthetic_batch
+from semantic_segmentation_amd.models_pix2pix import networks
+from semantic_segmentation_amd.unet import UNet
+
+dev = torch.device("cuda:0")
+B = int(os.environ.get("B", "2"))
+G = networks.define_G(1, 1, 64, "unet_256", "batch", True).to(dev).train()
+D = networks.define_D(2, 64, "basic", 3, "batch").to(dev).train()
+U = UNet(1, 1).to(dev).train()
+networks.upconv_arch = (1e-3 * torch.randn(8, 3)).to(dev).requires_grad_(True)
+crit = networks.GANLoss("vanilla").to(dev)
+for m in (G, D, U):
+    m.engine.trust_versions = True
+x, mask = synthetic_batch(B, 256, seed=3)
+x, mask = x.to(dev), mask.to(dev)
+maskf = mask.float()
+real = torch.rand(B, 1, 256, 256, device=dev)
+
+def zero(*nets):
+    for n in nets:
+        for p in n.parameters():
+            p.grad = None
+
+def g_step():
+    zero(G, D); l = steps.generator_step_loss(G, D, crit, maskf, real); l.backward(); return l
+def d_step():
+    zero(G, D); l = steps.discriminator_step_loss(G, D, crit, maskf, real); l.backward(); return l
+def u_step():
+    zero(U); l = steps.unet_step_loss(U, G, x, mask, 1.0); l.backward(); return l
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(iters): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / iters * 1e3
+
+eager = [timeit(f) for f in (g_step, d_step, u_step)]
+print("eager   g %.2f d %.2f u %.2f ms  trio %.1f img/s" % (*eager, B / sum(eager) * 1e3), flush=True)
+graphs = []
+pool = None
+for name, fn in (("d", d_step), ("u", u_step), ("g", g_step)):
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3): fn()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    try:
+        with torch.cuda.graph(gr, pool=pool):
+            loss = fn()
+    except Exception as e:
+        print("capture of", name, "failed:", repr(e)[:400], flush=True)
+        raise
+    pool = gr.pool()
+    graphs.append((name, gr, loss))
+    print("captured", name, flush=True)
+torch.cuda.synchronize()
+rep = {}
+for name, gr, loss in graphs:
+    rep[name] = timeit(gr.replay)
+    print("replay %s %.2f ms  loss %.5f" % (name, rep[name], float(loss)), flush=True)
+print("graphs  g %.2f d %.2f u %.2f ms  trio %.1f img/s" % (rep["g"], rep["d"], rep["u"], B / sum(rep.values()) * 1e3))

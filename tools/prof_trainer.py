@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""harness.EndToEndTrainer iterations (config 3, batches resident on the device, no arch step / validation / augmentation) for
+rocprofv3:  python tools/prof_trainer.py <batch> <iters> <graphs 0|1>"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from semantic_segmentation_amd.harness import EndToEndTrainer, SyntheticLungDataset
+from semantic_segmentation_amd.models_pix2pix import networks
+from semantic_segmentation_amd.unet import UNet
+
+B, iters, graphs = int(sys.argv[1]), int(sys.argv[2]), bool(int(sys.argv[3]))
+dev = torch.device("cuda:0")
+G = networks.define_G(1, 1, 64, "unet_256", "batch", True).to(dev).train()
+D = networks.define_D(2, 64, "basic", 3, "batch").to(dev).train()
+U = UNet(1, 1).to(dev).train()
+crit = networks.GANLoss("vanilla").to(dev)
+
+def mk(n, seed):
+    ds = SyntheticLungDataset(n, 256, seed)
+    return [{k: torch.stack([ds[i + j][k] for j in range(B)]).to(dev) for k in ("image", "mask")} for i in range(0, n, B)]
+
+tr = EndToEndTrainer(U, G, D, crit, mk(4 * B, 1), mk(B, 2), dev, unroll_steps=10 ** 9, valid_every=0, hip_graphs=graphs)
+tr.run(5, log_every=0)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+tr.run(iters, log_every=0)
+torch.cuda.synchronize()
+t = (time.perf_counter() - t0) / iters
+print(f"B={B} graphs={graphs}: {t * 1e3:.2f} ms / iteration = {B / t:.1f} img/s, launches in the steady state follow", flush=True)

@@ -10,5 +10,6 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --parity-leg none "$@" > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
 python3 tools/pmc_summary.py stats "$OUT/trace" $N "$OUT/kernel_stats.csv"
+python3 tools/pmc_summary.py timeline "$OUT/trace" $N "$OUT/step_timeline.txt"
 rm -rf "$OUT/trace"
 head -40 "$OUT/kernel_stats.csv"

@@ -14,6 +14,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d "$OUT/mfma" -o m -- python3 bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --parity-leg none > /dev/null 2> "$OUT/mfma.log"
 python3 tools/pmc_summary.py mfma "$OUT/mfma" $N "$OUT/pmc_mfma.json"
 python3 tools/pmc_summary.py stats "$OUT/trace" $N "$OUT/kernel_stats.csv"
+python3 tools/pmc_summary.py timeline "$OUT/trace" $N "$OUT/step_timeline.txt"
 python3 tools/pmc_summary.py pmc "$OUT/fetch" "$OUT/write" $N "$OUT/pmc_traffic.json"
 rm -rf "$OUT/trace" "$OUT/fetch" "$OUT/write" "$OUT/mfma"
 head -12 "$OUT/kernel_stats.csv"
