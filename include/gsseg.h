@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 42
+#define GS_ABI_VERSION 43
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -393,6 +393,14 @@ int64_t gs_upconv_split_wgrad_ws_floats(int Cin, int Cout);
 int gs_upconv_split_wgrad_det(const float* dwm, const float* w4, const float* w6, const float* w8, const float* softmax3,
                               float gscale, float* dw4, float* dw6, float* dw8, float* dots3, float* ws, int Cin, int Cout,
                               void* stream);
+/* The same split reading `nparts` split-K slabs of the merged weight gradient ([64 slots][Cout][Cin] each, `part_stride` floats
+ * apart: what gs_conv_wgrad_slabs_batch leaves for the four sub-pixel classes) and summing them in part order on the way --
+ * instead of gs_wgrad_reduce_unpack writing the summed 134 MB (1024 -> 512) and this pass reading them back.
+ * gs_upconv_split_wgrad_parts_ok: 1 when the shape is covered (Cin % 32 == 0, Cout % 8 == 0). */
+int gs_upconv_split_wgrad_parts_ok(int Cin, int Cout);
+int gs_upconv_split_wgrad_parts(const float* slabs, int nparts, int64_t part_stride, const float* w4, const float* w6,
+                                const float* w8, const float* softmax3, float gscale, float* dw4, float* dw6, float* dw8,
+                                float* dots3, float* ws, int Cin, int Cout, void* stream);
 
 /* layout helpers: fp32 NCHW <-> 16-bit NHWC */
 int gs_nchw_to_nhwc(const float* src, void* dst, int N, int C, int H, int W, int dst_pix_stride, int dst_coff,

@@ -1267,10 +1267,12 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 // slab, a second kernel sums the slabs in order.  GSSEG_DIRECT_WGRAD_BLOCKS overrides the block count.
 // (measured at batch 32, 256^2: stem weight gradient 136 / 124 / 145 us and head weight gradient 73 / 64 / 69 us with
 // 2048 / 1024 / 512 blocks; the fused stem backward 136 / 127 / 118 us -- GSSEG_STEM_BWD_BLOCKS, default 512.)
-static int64_t direct_wgrad_ppb(int64_t M) {
+static int64_t direct_wgrad_ppb(int64_t M, int64_t min_ppb = 64) {
     static const int blocks = getenv("GSSEG_DIRECT_WGRAD_BLOCKS") ? atoi(getenv("GSSEG_DIRECT_WGRAD_BLOCKS")) : 1024;
     int64_t ppb = cdiv64(M, blocks > 0 ? blocks : 1024);
-    if (ppb < 64) ppb = 64;
+    // (min_ppb = 8 for the few-output-channel weight gradient: few pixels -- the PatchGAN's last layer at batch 2: 1,800 --
+    // still spread over ~250 blocks; with 64 pixels per block 29 blocks walked 16 taps x 16 dependent loads each, 124 us)
+    if (ppb < min_ppb) ppb = min_ppb;
     return ppb;
 }
 static int64_t stem_bwd_ppb(int64_t M) {
@@ -1282,7 +1284,7 @@ static int64_t stem_bwd_ppb(int64_t M) {
 
 extern "C" int64_t gs_conv_direct_wgrad_ws_floats(int N, int OH, int OW, int Cin, int Cout, int k) {
     const int64_t M = (int64_t)N * OH * OW;
-    const int64_t nb1 = cdiv64(M, direct_wgrad_ppb(M)), nb2 = cdiv64(M, stem_bwd_ppb(M));
+    const int64_t nb1 = cdiv64(M, direct_wgrad_ppb(M, 8)), nb2 = cdiv64(M, stem_bwd_ppb(M));
     return (nb1 > nb2 ? nb1 : nb2) * ((int64_t)Cout * Cin * k * k + 4);
 }
 
@@ -1592,7 +1594,7 @@ static int smallcout_bwd_impl(const void* x, const float* w, const float* dy, vo
     if (dw) {
         GS_CHECK_ARG(x != nullptr && ws != nullptr, "gs_conv_smallcout_bwd: dw needs x and a workspace");
         const int64_t M = (int64_t)N * OH * OW;
-        const int64_t ppb = direct_wgrad_ppb(M);
+        const int64_t ppb = direct_wgrad_ppb(M, (k == 1 && Cin == 64) ? 64 : 8);
         a.pix_per_block = ppb;
         const int nb = (int)cdiv64(M, ppb);
         const int n = Cout * Cin * k * k;

@@ -98,7 +98,21 @@ __global__ __launch_bounds__(256) void adam_kernel(const OptTable tb, const floa
     };
     if (vec) {
         const int64_t end4 = start + ((end - start) & ~(int64_t)3);
-        for (int64_t i = start + (int64_t)threadIdx.x * 4; i < end4; i += 256 * 4) {
+        int64_t i = start + (int64_t)threadIdx.x * 4;
+        // two float4 groups per lane per trip: eight 16-byte loads in flight (the 1.09 GB generator: 3.8 -> TB/s of 28 B / parameter)
+        for (; i + 256 * 4 < end4; i += 2 * 256 * 4) {
+            const int64_t j = i + 256 * 4;
+            float4 pa = *reinterpret_cast<float4*>(p + i), pb = *reinterpret_cast<float4*>(p + j);
+            const float4 ga = *reinterpret_cast<const float4*>(g + i), gb = *reinterpret_cast<const float4*>(g + j);
+            float4 ma = *reinterpret_cast<float4*>(m + i), mb = *reinterpret_cast<float4*>(m + j);
+            float4 va = *reinterpret_cast<float4*>(v + i), vb = *reinterpret_cast<float4*>(v + j);
+            upd(pa.x, ga.x, ma.x, va.x); upd(pa.y, ga.y, ma.y, va.y); upd(pa.z, ga.z, ma.z, va.z); upd(pa.w, ga.w, ma.w, va.w);
+            upd(pb.x, gb.x, mb.x, vb.x); upd(pb.y, gb.y, mb.y, vb.y); upd(pb.z, gb.z, mb.z, vb.z); upd(pb.w, gb.w, mb.w, vb.w);
+            *reinterpret_cast<float4*>(p + i) = pa; *reinterpret_cast<float4*>(p + j) = pb;
+            *reinterpret_cast<float4*>(m + i) = ma; *reinterpret_cast<float4*>(m + j) = mb;
+            *reinterpret_cast<float4*>(v + i) = va; *reinterpret_cast<float4*>(v + j) = vb;
+        }
+        for (; i < end4; i += 256 * 4) {
             float4 pv = *reinterpret_cast<float4*>(p + i);
             const float4 gv = *reinterpret_cast<const float4*>(g + i);
             float4 mv = *reinterpret_cast<float4*>(m + i);

@@ -197,18 +197,49 @@ __global__ __launch_bounds__(256) void upconv_merge_pack_dgrad_tiled(const float
 }
 
 // gradient split: tile 8 co x 32 ci, LDS fp32 [64 slots][8 co][32 ci]
+// (nparts > 1: dWm is a stack of split-K slabs [nparts][64 slots][Cout][Cin] of the weight-gradient GEMMs, summed here in part
+// order -- the separate ordered-sum pass wrote and re-read the 134 MB of a 1024 -> 512 layer's merged gradient)
 __global__ __launch_bounds__(256) void upconv_split_wgrad_tiled(const float* __restrict__ dWm, const float* __restrict__ W4,
                                                                 const float* __restrict__ W6, const float* __restrict__ W8,
                                                                 const float* __restrict__ sm, float gscale, float* dW4,
-                                                                float* dW6, float* dW8, float* dots, int Cin, int Cout, float* dots_ws) {
+                                                                float* dW6, float* dW8, float* dots, int Cin, int Cout, float* dots_ws,
+                                                                int nparts, int64_t pstride) {
     __shared__ float lds[64 * 8 * 32];
     __shared__ float red[3][4];
     const int co0 = blockIdx.x * 8, ci0 = blockIdx.y * 32;
     const int64_t plane = (int64_t)Cout * Cin;
+    if (nparts <= 1) {
 #pragma unroll 8
-    for (int idx = threadIdx.x; idx < 64 * 8 * 32; idx += 256) {
-        const int ci_l = idx & 31, co_l = (idx >> 5) & 7, slot = idx >> 8;
-        lds[(slot * 8 + co_l) * 32 + (ci_l ^ (slot & 31))] = dWm[slot * plane + (int64_t)(co0 + co_l) * Cin + ci0 + ci_l];
+        for (int idx = threadIdx.x; idx < 64 * 8 * 32; idx += 256) {
+            const int ci_l = idx & 31, co_l = (idx >> 5) & 7, slot = idx >> 8;
+            lds[(slot * 8 + co_l) * 32 + (ci_l ^ (slot & 31))] = dWm[slot * plane + (int64_t)(co0 + co_l) * Cin + ci0 + ci_l];
+        }
+    } else {
+        constexpr int U = 8;
+        for (int base = threadIdx.x; base < 64 * 8 * 32; base += 256 * U) {
+            float v[U];
+            const float* src[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * 256;
+                const int ci_l = idx & 31, co_l = (idx >> 5) & 7, slot = idx >> 8;
+                src[u] = dWm + slot * plane + (int64_t)(co0 + co_l) * Cin + ci0 + ci_l;
+                v[u] = *src[u];
+            }
+            for (int p = 1; p < nparts; ++p) {
+                float t[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) t[u] = src[u][(int64_t)p * pstride];
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[u] += t[u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * 256;
+                const int ci_l = idx & 31, co_l = (idx >> 5) & 7, slot = idx >> 8;
+                lds[(slot * 8 + co_l) * 32 + (ci_l ^ (slot & 31))] = v[u];
+            }
+        }
     }
     __syncthreads();
     const float s0 = sm[0] * gscale, s1 = sm[1] * gscale, s2 = sm[2] * gscale;
@@ -436,15 +467,17 @@ static int split_wgrad_blocks(int Cin, int Cout) {
 
 static int upconv_split_wgrad_launch(const float* dwm, const float* w4, const float* w6, const float* w8,
                                      const float* softmax3, float gscale, float* dw4, float* dw6, float* dw8,
-                                     float* dots3, int Cin, int Cout, float* dots_ws, void* stream) {
+                                     float* dots3, int Cin, int Cout, float* dots_ws, void* stream, int nparts = 1,
+                                     int64_t pstride = 0) {
     GS_CHECK_ARG(dwm && w4 && w6 && w8 && softmax3 && dw4 && dw6 && dw8 && dots3 && Cin > 0 && Cout > 0,
                  "gs_upconv_split_wgrad: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     if (Cin % 32 == 0 && Cout % 8 == 0) {
         dim3 grid(Cout / 8, Cin / 32);
         upconv_split_wgrad_tiled<<<grid, 256, 0, st>>>(dwm, w4, w6, w8, softmax3, gscale, dw4, dw6, dw8, dots3, Cin, Cout,
-                                                       dots_ws);
+                                                       dots_ws, nparts, pstride);
     } else {
+        GS_CHECK_ARG(nparts <= 1, "gs_upconv_split_wgrad_parts: needs Cin %% 32 == 0 and Cout %% 8 == 0");
         upconv_split_wgrad_kernel<<<split_wgrad_blocks(Cin, Cout), 256, 0, st>>>(dwm, w4, w6, w8, softmax3, gscale, dw4, dw6,
                                                                                  dw8, dots3, Cin, Cout, dots_ws);
     }
@@ -464,6 +497,17 @@ extern "C" int gs_upconv_split_wgrad(const float* dwm, const float* w4, const fl
 
 extern "C" int64_t gs_upconv_split_wgrad_ws_floats(int Cin, int Cout) {
     return (Cin > 0 && Cout > 0) ? (int64_t)3 * split_wgrad_blocks(Cin, Cout) : 0;
+}
+
+// dwm = `nparts` split-K slabs [64 slots][Cout][Cin] at a distance of `part_stride` floats (the output of
+// gs_conv_wgrad_slabs_batch for the four classes): summed in part order while splitting.  0: not covered (sum first).
+extern "C" int gs_upconv_split_wgrad_parts_ok(int Cin, int Cout) { return (Cin % 32 == 0 && Cout % 8 == 0) ? 1 : 0; }
+extern "C" int gs_upconv_split_wgrad_parts(const float* slabs, int nparts, int64_t part_stride, const float* w4, const float* w6,
+                                           const float* w8, const float* softmax3, float gscale, float* dw4, float* dw6,
+                                           float* dw8, float* dots3, float* ws, int Cin, int Cout, void* stream) {
+    GS_CHECK_ARG(ws != nullptr && nparts >= 1 && part_stride >= (int64_t)64 * Cin * Cout, "gs_upconv_split_wgrad_parts: bad arguments");
+    return upconv_split_wgrad_launch(slabs, w4, w6, w8, softmax3, gscale, dw4, dw6, dw8, dots3, Cin, Cout, ws, stream, nparts,
+                                     part_stride);
 }
 
 extern "C" int gs_upconv_split_wgrad_det(const float* dwm, const float* w4, const float* w6, const float* w8,

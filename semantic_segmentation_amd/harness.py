@@ -70,14 +70,17 @@ class EndToEndTrainer:
                 eng = getattr(m.module, "engine", None)
             if eng is not None and hasattr(eng, "trust_versions"):
                 eng.trust_versions = True
+            if eng is not None and hasattr(eng, "accumulate_grads") and not data_parallel:
+                eng.accumulate_grads = True          # the Unet problem sums two backward passes of the net
         self._train_iter, self._val_iter = _cycle(train_loader), _cycle(val_loader)
         # HIP graphs (hip_graphs=True): at the script's batch size (2) an iteration is ~1,300 kernel launches of 2-100 us and the
         # Python / ctypes launch path (~16 us per launch) is what bounds it, not the GPU (tools/probe_graph_step.py: 105 -> 160
         # img/s).  After `graph_warmup` eager iterations the forward + backward of each of the three lower problems is captured
         # ONCE into a hipGraph (torch.cuda.CUDAGraph) and replayed; batches are copied into static input tensors, the mask
         # augmentation is drawn on the host outside the graph, optimiser steps / gradient exchange / arch step / validation stay
-        # eager.  Every graph is self-contained: the engines' weight-pack caches are dropped before a capture, so each replay
-        # re-packs the current weights inside the graph, and nothing a graph reads is owned by eager code that could free it.
+        # eager.  A graph reads nothing that eager code owns (and could free): inputs are the trainer's static tensors, weight packs
+        # are rebuilt inside a graph after every update of their weights (the engines' pack caches hand a capture only entries
+        # that were themselves built during a capture).
         self.hip_graphs, self.graph_warmup = bool(hip_graphs), int(graph_warmup)
         self._graphs: Dict[str, tuple] = {}
         self._static: Dict[str, torch.Tensor] = {}
@@ -137,15 +140,24 @@ class EndToEndTrainer:
             loss.backward()
             return loss.detach()
         ent = self._graphs.get(name)
+        if ent is None and name == "G" and self.train_gan and "D" not in self._graphs:
+            # the Generator problem is captured one iteration after the other two: its graph then REUSES the generator's forward
+            # packs that the Discriminator graph rebuilds after every update of G (captured entries of the engines' pack caches,
+            # see _PackCache) instead of merging the 1.09 GB of fp32 kernels a second time per iteration
+            optimizer.zero_grad(set_to_none=True)
+            loss = loss_fn()
+            loss.backward()
+            return loss.detach()
         if ent is None:
             from . import ops
             optimizer.zero_grad(set_to_none=True)              # the captured backward allocates the gradients in the graph's pool
             for a in extra_none:
                 a.grad = None
-            for m in (self.net, self.netG, self.netD):          # self-contained graph: every pack it uses is rebuilt inside it
-                eng = getattr(m, "engine", None)
-                if eng is not None and hasattr(eng, "invalidate_packs"):
-                    eng.invalidate_packs()
+            # nothing a graph reads may be owned by eager code (which could free it): the pack caches of the Pix2Pix engines hand
+            # a capture only entries that were built during a capture; the U-Net's packs are rebuilt inside its graph
+            eng = getattr(self.net, "engine", None)
+            if eng is not None and hasattr(eng, "invalidate_packs"):
+                eng.invalidate_packs()
             self._gkeep.append(ops._splitk_workspace(self.device, torch.cuda.current_stream().cuda_stream))   # pinned: the LRU must not free it
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, pool=self._gpool, stream=self._gstream):

@@ -79,18 +79,21 @@ def generator_backward(engine, ctx, arch, dout, need_dx):
             geoms.append(g)
         # the four classes in ONE launch.  Few-pixel layers do not split K: every element is written exactly once, straight
         # into dwm; otherwise the K parts go to slabs and one ordered sum over all classes follows (deterministic, no atomics)
-        dwm = torch.empty((4, 16, cpad, cin_t), dtype=torch.float32, device=dev)
         nparts = ops.conv_wgrad_parts(geoms[0])
-        wsl = empty(nparts * dwm.numel(), dtype=torch.float32) if nparts > 1 else None
-        ops.conv_wgrad_det_batch(geoms, R[d + 1], du, wsl, dwm)
-        if cpad != cout_t:
+        per = 4 * 16 * cpad * cin_t
+        wsl = empty(nparts * per, dtype=torch.float32) if nparts > 1 else None
+        # K-split layers: the split pass below sums the slabs itself (no separate ordered-sum pass over the merged gradient)
+        direct = nparts > 1 and cpad == cout_t and ops.upconv_split_wgrad_parts_ok(cin_t, cout_t)
+        dwm = None if direct else torch.empty((4, 16, cpad, cin_t), dtype=torch.float32, device=dev)
+        ops.conv_wgrad_det_batch(geoms, R[d + 1], du, wsl, dwm, reduce=not direct)
+        if not direct and cpad != cout_t:
             dwm = dwm[:, :, :cout_t, :].contiguous()
         dw4 = torch.empty_like(w4, memory_format=torch.contiguous_format)
         dw6 = torch.empty_like(w6, memory_format=torch.contiguous_format)
         dw8 = torch.empty_like(w8, memory_format=torch.contiguous_format)
         dots = torch.zeros(3, dtype=torch.float32, device=dev)
-        ops.upconv_split_wgrad(dwm, w4.detach().contiguous(), w6.detach().contiguous(), w8.detach().contiguous(), sm,
-                               inv_s, dw4, dw6, dw8, dots)
+        ops.upconv_split_wgrad(wsl if direct else dwm, w4.detach().contiguous(), w6.detach().contiguous(),
+                               w8.detach().contiguous(), sm, inv_s, dw4, dw6, dw8, dots, nparts=nparts if direct else 1)
         emit(w4, dw4); emit(w6, dw6); emit(w8, dw8)
         b0 = cell._ops._ops[0].op.bias
         if b0 is not None:                                     # merged bias = sum_j sm_j b_j

@@ -39,14 +39,19 @@ def _need_cuda(x):
         raise RuntimeError("semantic_segmentation_amd Pix2Pix networks run on the MI355X only (no CPU / ATen fallback)")
 
 
-def _bn_coeffs(bn, partials, ntiles, C, count, training, dev):
-    """scale/shift/mean/invstd [4,C] from conv-epilogue partial sums (train) or running statistics (eval)."""
+def _bn_coeffs(bn, partials, ntiles, C, count, training, dev, nbt_pending=None):
+    """scale/shift/mean/invstd [4,C] from conv-epilogue partial sums (train) or running statistics (eval).
+    nbt_pending: list collecting the `num_batches_tracked` counters of this pass -- the caller increments them with ONE
+    foreach launch (_flush_nbt) instead of a 5-us kernel per BatchNorm layer."""
     coef = torch.empty((4, C), dtype=torch.float32, device=dev)
     batch_stats = training or bn.running_mean is None
     if batch_stats:
         mom = bn.momentum
         if training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+            if nbt_pending is not None and mom is not None:
+                nbt_pending.append(bn.num_batches_tracked)
+            else:
+                bn.num_batches_tracked.add_(1)
         if mom is None:
             mom = 1.0 / float(bn.num_batches_tracked.item())
         upd = training and bn.running_mean is not None
@@ -63,16 +68,28 @@ def _bn_coeffs(bn, partials, ntiles, C, count, training, dev):
 DIRECT_IMAGE_LAYER = os.environ.get("GSSEG_PIX2PIX_DIRECT_IMAGE", "1") != "0"
 
 
+def _flush_nbt(pending):
+    if pending:
+        torch._foreach_add_(pending, 1)
+        pending.clear()
+
+
 class _PackCache:
+    """version-keyed 16-bit weight packs.  Entries built while a stream capture is running (harness hip_graphs) live in the
+    graph's memory pool and are rebuilt by every replay of that graph; a capture reuses ONLY such entries (a pack built by eager
+    code belongs to eager code, which may free it: a graph must not read it), eager code reuses any entry whose version matches
+    (eager updates bump the versions, so it never sees a captured entry of older weights)."""
+
     def __init__(self):
         self._d = {}
 
     def get(self, key, versions, build):
+        capturing = torch.cuda.is_current_stream_capturing()
         ent = self._d.get(key)
-        if ent is not None and ent[0] == versions:
+        if ent is not None and ent[0] == versions and (ent[2] or not capturing):
             return ent[1]
         val = build()
-        self._d[key] = (versions, val)
+        self._d[key] = (versions, val, capturing)
         return val
 
     def clear(self):
@@ -183,6 +200,7 @@ class GeneratorEngine:
         L: List[Optional[torch.Tensor]] = [None] * (D + 1)          # leaky(bn(y_k)), dense: next down-conv input
         R: List[Optional[torch.Tensor]] = [None] * (D + 1)          # [N,h_k,w_k,2c_k]: relu(skip) | relu(up)
 
+        nbt_pending = []                 # num_batches_tracked counters of this pass: ONE foreach increment at the end
         # ---- down path -------------------------------------------------------------------------------
         conv0 = parts[0][0]
         y1 = empty(N, hs[1], ws[1], c[1])
@@ -205,7 +223,7 @@ class GeneratorEngine:
             ops.conv_igemm(g, L[k - 1], wf, y, None, part)
             coef, stats = (None, False)
             if has_bn:
-                coef, stats = _bn_coeffs(downnorm, part, mt, c[k], N * hs[k] * ws[k], training, dev)
+                coef, stats = _bn_coeffs(downnorm, part, mt, c[k], N * hs[k] * ws[k], training, dev, nbt_pending)
             sc, sh = (coef[0], coef[1]) if has_bn else (None, None)
             ctx["levels"][k] = dict(y=y, coef=coef, stats=stats, geom=g, wd=wd, inp=L[k - 1])
             if k < D:
@@ -218,6 +236,7 @@ class GeneratorEngine:
                 ops.bn_act_apply(y, sc, sh, ACT_RELU, R[k], c[k], 0)
 
         # ---- up path -----------------------------------------------------------------------------------
+        sm_all = torch.softmax(arch.detach().float(), dim=-1).contiguous()      # every layer's mixing weights in one launch
         out = None
         mask_i = 0
         for d in range(D - 1, -1, -1):                               # block depth d consumes R[d+1]
@@ -226,7 +245,7 @@ class GeneratorEngine:
             cout_t = cell._ops._ops[0].op.weight.shape[1]
             li = cell._layer_index
             w4, w6, w8 = (cell._ops._ops[j].op.weight for j in range(3))
-            sm = torch.softmax(arch[li].detach().float(), dim=-1).contiguous()
+            sm = sm_all[li]
             cpad = cout_t if cout_t % 8 == 0 else ((cout_t + 7) // 8) * 8
             pf = self._merge_pack(d, w4, w6, w8, sm, cin_t, cout_t, cpad, dgrad=False, arch=arch)
             h, w = hs[d + 1], ws[d + 1]
@@ -247,7 +266,7 @@ class GeneratorEngine:
                 pslices = [part[cls * mt * 2 * cout_t:] for cls in range(4)] if part is not None else None
                 # the four sub-pixel classes in ONE launch (each is latency bound on its own at the script's batch size)
                 ops.conv_igemm_batch(geoms, R[d + 1], [pf[cls] for cls in range(4)], u, bias, pslices)
-                coef, stats = _bn_coeffs(upnorm, part, 4 * mt, cout_t, N * H2 * W2, training, dev)
+                coef, stats = _bn_coeffs(upnorm, part, 4 * mt, cout_t, N * H2 * W2, training, dev, nbt_pending)
                 keep, kscale = None, 1.0
                 if drop is not None and training and drop.p > 0:
                     if dropout_masks is not None:
@@ -282,6 +301,7 @@ class GeneratorEngine:
                     ops.nhwc_to_nchw(t, out, cpad, 0)
                 ctx["ups"][0] = dict(u=u, sm=sm, cin=cin_t, cout=cout_t, cpad=cpad, li=li)
         ctx["R"], ctx["L"] = R, L
+        _flush_nbt(nbt_pending)
         return out, (ctx if need_grad else None)
 
     def _pack_conv(self, w):
@@ -389,6 +409,7 @@ class DiscriminatorEngine:
             return torch.empty(shape, dtype=dtype, device=dev)
 
         recs = []
+        nbt_pending = []
         # stage 0: direct conv + bias + LeakyReLU (no norm)
         i0, conv0, _ = stages[0]
         k, s, p = conv0.kernel_size[0], conv0.stride[0], conv0.padding[0]
@@ -410,7 +431,7 @@ class DiscriminatorEngine:
             use_stats = training or bn.running_mean is None
             part = empty(ops.bn_partials_numel(mt, conv.out_channels), dtype=torch.float32) if use_stats else None
             ops.conv_igemm(g, cur, wf, y, None, part)
-            coef, stats = _bn_coeffs(bn, part, mt, conv.out_channels, N * oh * ow, training, dev)
+            coef, stats = _bn_coeffs(bn, part, mt, conv.out_channels, N * oh * ow, training, dev, nbt_pending)
             z = empty(N, oh, ow, conv.out_channels)
             ops.bn_act_apply(y, coef[0], coef[1], ACT_LEAKY02, z, conv.out_channels, 0)
             recs.append(dict(kind="mid", conv=conv, bn=bn, inp=cur, y=y, coef=coef, stats=stats, geom=g, wd=wd,
@@ -423,6 +444,7 @@ class DiscriminatorEngine:
         ops.conv_smallcout_fwd(cur, convl.weight.detach().contiguous(),
                                convl.bias.detach() if convl.bias is not None else None, logits, k, s, p)
         recs.append(dict(kind="last", conv=convl, inp=cur, k=k, s=s, p=p, ih=ch, iw=cw, cin=cc, name=f"model.{il}"))
+        _flush_nbt(nbt_pending)
         return logits, (dict(recs=recs, N=N, H=H, W=W) if need_grad else None)
 
     def _pack(self, w):

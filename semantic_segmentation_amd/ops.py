@@ -554,10 +554,12 @@ def upconv2x2_wgrad_det(geom, x, dy, ws, grad, N, IH, IW, Cin, Cout, OH, OW, x_s
     conv_wgrad_det(geom, dy, x, ws, grad, Cin, Cout, 4, gscale)
 
 
-def conv_wgrad_det_batch(geoms, x, dy, ws, grad, gscale=1.0):
+def conv_wgrad_det_batch(geoms, x, dy, ws, grad, gscale=1.0, reduce=True):
     """Deterministic weight gradients of up to four GEMMs (the sub-pixel classes of one merged transposed conv) in ONE
     launch, in the kernel layout grad[n][taps][Cout][Cin]: K parts in fp32 slabs (ws) + one ordered reduction over all
-    classes; a layer that does not split K writes grad directly (ws unused)."""
+    classes; a layer that does not split K writes grad directly (ws unused).  reduce=False (K split only): the slabs
+    [parts][n][taps][Cout][Cin] stay in ws for a consumer that sums them itself (upconv_split_wgrad(nparts=...)); grad may be
+    None then."""
     _dev(x)
     _f32(grad, "grad")
     if x.dtype != dy.dtype:
@@ -565,7 +567,9 @@ def conv_wgrad_det_batch(geoms, x, dy, ws, grad, gscale=1.0):
     n, g0 = len(geoms), geoms[0]
     per = g0.ntaps * g0.Cout * g0.Cin
     parts = int(_lib.load().gs_conv_wgrad_parts(g0))
-    if grad.numel() != n * per or not grad.is_contiguous():
+    if not reduce and parts <= 1:
+        raise ValueError("conv_wgrad_det_batch: reduce=False needs a K split (conv_wgrad_parts > 1)")
+    if reduce and (grad.numel() != n * per or not grad.is_contiguous()):
         raise ValueError("conv_wgrad_det_batch: grad must be contiguous [n][taps][Cout][Cin]")
     garr = (ctypes.POINTER(GsConvGeom) * n)(*[ctypes.pointer(g) for g in geoms])
     if parts > 1:
@@ -577,9 +581,9 @@ def conv_wgrad_det_batch(geoms, x, dy, ws, grad, gscale=1.0):
     _lib.call("gs_conv_wgrad_slabs_batch", n, garr, _p(x), _p(dy), _p(target), dt_code(x), _stream())
     if ev is not None:
         TIMER.stop("igemm_wgrad", ev, sum(_geom_flops(g) for g in geoms))
-    if parts > 1:
+    if parts > 1 and reduce:
         _lib.call("gs_wgrad_reduce_unpack", _p(ws), parts, _p(grad), n * g0.ntaps * g0.Cout, g0.Cin, 1, 0, float(gscale), _stream())
-    elif gscale != 1.0:
+    elif parts == 1 and gscale != 1.0:
         grad.mul_(gscale)
     return parts
 
@@ -963,12 +967,24 @@ def upconv8_image_fwd(x, pack_fwd, bias, out, u, N, h, w, Cin, Cout, act, in_str
               _p(out), _p(u), N, h, w, Cin, Cout, act, dt_code(x), _stream())
 
 
-def upconv_split_wgrad(dwm, w4, w6, w8, softmax3, gscale, dw4, dw6, dw8, dots3):
+def upconv_split_wgrad_parts_ok(Cin, Cout) -> bool:
+    return bool(_lib.load().gs_upconv_split_wgrad_parts_ok(int(Cin), int(Cout)))
+
+
+def upconv_split_wgrad(dwm, w4, w6, w8, softmax3, gscale, dw4, dw6, dw8, dots3, nparts=1):
+    """merged weight gradient [4][16][Cout][Cin] -> dW4 / dW6 / dW8 (+ the three architecture dot products).  nparts > 1: dwm is
+    the stack of split-K slabs of conv_wgrad_det_batch(reduce=False), summed in part order on the way."""
     for n, t in (("dwm", dwm), ("dw4", dw4), ("dw6", dw6), ("dw8", dw8), ("dots3", dots3)):
         _f32(t, n)
     Cin, Cout = w8.shape[0], w8.shape[1]
     # deterministic form: per-block partial dot products in a scratch tensor, summed in block order
     ws = torch.empty(int(_lib.load().gs_upconv_split_wgrad_ws_floats(Cin, Cout)), dtype=torch.float32, device=dwm.device)
+    if nparts > 1:
+        if dwm.numel() < nparts * 64 * Cin * Cout:
+            raise ValueError("upconv_split_wgrad: the slab stack is too small")
+        _lib.call("gs_upconv_split_wgrad_parts", _p(dwm), int(nparts), 64 * Cin * Cout, _p(w4), _p(w6), _p(w8), _p(softmax3),
+                  float(gscale), _p(dw4), _p(dw6), _p(dw8), _p(dots3), _p(ws), Cin, Cout, _stream())
+        return
     _lib.call("gs_upconv_split_wgrad_det", _p(dwm), _p(w4), _p(w6), _p(w8), _p(softmax3), float(gscale), _p(dw4), _p(dw6),
               _p(dw8), _p(dots3), _p(ws), Cin, Cout, _stream())
 
