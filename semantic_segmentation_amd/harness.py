@@ -134,20 +134,27 @@ class EndToEndTrainer:
     def _problem(self, name: str, loss_fn: Callable[[], torch.Tensor], optimizer, extra_none=()) -> torch.Tensor:
         """zero_grad + forward + backward of one problem: eager, or (hip_graphs, after the warm-up iterations) captured once into
         a hipGraph and replayed.  Returns the detached loss."""
+        def run():
+            """forward + backward; a tuple of losses is back-propagated term by term (see steps.unet_step_losses)"""
+            loss = loss_fn()
+            if isinstance(loss, tuple):
+                for term in loss:
+                    term.backward()
+                loss = sum(t.detach() for t in loss)
+            else:
+                loss.backward()
+            return loss.detach()
+
         if not self.hip_graphs or self.global_step < self.graph_warmup:
             optimizer.zero_grad(set_to_none=True)
-            loss = loss_fn()
-            loss.backward()
-            return loss.detach()
+            return run()
         ent = self._graphs.get(name)
         if ent is None and name == "G" and self.train_gan and "D" not in self._graphs:
             # the Generator problem is captured one iteration after the other two: its graph then REUSES the generator's forward
             # packs that the Discriminator graph rebuilds after every update of G (captured entries of the engines' pack caches,
             # see _PackCache) instead of merging the 1.09 GB of fp32 kernels a second time per iteration
             optimizer.zero_grad(set_to_none=True)
-            loss = loss_fn()
-            loss.backward()
-            return loss.detach()
+            return run()
         if ent is None:
             from . import ops
             optimizer.zero_grad(set_to_none=True)              # the captured backward allocates the gradients in the graph's pool
@@ -161,12 +168,11 @@ class EndToEndTrainer:
             self._gkeep.append(ops._splitk_workspace(self.device, torch.cuda.current_stream().cuda_stream))   # pinned: the LRU must not free it
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, pool=self._gpool, stream=self._gstream):
-                loss = loss_fn()
-                loss.backward()
+                loss = run()
             if self._gpool is None:
                 self._gpool = graph.pool()
             grads = [(p, p.grad) for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
-            ent = self._graphs[name] = (graph, loss.detach(), grads)
+            ent = self._graphs[name] = (graph, loss, grads)
         graph, loss, grads = ent
         graph.replay()
         for p, g in grads:                                      # (eager code in between -- the arch step -- may have dropped them)
@@ -209,8 +215,8 @@ class EndToEndTrainer:
             self.optimizer_D.step()
             out.update(loss_G=loss_g, loss_D=loss_d)            # 0-dim device tensors: no host sync per step
         # Unet problem (:176-226): real pair + generated pair from the (augmented) masks
-        loss_u = self._problem("U", lambda: steps.unet_step_loss(self.net, self.netG, image, mask, self.loss_lambda,
-                                                                  None if self.hip_graphs else self.mask_augment, aug),
+        loss_u = self._problem("U", lambda: steps.unet_step_losses(self.net, self.netG, image, mask, self.loss_lambda,
+                                                                    None if self.hip_graphs else self.mask_augment, aug),
                                self.optimizer_unet)
         self._exchange(self.net.parameters())
         self.optimizer_unet.step()

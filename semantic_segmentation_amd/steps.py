@@ -104,10 +104,13 @@ def unet_step_loss_isic(net, netG, images, true_masks, loss_lambda: float = 1.0,
     return loss + loss_lambda * seg_loss_jaccard(net(fake_image), fake_mask)
 
 
-def unet_step_loss(net, netG, images, true_masks, loss_lambda: float = 1.0,
-                   mask_augment: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
-                   augmented_masks: Optional[torch.Tensor] = None):
-    """loss(net(images), masks) + loss_lambda * loss(net(G(aug(masks))), aug(masks)); G is cut by the detach.
+def unet_step_losses(net, netG, images, true_masks, loss_lambda: float = 1.0,
+                     mask_augment: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
+                     augmented_masks: Optional[torch.Tensor] = None):
+    """The two terms of Unet.training_step (:176-226): (loss(net(images), masks), loss_lambda * loss(net(G(aug(masks))), aug(masks)));
+    G is cut by the detach.  Their sum is the reference's loss; a caller that runs `.backward()` on each term in turn gets the same
+    gradients (a + b in either order) with the second pass ACCUMULATING into `.grad` -- one foreach launch on this package's U-Net
+    engine (engine.accumulate_grads) instead of autograd summing the two passes parameter by parameter.
     `augmented_masks`: aug(masks) computed by the caller (the HIP-graph form of the harness draws the augmentation on the host
     outside the captured step); `mask_augment` is not applied then."""
     loss = seg_loss(net(images), true_masks)
@@ -118,8 +121,15 @@ def unet_step_loss(net, netG, images, true_masks, loss_lambda: float = 1.0,
     with torch.no_grad():
         fake_image = fake_image_postprocess(netG(fake_mask))
     fake_loss = seg_loss(net(fake_image), fake_mask)
-    return loss + loss_lambda * fake_loss
+    return loss, loss_lambda * fake_loss
 
+
+def unet_step_loss(net, netG, images, true_masks, loss_lambda: float = 1.0,
+                   mask_augment: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
+                   augmented_masks: Optional[torch.Tensor] = None):
+    """loss(net(images), masks) + loss_lambda * loss(net(G(aug(masks))), aug(masks)); G is cut by the detach."""
+    loss, fake_loss = unet_step_losses(net, netG, images, true_masks, loss_lambda, mask_augment, augmented_masks)
+    return loss + fake_loss
 
 def arch_step_loss(net, image_valid, mask_valid):
     return seg_loss(net(image_valid), mask_valid)
