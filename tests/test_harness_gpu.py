@@ -78,6 +78,34 @@ def test_hip_graph_iterations_match_eager():
         assert torch.allclose(a.float(), b.float(), rtol=1e-4, atol=1e-6)
 
 
+def test_hip_graphs_with_dropout_and_augmentation():
+    """the stock configuration under hip_graphs: dropout in the generator (random numbers drawn INSIDE the captured steps: every
+    replay must draw fresh ones), the host-side mask augmentation outside the graphs, validation and arch steps in between"""
+    from semantic_segmentation_amd.augment import MaskAugmenter
+    from semantic_segmentation_amd.harness import EndToEndTrainer, SyntheticLungDataset
+    from semantic_segmentation_amd.models_pix2pix import networks
+    from semantic_segmentation_amd.unet import UNet
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    net = UNet(1, 1).to(dev)
+    netG = networks.define_G(1, 1, 64, "unet_256", "batch", True, "normal", 0.02, [0])
+    netD = networks.define_D(2, 64, "basic", 3, "batch", "normal", 0.02, [0])
+    crit = networks.GANLoss("vanilla").to(dev)
+    mk = lambda n, seed: torch.utils.data.DataLoader(SyntheticLungDataset(n, 256, seed), batch_size=2, shuffle=False, drop_last=True)
+    tr = EndToEndTrainer(net, netG, netD, crit, mk(4, 1), mk(2, 2), dev, unet_lr=1e-4, unroll_steps=2, valid_every=4,
+                         mask_augment=MaskAugmenter(seed=0), hip_graphs=True)
+    tr.run(8, log_every=0)
+    torch.cuda.synchronize()
+    assert set(tr._graphs) == {"G", "D", "U"}
+    for rec in tr.history:
+        assert all(bool(torch.isfinite(torch.as_tensor(v)).all()) for v in rec.values()), rec
+    # the same batch comes back every second iteration (4 samples, batch 2): with fresh dropout masks and updated weights the
+    # generator loss of two replays on the same batch differs
+    lg = [float(rec["loss_G"]) for rec in tr.history]
+    assert lg[4] != lg[6] and lg[5] != lg[7], lg
+    assert 0.0 <= tr.val_best_score <= 1.0
+
+
 def test_unet_only_loss_decreases():
     """over-fit 2 synthetic batches with the fused RMSprop: the segmentation loss must drop"""
     from semantic_segmentation_amd.harness import SyntheticLungDataset
