@@ -54,6 +54,7 @@ class EndToEndTrainer:
         for a in networks.arch_parameters():
             if a.device != torch.device(device):
                 a.data = a.data.to(device)
+                a.grad = None                        # (a gradient accumulated on the host belongs to the host copy)
         # optimisers of the reference, fused
         self.optimizer_unet = gs_optim.RMSprop(net.parameters(), lr=unet_lr, weight_decay=1e-8, momentum=0.9)
         self.scheduler_unet = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer_unet, "max", patience=5)
