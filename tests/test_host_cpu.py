@@ -70,6 +70,27 @@ def test_geometry_builders():
     assert (d.Cin, d.Cout, d.tap_dy[0], d.tap_dy[8]) == (128, 64, 1, -1)
 
 
+def test_igemm_stat_rows_follow_the_kernel_form():
+    """gs_conv_igemm_mtiles is the host-side contract for the BatchNorm partial rows of a gs_conv_igemm launch: one row per 128-row
+    tile on the register-staged engine, one per 16 output rows for the geometries the weight-streaming form covers (<= 8192
+    output pixels, Cin % 64 == 0, Cout % 32 == 0, 2-D, a K of at least four 64-channel chunks)."""
+    from semantic_segmentation_amd import ops
+    cases = [((2, 16, 16, 512, 512, 4, 2, 1), True),      # M = 128
+             ((2, 2, 2, 512, 512, 4, 2, 1), True),        # M = 2: ceil(2 / 16) = 1 row
+             ((2, 128, 128, 64, 128, 4, 2, 1), True),     # M = 8192
+             ((32, 256, 256, 64, 64, 3, 1, 1), False),    # 2 M pixels
+             ((2, 16, 16, 512, 72, 4, 2, 1), False),      # Cout % 32
+             ((2, 16, 16, 40, 128, 4, 2, 1), False),      # Cin % 64
+             ((2, 16, 16, 64, 128, 1, 1, 0), False)]      # one tap x one chunk: nothing to pipeline
+    for args, streaming in cases:
+        g = ops.geom_conv(*args)
+        M = g.N * g.OHg * g.OWg
+        assert ops.conv_igemm_mtiles(g) == ((M + 15) // 16 if streaming else (M + 127) // 128), args
+    if os.environ.get("GSSEG_SKINNY", "1") != "0":
+        g = ops.geom_convT_class(2, 1, 1, 512, 512, 8, 3, 0, 0)      # 1x1 input: one of the class's 16 taps is visible -> 8 chunks
+        assert ops.conv_igemm_mtiles(g) == 1
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "semantic_segmentation_amd")
     for dp, _, files in os.walk(pkg):
