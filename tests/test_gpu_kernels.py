@@ -911,6 +911,58 @@ def test_igemm_split_k_skinny(dtn, dt, N, h, Cin, Cout, k, s, p):
     assert ops._SPLITK_WS                                            # one workspace per (device, stream), passed per call
 
 
+def test_igemm_weight_streaming_fuzz():
+    """Random geometries of the weight-streaming igemm form (csrc/skinny.hip): conv k1..4 / stride 1..2 / pad 0..2, rectangular
+    maps, strided input and output slices of wider buffers, bias + activation, BatchNorm partial rows -- against fp32 F.conv2d."""
+    import random
+    from semantic_segmentation_amd import ops
+    from semantic_segmentation_amd._lib import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_TANH
+    rng = random.Random(20261004)
+    g = torch.Generator().manual_seed(99)
+    done = 0
+    for trial in range(60):
+        dt = rng.choice([torch.float16, torch.bfloat16])
+        k = rng.choice([1, 2, 3, 4]); s = rng.choice([1, 2]); p = rng.choice([0, 1, 2])
+        N = rng.choice([1, 2, 3]); IH = rng.randint(1, 24); IW = rng.randint(1, 24)
+        Cin = 64 * rng.randint(1, 6); Cout = 32 * rng.randint(1, 10)
+        OH, OW = (IH + 2 * p - k) // s + 1, (IW + 2 * p - k) // s + 1
+        if OH < 1 or OW < 1 or p >= k:
+            continue
+        in_extra, out_extra = rng.choice([0, 64]), rng.choice([0, 32])
+        geom = ops.geom_conv(N, IH, IW, Cin, Cout, k, s, p)
+        geom.in_pix_stride, geom.in_coff = Cin + in_extra, rng.choice([0, in_extra])
+        geom.out_pix_stride, geom.out_coff = Cout + out_extra, rng.choice([0, out_extra])
+        M = N * OH * OW
+        x = rnd(g, N, Cin, IH, IW, dt=dt)
+        w = rnd(g, Cout, Cin, k, k, dt=dt, scale=0.05)
+        b = rnd(g, Cout)
+        act, actf = rng.choice([(ACT_NONE, lambda t: t), (ACT_RELU, torch.relu), (ACT_LEAKY02, lambda t: F.leaky_relu(t, 0.2)),
+                                (ACT_TANH, torch.tanh)])
+        raw = F.conv2d(x, w, None, stride=s, padding=p)
+        ref = actf(raw + b.view(1, -1, 1, 1))
+        wf = torch.empty(k * k, Cout, Cin, dtype=dt, device=dev())
+        ops.pack_weight(w.to(dev()), wf, None, False)
+        xin = torch.zeros(N, IH, IW, geom.in_pix_stride, dtype=dt, device=dev())
+        xin[..., geom.in_coff:geom.in_coff + Cin] = nhwc(x, dt)
+        y = torch.full((N, OH, OW, geom.out_pix_stride), 7.0, dtype=dt, device=dev())
+        nt = ops.conv_igemm_mtiles(geom)
+        part = torch.full((ops.bn_partials_numel(nt, Cout),), float("nan"), dtype=torch.float32, device=dev())
+        ops.conv_igemm(geom, xin, wf, y, b.to(dev()), part, act)
+        torch.cuda.synchronize()
+        got = from_nhwc(y[..., geom.out_coff:geom.out_coff + Cout])
+        assert rel_err(got, ref) < tol(dt), (trial, N, IH, IW, Cin, Cout, k, s, p)
+        if geom.out_pix_stride > Cout:                      # the neighbouring channels of the wider buffer are untouched
+            other = torch.ones(geom.out_pix_stride, dtype=torch.bool)
+            other[geom.out_coff:geom.out_coff + Cout] = False
+            assert bool((y[..., other.to(dev())] == 7.0).all()), trial
+        ps = part[: nt * 2 * Cout].view(nt, 2, Cout).double().sum(0).cpu()
+        r1, r2 = raw.double().sum(dim=(0, 2, 3)), (raw.double() ** 2).sum(dim=(0, 2, 3))
+        assert float((ps[0] - r1).abs().max() / (r1.abs().max() + 1e-6)) < 5e-3, trial
+        assert float((ps[1] - r2).abs().max() / (r2.abs().max() + 1e-6)) < 5e-3, trial
+        done += int(nt == (M + 15) // 16)
+    assert done >= 20, done                                  # most trials ran on the weight-streaming form
+
+
 @pytest.mark.parametrize("C", [1, 2])
 def test_seg_loss_global_dice_equals_full_batch(C):
     """Data-parallel exact global-batch Dice: two 'ranks' each hold half of a batch; with the three Dice
