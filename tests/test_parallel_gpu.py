@@ -132,5 +132,13 @@ def test_grad_reducer_on_unet_engine_rccl_single_rank():
                              valid_every=0, data_parallel=True)
         tr.run(2, log_every=0)
         assert tr.global_step == 2 and all(torch.isfinite(v).all() for rec in tr.history for v in rec.values())
+        # the same loop with the three lower problems replayed from hipGraphs: the gradient exchange runs eagerly, between a
+        # replay and the optimiser step, on the gradients the graph wrote
+        tr = EndToEndTrainer(netU, netG, netD, networks.GANLoss("vanilla").to(dev), mk(4, 1), mk(2, 2), dev, unroll_steps=2,
+                             valid_every=0, data_parallel=True, hip_graphs=True)
+        tr.run(5, log_every=0)
+        torch.cuda.synchronize()
+        assert set(tr._graphs) == {"G", "D", "U"}
+        assert tr.global_step == 5 and all(torch.isfinite(v).all() for rec in tr.history for v in rec.values())
     finally:
         dist.destroy_process_group()
