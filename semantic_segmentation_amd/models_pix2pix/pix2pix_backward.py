@@ -14,9 +14,9 @@ import torch
 
 from .. import ops
 from .._lib import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_TANH
-from .pix2pix_engine import g_tapw_identity
+from .pix2pix_engine import cached_geom, g_tapw_identity
 
-TAPS64 = [(ky - 3, kx - 3) for ky in range(8) for kx in range(8)]
+TAPS64 = tuple((ky - 3, kx - 3) for ky in range(8) for kx in range(8))
 
 
 def generator_backward(engine, ctx, arch, dout, need_dx):
@@ -31,7 +31,7 @@ def generator_backward(engine, ctx, arch, dout, need_dx):
     from ..parallel import GradEmitter
     emitter = GradEmitter(getattr(engine, "grad_ready_hook", None))
     grads = emitter.grads
-    names = {id(p): n for n, p in engine.net.named_parameters()}
+    names = {id(p): n for n, p in zip(engine.param_names(), engine.param_list())}
     darch = torch.zeros(arch.shape, dtype=torch.float32, device=dev)
 
     def empty(*shape, dtype=tdt):
@@ -74,9 +74,7 @@ def generator_backward(engine, ctx, arch, dout, need_dx):
         # weight gradient of the merged kernel, one sub-pixel class at a time
         geoms = []
         for cls in range(4):
-            g = ops.geom_convT_class(N, h, w, cin_t, cpad, 8, 3, cls >> 1, cls & 1)
-            g_tapw_identity(g)
-            geoms.append(g)
+            geoms.append(cached_geom(ops.geom_convT_class, N, h, w, cin_t, cpad, 8, 3, cls >> 1, cls & 1, identity_slots=True))
         # the four classes in ONE launch.  Few-pixel layers do not split K: every element is written exactly once, straight
         # into dwm; otherwise the K parts go to slabs and one ordered sum over all classes follows (deterministic, no atomics)
         nparts = ops.conv_wgrad_parts(geoms[0])
@@ -110,7 +108,7 @@ def generator_backward(engine, ctx, arch, dout, need_dx):
         # data gradient: stride-2 / pad-3 conv of du with the un-flipped merged kernel
         pd = engine._merge_pack(d, w4, w6, w8, sm, cin_t, cout_t, cpad, dgrad=True, arch=arch)
         dr = empty(N, h, w, cin_t)
-        g = ops.make_geom(N, 2 * h, 2 * w, cpad, h, w, cin_t, h, w, TAPS64, isy=2, isx=2)
+        g = cached_geom(ops.make_geom, N, 2 * h, 2 * w, cpad, h, w, cin_t, h, w, TAPS64, isy=2, isx=2)
         ops.conv_igemm(g, du, pd, dr)
         return dr
 
@@ -160,7 +158,7 @@ def generator_backward(engine, ctx, arch, dout, need_dx):
             ops.conv_wgrad_det(lv["geom"], lv["inp"], dy, wsl, dw, cout, cin, 16, inv_s)
             emit(conv.weight, dw)
             dL = empty(N, hs[k - 1], ws[k - 1], cin)
-            gds = [ops.geom_conv_s2_dgrad_class(N, hs[k - 1], ws[k - 1], cin, cout, 4, 1, cls >> 1, cls & 1) for cls in range(4)]
+            gds = [cached_geom(ops.geom_conv_s2_dgrad_class, N, hs[k - 1], ws[k - 1], cin, cout, 4, 1, cls >> 1, cls & 1) for cls in range(4)]
             ops.conv_igemm_batch(gds, dy, [lv["wd"]] * 4, dL)
     if getattr(engine, "after_backward", None) is not None:
         engine.after_backward()

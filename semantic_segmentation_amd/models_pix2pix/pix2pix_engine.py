@@ -68,6 +68,47 @@ def _bn_coeffs(bn, partials, ntiles, C, count, training, dev, nbt_pending=None):
 DIRECT_IMAGE_LAYER = os.environ.get("GSSEG_PIX2PIX_DIRECT_IMAGE", "1") != "0"
 
 
+_GEOMS = {}
+
+
+def cached_geom(builder, *args, identity_slots=False, **kw):
+    """ops.geom_* / ops.make_geom results, memoised: building one fills 64-entry tap tables from Python (5-10 us) and a step asked for
+    ~180 of them.  The geometries are read-only here (identity_slots: tap t lives in weight slot t, set once)."""
+    key = (builder.__name__, args, tuple(sorted(kw.items())), identity_slots)
+    g = _GEOMS.get(key)
+    if g is None:
+        g = builder(*args, **kw)
+        if identity_slots:
+            g_tapw_identity(g)
+        if len(_GEOMS) > 4096:
+            _GEOMS.clear()
+        _GEOMS[key] = g
+    return g
+
+
+class _ParamIndex:
+    """(name, owner module, leaf name) of every parameter in registration order -- the order autograd sees them.  Walking the module
+    tree costs ~0.1-0.2 ms per call and a step asked for it a dozen times; the tree of these networks is static while the
+    Parameter objects may be swapped (`.to()`), so the OWNERS are cached and the tensors are read from them on every call."""
+
+    def _pidx(self):
+        idx = self.__dict__.get("_pidx_cache")
+        if idx is None:
+            mods = dict(self.net.named_modules())
+            idx = []
+            for name, _ in self.net.named_parameters():
+                head, _, leaf = name.rpartition(".")
+                idx.append((name, mods[head], leaf))
+            self.__dict__["_pidx_cache"] = idx
+        return idx
+
+    def param_list(self):
+        return [m._parameters[leaf] for _, m, leaf in self._pidx()]
+
+    def param_names(self):
+        return [n for n, _, _ in self._pidx()]
+
+
 def _flush_nbt(pending):
     if pending:
         torch._foreach_add_(pending, 1)
@@ -120,7 +161,7 @@ class _EmitDict:
 # =====================================================================================================
 # Generator
 # =====================================================================================================
-class GeneratorEngine:
+class GeneratorEngine(_ParamIndex):
     def __init__(self, net, dtype=None):
         self.net = net
         self.dtype, self.tdt = _dtype_of(dtype)
@@ -165,7 +206,7 @@ class GeneratorEngine:
     def run(self, x, dropout_masks=None):
         from . import networks
         arch = networks.upconv_arch
-        params = [p for p in self.net.parameters()]
+        params = self.param_list()
         need_grad = torch.is_grad_enabled() and (x.requires_grad or arch.requires_grad or
                                                  any(p.requires_grad for p in params))
         return _GeneratorFunction.apply(self, self.net.training, need_grad, dropout_masks, x, arch, *params)
@@ -214,7 +255,7 @@ class GeneratorEngine:
             conv, downnorm = parts[k - 1][0], parts[k - 1][1]
             wf, wd = self.packs.get(("down", k), _ver(conv.weight),
                                     lambda conv=conv: self._pack_conv(conv.weight))
-            g = ops.geom_conv(N, hs[k - 1], ws[k - 1], c[k - 1], c[k], 4, 2, 1)
+            g = cached_geom(ops.geom_conv, N, hs[k - 1], ws[k - 1], c[k - 1], c[k], 4, 2, 1)
             y = empty(N, hs[k], ws[k], c[k])
             has_bn = downnorm is not None
             mt = ops.conv_igemm_mtiles(g)
@@ -255,14 +296,12 @@ class GeneratorEngine:
                 bias = sum(sm[j] * cell._ops._ops[j].op.bias.detach() for j in range(3)).float().contiguous()
             if d > 0:
                 u = empty(N, H2, W2, cout_t)
-                mt = ops.conv_igemm_mtiles(ops.geom_convT_class(N, h, w, cin_t, cout_t, 8, 3, 0, 0))
+                mt = ops.conv_igemm_mtiles(cached_geom(ops.geom_convT_class, N, h, w, cin_t, cout_t, 8, 3, 0, 0, identity_slots=True))
                 use_stats = training or upnorm.running_mean is None
                 part = empty(ops.bn_partials_numel(4 * mt, cout_t), dtype=torch.float32) if use_stats else None
                 geoms = []
                 for cls in range(4):
-                    g = ops.geom_convT_class(N, h, w, cin_t, cout_t, 8, 3, cls >> 1, cls & 1)
-                    g_tapw_identity(g)
-                    geoms.append(g)
+                    geoms.append(cached_geom(ops.geom_convT_class, N, h, w, cin_t, cout_t, 8, 3, cls >> 1, cls & 1, identity_slots=True))
                 pslices = [part[cls * mt * 2 * cout_t:] for cls in range(4)] if part is not None else None
                 # the four sub-pixel classes in ONE launch (each is latency bound on its own at the script's batch size)
                 ops.conv_igemm_batch(geoms, R[d + 1], [pf[cls] for cls in range(4)], u, bias, pslices)
@@ -292,9 +331,7 @@ class GeneratorEngine:
                 else:
                     geoms = []
                     for cls in range(4):
-                        g = ops.geom_convT_class(N, h, w, cin_t, cpad, 8, 3, cls >> 1, cls & 1)
-                        g_tapw_identity(g)
-                        geoms.append(g)
+                        geoms.append(cached_geom(ops.geom_convT_class, N, h, w, cin_t, cpad, 8, 3, cls >> 1, cls & 1, identity_slots=True))
                     ops.conv_igemm_batch(geoms, R[1], [pf[cls] for cls in range(4)], u, bpad, None)
                     t = empty(N, H2, W2, cpad)
                     ops.bn_act_apply(u, None, None, ACT_TANH, t, cpad, 0)
@@ -360,7 +397,7 @@ class _GeneratorFunction(torch.autograd.Function):
             raise RuntimeError("UnetGenerator forward ran without gradient tracking")
         from .pix2pix_backward import generator_backward
         grads, darch, dx = generator_backward(ctx.engine, ctx.ectx, ctx.arch, dout, ctx.x_needs_grad)
-        names = [n for n, _ in ctx.engine.net.named_parameters()]
+        names = ctx.engine.param_names()
         fetch = ctx.engine.grad_fetch               # data parallel: the reduced gradients
         out = [(fetch(n) if (fetch is not None and n in grads) else grads.get(n)) if p.requires_grad else None
                for n, p in zip(names, ctx.plist)]
@@ -370,7 +407,7 @@ class _GeneratorFunction(torch.autograd.Function):
 # =====================================================================================================
 # Discriminator
 # =====================================================================================================
-class DiscriminatorEngine:
+class DiscriminatorEngine(_ParamIndex):
     def __init__(self, net, dtype=None):
         self.net = net
         self.dtype, self.tdt = _dtype_of(dtype)
@@ -379,7 +416,7 @@ class DiscriminatorEngine:
         self.grad_ready_hook = self.after_backward = self.grad_fetch = None      # parallel.GradReducer.attach
 
     def run(self, x):
-        params = [p for p in self.net.parameters()]
+        params = self.param_list()
         need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
         return _DiscriminatorFunction.apply(self, self.net.training, need_grad, x, *params)
 
@@ -424,7 +461,7 @@ class DiscriminatorEngine:
             if conv.bias is not None or bn is None:
                 raise NotImplementedError("PatchGAN middle convs are expected as conv(no bias) -> BatchNorm -> LeakyReLU")
             wf, wd = self.packs.get(("conv", i), _ver(conv.weight), lambda conv=conv: self._pack(conv.weight))
-            g = ops.geom_conv(N, ch, cw, cc, conv.out_channels, k, s, p)
+            g = cached_geom(ops.geom_conv, N, ch, cw, cc, conv.out_channels, k, s, p)
             oh, ow = g.OH, g.OW
             y = empty(N, oh, ow, conv.out_channels)
             mt = ops.conv_igemm_mtiles(g)
@@ -504,9 +541,9 @@ class DiscriminatorEngine:
             grads[rec["bnname"] + ".bias"] = dbeta
             dz = empty(N, rec["ih"], rec["iw"], cin)
             if s == 1:
-                ops.conv_igemm(ops.geom_conv_dgrad_s1(N, rec["ih"], rec["iw"], cin, cout, k, p), dy, rec["wd"], dz)
+                ops.conv_igemm(cached_geom(ops.geom_conv_dgrad_s1, N, rec["ih"], rec["iw"], cin, cout, k, p), dy, rec["wd"], dz)
             else:
-                gds = [ops.geom_conv_s2_dgrad_class(N, rec["ih"], rec["iw"], cin, cout, k, p, cls >> 1, cls & 1)
+                gds = [cached_geom(ops.geom_conv_s2_dgrad_class, N, rec["ih"], rec["iw"], cin, cout, k, p, cls >> 1, cls & 1)
                        for cls in range(4)]
                 ops.conv_igemm_batch(gds, dy, [rec["wd"]] * 4, dz)
         first = recs[0]
@@ -545,7 +582,7 @@ class _DiscriminatorFunction(torch.autograd.Function):
         if ctx.ectx is None:
             raise RuntimeError("NLayerDiscriminator forward ran without gradient tracking")
         grads, dx = ctx.engine.backward(ctx.ectx, dlogits, ctx.x_needs_grad)
-        names = [n for n, _ in ctx.engine.net.named_parameters()]
+        names = ctx.engine.param_names()
         fetch = ctx.engine.grad_fetch               # data parallel: the reduced gradients
         out = [(fetch(n) if (fetch is not None and n in grads) else grads.get(n)) if p.requires_grad else None
                for n, p in zip(names, ctx.plist)]
