@@ -192,7 +192,7 @@ static UwPlan uw_plan(int N, int IH, int IW, int Cin, int Cout) {
     p.ntiles = N * (IH / th) * (IW / tw);
     const int pairs = p.ncit * p.ncot;
     const int target = gs_get_persistent_grid();
-    int parts = (target + pairs - 1) / pairs;
+    int parts = target / pairs;                                     // floor: one block per CU, no second round for a remainder
     if (parts > p.ntiles / 4) parts = p.ntiles / 4;                 // a part covers a few tiles: its slab costs 128 KB of traffic
     if (parts < 1) parts = 1;
     p.tpp = (p.ntiles + parts - 1) / parts;

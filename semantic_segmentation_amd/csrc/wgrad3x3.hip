@@ -616,7 +616,10 @@ static int w3_ksplit(int N, int H, int W, int Cin, int Cout, int* pps_out, int* 
     // must cover a few patches for that to be worth it (batch 2: 512 one-patch parts cost more than the MFMAs)
     static const int min_pps_env = getenv("GSSEG_W3_MINPPS") ? atoi(getenv("GSSEG_W3_MINPPS")) : 4;
     const int min_pps = (dma && !co128) ? (min_pps_env + 1) / 2 : min_pps_env;            // in patches of this kernel (256 / 128 pixels)
-    int ksplit = cdiv(target, pairs);
+    // (floor, not ceil: the blocks hold a CU each, so 3 tile pairs x ceil(256 / 3) = 258 blocks ran a second round for two
+    // stragglers -- the 192 -> 64 / 384 -> 128 / 768 -> 256 decoder convs of the 3-D net at 0.67-0.76 PFLOP/s against 1.05 for
+    // their 128 / 256-channel neighbours)
+    int ksplit = target / pairs;
     if (ksplit > npatches / min_pps) ksplit = npatches / min_pps;
     if (ksplit < 1) ksplit = 1;
     const int pps = cdiv(npatches, ksplit);
