@@ -128,6 +128,10 @@ class KernelTimer:
         ev1.record()
         self.records.append((kind, float(flops), float(nbytes), ev0, ev1))
 
+    def reset(self):
+        """forget the launches bracketed so far (warm-up steps run with the timer attached); the pool keeps its unused events"""
+        self.records = []
+
     def summary(self):
         torch.cuda.synchronize()
         out = {}
