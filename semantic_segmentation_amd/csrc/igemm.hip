@@ -940,7 +940,7 @@ static int upconv2x2_impl(const void* x, const void* w, const float* bias, void*
                           int out_pix_stride, int out_coff, int ooz, int ooy, int oox, int act, int dtype, void* stream);
 int pw_upconv2x2_fwd_fast(const void* x, const void* w, const float* bias, void* y, int N, int IH, int IW, int Cin,
                           int in_pix_stride, int in_coff, int Cout, int OH, int OW, int out_pix_stride, int out_coff, int ooy,
-                          int oox, int act, int dtype, void* stream);
+                          int oox, int act, int dtype, void* stream, int D, int Dout, int ooz);
 
 extern "C" int gs_upconv2x2_fwd(const void* x, const void* w, const float* bias, void* y, int N, int D, int IH, int IW,
                                 int Cin, int in_pix_stride, int in_coff, int Cout, int Dout, int OH, int OW,
@@ -977,10 +977,10 @@ static int upconv2x2_impl(const void* x, const void* w, const float* bias, void*
                  "gs_upconv2x2_fwd: Cout / output stride / offset must be multiples of 8");
     GS_CHECK_ARG(2 * IH - 1 + ooy < OH && 2 * IW - 1 + oox < OW && (is3d ? 2 * D - 1 + ooz < Dout : (Dout == 1 && ooz == 0)),
                  "gs_upconv2x2_fwd: output patch exceeds the output tensor");
-    if (!is3d && y_lo == nullptr && in_wrap == 0 && in_pix_stride >= in_coff + Cin && ooy >= 0 && oox >= 0) {
-        // LDS-DMA pointwise GEMM (pwgemm.hip) for the shapes it covers; everything else: the generic engine below
+    if (y_lo == nullptr && in_wrap == 0 && in_pix_stride >= in_coff + Cin && ooy >= 0 && oox >= 0) {
+        // LDS-DMA pointwise GEMM (pwgemm.hip) for the shapes it covers (2-D and 3-D); everything else: the generic engine below
         const int rc = pw_upconv2x2_fwd_fast(x, w, bias, y, N, IH, IW, Cin, in_pix_stride, in_coff, Cout, OH, OW, out_pix_stride,
-                                             out_coff, ooy, oox, act, dtype, stream);
+                                             out_coff, ooy, oox, act, dtype, stream, D, Dout, ooz);
         if (rc == 1) return GS_OK;
         if (rc != 0) return GS_ELAUNCH;
     }

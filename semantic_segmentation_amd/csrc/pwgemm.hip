@@ -29,6 +29,8 @@ struct PwArgs {
     int M, K, Cout, in_stride, in_coff;
     int iw_shift, ih_shift, IH, IW, OH, OW, out_stride, out_coff, ooy, oox;
     int ntn, nitems, xcd_order;
+    int D, Dout, ooz, ncls;       // 3-D (ConvTranspose3d k2 s2): images are depth slices n' = nb * D + d, eight sub-voxel classes, the
+                                  // output slice is nb * Dout + 2 d + cz + ooz; 2-D: D = Dout = 1, ooz = 0, ncls = 4
 };
 
 constexpr int PW_LDR = 72;        // staging row (64 + 8 elements): conflict-free transposes
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(512, 1) void upconv2x2_dma_kernel(const PwArgs a) {
         (void*)a.x, 0, DGRAD ? nimg * (unsigned)a.OH * (unsigned)a.OW * (unsigned)a.in_stride * 2u : (unsigned)a.M * (unsigned)a.in_stride * 2u,
         0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 4u * (unsigned)a.Cout * (unsigned)a.K * 2u, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)a.ncls * (unsigned)a.Cout * (unsigned)a.K * 2u, 0x00020000);
 
     // ---- DMA side: wave w fills pieces w, w+8, w+16, w+24 of both slabs; lane l -> row l >> 3, physical slot l & 7 ----
     const int drow = lane >> 3;
@@ -172,7 +174,8 @@ __global__ __launch_bounds__(512, 1) void upconv2x2_dma_kernel(const PwArgs a) {
     const bool odd = lane & 1;
     const unsigned int psel = odd ? 0x03020706u : 0x05040100u;
     const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.y, 0, DGRAD ? (unsigned)a.M * (unsigned)a.out_stride * 2u : nimg * (unsigned)a.OH * (unsigned)a.OW * (unsigned)a.out_stride * 2u,
+        (void*)a.y, 0, DGRAD ? (unsigned)a.M * (unsigned)a.out_stride * 2u
+                             : (nimg / (unsigned)a.D) * (unsigned)a.Dout * (unsigned)a.OH * (unsigned)a.OW * (unsigned)a.out_stride * 2u,
         0x00020000);
     auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) {
         int e_m0 = m0, e_n0 = n0;
@@ -185,15 +188,17 @@ __global__ __launch_bounds__(512, 1) void upconv2x2_dma_kernel(const PwArgs a) {
             for (int q = 0; q < 4; ++q) {
                 const int p = e_m0 + wm * 64 + i * 32 + q * 8 + (lane >> 3);
                 const int ix = p & (a.IW - 1), iy = (p >> a.iw_shift) & (a.IH - 1), n = p >> (a.iw_shift + a.ih_shift);
+                const int nb = n / a.D, no = nb * a.Dout + 2 * (n - nb * a.D) + a.ooz;      // 2-D: no = n
                 pixoff[i][q] = DGRAD ? (unsigned)(p * a.out_stride * 2)
-                                     : (unsigned)((((n * a.OH + 2 * iy + a.ooy) * a.OW + 2 * ix + a.oox) * a.out_stride) * 2);
+                                     : (unsigned)((((no * a.OH + 2 * iy + a.ooy) * a.OW + 2 * ix + a.oox) * a.out_stride) * 2);
             }
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int col0 = e_n0 + wn * 128 + jj * 64;            // 64 columns: of one sub-pixel class / of dX
             const int cls = DGRAD ? 0 : col0 / a.Cout, co0 = col0 - cls * a.Cout;
             const bool dead = DGRAD && col0 >= a.Cout;             // partial last column tile
-            const unsigned clsoff = dead ? VOOB : (unsigned)((((cls >> 1) * a.OW + (cls & 1)) * (DGRAD ? 0 : a.out_stride) + a.out_coff + co0 + (lane & 7) * 8) * 2);
+            // class bits (cz, cy, cx): one output slice / row / column further
+            const unsigned clsoff = dead ? VOOB : (unsigned)(((((cls >> 2) * a.OH + ((cls >> 1) & 1)) * a.OW + (cls & 1)) * (DGRAD ? 0 : a.out_stride) + a.out_coff + co0 + (lane & 7) * 8) * 2);
             float bv[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) bv[j] = (!DGRAD && a.bias != nullptr) ? a.bias[co0 + j * 32 + l31] : 0.f;
@@ -291,21 +296,24 @@ int ilog2_exact(int v) {
 // then uses the generic engine), a negative GS_E* code on a launch error.  GSSEG_UP_DMA=0 switches it off.
 int pw_upconv2x2_fwd_fast(const void* x, const void* w, const float* bias, void* y, int N, int IH, int IW, int Cin,
                           int in_pix_stride, int in_coff, int Cout, int OH, int OW, int out_pix_stride, int out_coff, int ooy,
-                          int oox, int act, int dtype, void* stream) {
+                          int oox, int act, int dtype, void* stream, int D, int Dout, int ooz) {
     static const int env = getenv("GSSEG_UP_DMA") ? atoi(getenv("GSSEG_UP_DMA")) : 1;
-    const int64_t M = (int64_t)N * IH * IW;
+    const bool is3d = D > 1 || Dout > 1;
+    const int ncls = is3d ? 8 : 4;
+    const int64_t M = (int64_t)N * D * IH * IW;
     const int iws = ilog2_exact(IW), ihs = ilog2_exact(IH);
     if (env == 0 || act != GS_ACT_NONE || Cin % 128 != 0 || Cout % 64 != 0 || M % 256 != 0 || iws < 0 || ihs < 0 ||
         in_pix_stride % 8 != 0 || in_coff % 8 != 0 || out_pix_stride % 8 != 0 || out_coff % 8 != 0 ||
-        M * in_pix_stride * 2 >= 2147483000LL || (int64_t)N * OH * OW * out_pix_stride * 2 >= 2147483000LL ||
-        (int64_t)4 * Cout * Cin * 2 >= 2147483000LL)
+        M * in_pix_stride * 2 >= 2147483000LL || (int64_t)N * Dout * OH * OW * out_pix_stride * 2 >= 2147483000LL ||
+        (int64_t)ncls * Cout * Cin * 2 >= 2147483000LL || ooz < 0)
         return 0;
     PwArgs a;
     a.x = (const unsigned short*)x; a.w = (const unsigned short*)w; a.bias = bias; a.y = (unsigned short*)y;
     a.M = (int)M; a.K = Cin; a.Cout = Cout; a.in_stride = in_pix_stride; a.in_coff = in_coff;
     a.iw_shift = iws; a.ih_shift = ihs; a.IH = IH; a.IW = IW; a.OH = OH; a.OW = OW;
     a.out_stride = out_pix_stride; a.out_coff = out_coff; a.ooy = ooy; a.oox = oox;
-    a.ntn = 4 * Cout / 256;
+    a.D = D; a.Dout = Dout; a.ooz = ooz; a.ncls = ncls;
+    a.ntn = ncls * Cout / 256;
     a.nitems = (int)(M / 256) * a.ntn;
     const int pg = gs_get_persistent_grid();              // 256, or fewer when CUs are left to RCCL
     const int blocks = a.nitems < pg ? a.nitems : pg;
@@ -344,6 +352,7 @@ extern "C" int gs_upconv2x2_dgrad(const void* dy, const void* wd, void* dx, int 
     a.M = (int)M; a.K = Cout; a.Cout = Cin; a.in_stride = dy_pix_stride; a.in_coff = dy_coff;
     a.iw_shift = iws; a.ih_shift = ihs; a.IH = IH; a.IW = IW; a.OH = OH; a.OW = OW;
     a.out_stride = dx_pix_stride; a.out_coff = dx_coff; a.ooy = ooy; a.oox = oox;
+    a.D = 1; a.Dout = 1; a.ooz = 0; a.ncls = 4;
     a.ntn = cdiv(Cin, 256);
     a.nitems = (int)(M / 256) * a.ntn;
     const int pg = gs_get_persistent_grid();              // 256, or fewer when CUs are left to RCCL

@@ -289,6 +289,29 @@ def test_upconv2x2x2_merged_fwd_3d(dtn, dt):
     assert float(y[..., :8].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dtn,dt", DTS)
+@pytest.mark.parametrize("N,D,h,w,Cin,Cout", [(1, 4, 8, 8, 128, 64), (2, 2, 8, 16, 256, 128), (1, 8, 16, 16, 128, 128)])
+def test_upconv2x2x2_dma_gemm_path_3d(dtn, dt, N, D, h, w, Cin, Cout):
+    """The same ConvTranspose3d on the LDS-DMA pointwise GEMM (csrc/pwgemm.hip: power-of-two maps, Cin % 128 == 0, Cout % 64 == 0,
+    N*D*h*w % 256 == 0): eight sub-voxel classes scattered into a channel slice of a wider, deeper concat buffer."""
+    from semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = rnd(g, N, Cin, D, h, w, dt=dt)
+    wt = rnd(g, Cin, Cout, 2, 2, 2, dt=dt, scale=0.05)
+    b = rnd(g, Cout)
+    ref = F.conv_transpose3d(x, wt, b, stride=2)
+    wf = wt.permute(2, 3, 4, 1, 0).reshape(8, Cout, Cin).contiguous().to(dt).to(dev())
+    xin = torch.zeros(N, D, h, w, Cin + 64, dtype=dt, device=dev())
+    xin[..., 64:] = x.permute(0, 2, 3, 4, 1).to(dt).to(dev())
+    y = torch.full((N, 2 * D, 2 * h, 2 * w, Cout + 64), 3.0, dtype=dt, device=dev())
+    ops.upconv2x2_fwd(xin, wf, b.to(dev()), y, N, D, h, w, Cin, Cout, 2 * D, 2 * h, 2 * w, in_stride=Cin + 64, in_coff=64,
+                      out_stride=Cout + 64, out_coff=0)
+    torch.cuda.synchronize()
+    got = y[..., :Cout].float().cpu().permute(0, 4, 1, 2, 3)
+    assert rel_err(got, ref) < tol(dt)
+    assert bool((y[..., Cout:] == 3.0).all())
+
+
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtn,dt", DTS)
 @pytest.mark.parametrize("N,H,W,C,pool", [(2, 8, 6, 64, True), (2, 9, 7, 64, True), (3, 5, 5, 128, False),
