@@ -17,6 +17,7 @@ parameter gradient is multiplied by 1/S on its way out (exact).
 """
 from __future__ import annotations
 
+import functools
 import math
 import os
 from typing import Callable, Dict, List, Optional
@@ -76,6 +77,24 @@ def _pack_key(p: torch.Tensor):
         _NOCACHE[0] += 1
         return (_NOCACHE[0],)
     return (p.data_ptr(), p._version, p.dtype, tuple(p.shape))
+
+
+STREAM_SMALL_CONV = os.environ.get("GSSEG_STREAM_CONV", "1") != "0"
+
+
+@functools.lru_cache(maxsize=4096)
+def stream_conv(N, h, w, cin, cout):
+    """A 3x3 conv with so few output pixels that the halo kernels would start <= 128 workgroups on 256 CUs (the deep levels at small
+    batch: 2 x 32 x 32 pixels x 512 channels = 64 items with 32-stage K loops, 39-69 us each) runs on the weight-streaming igemm form
+    instead (csrc/skinny.hip: K split over one block per CU).  cin / cout: the GEMM's K channels and columns (swapped for a data
+    gradient).  The C side has the last word (GSSEG_SKINNY, shape limits): gs_conv_igemm_mtiles tells which form takes it."""
+    M = N * h * w
+    if not STREAM_SMALL_CONV or M > 8192 or cin % 64 or cout % 32:
+        return False
+    tiles = (-(-w // 32)) * (-(-h // 8)) if w >= 24 else (-(-w // 16)) * (-(-h // 16))
+    if N * tiles * (-(-cout // 64)) > 128:
+        return False
+    return ops.conv_igemm_mtiles(ops.geom_conv(N, h, w, cin, cout, 3, 1, 1)) == -(-M // 16)
 
 
 def pack_reuse_allowed(need_grad: bool, trust_versions: bool = False) -> bool:
@@ -368,9 +387,12 @@ class UNetEngine:
             rec.wide = wide
             nonlocal partials
             g = None if image else ops.geom_conv(N, h, w, cin, cout, 3, 1, 1)
+            # (training-mode statistics only: in eval mode a sample's logits must not depend on which other samples share its
+            # batch, bit for bit -- the K split of the streaming form follows the pixel count)
+            streaming = (not image) and batch_stats and ops.USE_HALO_CONV and stream_conv(N, h, w, cin, cout)
             if image:
                 ntiles = ops.conv_smallcin_mtiles(N, h, w)
-            elif ops.USE_HALO_CONV:
+            elif ops.USE_HALO_CONV and not streaming:
                 ntiles = ops.conv3x3_stat_rows(N, h, w, cin, cout)
             else:
                 ntiles = ops.conv_igemm_mtiles(g)
@@ -401,7 +423,7 @@ class UNetEngine:
             else:
                 wf, wd = (self._packed_padded(wkey, wparam, cin, need_grad) if wide
                           else self._packed(wkey, wparam, False, need_grad))
-                if ops.USE_HALO_CONV:
+                if ops.USE_HALO_CONV and not streaming:
                     ops.conv3x3(inp, wf, y, N, h, w, cin, cout, ops.TAPS3_FWD, None, partials)
                 else:
                     ops.conv_igemm(g, inp, wf, y, None, partials)
@@ -895,6 +917,8 @@ class UNetEngine:
                 npart = max(npart, ops.bn_partials_numel(ops.stem_bwd_tiles(N, hs[i], ws_[i]), 64))
             if i < 4 and ops.USE_HALO_CONV:          # the data-gradient convolution's partials over d(concat) (fused bias gradient)
                 npart = max(npart, ops.bn_partials_numel(ops.conv3x3_mtiles(N, hs[i], ws_[i], 2 * C[i]), 2 * C[i]))
+                if N * hs[i] * ws_[i] <= 8192:      # ... one row per 16 pixels when the weight-streaming form runs it
+                    npart = max(npart, ops.bn_partials_numel(-(-(N * hs[i] * ws_[i]) // 16), 2 * C[i]))
         partials = empty(npart, dtype=torch.float32)
         col_ws = empty(1024 * 1024, dtype=torch.float32)
 
@@ -1035,7 +1059,15 @@ class UNetEngine:
                     ops.unpack_wgrad(dwp, dw, cout, cin, 9, False, inv_s)
                 if need_dinp:
                     dinp = empty(N, h, w, cin)
-                    if ops.USE_HALO_CONV and colsum is not None:
+                    if ops.USE_HALO_CONV and rec.inp_stride is None and rec.train_stats and stream_conv(N, h, w, cout, cin):
+                        # few pixels: the data gradient on the weight-streaming form too (its partial rows feed the fused bias gradient)
+                        gd = ops.geom_conv_dgrad_s1(N, h, w, cin, cout, 3, 1)
+                        if colsum is not None:
+                            ops.conv_igemm(gd, dy, rec.wd, dinp, None, partials)
+                            ops.bn_partials_colsum(partials, ops.conv_igemm_mtiles(gd), cin, colsum[0], colsum[1], inv_s, colsum[2])
+                        else:
+                            ops.conv_igemm(gd, dy, rec.wd, dinp)
+                    elif ops.USE_HALO_CONV and colsum is not None:
                         ops.conv3x3(dy, rec.wd, dinp, N, h, w, cout, cin, ops.TAPS3_DGRAD, bn_partials=partials)
                         ops.bn_partials_colsum(partials, ops.conv3x3_stat_rows(N, h, w, cout, cin), cin, colsum[0], colsum[1], inv_s, colsum[2])
                     elif ops.USE_HALO_CONV:
