@@ -76,7 +76,53 @@ def main():
 
         tg, td, tu = timeit(g_step, 10, 3), timeit(d_step, 10, 3), timeit(u_step, 10, 3)
         print(f"config3 B={B:3d}: generator step {tg * 1e3:8.2f} ms | discriminator step {td * 1e3:8.2f} ms | "
-              f"unet step (2 U-Net fwd+bwd + G fwd + post-proc) {tu * 1e3:8.2f} ms | trio {B / (tg + td + tu):8.1f} img/s")
+              f"unet step (2 U-Net fwd+bwd + G fwd + post-proc) {tu * 1e3:8.2f} ms | trio {B / (tg + td + tu):8.1f} img/s", flush=True)
+        # the same three steps captured into hipGraphs and replayed (the launch path, ~16 us of Python / ctypes per launch, is what
+        # bounds the eager numbers at batch 2).  Each graph contains the pack re-builds the eager emulation above pays per call:
+        # captured in the order Discriminator (all generator packs stale: re-merged inside its graph), Unet (re-uses them; its own
+        # packs re-built), Generator (re-uses the forward packs, re-merges the data-gradient packs) -- a capture only re-uses packs
+        # that were built during a capture (pix2pix_engine._PackCache)
+        if os.environ.get("GSSEG_BENCH_GRAPHS", "1") != "0":
+            side = torch.cuda.Stream()
+            pool, graphs = None, {}
+
+            def body_g():
+                zero(G, D); steps.generator_step_loss(G, D, crit, maskf, real).backward()
+
+            def body_d():
+                zero(G, D); steps.discriminator_step_loss(G, D, crit, maskf, real).backward()
+
+            def body_u():
+                zero(U); steps.unet_step_loss(U, G, x, mask, 1.0).backward()
+
+            def stale_d():
+                torch.autograd.graph.increment_version(list(G.parameters()))
+
+            def stale_u():
+                U.engine.invalidate_packs()
+
+            def stale_g():
+                for key in [k for k in G._engine.packs._d if k[0] == "merged" and k[2]]:
+                    del G._engine.packs._d[key]
+
+            for name, body, stale in (("d", body_d, stale_d), ("u", body_u, stale_u), ("g", body_g, stale_g)):
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        body()
+                    zero(G, D, U)
+                    stale()
+                    gr = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gr, pool=pool, stream=side):
+                        body()
+                    pool = pool or gr.pool()
+                    graphs[name] = gr
+                torch.cuda.current_stream().wait_stream(side)
+            with torch.cuda.stream(side):
+                rg, rd, ru = (timeit(graphs[k].replay, 20, 3) for k in ("g", "d", "u"))
+            print(f"config3 B={B:3d}: the same steps replayed from hipGraphs: generator {rg * 1e3:8.2f} ms | discriminator {rd * 1e3:8.2f} ms | "
+                  f"unet {ru * 1e3:8.2f} ms | trio {B / (rg + rd + ru):8.1f} img/s", flush=True)
+            del graphs, pool
     # the whole iteration through harness.EndToEndTrainer (three problems + their fused optimiser steps; no arch step, no
     # validation, no augmentation): the eager loop against forward + backward captured into hipGraphs
     from semantic_segmentation_amd.harness import EndToEndTrainer, SyntheticLungDataset
