@@ -142,6 +142,30 @@ def main():
             del tr
     if only3:
         return
+    # config 1 (BASELINE configs[0], the reference's CPU-runnable case): UNet(1,2) 128x128 batch 4 forward + backward -- eager and
+    # replayed from a hipGraph (launch-bound at this size)
+    U1 = UNet(1, 2).to(dev).train()
+    x1, m1 = synthetic_batch(4, 128, seed=9)
+    x1, m1 = x1.to(dev), m1.to(dev)
+
+    def c1_step():
+        zero(U1)
+        seg_loss(U1(x1), m1).backward()
+    t_e = timeit(c1_step, 20, 3)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            c1_step()
+        zero(U1)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=side):
+            c1_step()
+        t_g = timeit(gr.replay, 20, 3)
+    torch.cuda.current_stream().wait_stream(side)
+    print(f"config1 UNet(1,2) 128x128 B=4 fwd+bwd: eager {t_e * 1e3:6.2f} ms = {4 / t_e:7.1f} img/s | hipGraph replay {t_g * 1e3:6.2f} ms = "
+          f"{4 / t_g:7.1f} img/s", flush=True)
+    del gr, U1
     # inference: eval-mode U-Net forward, BatchNorm folded into the convs vs the two-pass form
     from semantic_segmentation_amd.unet import unet_engine
     U2 = UNet(1, 2).to(dev).eval()
