@@ -106,6 +106,57 @@ def test_hip_graphs_with_dropout_and_augmentation():
     assert 0.0 <= tr.val_best_score <= 1.0
 
 
+def test_capture_step_unet_matches_eager():
+    """graphs.capture_step on a plain U-Net step (static inputs, gradients set to None and packs dropped before the capture): every
+    replay reproduces the eager step bit for bit -- also after the batch in the static tensors and the weights have changed"""
+    from semantic_segmentation_amd.graphs import capture_step
+    from semantic_segmentation_amd.harness import synthetic_batch
+    from semantic_segmentation_amd.losses import seg_loss
+    from semantic_segmentation_amd.unet import UNet
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    net = UNet(1, 2).to(dev).train()
+    net.engine.trust_versions = True
+    xs, ms = [], []
+    for seed in (1, 2):
+        x, m = synthetic_batch(2, 64, seed=seed)
+        xs.append(x.to(dev)); ms.append(m.to(dev))
+    x_st, m_st = xs[0].clone(), ms[0].clone()
+
+    def step():
+        loss = seg_loss(net(x_st), m_st)
+        loss.backward()
+        return loss.detach()
+
+    def prepare():
+        for p in net.parameters():
+            p.grad = None
+        net.engine.invalidate_packs()
+
+    def eager(i):
+        sd = {k: v.clone() for k, v in net.state_dict().items()}
+        x_st.copy_(xs[i]); m_st.copy_(ms[i])
+        prepare()
+        loss = float(step())
+        grads = [p.grad.clone() for p in net.parameters()]
+        net.load_state_dict(sd)                  # undo the BatchNorm running-statistics update
+        return loss, grads
+
+    cap = capture_step(step, prepare=prepare)
+    for i in (1, 0, 1):
+        with torch.no_grad():
+            for p in net.parameters():
+                p.mul_(1.0 + 0.01 * (i + 1))     # weights change between replays: the packs are re-built inside the graph
+        l_ref, g_ref = eager(i)
+        x_st.copy_(xs[i]); m_st.copy_(ms[i])
+        with torch.cuda.stream(cap.stream):
+            l_got = float(cap.replay())
+        torch.cuda.synchronize()
+        assert l_got == l_ref, (i, l_got, l_ref)
+        for p, g in zip(net.parameters(), g_ref):
+            assert torch.equal(p.grad, g)
+
+
 def test_unet_only_loss_decreases():
     """over-fit 2 synthetic batches with the fused RMSprop: the segmentation loss must drop"""
     from semantic_segmentation_amd.harness import SyntheticLungDataset

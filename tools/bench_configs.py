@@ -105,19 +105,13 @@ def main():
                 for key in [k for k in G._engine.packs._d if k[0] == "merged" and k[2]]:
                     del G._engine.packs._d[key]
 
+            from semantic_segmentation_amd.graphs import capture_step
             for name, body, stale in (("d", body_d, stale_d), ("u", body_u, stale_u), ("g", body_g, stale_g)):
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    for _ in range(2):
-                        body()
+                def prepare(stale=stale):
                     zero(G, D, U)
                     stale()
-                    gr = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gr, pool=pool, stream=side):
-                        body()
-                    pool = pool or gr.pool()
-                    graphs[name] = gr
-                torch.cuda.current_stream().wait_stream(side)
+                graphs[name] = capture_step(body, prepare=prepare, stream=side, pool=pool)
+                pool = pool or graphs[name].pool()
             with torch.cuda.stream(side):
                 rg, rd, ru = (timeit(graphs[k].replay, 20, 3) for k in ("g", "d", "u"))
             print(f"config3 B={B:3d}: the same steps replayed from hipGraphs: generator {rg * 1e3:8.2f} ms | discriminator {rd * 1e3:8.2f} ms | "
@@ -152,17 +146,10 @@ def main():
         zero(U1)
         seg_loss(U1(x1), m1).backward()
     t_e = timeit(c1_step, 20, 3)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(2):
-            c1_step()
-        zero(U1)
-        gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr, stream=side):
-            c1_step()
+    from semantic_segmentation_amd.graphs import capture_step
+    gr = capture_step(c1_step, prepare=lambda: zero(U1))
+    with torch.cuda.stream(gr.stream):
         t_g = timeit(gr.replay, 20, 3)
-    torch.cuda.current_stream().wait_stream(side)
     print(f"config1 UNet(1,2) 128x128 B=4 fwd+bwd: eager {t_e * 1e3:6.2f} ms = {4 / t_e:7.1f} img/s | hipGraph replay {t_g * 1e3:6.2f} ms = "
           f"{4 / t_g:7.1f} img/s", flush=True)
     del gr, U1
