@@ -3,6 +3,8 @@ same op, on the same 16-bit-rounded inputs.  GPU only (`-m gpu`)."""
 import math
 
 import numpy as np
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -931,7 +933,8 @@ def test_igemm_split_k_skinny(dtn, dt, N, h, Cin, Cout, k, s, p):
     if p2 is not None:
         r2 = (ref_raw.double() ** 2).sum(dim=(0, 2, 3))
         assert float((p2 - r2).abs().max() / (r2.abs().max() + 1e-6)) < 3e-3
-    assert ops._SPLITK_WS                                            # one workspace per (device, stream), passed per call
+    if os.environ.get("GSSEG_SPLITK", "1") != "0":
+        assert ops._SPLITK_WS                                        # one workspace per (device, stream), passed per call
 
 
 def test_igemm_weight_streaming_fuzz():
@@ -983,7 +986,8 @@ def test_igemm_weight_streaming_fuzz():
         assert float((ps[0] - r1).abs().max() / (r1.abs().max() + 1e-6)) < 5e-3, trial
         assert float((ps[1] - r2).abs().max() / (r2.abs().max() + 1e-6)) < 5e-3, trial
         done += int(nt == (M + 15) // 16)
-    assert done >= 20, done                                  # most trials ran on the weight-streaming form
+    if os.environ.get("GSSEG_SKINNY", "1") != "0" and os.environ.get("GSSEG_SPLITK", "1") != "0":
+        assert done >= 20, done                              # most trials ran on the weight-streaming form
 
 
 @pytest.mark.parametrize("C", [1, 2])
