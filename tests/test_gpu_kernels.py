@@ -1,10 +1,9 @@
 """Per-kernel parity tests: every C-ABI entry point against a plain fp32 torch (CPU) statement of the
 same op, on the same 16-bit-rounded inputs.  GPU only (`-m gpu`)."""
 import math
-
-import numpy as np
 import os
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
