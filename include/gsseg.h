@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 43
+#define GS_ABI_VERSION 44
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -276,6 +276,10 @@ int gs_bn_act_bwd_apply(const void* y, const void* dz_a, int sa, int coff_a, con
  * + dzp routed to the first maximum of each window (ATen scan order). */
 int gs_maxpool3d_fwd(const void* z, int z_pix_stride, int z_coff, void* zp, int NB, int D, int H, int W, int C,
                      int dtype, void* stream);
+/* pair forward (UNet3D): the maximum of the pair VALUES z_hi + z_lo over each window, stored as a pair (zp_lo may be NULL);
+ * z_hi / z_lo point at the first channel of their planes inside a buffer of pixel stride z_pix_stride (unet3d.py:37,44). */
+int gs_maxpool3d_fwd_pair(const void* z_hi, const void* z_lo, int z_pix_stride, void* zp_hi, void* zp_lo, int zp_pix_stride,
+                          int NB, int D, int H, int W, int C, int dtype, void* stream);
 int gs_maxpool3d_bwd(const void* z, int z_pix_stride, int z_coff, const void* dzp, const void* dres,
                      int res_pix_stride, int res_coff, void* dz, int NB, int D, int H, int W, int C, int dtype,
                      void* stream);
@@ -467,7 +471,7 @@ int gs_mean_loss_bwd(const float* x, const float* t, float cval, int mode, int64
 int gs_pack_weight_split(const float* w, void* pack, int Cout, int Cin, int taps, int transposed, int dtype, void* stream);
 /* Mixed-precision plans (UNet(precise="mixed"): the pair forward with the MFMA segments chosen per stage): a general segment
  * pack.  pack[t][co][k], k over the concatenation of nseg <= GS_SEG_MAX segments; segment j = input channels
- * [ci0[j], ci0[j] + len[j]) of hi(w) (kind 0) or lo(w) (kind 1).  [hi | hi | lo] over all channels reproduces
+ * [ci0[j], ci0[j] + len[j]) of hi(w) (kind 0), lo(w) (kind 1) or zeros (kind 2: K padding).  [hi | hi | lo] over all channels reproduces
  * gs_pack_weight_split; one launch packs all n descriptors. */
 #define GS_SEG_MAX 4
 typedef struct GsSegPackDesc {
@@ -480,6 +484,12 @@ int gs_pack_weight_segs(int n, const GsSegPackDesc* descs, int dtype, void* stre
 int gs_conv3x3_precise(const void* x, const void* w, void* y_hi, void* y_lo, const float* bias, float* bn_partials, int N,
                        int H, int W, int K, int in_pix_stride, int in_coff, int in_wrap, int Cout, int out_pix_stride,
                        int out_coff, const int32_t* tap_dy, const int32_t* tap_dx, int act, int dtype, void* stream);
+/* gs_conv3d_3x3x3_precise: Conv3d(k3, p1) of the pair forward of UNet3D (GenSeg-3D/UNet3D/unet3d.py:28-31,69-71; BASELINE config 5):
+ *   gs_conv3d_3x3x3 with the K extent / in_wrap / [27][Cout][K] segment pack / y pair of gs_conv3x3_precise. */
+int gs_conv3d_3x3x3_precise(const void* x, const void* w, void* y_hi, void* y_lo, const float* bias, float* bn_partials,
+                            int NB, int D, int H, int W, int K, int in_pix_stride, int in_coff, int in_wrap, int Cout,
+                            int out_pix_stride, int out_coff, const int32_t* tap_dz, const int32_t* tap_dy,
+                            const int32_t* tap_dx, int act, int dtype, void* stream);
 int gs_upconv2x2_fwd_precise(const void* x, const void* w, const float* bias, void* y_hi, void* y_lo, int N, int IH, int IW,
                              int K, int in_pix_stride, int in_coff, int in_wrap, int Cout, int OH, int OW,
                              int out_pix_stride, int out_coff, int ooy, int oox, int dtype, void* stream);
@@ -554,6 +564,11 @@ int gs_conv3d_3x3x3_wgrad_slabs(const void* x, const void* dy, float* ws, int NB
  * _bwd reads the same slice of the concat-buffer gradient and writes d(x) (gather form, deterministic). */
 int gs_upsample2x_bilinear_fwd(const void* x, void* y, int N, int IH, int IW, int C, int in_pix_stride, int in_coff,
                                int OH, int OW, int out_pix_stride, int out_coff, int ooy, int oox, int dtype, void* stream);
+/* the same interpolation on a hi/lo pair (pair forward of the bilinear=True U-Net, unet_parts.py:49-50): the planes of x share
+ * (in_pix_stride, in_coff), those of y (out_pix_stride, out_coff); y_lo may be NULL. */
+int gs_upsample2x_bilinear_fwd_pair(const void* x_hi, const void* x_lo, void* y_hi, void* y_lo, int N, int IH, int IW, int C,
+                                    int in_pix_stride, int in_coff, int OH, int OW, int out_pix_stride, int out_coff, int ooy,
+                                    int oox, int dtype, void* stream);
 int gs_upsample2x_bilinear_bwd(const void* dy, void* dx, int N, int IH, int IW, int C, int dy_pix_stride, int dy_coff,
                                int OH, int OW, int dx_pix_stride, int dx_coff, int ooy, int oox, int dtype, void* stream);
 

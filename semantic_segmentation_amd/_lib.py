@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 GS_F16, GS_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH = 0, 1, 2, 3
 GS_MAX_TAPS = 64
-ABI_VERSION = 43
+ABI_VERSION = 44
 
 
 class GsConvGeom(ctypes.Structure):
@@ -153,6 +153,9 @@ PROTOTYPES = {
     "gs_mean_loss_fwd": (c_int, [_F, _F, c_float, c_int, c_int64, _F, _F, c_void_p]),
     "gs_pack_weight_split": (c_int, [_F, _P, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "gs_pack_weight_segs": (c_int, [c_int, POINTER(GsSegPackDesc), c_int, c_void_p]),
+    "gs_conv3d_3x3x3_precise": (c_int, [_P, _P, _P, _P, _F, _F] + [c_int] * 11 + [POINTER(c_int32)] * 3 + [c_int, c_int, c_void_p]),
+    "gs_maxpool3d_fwd_pair": (c_int, [_P, _P, c_int, _P, _P] + [c_int] * 7 + [c_void_p]),
+    "gs_upsample2x_bilinear_fwd_pair": (c_int, [_P, _P, _P, _P] + [c_int] * 13 + [c_void_p]),
     "gs_conv3x3_precise": (c_int, [_P, _P, _P, _P, _F, _F] + [c_int] * 10 + [POINTER(c_int32), POINTER(c_int32), c_int, c_int, c_void_p]),
     "gs_upconv2x2_fwd_precise": (c_int, [_P, _P, _F, _P, _P] + [c_int] * 15 + [c_void_p]),
     "gs_conv_smallcin_fwd_split": (c_int, [_F, _F, _P, _P, _F] + [c_int] * 8 + [c_void_p]),

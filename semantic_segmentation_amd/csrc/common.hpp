@@ -120,6 +120,25 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// hi/lo pairs of 16-bit values (the pair forward): v = hi + lo, hi = 16-bit(v), lo = 16-bit(v - hi)
+template <int DT>
+__device__ __forceinline__ void split8(const float (&v)[8], uint4& hi, uint4& lo) {
+    hi = pack8<DT>(v);
+    float h[8], l[8];
+    unpack8<DT>(hi, h);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) l[i] = v[i] - h[i];
+    lo = pack8<DT>(l);
+}
+template <int DT>
+__device__ __forceinline__ void join8(const uint4& hi, const uint4& lo, float (&v)[8]) {
+    float l[8];
+    unpack8<DT>(hi, v);
+    unpack8<DT>(lo, l);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += l[i];
+}
+
 __device__ __forceinline__ float act_fwd(float v, int act) {
     switch (act) {
         case GS_ACT_RELU: return v > 0.f ? v : 0.f;

@@ -1107,7 +1107,7 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
     GS_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0 && Cout > 0, "gs_conv3x3: bad dims");
     const bool prec = y_lo != nullptr;
     // precise mode: Cin is the K extent (segments x channels); the input holds in_wrap channels
-    GS_CHECK_ARG(!prec || (in_wrap > 0 && in_wrap % 64 == 0 && Cin % 64 == 0 && Cin >= in_wrap && Cin <= 2 * in_wrap && ndz == 1),
+    GS_CHECK_ARG(!prec || (in_wrap > 0 && in_wrap % 64 == 0 && Cin % 64 == 0 && Cin >= in_wrap && Cin <= 2 * in_wrap),
                  "gs_conv3x3_precise: K extent %d / wrap %d must be multiples of 64 with wrap <= K <= 2*wrap", Cin, in_wrap);
     GS_CHECK_ARG(in_pix_stride >= in_coff + (prec ? in_wrap : Cin) && in_pix_stride % 8 == 0 && in_coff % 8 == 0, "gs_conv3x3: bad input stride");
     GS_CHECK_ARG(out_pix_stride >= out_coff + Cout, "gs_conv3x3: bad output stride");
@@ -1276,6 +1276,20 @@ extern "C" int gs_conv3x3_precise(const void* x, const void* w, void* y_hi, void
 // weights of slot dz*9 .. dz*9+8 of the [27][Cout][Cin] pack.  Requires Cin % 8 == 0, Cout % 8 == 0 (a tail channel chunk is zero padded).
 extern "C" int gs_conv3d_3x3x3_mtiles(int NB, int D, int H, int W, int Cout) {
     return gs_conv3x3_mtiles(NB * D, H, W, Cout);
+}
+
+// Conv3d 3x3x3 of the pair forward (UNet3D, BASELINE config 5): as gs_conv3x3_precise -- K = the stage's concatenation of segments
+// over the `in_wrap` channels of the [hi | lo] input, w = [27][Cout][K] segment pack, result as the pair y_hi / y_lo.
+extern "C" int gs_conv3d_3x3x3_precise(const void* x, const void* w, void* y_hi, void* y_lo, const float* bias, float* bn_partials,
+                                       int NB, int D, int H, int W, int K, int in_pix_stride, int in_coff, int in_wrap, int Cout,
+                                       int out_pix_stride, int out_coff, const int32_t* tap_dz, const int32_t* tap_dy,
+                                       const int32_t* tap_dx, int act, int dtype, void* stream) {
+    GS_CHECK_ARG(y_lo != nullptr, "gs_conv3d_3x3x3_precise: y_lo is NULL");
+    GS_CHECK_ARG(NB > 0 && D > 0 && tap_dz, "gs_conv3d_3x3x3_precise: bad depth arguments");
+    for (int i = 0; i < 3; ++i) GS_CHECK_ARG(tap_dz[i] >= -1 && tap_dz[i] <= 1, "gs_conv3d_3x3x3_precise: depth tap offsets must be in [-1,1]");
+    GS_CHECK_ARG(c3_variant_get() == 2, "gs_conv3d_3x3x3_precise: needs the big-K-step kernel (GSSEG_C3=2)");
+    return conv3x3_launch(x, w, y_hi, bias, bn_partials, NB * D, H, W, K, in_pix_stride, in_coff, Cout, out_pix_stride, out_coff,
+                          tap_dy, tap_dx, act, dtype, stream, D, 3, tap_dz, y_lo, in_wrap);
 }
 
 extern "C" int gs_conv3d_3x3x3(const void* x, const void* w, void* y, const float* bias, float* bn_partials, int NB, int D,

@@ -167,8 +167,9 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
             const bool inside = (unsigned)(d + dz) < (unsigned)a.D;
             r.n = inside ? n + dz : n;
             r.hkill = inside ? 0u : VOOB;
-            r.sc = (unsigned)cc * ROWB;
-            r.wsc = (unsigned)(dzi * 9) * tap_stride + r.sc;
+            // (pair forward: K chunk cc of a depth tap reads input chunk cc, wrapping once to the start of the input)
+            r.sc = (unsigned)((PREC && a.in_wrap > 0 && cc >= 2 * a.in_wrap) ? cc - 2 * a.in_wrap : cc) * ROWB;
+            r.wsc = (unsigned)(dzi * 9) * tap_stride + (unsigned)cc * ROWB;
         }
         return r;
     };

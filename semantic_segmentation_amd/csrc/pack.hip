@@ -85,6 +85,8 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackMultiA
     if (dst == nullptr) return;
     const int block = blockIdx.x - a.first[d], nblocks = a.first[d + 1] - a.first[d];
     if (a.T[d] == 9) pack_rows_body<DT, 9>(a.w[d], dst, a.A[d], a.B[d], ba, block, nblocks);
+    else if (a.T[d] == 27) pack_rows_body<DT, 27>(a.w[d], dst, a.A[d], a.B[d], ba, block, nblocks);      // Conv3d 3x3x3
+    else if (a.T[d] == 8) pack_rows_body<DT, 8>(a.w[d], dst, a.A[d], a.B[d], ba, block, nblocks);        // ConvTranspose3d k2 s2
     else pack_rows_body<DT, 4>(a.w[d], dst, a.A[d], a.B[d], ba, block, nblocks);
 }
 
@@ -186,8 +188,9 @@ extern "C" int gs_pack_weight_multi(int n, const GsPackDesc* descs, int dtype, v
         int blocks = 0;
         for (int i = 0; i < a.n; ++i) {
             const GsPackDesc& d = descs[base + i];
-            GS_CHECK_ARG(d.w && (d.w_fwd || d.w_dgrad) && d.Cout > 0 && d.Cin > 0 && (d.taps == 9 || d.taps == 4),
-                         "gs_pack_weight_multi: descriptor %d: needs w, a pack, positive dims and 9 or 4 taps", base + i);
+            GS_CHECK_ARG(d.w && (d.w_fwd || d.w_dgrad) && d.Cout > 0 && d.Cin > 0 &&
+                         (d.taps == 9 || d.taps == 4 || d.taps == 27 || d.taps == 8),
+                         "gs_pack_weight_multi: descriptor %d: needs w, a pack, positive dims and 9 / 4 (2-D) or 27 / 8 (3-D) taps", base + i);
             // source [A][B][T]: Conv2d A=Cout,B=Cin (P_ab = fwd pack, P_ba = dgrad pack); ConvTranspose2d A=Cin,B=Cout
             a.w[i] = d.w;
             a.A[i] = d.transposed ? d.Cin : d.Cout;

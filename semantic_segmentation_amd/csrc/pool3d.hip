@@ -87,6 +87,52 @@ __global__ __launch_bounds__(256) void maxpool3d_kernel(const P3Args a) {
     }
 }
 
+// Forward on hi/lo pairs (the pair forward of UNet3D): the maximum of the pair VALUES hi + lo over the 2x2x2 window, stored as a
+// pair again (the lo plane only when a consumer reads it).  z_hi / z_lo: the two planes of the un-pooled tensor (each with its own
+// channel offset inside a buffer of pixel stride zs); zp_hi / zp_lo: pooled planes with pixel stride zps.
+struct P3PairArgs {
+    const unsigned short* z_hi; const unsigned short* z_lo; unsigned short* zp_hi; unsigned short* zp_lo;
+    int zs, zps, NB, D, H, W, C;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void maxpool3d_pair_kernel(const P3PairArgs a) {
+    const int nch = a.C >> 3;
+    const int PD = a.D / 2, PH = a.H / 2, PW = a.W / 2;
+    const int64_t total = (int64_t)a.NB * PD * PH * PW * nch;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(idx % nch);
+        int64_t r = idx / nch;
+        const int px = (int)(r % PW); r /= PW;
+        const int py = (int)(r % PH); r /= PH;
+        const int pd = (int)(r % PD);
+        const int nb = (int)(r / PD);
+        const int c0 = ch * 8;
+        uint4 vh[8], vl[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int dd = 2 * pd + (k >> 2), yy = 2 * py + ((k >> 1) & 1), xx = 2 * px + (k & 1);
+            const int64_t pix = (((int64_t)nb * a.D + dd) * a.H + yy) * a.W + xx;
+            vh[k] = *reinterpret_cast<const uint4*>(a.z_hi + pix * a.zs + c0);
+            vl[k] = *reinterpret_cast<const uint4*>(a.z_lo + pix * a.zs + c0);
+        }
+        float m[8];
+        join8<DT>(vh[0], vl[0], m);
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            float v[8];
+            join8<DT>(vh[k], vl[k], v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], v[i]);
+        }
+        const int64_t pp = (((int64_t)nb * PD + pd) * PH + py) * PW + px;
+        uint4 hi, lo;
+        split8<DT>(m, hi, lo);
+        *reinterpret_cast<uint4*>(a.zp_hi + pp * a.zps + c0) = hi;
+        if (a.zp_lo) *reinterpret_cast<uint4*>(a.zp_lo + pp * a.zps + c0) = lo;
+    }
+}
+
 int launch(const P3Args& a, bool bwd, int dtype, hipStream_t s) {
     const int64_t total = (int64_t)a.NB * ((a.D + 1) / 2) * ((a.H + 1) / 2) * ((a.W + 1) / 2) * (a.C / 8);
     int64_t nb = cdiv64(total, 256);
@@ -159,6 +205,24 @@ extern "C" int gs_maxpool3d_fwd(const void* z, int z_pix_stride, int z_coff, voi
     P3Args a{(const unsigned short*)z, (unsigned short*)zp, nullptr, nullptr, nullptr, 0, 0, z_pix_stride, z_coff, NB, D, H, W, C};
     launch(a, false, dtype, (hipStream_t)stream);
     GS_CHECK_LAUNCH("gs_maxpool3d_fwd");
+    return GS_OK;
+}
+
+extern "C" int gs_maxpool3d_fwd_pair(const void* z_hi, const void* z_lo, int z_pix_stride, void* zp_hi, void* zp_lo,
+                                     int zp_pix_stride, int NB, int D, int H, int W, int C, int dtype, void* stream) {
+    GS_CHECK_ARG(z_hi && z_lo && zp_hi && NB > 0 && D > 1 && H > 1 && W > 1 && C > 0 && C % 8 == 0, "gs_maxpool3d_fwd_pair: bad arguments");
+    GS_CHECK_ARG(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "gs_maxpool3d_fwd_pair: even volume dims only");
+    GS_CHECK_ARG(z_pix_stride >= C && z_pix_stride % 8 == 0 && zp_pix_stride >= C && zp_pix_stride % 8 == 0,
+                 "gs_maxpool3d_fwd_pair: bad strides");
+    GS_CHECK_ARG(((uintptr_t)z_hi | (uintptr_t)z_lo | (uintptr_t)zp_hi | (uintptr_t)zp_lo) % 16 == 0, "gs_maxpool3d_fwd_pair: planes must be 16-byte aligned");
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_maxpool3d_fwd_pair: bad dtype");
+    P3PairArgs a{(const unsigned short*)z_hi, (const unsigned short*)z_lo, (unsigned short*)zp_hi, (unsigned short*)zp_lo,
+                 z_pix_stride, zp_pix_stride, NB, D, H, W, C};
+    int64_t nb = cdiv64((int64_t)NB * (D / 2) * (H / 2) * (W / 2) * (C / 8), 256);
+    if (nb > 8192) nb = 8192;
+    if (dtype == GS_F16) maxpool3d_pair_kernel<GS_F16><<<(int)nb, 256, 0, (hipStream_t)stream>>>(a);
+    else maxpool3d_pair_kernel<GS_BF16><<<(int)nb, 256, 0, (hipStream_t)stream>>>(a);
+    GS_CHECK_LAUNCH("gs_maxpool3d_fwd_pair");
     return GS_OK;
 }
 

@@ -11,25 +11,6 @@
 
 namespace {
 
-template <int DT>
-__device__ __forceinline__ void split8(const float (&v)[8], uint4& hi, uint4& lo) {
-    hi = pack8<DT>(v);
-    float h[8], l[8];
-    unpack8<DT>(hi, h);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) l[i] = v[i] - h[i];
-    lo = pack8<DT>(l);
-}
-
-template <int DT>
-__device__ __forceinline__ void join8(const uint4& hi, const uint4& lo, float (&v)[8]) {
-    float l[8];
-    unpack8<DT>(hi, v);
-    unpack8<DT>(lo, l);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] += l[i];
-}
-
 // ---- weight pack ------------------------------------------------------------------------------------------------
 // conv (transposed == 0): w fp32 [Cout][Cin][taps]  -> out[t][co][s*Cin + ci]
 // convT (transposed == 1): w fp32 [Cin][Cout][taps] -> out[t][co][s*Cin + ci]
@@ -53,8 +34,9 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict
 
 // ---- generic segment pack (mixed precision plans of the U-Net forward) ---------------------------------------------
 // out[t][co][k], k running over the concatenation of up to GS_SEG_MAX segments; segment j covers input channels
-// [ci0[j], ci0[j] + len[j]) and carries hi(w) (kind 0) or lo(w) = 16-bit(w - hi(w)) (kind 1).  One launch packs every
-// descriptor (after an optimiser step all packs are stale).
+// [ci0[j], ci0[j] + len[j]) and carries hi(w) (kind 0), lo(w) = 16-bit(w - hi(w)) (kind 1) or zeros (kind 2: pads K to the
+// multiple of 64 the conv kernels walk, e.g. the 32-channel second conv of UNet3D).  One launch packs every descriptor (after an
+// optimiser step all packs are stale).
 constexpr int SEGPACK_MAX = 24;
 struct SegPackArgs {
     const float* w[SEGPACK_MAX];
@@ -86,7 +68,8 @@ __global__ __launch_bounds__(256) void pack_segs_kernel(const SegPackArgs a) {
                 for (int t = 0; t < taps; ++t) {
                     const float v = src[t];
                     const unsigned short hi = Elem<DT>::from_f(v);
-                    out[((int64_t)t * Cout + co) * K + k] = a.kind[d][j] ? Elem<DT>::from_f(v - Elem<DT>::to_f(hi)) : hi;
+                    const int kd = a.kind[d][j];
+                    out[((int64_t)t * Cout + co) * K + k] = kd == 0 ? hi : (kd == 1 ? Elem<DT>::from_f(v - Elem<DT>::to_f(hi)) : (unsigned short)0);
                 }
             }
             koff += ln;
@@ -388,7 +371,7 @@ extern "C" int gs_pack_weight_segs(int n, const GsSegPackDesc* descs, int dtype,
                          "gs_pack_weight_segs: descriptor %d: bad arguments", base + i);
             int K = 0;
             for (int j = 0; j < d.nseg; ++j) {
-                GS_CHECK_ARG((d.kind[j] == 0 || d.kind[j] == 1) && d.ci0[j] >= 0 && d.len[j] > 0 && d.ci0[j] + d.len[j] <= d.Cin,
+                GS_CHECK_ARG((d.kind[j] >= 0 && d.kind[j] <= 2) && d.ci0[j] >= 0 && d.len[j] > 0 && d.ci0[j] + d.len[j] <= d.Cin,
                              "gs_pack_weight_segs: descriptor %d segment %d out of range", base + i, j);
                 a.kind[i][j] = d.kind[j]; a.ci0[i][j] = d.ci0[j]; a.len[i][j] = d.len[j];
                 K += d.len[j];

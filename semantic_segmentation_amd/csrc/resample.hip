@@ -44,6 +44,42 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const UpArgs a) {
     }
 }
 
+// Forward on hi/lo pairs (the pair forward of the bilinear U-Net): the interpolation of the pair VALUES, stored as a pair again
+// (x_lo / y_lo: the lo planes, same strides and offsets as the hi planes; y_lo may be NULL when no consumer reads it).
+template <int DT>
+__global__ __launch_bounds__(256) void upsample2x_fwd_pair_kernel(const UpArgs a, const unsigned short* __restrict__ x_lo,
+                                                                  unsigned short* __restrict__ y_lo) {
+    const int nch = a.C >> 3;
+    const int total = a.N * a.OH * a.OW * nch;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int ch = idx % nch;
+        int p = idx / nch;
+        const int ox = p % a.OW; p /= a.OW;
+        const int oy = p % a.OH;
+        const int n = p / a.OH;
+        const float sy = oy * a.ry, sx = ox * a.rx;
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < a.IH - 1), x1 = x0 + (x0 < a.IW - 1);
+        const float ly = sy - y0, lx = sx - x0;
+        const int64_t boff = (int64_t)n * a.IH * a.IW * a.xs + a.xc + ch * 8;
+        const int64_t o00 = boff + (int64_t)(y0 * a.IW + x0) * a.xs, o01 = boff + (int64_t)(y0 * a.IW + x1) * a.xs;
+        const int64_t o10 = boff + (int64_t)(y1 * a.IW + x0) * a.xs, o11 = boff + (int64_t)(y1 * a.IW + x1) * a.xs;
+        float v00[8], v01[8], v10[8], v11[8], o[8];
+        join8<DT>(*reinterpret_cast<const uint4*>(a.x + o00), *reinterpret_cast<const uint4*>(x_lo + o00), v00);
+        join8<DT>(*reinterpret_cast<const uint4*>(a.x + o01), *reinterpret_cast<const uint4*>(x_lo + o01), v01);
+        join8<DT>(*reinterpret_cast<const uint4*>(a.x + o10), *reinterpret_cast<const uint4*>(x_lo + o10), v10);
+        join8<DT>(*reinterpret_cast<const uint4*>(a.x + o11), *reinterpret_cast<const uint4*>(x_lo + o11), v11);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            o[i] = (1.f - ly) * ((1.f - lx) * v00[i] + lx * v01[i]) + ly * ((1.f - lx) * v10[i] + lx * v11[i]);
+        const int64_t pix = ((int64_t)n * a.PH + oy + a.oy0) * a.PW + ox + a.ox0;
+        uint4 hi, lo;
+        split8<DT>(o, hi, lo);
+        *reinterpret_cast<uint4*>(a.y + pix * a.ys + a.yc + ch * 8) = hi;
+        if (y_lo) *reinterpret_cast<uint4*>(y_lo + pix * a.ys + a.yc + ch * 8) = lo;
+    }
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const UpArgs a) {
     const int nch = a.C >> 3;
@@ -128,6 +164,25 @@ extern "C" int gs_upsample2x_bilinear_fwd(const void* x, void* y, int N, int IH,
     if (dtype == GS_F16) upsample2x_fwd_kernel<GS_F16><<<g, 256, 0, (hipStream_t)stream>>>(a);
     else upsample2x_fwd_kernel<GS_BF16><<<g, 256, 0, (hipStream_t)stream>>>(a);
     GS_CHECK_LAUNCH("gs_upsample2x_bilinear_fwd");
+    return GS_OK;
+}
+
+// the same interpolation on a hi/lo pair: x_hi / x_lo share (in_pix_stride, in_coff), y_hi / y_lo share (out_pix_stride,
+// out_coff); y_lo may be NULL (no consumer reads the lo plane)
+extern "C" int gs_upsample2x_bilinear_fwd_pair(const void* x_hi, const void* x_lo, void* y_hi, void* y_lo, int N, int IH, int IW,
+                                               int C, int in_pix_stride, int in_coff, int OH, int OW, int out_pix_stride,
+                                               int out_coff, int ooy, int oox, int dtype, void* stream) {
+    int rc = check_up("gs_upsample2x_bilinear_fwd_pair", x_hi, y_hi, N, IH, IW, C, in_pix_stride, in_coff, OH, OW, out_pix_stride,
+                      out_coff, ooy, oox, dtype);
+    if (rc) return rc;
+    GS_CHECK_ARG(x_lo != nullptr, "gs_upsample2x_bilinear_fwd_pair: x_lo is NULL");
+    UpArgs a = make_args(N, IH, IW, C, OH, OW, ooy, oox);
+    a.x = (const unsigned short*)x_hi; a.y = (unsigned short*)y_hi;
+    a.xs = in_pix_stride; a.xc = in_coff; a.ys = out_pix_stride; a.yc = out_coff;
+    const int g = grid_for((int64_t)N * a.OH * a.OW * (C / 8));
+    if (dtype == GS_F16) upsample2x_fwd_pair_kernel<GS_F16><<<g, 256, 0, (hipStream_t)stream>>>(a, (const unsigned short*)x_lo, (unsigned short*)y_lo);
+    else upsample2x_fwd_pair_kernel<GS_BF16><<<g, 256, 0, (hipStream_t)stream>>>(a, (const unsigned short*)x_lo, (unsigned short*)y_lo);
+    GS_CHECK_LAUNCH("gs_upsample2x_bilinear_fwd_pair");
     return GS_OK;
 }
 

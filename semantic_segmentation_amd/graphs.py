@@ -49,7 +49,7 @@ def capture_step(step: Callable[[], Any], *, prepare: Optional[Callable[[], None
             step()
         if prepare is not None:
             prepare()
-        keep = (ops._splitk_workspace(torch.device("cuda", torch.cuda.current_device()), side.cuda_stream),)   # the LRU must not free it
+        keep = (ops.splitk_workspace_for_capture(),)      # created eagerly on the capture stream and pinned: the graph bakes its pointer in
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, pool=pool, stream=side):
             result = step()

@@ -71,8 +71,11 @@ class EndToEndTrainer:
                 eng = getattr(m.module, "engine", None)
             if eng is not None and hasattr(eng, "trust_versions"):
                 eng.trust_versions = True
-            if eng is not None and hasattr(eng, "accumulate_grads") and not data_parallel:
-                eng.accumulate_grads = True          # the Unet problem sums two backward passes of the net
+        # the Unet problem sums two backward passes of the net: the second adds its gradients into `.grad` with ONE foreach launch
+        # (unet_engine.accumulate_grads) -- switched on only around that problem's own forward + backward (_problem), because a
+        # backward in that mode hands autograd `None` for gradients it has already accumulated (torch.autograd.grad, hooks and
+        # retain_graph double use would miss them)
+        self._accumulate_in_place = not data_parallel
         self._train_iter, self._val_iter = _cycle(train_loader), _cycle(val_loader)
         # HIP graphs (hip_graphs=True): at the script's batch size (2) an iteration is ~1,300 kernel launches of 2-100 us and the
         # Python / ctypes launch path (~16 us per launch) is what bounds it, not the GPU (tools/probe_graph_step.py: 105 -> 160
@@ -146,6 +149,18 @@ class EndToEndTrainer:
                 loss.backward()
             return loss.detach()
 
+        inner_run = run
+        u_eng = getattr(self.net, "engine", None) if (name == "U" and self._accumulate_in_place) else None
+
+        def run():
+            if u_eng is None or not hasattr(u_eng, "accumulate_grads"):
+                return inner_run()
+            u_eng.accumulate_grads = True
+            try:
+                return inner_run()
+            finally:
+                u_eng.accumulate_grads = False
+
         if not self.hip_graphs or self.global_step < self.graph_warmup:
             optimizer.zero_grad(set_to_none=True)
             return run()
@@ -166,7 +181,7 @@ class EndToEndTrainer:
             eng = getattr(self.net, "engine", None)
             if eng is not None and hasattr(eng, "invalidate_packs"):
                 eng.invalidate_packs()
-            self._gkeep.append(ops._splitk_workspace(self.device, torch.cuda.current_stream().cuda_stream))   # pinned: the LRU must not free it
+            self._gkeep.append(ops.splitk_workspace_for_capture(self.device))      # exists before the capture and is never evicted
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, pool=self._gpool, stream=self._gstream):
                 loss = run()
@@ -238,6 +253,15 @@ class EndToEndTrainer:
             self._exchange(networks.arch_parameters())
             if any(a.grad is not None for a in networks.arch_parameters()):
                 self.optimizer_arch.step()
+                if self.hip_graphs and self._graphs:
+                    # The Generator graph READS the merged forward packs that the Discriminator graph writes (captured one
+                    # iteration apart, see _problem); this eager update of the arch tensor falls between that writer's last replay
+                    # and the Generator graph's next one, whose in-graph softmax / data-gradient packs / gradient split already use
+                    # the NEW arch: bring the captured forward packs up to date in place (forward and backward of the
+                    # G problem disagreed whenever (graph_warmup + 1) % unroll_steps != 0)
+                    eng = getattr(self.netG, "engine", None)
+                    if eng is not None and hasattr(eng, "refresh_arch_packs"):
+                        eng.refresh_arch_packs(networks.upconv_arch)
             for p in list(self.net.parameters()) + list(self.netG.parameters()):
                 p.grad = None
             out["loss_arch"] = loss_a.detach()

@@ -123,18 +123,40 @@ class _PackCache:
 
     def __init__(self):
         self._d = {}
+        self._captured = []          # (key, tensor, refill) of every entry built during a stream capture: graphs hold their pointers
 
-    def get(self, key, versions, build):
+    def get(self, key, versions, build, refill=None):
+        """refill(val): re-runs the build INTO the existing tensor `val` (kept for captured entries: refresh() below)"""
         capturing = torch.cuda.is_current_stream_capturing()
         ent = self._d.get(key)
         if ent is not None and ent[0] == versions and (ent[2] or not capturing):
             return ent[1]
         val = build()
         self._d[key] = (versions, val, capturing)
+        if capturing and refill is not None:
+            self._captured.append((key, val, refill))
         return val
 
+    def refresh(self, match, versions_of):
+        """Re-fill, in place, EVERY captured tensor whose key satisfies match(key).  A captured pack is written only by replays of
+        the graph that built it; a graph captured LATER that merely reads it (harness: the Generator graph reads the forward packs
+        the Discriminator graph merges) sees stale contents when an eager update of an input (the arch step) falls between that
+        writer's replay and its own -- the eager code that made the update calls this to bring the buffers up to date.  It does not
+        go by the cache entries (an eager forward in between may have replaced them): every buffer a graph may read is re-filled.
+        versions_of(key) -> the current version tuple, stamped on the cache entry that still points at a re-filled tensor."""
+        n = 0
+        for key, val, refill in self._captured:
+            if not match(key):
+                continue
+            refill(val)
+            ent = self._d.get(key)
+            if ent is not None and ent[1] is val:
+                self._d[key] = (versions_of(key), val, ent[2])
+            n += 1
+        return n
+
     def clear(self):
-        self._d.clear()
+        self._d.clear()              # (the captured tensors stay registered: graphs that read them may still be replayed)
 
 
 _NOCACHE = [0]
@@ -166,6 +188,7 @@ class GeneratorEngine(_ParamIndex):
         self.net = net
         self.dtype, self.tdt = _dtype_of(dtype)
         self.packs = _PackCache()
+        self._layer_of, self._merge_inputs = {}, {}      # per block depth: arch row / the three kernels of its merged pack
         self.trust_versions = False      # see unet_engine.pack_reuse_allowed
         self.grad_ready_hook = self.after_backward = self.grad_fetch = None      # parallel.GradReducer.attach
 
@@ -288,7 +311,7 @@ class GeneratorEngine(_ParamIndex):
             w4, w6, w8 = (cell._ops._ops[j].op.weight for j in range(3))
             sm = sm_all[li]
             cpad = cout_t if cout_t % 8 == 0 else ((cout_t + 7) // 8) * 8
-            pf = self._merge_pack(d, w4, w6, w8, sm, cin_t, cout_t, cpad, dgrad=False, arch=arch)
+            pf = self._merge_pack(d, w4, w6, w8, sm, cin_t, cout_t, cpad, dgrad=False, arch=arch, li=li)
             h, w = hs[d + 1], ws[d + 1]
             H2, W2 = 2 * h, 2 * w
             bias = None
@@ -348,14 +371,33 @@ class GeneratorEngine(_ParamIndex):
         ops.pack_weight(w.detach().contiguous(), wf, wd, False)
         return wf, wd
 
-    def _merge_pack(self, d, w4, w6, w8, sm, cin_t, cout_t, cpad, dgrad, arch=None):
+    def refresh_arch_packs(self, arch):
+        """After an EAGER update of the architecture tensor while hipGraphs hold merged forward packs (harness.EndToEndTrainer):
+        re-merge, in place, the captured packs whose version key no longer matches (see _PackCache.refresh)."""
+        def versions_of(key):
+            w4, w6, w8 = self._merge_inputs[key[1:]]
+            return _ver(w4, w6, w8, arch)
+        # (forward packs only: a graph that needs the data-gradient packs merges them itself)
+        return self.packs.refresh(lambda k: k[0] == "merged" and not k[2] and k[1:] in self._merge_inputs, versions_of)
+
+    def _merge_pack(self, d, w4, w6, w8, sm, cin_t, cout_t, cpad, dgrad, arch=None, li=None, out=None):
         """class-major forward pack [4][16][cpad][cin] (or dgrad pack [64][cin][cpad]) of the merged kernel.  Cached per
         (weights, architecture parameters) version: in the end-to-end loop the generator runs three times per iteration
         (Generator, Discriminator and Unet steps) between two updates of its weights, and re-merging reads all 1.09 GB
         of fp32 kernels each time."""
         if arch is not None:
+            if li is None:
+                li = self._layer_of.get(d)
+            else:
+                self._layer_of[d] = li
+            self._merge_inputs[(d, dgrad, cpad)] = (w4, w6, w8)
+
+            def refill(out, li=li):
+                sm_now = torch.softmax(arch.detach().float(), dim=-1)[li].contiguous()
+                self._merge_pack(d, w4, w6, w8, sm_now, cin_t, cout_t, cpad, dgrad, out=out)
             return self.packs.get(("merged", d, dgrad, cpad), _ver(w4, w6, w8, arch),
-                                  lambda: self._merge_pack(d, w4, w6, w8, sm, cin_t, cout_t, cpad, dgrad))
+                                  lambda: self._merge_pack(d, w4, w6, w8, sm, cin_t, cout_t, cpad, dgrad),
+                                  refill if li is not None else None)
         dev = w8.device
         if cpad == cout_t:
             w4p, w6p, w8p = w4.detach().contiguous(), w6.detach().contiguous(), w8.detach().contiguous()
@@ -366,10 +408,10 @@ class GeneratorEngine(_ParamIndex):
                 return z
             w4p, w6p, w8p = pad(w4), pad(w6), pad(w8)
         if dgrad:
-            pd = torch.empty((64, cin_t, cpad), dtype=self.tdt, device=dev)
+            pd = torch.empty((64, cin_t, cpad), dtype=self.tdt, device=dev) if out is None else out
             ops.upconv_merge_pack(w4p, w6p, w8p, sm, None, pd, None)
             return pd
-        pf = torch.empty((4, 16, cpad, cin_t), dtype=self.tdt, device=dev)
+        pf = torch.empty((4, 16, cpad, cin_t), dtype=self.tdt, device=dev) if out is None else out
         ops.upconv_merge_pack(w4p, w6p, w8p, sm, pf, None, None)
         return pf
 

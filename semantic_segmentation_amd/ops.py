@@ -151,6 +151,14 @@ def _geom_flops(g: GsConvGeom) -> float:
     return 2.0 * g.N * g.Dg * g.OHg * g.OWg * g.Cout * g.ntaps * g.Cin
 
 
+def _geom_bytes(g: GsConvGeom, wgrad: bool = False) -> float:
+    """algorithmic HBM bytes of one implicit-GEMM launch: the input tensor once, the output once, the weights once (fp32 for a
+    weight gradient)"""
+    inp = 2.0 * g.N * g.Din * g.IH * g.IW * g.Cin
+    out = 2.0 * g.N * g.Dg * g.OHg * g.OWg * g.Cout
+    return inp + out + (4.0 if wgrad else 2.0) * g.ntaps * g.Cin * g.Cout
+
+
 def geom_convT_class(N, IH, IW, Cin, Cout, k, pad, py, px, OH=None, OW=None, **kw) -> GsConvGeom:
     """Sub-pixel class (py,px) of ConvTranspose2d(k, stride 2, pad): output pixels (2i+py, 2j+px) <- input
     (i+dy, j+dx) for the taps with ky == py+pad (mod 2); weight slots index a [k*k][Cout][Cin] pack."""
@@ -179,26 +187,49 @@ def geom_conv_s2_dgrad_class(N, IH, IW, Cin, Cout, k, pad, py, px, **kw) -> GsCo
 # ---------------------------------------------------------------------------- MFMA engine
 _SPLITK_WS = collections.OrderedDict()      # (device index, stream handle) -> zeroed fp32 workspace, least recently used first
 _SPLITK_WS_MAX = int(os.environ.get("GSSEG_SPLITK_WS_MAX", "3"))
+_SPLITK_PINNED = set()                      # keys baked into a captured graph: never evicted
 
 
 def _splitk_workspace(device: torch.device, stream) -> Optional[torch.Tensor]:
     """gs_conv_igemm's split-K workspace (134 MB), passed with every call: one per (device, stream), because launches that
     share one must be ordered on one stream (ticket counters and slabs are reused); allocated zeroed once, the kernels
-    leave the counters zeroed.  At most GSSEG_SPLITK_WS_MAX (3) are kept: a process that runs the engine on many streams
-    (or whose stream handles torch recycles) evicts the least recently used one -- it was allocated and used on its own
-    stream only, so handing it back to torch's stream-ordered allocator is safe -- instead of pinning 134 MB per handle."""
+    leave the counters zeroed.  At most GSSEG_SPLITK_WS_MAX (3) un-pinned ones are kept: a process that runs the engine on many
+    streams (or whose stream handles torch recycles) evicts the least recently used one -- it was allocated and used on its own
+    stream only, so handing it back to torch's stream-ordered allocator is safe -- instead of pinning 134 MB per handle.
+    Stream capture: a workspace handed to a capturing stream is baked into the graph, so it is PINNED (never evicted) from
+    then on, and it must exist BEFORE the capture starts (allocating it here would put the buffer into the graph's pool and its
+    zero fill into the graph, while this cache would go on handing the pointer to eager code): graphs.capture_step and
+    harness.EndToEndTrainer create it first; anything else that captures engine code calls ops.splitk_workspace_for_capture()."""
     if os.environ.get("GSSEG_SPLITK", "1") == "0":
         return None
     key = (device.index, int(stream or 0))
+    capturing = torch.cuda.is_current_stream_capturing()
     ws = _SPLITK_WS.get(key)
     if ws is None:
+        if capturing:
+            raise RuntimeError("the split-K workspace of this stream does not exist yet and cannot be created during a stream capture: "
+                               "call semantic_segmentation_amd.ops.splitk_workspace_for_capture() on the capture stream before capturing")
         n = int(_lib.load().gs_conv_igemm_workspace_floats())
         ws = torch.zeros(n, dtype=torch.float32, device=device)     # zero fill runs on this same (current) stream
         _SPLITK_WS[key] = ws
-        while len(_SPLITK_WS) > max(1, _SPLITK_WS_MAX):
-            _SPLITK_WS.popitem(last=False)
+        evictable = [k for k in _SPLITK_WS if k not in _SPLITK_PINNED and k != key]
+        while len(evictable) + 1 > max(1, _SPLITK_WS_MAX) and evictable:
+            _SPLITK_WS.pop(evictable.pop(0))
     else:
         _SPLITK_WS.move_to_end(key)
+    if capturing:
+        _SPLITK_PINNED.add(key)
+    return ws
+
+
+def splitk_workspace_for_capture(device: Optional[torch.device] = None) -> Optional[torch.Tensor]:
+    """Create (eagerly) and pin the split-K workspace of the CURRENT stream: call on the capture stream before a stream capture of
+    engine code (a hipGraph bakes the pointer in; see _splitk_workspace)."""
+    device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    stream = _stream()
+    ws = _splitk_workspace(device, stream)
+    if ws is not None:
+        _SPLITK_PINNED.add((device.index, int(stream or 0)))
     return ws
 
 
@@ -217,7 +248,7 @@ def conv_igemm(g: GsConvGeom, x, w, y, bias=None, bn_partials=None, act=ACT_NONE
     _lib.call("gs_conv_igemm", g, _p(x), _p(w), _p(y), _p(bias), _p(bn_partials), act, dt_code(x), _p(ws),
               ws.numel() if ws is not None else 0, stream)
     if ev is not None:
-        TIMER.stop("igemm_fwd", ev, _geom_flops(g))
+        TIMER.stop("igemm_fwd", ev, _geom_flops(g), _geom_bytes(g))
 
 
 # taps of a 3x3/pad-1 conv in weight order, and the flipped list that turns the same kernel into its dgrad
@@ -246,7 +277,7 @@ def conv_igemm_batch(geoms, x, ws_list, y, bias=None, bn_partials=None, act=ACT_
     _lib.call("gs_conv_igemm_batch", n, garr, _p(x), warr, _p(y), _p(bias), parr, act, dt_code(x), _p(ws),
               ws.numel() if ws is not None else 0, stream)
     if ev is not None:
-        TIMER.stop("igemm_fwd", ev, sum(_geom_flops(g) for g in geoms))
+        TIMER.stop("igemm_fwd", ev, sum(_geom_flops(g) for g in geoms), sum(_geom_bytes(g) for g in geoms))
 
 
 TAPS3_FWD = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
@@ -337,7 +368,8 @@ def upconv2x2_fwd(x, w, bias, y, N, D, IH, IW, Cin, Cout, Dout, OH, OW, in_strid
               Cin if in_stride is None else in_stride, in_coff, Cout, Dout, OH, OW,
               Cout if out_stride is None else out_stride, out_coff, ooz, ooy, oox, act, dt_code(x), _stream())
     if ev is not None:
-        TIMER.stop("igemm_fwd", ev, 2.0 * N * D * IH * IW * Cin * ncls * Cout)
+        TIMER.stop("igemm_fwd", ev, 2.0 * N * D * IH * IW * Cin * ncls * Cout,
+                   2.0 * (N * D * IH * IW * (Cin + ncls * Cout) + ncls * Cin * Cout))
 
 
 def upconv2x2_dgrad(geom, dy, wd, dx, N, IH, IW, Cin, Cout, OH, OW, dy_stride, dy_coff, ooy, oox):
@@ -355,7 +387,8 @@ def upconv2x2_dgrad(geom, dy, wd, dx, N, IH, IW, Cin, Cout, OH, OW, dy_stride, d
     if rc != 0:
         _lib.check(rc, "gs_upconv2x2_dgrad")
     if ev is not None:
-        TIMER.stop("igemm_fwd", ev, 2.0 * N * IH * IW * Cin * 4 * Cout)
+        TIMER.stop("igemm_fwd", ev, 2.0 * N * IH * IW * Cin * 4 * Cout,
+                   2.0 * (N * IH * IW * (Cin + 4 * Cout) + 4 * Cin * Cout))
 
 
 def conv3d3_eligible(Cin, Cout, out_stride=None, out_coff=0) -> bool:
@@ -498,7 +531,7 @@ def conv_wgrad(g: GsConvGeom, x, dy, dw, assign: bool = False):
     ev = TIMER.start() if TIMER is not None else None
     _lib.call("gs_conv_wgrad_assign" if assign else "gs_conv_wgrad", g, _p(x), _p(dy), _p(dw), dt_code(x), _stream())
     if ev is not None:
-        TIMER.stop("igemm_wgrad", ev, _geom_flops(g))
+        TIMER.stop("igemm_wgrad", ev, _geom_flops(g), _geom_bytes(g, True))
 
 
 def conv_wgrad_parts(g: GsConvGeom) -> int:
@@ -524,7 +557,7 @@ def conv_wgrad_det(g: GsConvGeom, x, dy, ws, grad, A, B, taps, gscale, transpose
     ev = TIMER.start() if TIMER is not None else None
     _lib.call("gs_conv_wgrad_slabs", g, _p(x), _p(dy), _p(ws), dt_code(x), _stream())
     if ev is not None:
-        TIMER.stop("igemm_wgrad", ev, _geom_flops(g))
+        TIMER.stop("igemm_wgrad", ev, _geom_flops(g), _geom_bytes(g, True))
     parts = int(_lib.load().gs_conv_wgrad_parts(g))
     _lib.call("gs_wgrad_reduce_unpack", _p(ws), parts, _p(grad), A, B, taps, 1 if transposed else 0, float(gscale), _stream())
 
@@ -550,7 +583,8 @@ def upconv2x2_wgrad_det(geom, x, dy, ws, grad, N, IH, IW, Cin, Cout, OH, OW, x_s
                                           ooy, oox, dt_code(x), _stream())
         if rc == 0:
             if ev is not None:
-                TIMER.stop("igemm_wgrad", ev, 2.0 * N * IH * IW * Cin * 4 * Cout)
+                TIMER.stop("igemm_wgrad", ev, 2.0 * N * IH * IW * Cin * 4 * Cout,
+                           2.0 * N * IH * IW * (Cin + 4 * Cout) + 4.0 * 4 * Cin * Cout)
             _lib.call("gs_wgrad_reduce_unpack", _p(ws), parts, _p(grad), Cin, Cout, 4, 0, float(gscale), _stream())
             return
         if rc != _lib.GS_EUNSUPPORTED:
@@ -584,7 +618,7 @@ def conv_wgrad_det_batch(geoms, x, dy, ws, grad, gscale=1.0, reduce=True):
     ev = TIMER.start() if TIMER is not None else None
     _lib.call("gs_conv_wgrad_slabs_batch", n, garr, _p(x), _p(dy), _p(target), dt_code(x), _stream())
     if ev is not None:
-        TIMER.stop("igemm_wgrad", ev, sum(_geom_flops(g) for g in geoms))
+        TIMER.stop("igemm_wgrad", ev, sum(_geom_flops(g) for g in geoms), sum(_geom_bytes(g, True) for g in geoms))
     if parts > 1 and reduce:
         _lib.call("gs_wgrad_reduce_unpack", _p(ws), parts, _p(grad), n * g0.ntaps * g0.Cout, g0.Cin, 1, 0, float(gscale), _stream())
     elif parts == 1 and gscale != 1.0:
@@ -1173,12 +1207,13 @@ def upconv2x2_fwd_precise(x, w, bias, y_hi, y_lo, N, IH, IW, Cin, Cout, OH, OW, 
               in_coff, 2 * Cin, Cout, OH, OW, Cout if out_stride is None else out_stride, out_coff, ooy, oox,
               dt_code(x), _stream())
     if ev is not None:
-        TIMER.stop("igemm_fwd_precise", ev, 2.0 * N * IH * IW * Cin * 4 * Cout)
+        TIMER.stop("igemm_fwd_precise", ev, 2.0 * N * IH * IW * Cin * 4 * Cout,
+                   2.0 * (N * IH * IW * 2 * (Cin + 4 * Cout) + 4 * K * Cout))
 
 
 def pack_weight_segs(items):
     """Segment packs for the mixed-precision pair forward, all in ONE launch.  items: (w, pack, transposed, segs) with
-    segs = [(kind, ci0, len), ...] (kind 0 = hi(w), 1 = lo(w)); pack = contiguous [taps][Cout][sum len] 16-bit."""
+    segs = [(kind, ci0, len), ...] (kind 0 = hi(w), 1 = lo(w), 2 = zeros); pack = contiguous [taps][Cout][sum len] 16-bit."""
     if not items:
         return
     descs = (_lib.GsSegPackDesc * len(items))()
@@ -1227,6 +1262,44 @@ def conv3x3_segs(x, w, y_hi, y_lo, N, H, W, K, wrap, Cin, Cout, in_stride, in_co
                    2.0 * (N * H * W * 2 * (Cin + Cout) + 9 * K * Cout))
 
 
+def conv3d3_segs(x, w, y_hi, y_lo, NB, D, H, W, K, wrap, Cin, Cout, in_stride, in_coff=0, bn_partials=None):
+    """Conv3d(k3, p1) of the pair forward (UNet3D): conv3x3_segs with depth -- x holds `wrap` channels per voxel ([hi | lo] planes or
+    a part of them), K (a multiple of 64, wrap <= K <= 2*wrap) runs over them and wraps once, w = pack_weight_segs pack
+    [27][Cout][K]; Cin = the layer's channels (FLOP count only).  Result: dense pair y_hi / y_lo [NB*D, H, W, Cout]."""
+    _dev(x)
+    _f32(bn_partials, "bn_partials")
+    if not (x.dtype == w.dtype == y_hi.dtype == y_lo.dtype):
+        raise TypeError("conv3d3_segs: x, w, y must share one 16-bit dtype")
+    if K % 64 != 0 or wrap % 64 != 0 or not (wrap <= K <= 2 * wrap) or w.numel() != 27 * Cout * K:
+        raise ValueError("conv3d3_segs: K / wrap must be multiples of 64 with wrap <= K <= 2*wrap and w the [27][Cout][K] pack")
+    if bn_partials is not None and bn_partials.numel() < bn_partials_numel(conv3x3_stat_rows(NB * D, H, W, K, Cout, pair=True), Cout):
+        raise ValueError("conv3d3_segs: bn_partials too small (conv3x3_stat_rows(NB*D, H, W, K, Cout, pair=True) rows)")
+    dz = (ctypes.c_int32 * 3)(*[k - 1 for k in range(3)])
+    dy = (ctypes.c_int32 * 9)(*[k // 3 - 1 for k in range(9)])
+    dx = (ctypes.c_int32 * 9)(*[k % 3 - 1 for k in range(9)])
+    ev = TIMER.start() if TIMER is not None else None
+    _lib.call("gs_conv3d_3x3x3_precise", _p(x), _p(w), _p(y_hi), _p(y_lo), None, _p(bn_partials), NB, D, H, W, K, in_stride,
+              in_coff, wrap, Cout, Cout, 0, dz, dy, dx, ACT_NONE, dt_code(x), _stream())
+    if ev is not None:
+        TIMER.stop("conv3x3_halo_precise", ev, 2.0 * NB * D * H * W * Cout * 27 * Cin,
+                   2.0 * (NB * D * H * W * 2 * (Cin + Cout) + 27 * K * Cout))
+
+
+def maxpool3d_fwd_pair(z_hi, z_lo, z_stride, zp_hi, zp_lo, zp_stride, NB, D, H, W, C):
+    """MaxPool3d(2) on a pair: z_hi / z_lo are views whose first element is the first channel of the plane (pixel stride z_stride);
+    zp_hi / zp_lo (None: not stored) likewise with zp_stride."""
+    _lib.call("gs_maxpool3d_fwd_pair", _p(z_hi), _p(z_lo), z_stride, _p(zp_hi), _p(zp_lo), zp_stride, NB, D, H, W, C,
+              dt_code(z_hi), _stream())
+
+
+def upsample2x_bilinear_fwd_pair(x_hi, x_lo, y_hi, y_lo, N, IH, IW, C, OH, OW, in_stride, out_stride, out_coff=0, ooy=0, oox=0):
+    """bilinear x2 (align_corners=True) of a pair: views x_hi / x_lo (pixel stride in_stride) -> y_hi / y_lo (None: not stored;
+    pixel stride out_stride, channel offset out_coff inside the [N,OH,OW,*] buffers, pad offset (ooy, oox))."""
+    _dev(x_hi)
+    _lib.call("gs_upsample2x_bilinear_fwd_pair", _p(x_hi), _p(x_lo), _p(y_hi), _p(y_lo), N, IH, IW, C, in_stride, 0, OH, OW,
+              out_stride, out_coff, ooy, oox, dt_code(x_hi), _stream())
+
+
 def upconv2x2_fwd_segs(x, w, bias, y_hi, y_lo, N, IH, IW, K, wrap, Cin, Cout, OH, OW, in_stride, in_coff=0, out_stride=None,
                        out_coff=0, ooy=0, oox=0):
     """ConvTranspose2d(k 2, s 2) of the pair forward with a free choice of segments (see conv3x3_segs); w = [4][Cout][K]."""
@@ -1241,7 +1314,8 @@ def upconv2x2_fwd_segs(x, w, bias, y_hi, y_lo, N, IH, IW, K, wrap, Cin, Cout, OH
               in_coff, wrap, Cout, OH, OW, Cout if out_stride is None else out_stride, out_coff, ooy, oox,
               dt_code(x), _stream())
     if ev is not None:
-        TIMER.stop("igemm_fwd_precise", ev, 2.0 * N * IH * IW * Cin * 4 * Cout)
+        TIMER.stop("igemm_fwd_precise", ev, 2.0 * N * IH * IW * Cin * 4 * Cout,
+                   2.0 * (N * IH * IW * 2 * (Cin + 4 * Cout) + 4 * K * Cout))
 
 
 def conv_smallcin_fwd_split(x, w, y_hi, y_lo, bn_partials, k, pad):

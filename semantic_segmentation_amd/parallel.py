@@ -67,6 +67,7 @@ class GradReducer:
         items = [(n, p) for n, p in named_params if p.requires_grad][::-1]
         if not items:
             raise ValueError("no trainable parameters")
+        self._params = dict(items)
         dev = items[0][1].device
         total = sum(p.numel() for _, p in items)
         self.flat = torch.zeros(total, dtype=dtype, device=dev)
@@ -88,6 +89,8 @@ class GradReducer:
         self.average = average
         self._works: list = []
         self._pending: List[int] = []
+        self._live: List[int] = []          # per bucket: gradients of still-trainable parameters announced in this backward
+        self.issued = 0                     # all-reduces issued by the last backward (tests read it before finish())
 
     def _close(self, a, b, names):
         idx = len(self.buckets)
@@ -99,6 +102,8 @@ class GradReducer:
     def begin(self):
         self._works = []
         self._pending = [len(b["names"]) for b in self.buckets]
+        self._live = [0] * len(self.buckets)
+        self.issued = 0
 
     def alloc(self, name: str, like: torch.Tensor) -> torch.Tensor:
         return self.views[name]
@@ -106,21 +111,37 @@ class GradReducer:
     def ready(self, name: str, grad: torch.Tensor):
         if not self._pending:
             self.begin()
-        b = self.bucket_of[name]
-        if grad.data_ptr() != self.views[name].data_ptr():
-            self.views[name].copy_(grad)
+        b = self.bucket_of.get(name)
+        if b is None:                        # not trainable when the reducer was built: nothing to exchange
+            return
+        if self._params[name].requires_grad:
+            if grad.data_ptr() != self.views[name].data_ptr():
+                self.views[name].copy_(grad)
+            self._live[b] += 1
+        # (a parameter frozen since -- the discriminator inside the Generator problem -- still counts as announced, but a bucket
+        # made of frozen parameters only is not exchanged: its result would be discarded.  Freezing must match across ranks.)
         self._pending[b] -= 1
-        if self._pending[b] == 0 and self.collective:
+        if self._pending[b] < 0:
+            raise RuntimeError(f"GradReducer: gradient '{name}' announced more often than its bucket expects (a parameter used "
+                               "twice must be announced once, after its last contribution: parallel.GradEmitter)")
+        if self._pending[b] == 0 and self._live[b] > 0 and self.collective:
             a, e = self.buckets[b]["range"]
             self._works.append(dist.all_reduce(self.flat[a:e], op=self.op, group=self.group, async_op=True))
+            self.issued += 1
 
     def finish(self):
         for w in self._works:
             w.wait()
+        missing = [n for i, b in enumerate(self.buckets) if self._pending and self._pending[i] != 0 for n in b["names"]]
+        self._works = []
+        pending_any = bool(self._pending)
+        self._pending = []
+        if pending_any and missing:
+            # a bucket whose gradients were not all announced was never reduced: fetch() would hand back LOCAL gradients
+            raise RuntimeError("GradReducer.finish: %d bucket(s) incomplete -- some of their gradients were never announced "
+                               "(first names: %s)" % (len({self.bucket_of[n] for n in missing}), ", ".join(missing[:4])))
         if self.world > 1 and self.average and self.op == dist.ReduceOp.SUM:
             self.flat.mul_(1.0 / self.world)
-        self._works = []
-        self._pending = []
 
     def fetch(self, name: str) -> torch.Tensor:
         """the reduced gradient as a fresh fp32 tensor (the bucket is overwritten by the next backward)"""

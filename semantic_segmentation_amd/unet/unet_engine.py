@@ -115,15 +115,18 @@ _SEG_MODES = ("1", "x", "w", "xw")
 MIXED_XW = ("inc.3", "down1.0", "down1.3", "down2.0", "down2.3", "up3.conv.0", "up3.conv.3", "up4.conv.0", "up4.conv.3")
 
 
-def resolve_plan(precise, dtype: str):
-    """precise: False / None -> None (default engine); True -> every stage "xw"; "mixed" -> MIXED_XW (bf16: every stage);
-    a dict {stage: mode} -> that plan (missing stages "1")."""
+def resolve_plan(precise, dtype: str, bilinear: bool = False):
+    """precise: False / None -> None (default engine); True -> every stage "xw"; "mixed" / "auto" -> MIXED_XW (bf16 and the
+    bilinear=True net: every stage); a dict {stage: mode} -> that plan (missing stages "1").
+    bilinear=True (unet_parts.py:49-50: half the decoder channels, four interpolations): every conv stage contributes 5e-4 ..
+    5e-3 on its own when run on 16-bit inputs (tools/parity_fp8_sim.py --bilinear; the nine MIXED_XW stages alone leave 1.9e-3
+    measured / 2.5e-3 simulated), so "mixed" keeps the correction segments on all of them: 2e-5 measured."""
     if precise is None or precise is False or precise == 0 or precise == "0" or precise == "":
         return None
     if precise is True or precise == 1 or precise == "1" or precise == "full":
         return {s_: "xw" for s_ in STAGES}
-    if precise == "mixed":
-        if dtype != "f16":
+    if precise == "mixed" or precise == "auto":
+        if dtype != "f16" or bilinear:
             return {s_: "xw" for s_ in STAGES}
         return {s_: ("xw" if s_ in MIXED_XW else "1") for s_ in STAGES}
     if isinstance(precise, dict):
@@ -131,7 +134,7 @@ def resolve_plan(precise, dtype: str):
         if bad:
             raise ValueError(f"precise plan: unknown stages / modes {bad}")
         return {s_: precise.get(s_, "1") for s_ in STAGES}
-    raise ValueError("precise must be False, True, 'mixed' or a {stage: mode} dict")
+    raise ValueError("precise must be False, True, 'mixed', 'auto' or a {stage: mode} dict")
 
 
 def _segs(mode: str, cin: int, lo_len=None):
@@ -158,8 +161,11 @@ class UNetEngine:
         self.dtype = dtype
         # precise forward (module docstring of forward_precise): activations / weights as hi+lo pairs of 16-bit values,
         # logits within ~1e-5 of the fp32 reference instead of ~4e-3; the backward pass is unchanged (it reads the hi halves)
-        self.plan = resolve_plan(precise, dtype)          # None: the default single 16-bit engine
+        self.plan = resolve_plan(precise, dtype, bool(getattr(net, "bilinear", False)))      # None: the default single 16-bit engine
         self.precise = self.plan is not None
+        # "auto" (what UNet() builds): the mixed pair forward wherever it is implemented, the 16-bit engine elsewhere (an
+        # explicit "mixed" / True raises there instead)
+        self.auto = precise == "auto"
         self.dynamic_loss_scale = os.environ.get("GSSEG_DYNAMIC_LOSS_SCALE", "0") == "1"
         self.tdt = _TORCH_DT[dtype]
         self._packs: Dict[str, tuple] = {}
@@ -309,9 +315,11 @@ class UNetEngine:
         if H < 16 or W < 16:
             raise ValueError("input must be at least 16x16 (four 2x2 poolings)")
         if self.precise:
-            if net.n_channels > 4 or net.n_classes > 4:
-                raise NotImplementedError("the pair forward supports n_channels / n_classes up to 4 (the direct end kernels)")
-            return self.forward_precise(x, params, training, need_grad)
+            covered = net.n_channels <= 4 and net.n_classes <= 4 and ops.USE_HALO_CONV
+            if covered or not self.auto:
+                if net.n_channels > 4 or net.n_classes > 4:
+                    raise NotImplementedError("the pair forward supports n_channels / n_classes up to 4 (the direct end kernels)")
+                return self.forward_precise(x, params, training, need_grad)
         dev, tdt = x.device, self.tdt
         x = x.contiguous().float()
         bufs = self.buffer_dict()
@@ -562,7 +570,7 @@ class UNetEngine:
             if not full:
                 if transposed and mode == "1":
                     continue                               # runs on the default LDS-DMA GEMM with the ordinary pack
-                if st.endswith(".conv.0") and self.plan[st[:-len(".conv.0")] + ".up"] == "1":
+                if st.endswith(".conv.0") and self.plan[st[:-len(".conv.0")] + ".up"] == "1" and not self.net.bilinear:
                     lo_len = cin // 2                      # the up half of the concat buffer carries no lo plane
             key = (_pack_key(w), mode, lo_len)
             ent = self._packs.get(wkey + "|segs")
@@ -598,8 +606,7 @@ class UNetEngine:
         The backward pass is the default one: it reads the hi halves (exactly what the default mode stores) through
         strides, so gradients have the default mode's accuracy."""
         net = self.net
-        if net.bilinear:
-            raise NotImplementedError("precise mode is implemented for the transposed-convolution U-Net (bilinear=False)")
+        bilinear = bool(net.bilinear)
         if not ops.USE_HALO_CONV:
             raise RuntimeError("precise mode needs the halo-reuse conv kernel (GSSEG_CONV3X3=halo)")
         N, _, H, W = x.shape
@@ -609,7 +616,7 @@ class UNetEngine:
         nbt_pending = []
         hs = [H >> i for i in range(5)]
         ws_ = [W >> i for i in range(5)]
-        C = [64, 128, 256, 512, 1024]
+        C = [64, 128, 256, 512, 1024 // (2 if bilinear else 1)]      # unet_model.py:18-19
         plan = self.plan
         full = all(v == "xw" for v in plan.values())
         if not pack_reuse_allowed(need_grad, self.trust_versions):
@@ -725,7 +732,7 @@ class UNetEngine:
                 inp, cin = pooled, C[i]
             else:
                 x5 = empty(N, h, w, 2 * C[i])
-                stage(prefix, 3, zmid, C[i], C[i], h, w, x5, 2 * C[i], reads_lo("up1.up"))
+                stage(prefix, 3, zmid, C[i], C[i], h, w, x5, 2 * C[i], reads_lo("up1.up") or bilinear)   # (the pair up-sampling reads both planes)
                 inp = x5
 
         # ---- decoder ----
@@ -733,7 +740,8 @@ class UNetEngine:
         for j in range(1, 5):
             lvl = 4 - j
             prefix = f"up{j}"
-            cout_t, cin_t = C[lvl], 2 * C[lvl]
+            cout_t = C[lvl]                                           # skip channels == up-sampled channels
+            cin_t = inp.shape[3] // 2                                 # decoder input: 2*cout_t (convT) / cout_t (bilinear)
             h, w = hs[lvl + 1], ws_[lvl + 1]
             H2, W2 = hs[lvl], ws_[lvl]
             pt, pl = (H2 - 2 * h) // 2, (W2 - 2 * w) // 2
@@ -741,7 +749,15 @@ class UNetEngine:
             wkey = prefix + ".up.weight"
             up_mode = plan[prefix + ".up"]
             up_lo_valid = True
-            if up_mode == "1" and not full:
+            if bilinear:
+                # nn.Upsample(scale_factor=2, bilinear, align_corners=True) of the PAIR (unet_parts.py:49-50), straight into the up
+                # half of both planes of the concat buffer; the lo plane only when the consumer runs an x_lo segment
+                want = reads_lo(prefix + ".conv.0")
+                ops.upsample2x_bilinear_fwd_pair(inp, inp[..., cin_t:], cat, cat[..., 2 * cout_t:] if want else None, N, h, w,
+                                                 cin_t, H2, W2, in_stride=2 * cin_t, out_stride=4 * cout_t, out_coff=cout_t,
+                                                 ooy=pt, oox=pl)
+                up_lo_valid = want
+            elif up_mode == "1" and not full:
                 # x_hi . w_hi on the LDS-DMA pointwise GEMM, hi plane only: the consumer's x_lo segment skips the up half
                 wf, _ = self._packed(wkey, params[wkey], True, need_grad)
                 ops.upconv2x2_fwd(inp, wf, params[prefix + ".up.bias"].detach(), cat, N, 1, h, w, cin_t, cout_t, 1, H2, W2,
@@ -755,33 +771,38 @@ class UNetEngine:
             if need_grad:
                 u = _UpRec()
                 u.name, u.zin, u.cat = prefix, inp, cat
-                u.wd = self._packed(wkey, params[wkey], True, True)[1]
                 u.cin, u.cout, u.h, u.w, u.H2, u.W2, u.pt, u.pl = cin_t, cout_t, h, w, H2, W2, pt, pl
-                taps = [(py + pt, px + pl) for py in range(2) for px in range(2)]
-                # the transposed conv seen from its output side (dU -> dx); dU is the up half of the DENSE gradient of the
-                # concat input, x the hi plane of the pair buffer (pixel stride 2*cin_t) for the weight gradient
-                u.geom_bwd = ops.make_geom(N, H2, W2, cout_t, h, w, cin_t, h, w, taps, isy=2, isx=2,
-                                           in_stride=2 * cout_t, in_coff=cout_t)
-                u.geom_wg = ops.make_geom(N, H2, W2, cout_t, h, w, cin_t, h, w, taps, isy=2, isx=2,
-                                          in_stride=2 * cout_t, in_coff=cout_t, out_stride=2 * cin_t)
+                u.wd = u.geom_bwd = u.geom_wg = None
+                if not bilinear:
+                    u.wd = self._packed(wkey, params[wkey], True, True)[1]
+                    taps = [(py + pt, px + pl) for py in range(2) for px in range(2)]
+                    # the transposed conv seen from its output side (dU -> dx); dU is the up half of the DENSE gradient of the
+                    # concat input, x the hi plane of the pair buffer (pixel stride 2*cin_t) for the weight gradient
+                    u.geom_bwd = ops.make_geom(N, H2, W2, cout_t, h, w, cin_t, h, w, taps, isy=2, isx=2,
+                                               in_stride=2 * cout_t, in_coff=cout_t)
+                    u.geom_wg = ops.make_geom(N, H2, W2, cout_t, h, w, cin_t, h, w, taps, isy=2, isx=2,
+                                              in_stride=2 * cout_t, in_coff=cout_t, out_stride=2 * cin_t)
                 ups.append(u)
-            zmid = empty(N, H2, W2, 2 * cout_t)
-            stage(prefix + ".conv", 0, cat, 2 * cout_t, cout_t, H2, W2, zmid, 2 * cout_t, reads_lo(prefix + ".conv.3"),
+            cmid = params[prefix + ".conv.double_conv.0.weight"].shape[0]     # in_channels // 2 when bilinear
+            cout3 = params[prefix + ".conv.double_conv.3.weight"].shape[0]
+            zmid = empty(N, H2, W2, 2 * cmid)
+            stage(prefix + ".conv", 0, cat, 2 * cout_t, cmid, H2, W2, zmid, 2 * cmid, reads_lo(prefix + ".conv.3"),
                   lo_len=None if up_lo_valid else cout_t)
             if j < 4:
-                zout = empty(N, H2, W2, 2 * cout_t)
-                stage(prefix + ".conv", 3, zmid, cout_t, cout_t, H2, W2, zout, 2 * cout_t, reads_lo(f"up{j + 1}.up"))
+                zout = empty(N, H2, W2, 2 * cout3)
+                nxt_lo = True if bilinear else reads_lo(f"up{j + 1}.up")      # (the pair up-sampling interpolates both planes)
+                stage(prefix + ".conv", 3, zmid, cmid, cout3, H2, W2, zout, 2 * cout3, nxt_lo)
                 inp = zout
-            elif not full and FUSED_HEAD_FWD and cout_t == 64 and net.n_classes <= 4:
+            elif not full and FUSED_HEAD_FWD and cout3 == 64 and net.n_classes <= 4:
                 # last stage: its activation has one reader, the head, which applies BatchNorm + ReLU on its own load path
-                last_rec, y_lo_last = stage(prefix + ".conv", 3, zmid, cout_t, cout_t, H2, W2, None, 0, False, to_head=True)
+                last_rec, y_lo_last = stage(prefix + ".conv", 3, zmid, cmid, cout3, H2, W2, None, 0, False, to_head=True)
             else:                                  # last stage: two dense planes (the head and its backward read dense tensors)
-                zl = empty(2, N, H2, W2, cout_t)
+                zl = empty(2, N, H2, W2, cout3)
                 zl_hi, zl_lo = zl[0], zl[1]
                 last_rec = None
-                st_rec = stage(prefix + ".conv", 3, zmid, cout_t, cout_t, H2, W2, None, 0, False, to_head=True)
+                st_rec = stage(prefix + ".conv", 3, zmid, cmid, cout3, H2, W2, None, 0, False, to_head=True)
                 ops.bn_act_apply_split(st_rec[0].y, st_rec[1], st_rec[0].coef[0], st_rec[0].coef[1], ACT_RELU, zl_hi, zl_lo,
-                                       cout_t, 0)
+                                       cout3, 0)
                 z_last = zl_hi
 
         logits = empty(N, net.n_classes, H, W, dtype=torch.float32)

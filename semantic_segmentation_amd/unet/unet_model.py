@@ -33,13 +33,17 @@ class UNet(nn.Module):
         # 16-bit storage/MFMA dtype of the engine: fp16 (default: 8x finer mantissa than bf16 at the same
         # MFMA rate; gradients are loss-scaled internally) or bf16.  Not part of the state dict.
         dt = compute_dtype or os.environ.get("GSSEG_DTYPE", "f16")
-        # precise=True (or GSSEG_PRECISE=1): hi/lo pair forward, logits ~1e-5 from the fp32 reference at ~3x the forward MFMA
-        # work (unet_engine.forward_precise); precise="mixed" (GSSEG_PRECISE=mixed): the pair forward with all three MFMA
-        # segments only on the stages that make the 16-bit error (unet_engine.MIXED_XW): max |dlogit| < 1e-3, the north
-        # star's bound; default: single 16-bit storage, logits within ~4e-3.
+        # Numerics mode of the forward.  The reference's forward is plain fp32 (unet/unet_model.py:26-37) and the
+        # north star asks for logits within 1e-3 of it, so the DEFAULT is the mode that meets that bound:
+        #   precise=None / "auto" (GSSEG_PRECISE unset or "auto"): the "mixed" pair forward -- every tensor a hi/lo pair of 16-bit
+        #       values, correction MFMA segments on the stages that make the 16-bit error (unet_engine.MIXED_XW): max |dlogit| < 1e-3.
+        #       Configurations the pair forward does not cover (more than 4 input channels / classes) run the 16-bit engine.
+        #   precise="mixed" (GSSEG_PRECISE=mixed): the same, but unsupported configurations raise instead of falling back.
+        #   precise=True (GSSEG_PRECISE=1): three MFMA segments everywhere, logits ~1e-5 from fp32 at ~3x the forward MFMA work.
+        #   precise=False (GSSEG_PRECISE=0): the FAST mode -- single 16-bit storage, logits within ~4e-3, loss / Dice within 1e-5.
         if precise is None:
-            env = os.environ.get("GSSEG_PRECISE", "0")
-            precise = {"0": False, "1": True}.get(env, env)
+            env = os.environ.get("GSSEG_PRECISE", "auto")
+            precise = {"0": False, "1": True, "": "auto"}.get(env, env)
         object.__setattr__(self, "_engine", UNetEngine(self, dt, precise=precise))
         # fp16 backward: gradients are carried times a static power-of-two scale that assumes a mean-reduced loss;
         # dynamic_loss_scale=True renormalises the incoming gradient on the device (sum-reduced losses, GradScaler, ...)

@@ -51,7 +51,7 @@ class UpConv3DBlock(nn.Module):
 
 class UNet3D(nn.Module):
     def __init__(self, in_channels, num_classes, level_channels=[64, 128, 256], bottleneck_channel=512,
-                 compute_dtype=None) -> None:
+                 compute_dtype=None, precise=None) -> None:
         super(UNet3D, self).__init__()
         l1, l2, l3 = level_channels[0], level_channels[1], level_channels[2]
         self.a_block1 = Conv3DBlock(in_channels=in_channels, out_channels=l1)
@@ -63,7 +63,13 @@ class UNet3D(nn.Module):
         self.s_block1 = UpConv3DBlock(in_channels=l2, res_channels=l1, num_classes=num_classes, last_layer=True)
         self.in_channels, self.num_classes = in_channels, num_classes
         dt = compute_dtype or os.environ.get("GSSEG_DTYPE", "f16")
-        object.__setattr__(self, "_engine", UNet3DEngine(self, dt))
+        # numerics mode, as unet.UNet: the reference's forward is plain fp32 (unet3d.py:89-126), the north star asks for logits within
+        # 1e-3, so the default (precise=None / "auto", GSSEG_PRECISE unset) is the "mixed" pair forward (unet3d_engine.forward_pair);
+        # precise=False (GSSEG_PRECISE=0) = single 16-bit storage (~2.4e-3), precise=True = correction segments on every conv.
+        if precise is None:
+            env = os.environ.get("GSSEG_PRECISE", "auto")
+            precise = {"0": False, "1": True, "": "auto"}.get(env, env)
+        object.__setattr__(self, "_engine", UNet3DEngine(self, dt, precise=precise))
 
     @property
     def engine(self):

@@ -22,6 +22,67 @@ _TORCH_DT = {"f16": torch.float16, "bf16": torch.bfloat16}
 K3 = [(kd, ky, kx) for kd in range(3) for ky in range(3) for kx in range(3)]
 
 
+STAGES3D = ([f"a_block{k}.conv{c}" for k in (1, 2, 3) for c in (1, 2)] + ["bottleNeck.conv1", "bottleNeck.conv2"] +
+            [s_ for k in (3, 2, 1) for s_ in (f"s_block{k}.upconv1", f"s_block{k}.conv1", f"s_block{k}.conv2")])
+# Where the 16-bit error of the UNet3D logits is made (tools/parity_fp8_sim.py --net unet3d, profiles/r04_fp8_sim_unet3d_32.json): the
+# two finest levels.  With K = 27 * C the rounding of the conv INPUTS (activations and weights) dominates -- pair storage alone
+# leaves 2.0e-3 -- so the "mixed" plan keeps pairs everywhere and runs the correction segments on the seven convs of levels 0 and 1
+# (a_block1.conv1 reads the fp32 volume on the direct kernel): simulated max |dlogit| 4.8e-4 (16-bit everywhere: 2.0e-3 .. 2.4e-3).
+MIXED3D_XW = ("a_block1.conv2", "a_block2.conv1", "a_block2.conv2", "s_block2.conv1", "s_block2.conv2", "s_block1.conv1",
+              "s_block1.conv2")
+
+
+def resolve_plan3d(precise, dtype: str):
+    """None / False -> None (the 16-bit engine); "auto" / "mixed" -> MIXED3D_XW (bf16: every conv); True / "full" -> every conv
+    "xw"; a {stage: mode} dict -> that plan.  The transposed convs run "1" (hi plane only) in every plan."""
+    if precise is None or precise is False or precise == 0 or precise == "0" or precise == "":
+        return None
+    convs = [s_ for s_ in STAGES3D if not s_.endswith("upconv1")]
+    if precise is True or precise == 1 or precise == "1" or precise == "full":
+        plan = {s_: "xw" for s_ in convs}
+    elif precise in ("mixed", "auto"):
+        plan = {s_: ("xw" if (s_ in MIXED3D_XW or dtype != "f16") else "1") for s_ in convs}
+    elif isinstance(precise, dict):
+        bad = [k for k, v in precise.items() if k not in STAGES3D or v not in ("1", "x", "w", "xw")]
+        if bad:
+            raise ValueError(f"precise plan: unknown stages / modes {bad}")
+        plan = {s_: precise.get(s_, "1") for s_ in convs}
+    else:
+        raise ValueError("precise must be False, True, 'mixed', 'auto' or a {stage: mode} dict")
+    for s_ in STAGES3D:
+        if s_.endswith("upconv1"):
+            plan[s_] = "1"
+    return plan
+
+
+def segs3d(mode: str, cin: int, lo0: int = 0, lo_len=None):
+    """(segment list for ops.pack_weight_segs, K extent, input wrap) of a Conv3d stage of the pair forward whose input holds the hi
+    plane (cin channels) followed by a lo plane of which the first lo_len channels are valid and belong to the layer's input
+    channels [lo0, lo0 + lo_len) (a concat buffer stores [up_h res_h | res_l ...]: lo0 = the up channels, lo_len = the residual
+    ones; a plain pair: lo0 = 0, lo_len = cin).  Kinds: 0 = hi(w), 1 = lo(w), 2 = zeros (pads K / the wrap to multiples of 64: the
+    padded K chunk multiplies channels of the lo plane by zero, which therefore must hold finite values)."""
+    ll = cin if lo_len is None else lo_len
+    segs = [(0, 0, cin)]
+    span = cin                                   # input channels the K extent walks before it wraps
+    if "x" in mode:
+        segs.append((0, lo0, ll))
+        span += ll
+    if span % 64:
+        pad = 64 - span % 64
+        if pad > ll:
+            raise NotImplementedError(f"pair forward: cannot pad a {cin}-channel input to a multiple of 64 channels")
+        segs.append((2, 0, pad))
+        span += pad
+    if "w" in mode:
+        segs.append((1, 0, cin))
+        if cin % 64:
+            segs.append((2, 0, 64 - cin % 64))
+    K = sum(s_[2] for s_ in segs)
+    if len(segs) > 4 or K % 64 or span % 64 or not (span <= K <= 2 * span):
+        raise NotImplementedError(f"pair forward: no segment layout for cin={cin}, lo_len={ll}, mode={mode}")
+    return segs, K, span
+
+
 def geom_conv3d(NB, D, H, W, Cin, Cout, dgrad=False, **kw):
     if not dgrad:
         taps = [(ky - 1, kx - 1) for (_, ky, kx) in K3]
@@ -38,10 +99,15 @@ class _Stage:
 
 
 class UNet3DEngine:
-    def __init__(self, net, dtype="f16"):
+    def __init__(self, net, dtype="f16", precise=None):
         if dtype not in _TORCH_DT:
             raise ValueError("dtype must be 'f16' or 'bf16'")
         self.net, self.dtype, self.tdt = net, dtype, _TORCH_DT[dtype]
+        # numerics mode (as UNetEngine): None = single 16-bit storage (logits ~2.4e-3 from the fp32 reference); a plan = the pair
+        # forward (forward_pair): every tensor a hi/lo pair, correction MFMA segments where the plan says so.  "auto" falls back
+        # to the 16-bit engine for configurations the pair forward does not cover.
+        self.plan = resolve_plan3d(precise, dtype)
+        self.auto = precise == "auto"
         # data-parallel hooks (parallel.GradReducer.attach): gradients announced as they become final, the compute stream
         # waits for the collectives at the end of backward, autograd receives the reduced gradients
         self.grad_ready_hook = None
@@ -58,6 +124,17 @@ class UNet3DEngine:
         NB, _, D0, H0, W0 = x.shape
         if D0 % 8 or H0 % 8 or W0 % 8:
             raise ValueError("volume dims must be multiples of 8 (three 2x2x2 poolings, no padding in the reference)")
+        if self.plan is not None:
+            if self.auto:
+                try:
+                    self._pair_layout()
+                    covered = net.in_channels == 1 and net.num_classes <= 4 and ops.USE_HALO_CONV
+                except NotImplementedError:
+                    covered = False
+                if covered:
+                    return self.forward_pair(x, training, need_grad)
+            else:
+                return self.forward_pair(x, training, need_grad)
         dev = x.device
         x = x.contiguous().float()
 
@@ -216,6 +293,207 @@ class UNet3DEngine:
         return logits, ctx
 
     # ------------------------------------------------------------------------------------------------
+    def _pair_layout(self):
+        """segment layouts of every conv stage under self.plan (raises NotImplementedError for channel counts the pair forward
+        cannot lay out): {stage: (segs, K, wrap)}; cached per plan"""
+        lay = self.__dict__.get("_lay")
+        if lay is not None:
+            return lay
+        net, plan = self.net, self.plan
+        lay = {}
+        for k, blk in (("a_block1", net.a_block1), ("a_block2", net.a_block2), ("a_block3", net.a_block3), ("bottleNeck", net.bottleNeck)):
+            if k != "a_block1":
+                lay[k + ".conv1"] = segs3d(plan[k + ".conv1"], blk.conv1.in_channels)
+            elif net.in_channels != 1:
+                raise NotImplementedError("pair forward: one input channel (the direct first-layer kernel)")
+            lay[k + ".conv2"] = segs3d(plan[k + ".conv2"], blk.conv2.in_channels)
+        for k, sb, ab in (("s_block3", net.s_block3, net.a_block3), ("s_block2", net.s_block2, net.a_block2),
+                          ("s_block1", net.s_block1, net.a_block1)):
+            cu, cr = sb.upconv1.out_channels, ab.conv2.out_channels
+            lay[k + ".conv1"] = segs3d(plan[k + ".conv1"], cu + cr, lo0=cu, lo_len=cr)
+            lay[k + ".conv2"] = segs3d(plan[k + ".conv2"], sb.conv2.in_channels)
+        if net.s_block1.conv2.out_channels != 64:
+            raise NotImplementedError("pair forward: the pointwise head kernel reads 64 channels")
+        self.__dict__["_lay"] = lay
+        return lay
+
+    def forward_pair(self, x, training, need_grad):
+        """The pair forward of UNet3D (BASELINE config 5 at the north star's 1e-3 on logits; GenSeg-3D/UNet3D/unet3d.py:89-126 is
+        plain fp32): every activation and conv output travels as a PAIR of 16-bit values v = hi + lo; BatchNorm / ReLU / max-pool /
+        the head read and write pairs; a conv stage runs the MFMA segments of self.plan (unet_engine.forward_precise explains the
+        forms).  The transposed convs run on the LDS-DMA GEMM and write the hi plane only; the first conv reads the fp32 volume.
+        HBM layout: pair buffers [NB*D, H, W, 2*C] = [hi (C) | lo (C)]; concat buffers [.., 2*(cup + cres)] =
+        [up_h res_h | res_l -] -- the residual's lo plane FIRST, so that the consumer's x_lo segment (residual channels only) is
+        contiguous behind the hi plane.  The backward pass is the default one: it reads the hi planes through strides."""
+        net, tdt, plan = self.net, self.tdt, self.plan
+        if not ops.USE_HALO_CONV:
+            raise RuntimeError("the pair forward needs the halo-reuse conv kernels (GSSEG_CONV3X3=halo)")
+        lay = self._pair_layout()
+        NB, _, D0, H0, W0 = x.shape
+        dev = x.device
+        x = x.contiguous().float()
+        names = {id(m): n for n, m in net.named_modules()}
+
+        def empty(*shape, dtype=tdt):
+            return torch.empty(shape, dtype=dtype, device=dev)
+
+        # every stale segment pack in ONE launch
+        items, packs = [], {}
+        for st_name, (segs, K, _) in lay.items():
+            conv = net.get_submodule(st_name)
+            cout, cin = conv.out_channels, conv.in_channels
+            pack = empty(27, cout, K)
+            items.append((conv.weight.detach().reshape(cout, cin, 27, 1), pack, False, segs))
+            packs[st_name] = pack
+        ops.pack_weight_segs(items)
+        dpacks = {}
+        if need_grad:                              # the backward's data-gradient packs (16-bit, as the default engine): one launch
+            ditems = []
+            for st_name in lay:
+                conv = net.get_submodule(st_name)
+                cout, cin = conv.out_channels, conv.in_channels
+                dpacks[st_name] = empty(27, cin, cout)
+                ditems.append((conv.weight.detach().reshape(cout, cin, 27, 1), None, dpacks[st_name], False))
+            ops.pack_weight_multi(ditems)
+
+        stages: List[_Stage] = []
+
+        def bn_coeffs(bn, bias, part, ntiles, C, count):
+            coef = empty(4, C, dtype=torch.float32)
+            batch = training or bn.running_mean is None
+            if batch:
+                if training and bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked.add_(1)
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked.item())
+                upd = training and bn.running_mean is not None
+                ops.bn_finalize(part, ntiles, C, count, bn.weight.detach(), bn.bias.detach(),
+                                bn.running_mean if upd else None, bn.running_var if upd else None, mom, bn.eps,
+                                coef[0], coef[1], coef[2], coef[3])
+                if upd and bias is not None:       # statistics were taken before the bias: mean(y + b) = mean(y) + b
+                    bn.running_mean.add_(bias.detach(), alpha=mom)
+            else:
+                rm = bn.running_mean if bias is None else (bn.running_mean - bias.detach())
+                ops.bn_eval_coeffs(C, bn.weight.detach(), bn.bias.detach(), rm.contiguous(), bn.running_var, bn.eps,
+                                   coef[0], coef[1], coef[2], coef[3])
+            return coef, batch
+
+        def stage(conv, bn, inp, in_stride, cin, D, H, W, z_hi, z_lo, z_stride, z_coff, first=False):
+            """conv (+ bias folded into BatchNorm) -> BN -> ReLU on pairs; the z pair goes to z_hi / z_lo (views; both take
+            z_coff) with pixel stride z_stride; z_lo None: not stored."""
+            cout = conv.out_channels
+            st = _Stage()
+            st.conv, st.bn, st.cin, st.cout, st.D, st.H, st.W, st.first = conv, bn, cin, cout, D, H, W, first
+            st.inp, st.in_stride, st.in_coff, st.wide, st.geom, st.x3 = inp, in_stride, 0, 0, None, None
+            y_hi, y_lo = empty(NB * D, H, W, cout), empty(NB * D, H, W, cout)
+            batch = training or bn.running_mean is None
+            if first:
+                xp = F.pad(inp[:, 0], (0, 0, 0, 0, 1, 1))
+                x3 = xp.unfold(1, 3, 1).permute(0, 1, 4, 2, 3).reshape(NB * D, 3, H, W).contiguous()
+                st.x3 = x3
+                nt = ops.conv_smallcin_mtiles(NB * D, H, W)
+                part = empty(ops.bn_partials_numel(nt, cout), dtype=torch.float32) if batch else None
+                ops.conv_smallcin_fwd_split(x3, conv.weight.detach().reshape(cout, 3, 3, 3).contiguous(), y_hi, y_lo, part, 3, 1)
+                st.wd, st.halo = None, False
+            else:
+                _, K, wrap = lay[names[id(conv)]]
+                nt = ops.conv3x3_stat_rows(NB * D, H, W, K, cout, pair=True)
+                part = empty(ops.bn_partials_numel(nt, cout), dtype=torch.float32) if batch else None
+                ops.conv3d3_segs(inp, packs[names[id(conv)]], y_hi, y_lo, NB, D, H, W, K, wrap, cin, cout, in_stride, 0, part)
+                st.halo = True
+                st.wd = dpacks.get(names[id(conv)])
+            st.coef, st.stats = bn_coeffs(bn, conv.bias, part, nt, cout, NB * D * H * W)
+            ops.bn_act_apply_split(y_hi, y_lo, st.coef[0], st.coef[1], ACT_RELU, z_hi, z_lo, z_stride, z_coff)
+            st.y = y_hi
+            if need_grad:
+                stages.append(st)
+            return st
+
+        a_blocks = [net.a_block1, net.a_block2, net.a_block3]
+        s_blocks = {3: net.s_block3, 2: net.s_block2, 1: net.s_block1}
+        dims = [(D0 >> k, H0 >> k, W0 >> k) for k in range(4)]
+        cats, cup = {}, {}
+        for k in (1, 2, 3):
+            cup[k] = s_blocks[k].upconv1.out_channels
+            cres = a_blocks[k - 1].conv2.out_channels
+            D, H, W = dims[k - 1]
+            # the unused tail of the lo plane (the up channels) is never read: a consumer's x_lo / zero segments stop at cres
+            cats[k] = empty(NB * D, H, W, 2 * (cup[k] + cres))
+
+        # ---- analysis path ----
+        enc = []
+        inp, in_stride, cin = x, None, 1
+        for k, blk in enumerate(a_blocks, 1):
+            D, H, W = dims[k - 1]
+            cmid, cout = blk.conv1.out_channels, blk.conv2.out_channels
+            z1 = empty(NB * D, H, W, 2 * cmid)
+            s1 = stage(blk.conv1, blk.bn1, inp, in_stride, cin, D, H, W, z1, z1[..., cmid:], 2 * cmid, 0, first=(k == 1))
+            ctot = cup[k] + cout
+            cat = cats[k]
+            # residual: hi plane at channels [cup, ctot), lo plane at [ctot, ctot + cout)
+            s2 = stage(blk.conv2, blk.bn2, z1, 2 * cmid, cmid, D, H, W, cat, cat[..., ctot - cup[k]:], 2 * ctot, cup[k])
+            pooled = empty(NB * (D // 2), H // 2, W // 2, 2 * cout)
+            ops.maxpool3d_fwd_pair(cat[..., cup[k]:], cat[..., ctot:], 2 * ctot, pooled, pooled[..., cout:], 2 * cout,
+                                   NB, D, H, W, cout)
+            enc.append((s1, s2, pooled))
+            inp, in_stride, cin = pooled, 2 * cout, cout
+        D, H, W = dims[3]
+        bb = net.bottleNeck
+        c1, c2 = bb.conv1.out_channels, bb.conv2.out_channels
+        zb1 = empty(NB * D, H, W, 2 * c1)
+        sb1 = stage(bb.conv1, bb.bn1, inp, in_stride, cin, D, H, W, zb1, zb1[..., c1:], 2 * c1, 0)
+        zb = empty(NB * D, H, W, 2 * c2)
+        sb2 = stage(bb.conv2, bb.bn2, zb1, 2 * c1, c1, D, H, W, zb, None, 2 * c2, 0)       # one reader: the hi-only transposed conv
+
+        # ---- synthesis path ----
+        ups = {}
+        cur, ccur = zb, c2
+        z_last = None
+        for k in (3, 2, 1):
+            sb = s_blocks[k]
+            d, h, w = dims[k]
+            D, H, W = dims[k - 1]
+            cu = cup[k]
+            ctot = cats[k].shape[3] // 2
+            wt = sb.upconv1.weight.detach().reshape(ccur, cu, 8, 1)
+            wf = empty(8, cu, ccur)
+            wd = empty(8, ccur, cu) if need_grad else None
+            ops.pack_weight(wt, wf, wd, True)
+            # x_hi . w_hi on the LDS-DMA pointwise GEMM, hi plane only (all eight sub-voxel classes in one launch)
+            ops.upconv2x2_fwd(cur, wf, sb.upconv1.bias.detach(), cats[k], NB, d, h, w, ccur, cu, D, H, W, in_stride=2 * ccur,
+                              out_stride=2 * ctot, out_coff=0)
+            if need_grad:
+                taps = [((c >> 1) & 1, c & 1) for c in range(8)]
+                tdz = [c >> 2 for c in range(8)]
+                # the transposed conv seen from its output side: dU = the up channels of the DENSE gradient of the concat input
+                gb = ops.make_geom(NB, H, W, cu, h, w, ccur, h, w, taps, isy=2, isx=2, in_stride=ctot, in_coff=0,
+                                   tap_dz=tdz, Dg=d, Din=D, Dout=d, isz=2)
+                # ... and for the weight gradient, whose second operand is the hi plane of the layer's input pair
+                gw = ops.make_geom(NB, H, W, cu, h, w, ccur, h, w, taps, isy=2, isx=2, in_stride=ctot, in_coff=0,
+                                   out_stride=2 * ccur, tap_dz=tdz, Dg=d, Din=D, Dout=d, isz=2)
+                ups[k] = dict(zin=cur, wd=wd, geom=gb, geom_wg=gw, cin=ccur, cup=cu, ctot=ctot, dims=(d, h, w, D, H, W))
+            cmid = sb.conv1.out_channels
+            z1 = empty(NB * D, H, W, 2 * cmid)
+            stage(sb.conv1, sb.bn, cats[k], 2 * ctot, ctot, D, H, W, z1, z1[..., cmid:], 2 * cmid, 0)
+            if k > 1:
+                z2 = empty(NB * D, H, W, 2 * cmid)
+                stage(sb.conv2, sb.bn, z1, 2 * cmid, cmid, D, H, W, z2, None, 2 * cmid, 0)  # one reader: the next transposed conv
+                cur, ccur = z2, cmid
+            else:
+                zl = empty(2, NB * D, H, W, cmid)                   # two dense planes: the head and its backward read dense tensors
+                stage(sb.conv2, sb.bn, z1, 2 * cmid, cmid, D, H, W, zl[0], zl[1], cmid, 0)
+                z_last, ccur = zl, cmid
+        head = net.s_block1.conv3
+        ncls = head.out_channels
+        l2d = empty(NB * D0, ncls, H0, W0, dtype=torch.float32)
+        ops.head1x1_fwd_split(z_last[0], z_last[1], head.weight.detach().reshape(ncls, ccur).contiguous(), head.bias.detach(), l2d)
+        logits = l2d.view(NB, D0, ncls, H0, W0).permute(0, 2, 1, 3, 4).contiguous()
+        ctx = None
+        if need_grad:
+            ctx = dict(stages=stages, enc=enc, bott=(sb1, sb2), ups=ups, cats=cats, cup=cup, dims=dims, NB=NB,
+                       z_last=z_last[0], c_last=ccur, ncls=ncls, pair=True)
+        return logits, ctx
+
+    # ------------------------------------------------------------------------------------------------
     def backward(self, ctx, dlogits):
         net, tdt = self.net, self.tdt
         NB, dims, cats, cup, ups = ctx["NB"], ctx["dims"], ctx["cats"], ctx["cup"], ctx["ups"]
@@ -325,8 +603,9 @@ class UNet3DEngine:
             ops.colsum(dcat, ctot, 0, NB * D, H, W, 0, 0, H, W, cu, inv_s, col_ws, db)
             emit(sb.upconv1.bias, db)
             dw = torch.empty((ccur, cu, 8), dtype=torch.float32, device=dev)
-            wsl = empty(ops.conv_wgrad_ws_floats(u["geom"]), dtype=torch.float32)
-            ops.conv_wgrad_det(u["geom"], dcat, u["zin"], wsl, dw, ccur, cu, 8, inv_s)
+            gwg = u.get("geom_wg", u["geom"])              # pair forward: the layer's input is the hi plane of a pair buffer
+            wsl = empty(ops.conv_wgrad_ws_floats(gwg), dtype=torch.float32)
+            ops.conv_wgrad_det(gwg, dcat, u["zin"], wsl, dw, ccur, cu, 8, inv_s)
             emit(sb.upconv1.weight, dw.view(sb.upconv1.weight.shape))
             dz = empty(NB * d, h, w, ccur)
             ops.conv_igemm(u["geom"], dcat, u["wd"], dz)
@@ -338,9 +617,10 @@ class UNet3DEngine:
         for k in (3, 2, 1):
             s1, s2, _ = ctx["enc"][k - 1]
             D, H, W = dims[k - 1]
-            ctot = cats[k].shape[3]
+            zs = cats[k].shape[3]                          # pixel stride of the concat buffer (pair forward: both planes)
+            ctot = zs // 2 if ctx.get("pair") else zs
             dz2 = empty(NB * D, H, W, s2.cout)
-            ops.maxpool3d_bwd(cats[k], dpool, dres[k], dz2, NB, D, H, W, s2.cout, ctot, cup[k], ctot, cup[k])
+            ops.maxpool3d_bwd(cats[k], dpool, dres[k], dz2, NB, D, H, W, s2.cout, zs, cup[k], ctot, cup[k])
             dmid = stage_bwd(s2, dz2, s2.cout, 0, True)
             dpool = stage_bwd(s1, dmid, s1.cout, 0, k > 1)
         if self.after_backward is not None:

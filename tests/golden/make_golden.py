@@ -131,6 +131,9 @@ def make_unet_compact(name, n_classes, batch, size, seed):
         "n_classes": n_classes, "seed": seed, "batch": batch, "size": size, "data_seed": 1234 + seed,
         "xsum": tensor_checksum(x), "masksum": tensor_checksum(mask.float()),
         "logits_sub": lg[:, :, ::8, ::8].numpy().copy(), "top_idx": top, "top_val": lg.flatten()[torch.from_numpy(top)].numpy(),
+        # the FULL logits of the first four images (2 MB): the tolerance-meeting mode is checked over 0.5 M contiguous logits at
+        # the size the metric is quoted on, not only on the 1.6 % sub-sample
+        "logits_full4": lg[:4].numpy().copy(),
         "logits_absmean": lg.abs().mean().item(), "logits_sum": lg.double().sum().item(),
         "loss_ce": l1.item(), "loss_dice": l2.item(), "loss": loss.item(),
     }
@@ -221,6 +224,9 @@ def make_ops_micro():
     """Per-op micro fixtures at tiny shapes from the reference's own modules."""
     from unet.unet_parts import DoubleConv, Down, Up, OutConv
     from models_pix2pix import networks
+    # the modules below draw their default weights from the GLOBAL generator: seed it here, so that a full run (whose earlier
+    # generators advance it) reproduces the same fixture as `--only ops` (VERDICT r3: hygiene flaw of this script)
+    torch.manual_seed(0)
     g = torch.Generator().manual_seed(11)
     out = {}
 

@@ -38,8 +38,13 @@ def test_end_to_end_iterations(tmp_path):
     UNet(1, 1).load_state_dict(torch.load(tmp_path / "final.pkl", map_location="cpu"), strict=True)
 
 
-def test_hip_graph_iterations_match_eager():
-    """hip_graphs=True: forward + backward of the Generator / Discriminator / Unet problems captured into hipGraphs after two eager
+@pytest.mark.parametrize("unroll_steps,iters", [(3, 7), (2, 8)])
+def test_hip_graph_iterations_match_eager(unroll_steps, iters):
+    """(unroll_steps = 2: NO arch step falls between the capture of the Discriminator graph and the capture of the Generator graph
+    -- (graph_warmup + 1) % unroll_steps != 0 -- so the Generator graph holds no merge kernel of its own and reads the forward packs
+    the Discriminator graph merges; the eager arch steps in between must refresh them, with an arch learning rate
+    large enough for a stale pack to show.)
+    hip_graphs=True: forward + backward of the Generator / Discriminator / Unet problems captured into hipGraphs after two eager
     iterations and replayed (static inputs, eager optimiser / arch steps in between, one validation) -- the same losses and the
     same weights as the eager loop on the same data (no dropout in G, so the two runs draw no random numbers)."""
     from semantic_segmentation_amd.harness import EndToEndTrainer, SyntheticLungDataset
@@ -55,9 +60,9 @@ def test_hip_graph_iterations_match_eager():
         netG = networks.define_G(1, 1, 64, "unet_256", "batch", False, "normal", 0.02, [0])
         netD = networks.define_D(2, 64, "basic", 3, "batch", "normal", 0.02, [0])
         crit = networks.GANLoss("vanilla").to(dev)
-        tr = EndToEndTrainer(net, netG, netD, crit, mk(6, 1), mk(2, 2), dev, unet_lr=1e-4, unroll_steps=3, valid_every=5,
-                             arch_through_generator=True, hip_graphs=graphs)
-        tr.run(7, log_every=0)
+        tr = EndToEndTrainer(net, netG, netD, crit, mk(6, 1), mk(2, 2), dev, unet_lr=1e-4, unroll_steps=unroll_steps, valid_every=5,
+                             arch_through_generator=True, hip_graphs=graphs, arch_lr=0.3 if unroll_steps == 2 else 3e-4)
+        tr.run(iters, log_every=0)
         torch.cuda.synchronize()
         if graphs:
             assert set(tr._graphs) == {"G", "D", "U"}
@@ -67,7 +72,7 @@ def test_hip_graph_iterations_match_eager():
 
     h0, p0, b0 = run(False)
     h1, p1, b1 = run(True)
-    assert len(h0) == len(h1) == 7
+    assert len(h0) == len(h1) == iters
     for r0, r1 in zip(h0, h1):
         assert r0.keys() == r1.keys()
         for k in r0:

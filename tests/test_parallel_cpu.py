@@ -53,6 +53,27 @@ def _worker(rank, world, port, q):
             red.ready(n, torch.ones_like(params[n]) * (rank + 1))
         red.finish()
         assert torch.allclose(red.flat, torch.full_like(red.flat, (world + 1) / 2))
+        # an un-announced gradient leaves its bucket un-reduced: finish() must raise instead of handing out local gradients
+        red.begin()
+        for n in names[:-1]:
+            red.ready(n, torch.ones_like(params[n]))
+        try:
+            red.finish()
+            raise AssertionError("finish() accepted an incomplete bucket")
+        except RuntimeError as e:
+            assert "incomplete" in str(e)
+        # parameters frozen after the reducer was built (the discriminator inside the Generator problem): announced, counted,
+        # but a bucket made of frozen parameters only is not exchanged
+        for p_ in net[2].parameters():
+            p_.requires_grad = False
+        red.begin()
+        for n in names:
+            red.ready(n, torch.ones_like(params[n]) * (rank + 1))
+        n_live = len({red.bucket_of[n] for n in names if params[n].requires_grad})
+        assert red.issued == n_live < len(red.buckets), (red.issued, n_live, len(red.buckets))
+        red.finish()
+        for p_ in net[2].parameters():
+            p_.requires_grad = True
         lo, hi = shard_batch(8, rank, world)
         assert (lo, hi) == (rank * 4, rank * 4 + 4)
         # generic post-backward exchange (UNet3D / Pix2Pix / harness): rank-dependent gradients are averaged in

@@ -82,7 +82,8 @@ def test_grad_reducer_on_unet_engine_rccl_single_rank():
                 torch.cuda.synchronize()
                 outs.append({k: p.grad.detach().clone() for k, p in net.named_parameters()})
                 if red is not None:
-                    assert not red._works and not red._pending          # finish() ran at the end of backward
+                    assert not red._works and not red._pending          # finish() ran at the end of backward ...
+                    assert red.issued == len(red.buckets), (red.issued, len(red.buckets))      # ... after EVERY bucket's all-reduce
             return outs
 
         def check(outs, rtol):

@@ -126,7 +126,7 @@ def test_gan_steps_train_mode(golden_dir):
     # had fed all-ones dropout masks at p = 0.5, i.e. scaled the kept activations by 2, while the fixture has p = 0.)
     assert abs(rep["loss_G"] - rep["loss_G_ref"]) < 1e-4 * abs(rep["loss_G_ref"]), rep
     assert abs(rep["loss_D"] - rep["loss_D_ref"]) < 2e-4, rep
-    assert rep["fake_train_mean_abs"] < 5e-4 and rep["fake_train_max_abs"] < 5e-3, rep
+    assert rep["fake_train_mean_abs"] < 2.3e-4 and rep["fake_train_max_abs"] < 2e-3, rep       # 1.5x measured (1.5e-4 / 1.31e-3)
     assert rep["G_grad_norm_rel_err_median"] < 3e-3 and rep["G_grad_norm_rel_err_worst"] < 5e-2, rep
     assert dworst < 5e-3, rep
     assert rep["arch_grad_rel_err"] < 5e-3, rep
@@ -198,7 +198,7 @@ def test_gan_steps_train_mode_batch8_vs_golden(golden_dir):
     _dump()
     # measured: fake mean 1.3e-4 / max 1.2e-3, loss_G 4.4e-6 rel, loss_D 3e-5, G gradient norms median 3.9e-4 / worst
     # 8.2e-3, sampled elements 5 % of the tensor RMS (median), arch 3.8e-4, BN buffers 5.9e-4 (G) / 2.5e-4 (D), D norms 1.3e-3
-    assert rep["fake_mean_abs"] < 5e-4 and rep["fake_max_abs"] < 5e-3, rep
+    assert rep["fake_mean_abs"] < 1.9e-4 and rep["fake_max_abs"] < 1.8e-3, rep                 # 1.5x measured (1.26e-4 / 1.16e-3)
     assert abs(rep["loss_G"] - rep["loss_G_ref"]) < 1e-4 * abs(rep["loss_G_ref"]), rep
     assert abs(rep["loss_D"] - rep["loss_D_ref"]) < 2e-4, rep
     assert rep["G_grad_norm_rel_err_median"] < 2e-3 and rep["G_grad_norm_rel_err_worst"] < 3e-2, rep

@@ -26,14 +26,28 @@ def vol_loss(logits, mask):
     return seg_loss(logits.reshape(n, c, d * h, w), mask.reshape(n, d * h, w))
 
 
-@pytest.mark.parametrize("name", ["unet3d_c2_16", "unet3d_c1_16"])
-def test_unet3d_step_vs_golden(golden_dir, name):
+# numerics modes: "default" = UNet3D(...) as the reference's scripts build it = the "mixed" pair forward, which
+# must meet the north star's 1e-3 on logits (measured 3.4e-4 .. 5.1e-4); "fast" = UNet3D(..., precise=False), single 16-bit storage,
+# asserted at 1.5x its measured error (2.0e-3 .. 2.4e-3; OUTSIDE the tolerance)
+LIMITS = {"default": dict(max=1e-3, mean=1.2e-4, loss=2e-5, bn=6e-4, gworst=1e-2, gmed=3e-3, ev=1e-5),
+          "fast": dict(max=3.6e-3, mean=6.6e-4, loss=1e-3, bn=1.2e-3, gworst=2.4e-2, gmed=5.4e-3, ev=8e-5)}
+
+
+def build3d(n_classes, seed, mode, in_channels=1):
     from semantic_segmentation_amd.unet3d import UNet3D
+    sd = oracle.unet3d_state_dict(in_channels, n_classes, seed=seed)
+    net = UNet3D(in_channels, n_classes, precise=None if mode == "default" else False)
+    net.load_state_dict(sd, strict=True)
+    assert (net.engine.plan is not None) == (mode == "default")
+    return net, sd
+
+
+@pytest.mark.parametrize("mode", ["default", "fast"])
+@pytest.mark.parametrize("name", ["unet3d_c2_16", "unet3d_c1_16"])
+def test_unet3d_step_vs_golden(golden_dir, name, mode):
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     n_classes, seed = int(z["n_classes"]), int(z["seed"])
-    sd = oracle.unet3d_state_dict(1, n_classes, seed=seed)
-    net = UNet3D(1, n_classes)
-    net.load_state_dict(sd, strict=True)
+    net, sd = build3d(n_classes, seed, mode)
     net = net.cuda().train()
     x = torch.from_numpy(z["x"]).cuda()
     mask = torch.from_numpy(z["mask"].astype(np.int64)).cuda()
@@ -58,22 +72,32 @@ def test_unet3d_step_vs_golden(golden_dir, name):
            "loss_ref": float(z["loss"]), "grad_norm_rel_err_median": float(np.median(list(errs.values()))),
            "grad_norm_rel_err_worst": float(max(errs.values())), "worst_key": max(errs, key=errs.get),
            "bn_buffer_rel_err_worst": bworst}
-    REPORT[name] = rep
+    # the exact-zero gradient of a conv bias in front of a batch-statistics BatchNorm (the reference's value is fp32 rounding noise)
+    # reads as a 100 % "error": excluded from the worst-case bound, asserted to be exactly zero instead
+    zero_bias = [k for k in errs if k.endswith(".bias") and ".conv" in k and "conv3" not in k]
+    for k in zero_bias:
+        assert float(dict(net.named_parameters())[k].grad.abs().max()) == 0.0, k
+    rep["grad_norm_rel_err_worst_nonbias"] = float(max(v for k, v in errs.items() if k not in zero_bias))
+    key = name if mode == "fast" else "default_" + name
+    REPORT[key] = rep
     _dump()
-    assert abs(rep["loss"] - rep["loss_ref"]) < 1e-3, rep
-    assert rep["logit_mean_abs"] < 2e-3 and rep["logit_max_abs"] < 2e-2, rep
-    assert rep["grad_norm_rel_err_median"] < 0.05, rep
-    assert bworst < 1e-2, rep
+    lim = LIMITS[mode]
+    assert abs(rep["loss"] - rep["loss_ref"]) < lim["loss"], rep
+    assert rep["logit_mean_abs"] < lim["mean"] and rep["logit_max_abs"] < lim["max"], rep
+    # gradient norms: measured median 1.9e-3 / 3.6e-3, worst 6.3e-3 / 1.6e-2 (default / fast)
+    assert rep["grad_norm_rel_err_median"] < lim["gmed"] and rep["grad_norm_rel_err_worst_nonbias"] < lim["gworst"], rep
+    assert bworst < lim["bn"], rep
     net.eval()
     with torch.no_grad():
         le = net(x)
     de = np.abs(le.cpu().numpy() - z["logits_eval"])
-    REPORT[name]["eval_logit_max_abs"] = float(de.max())
+    REPORT[key]["eval_logit_max_abs"] = float(de.max())
     _dump()
-    assert de.max() < 2e-2 * max(1.0, np.abs(z["logits_eval"]).max())
+    assert de.max() < lim["ev"] * max(1.0, np.abs(z["logits_eval"]).max())         # measured 2.6e-6 / 5.4e-5
 
 
-def test_unet3d_128_vs_reference_fixture(golden_dir):
+@pytest.mark.parametrize("mode", ["default", "fast"])
+def test_unet3d_128_vs_reference_fixture(golden_dir, mode):
     """BASELINE config 5 at its per-GPU size -- UNet3D(1,2), one 128^3 volume, train mode -- against the compact fixture from
     the imported reference (tests/golden/make_golden.py --only unet3d_128: logits sub-sampled 8x8x8 + the 64 largest-|logit|
     positions, the loss, every gradient summary, the BatchNorm buffers).  Inputs are regenerated from the seed."""
@@ -86,9 +110,7 @@ def test_unet3d_128_vs_reference_fixture(golden_dir):
     mask = (torch.rand(1, size, size, size, generator=g) > 0.6).long()
     assert np.allclose(tensor_checksum(x), z["xsum"], rtol=1e-6, atol=1e-6), "the synthetic input stream drifted"
     assert np.allclose(tensor_checksum(mask.float()), z["masksum"], rtol=0, atol=0)
-    sd = oracle.unet3d_state_dict(1, n_classes, seed=seed)
-    net = UNet3D(1, n_classes)
-    net.load_state_dict(sd, strict=True)
+    net, sd = build3d(n_classes, seed, mode)
     net = net.cuda().train()
     logits = net(x.cuda())
     loss = vol_loss(logits, mask.cuda())
@@ -111,12 +133,15 @@ def test_unet3d_128_vs_reference_fixture(golden_dir):
     rep = {"logit_sub_max_abs": float(d_sub.max()), "logit_sub_mean_abs": float(d_sub.mean()), "logit_top64_max_abs": float(d_top.max()),
            "loss": float(loss.item()), "loss_ref": float(z["loss"]), "grad_norm_rel_err_median": float(np.median(list(errs.values()))),
            "grad_norm_rel_err_worst": float(max(errs.values())), "worst_key": max(errs, key=errs.get), "bn_buffer_rel_err_worst": bworst}
-    REPORT["unet3d_c2_128"] = rep
+    zero_bias = [k for k in errs if k.endswith(".bias") and ".conv" in k and "conv3" not in k]
+    rep["grad_norm_rel_err_worst_nonbias"] = float(max(v for k, v in errs.items() if k not in zero_bias))
+    REPORT["unet3d_c2_128" if mode == "fast" else "default_unet3d_c2_128"] = rep
     _dump()
-    assert abs(rep["loss"] - rep["loss_ref"]) < 1e-3, rep
-    assert rep["logit_sub_mean_abs"] < 2e-3 and rep["logit_sub_max_abs"] < 2e-2 and rep["logit_top64_max_abs"] < 2e-2, rep
-    assert rep["grad_norm_rel_err_median"] < 0.05, rep
-    assert bworst < 1e-2, rep
+    lim = LIMITS[mode]
+    assert abs(rep["loss"] - rep["loss_ref"]) < lim["loss"], rep
+    assert rep["logit_sub_mean_abs"] < lim["mean"] and rep["logit_sub_max_abs"] < lim["max"] and rep["logit_top64_max_abs"] < lim["max"], rep
+    assert rep["grad_norm_rel_err_median"] < lim["gmed"] and rep["grad_norm_rel_err_worst_nonbias"] < lim["gworst"], rep
+    assert bworst < lim["bn"], rep
 
 
 @pytest.mark.parametrize("cin,ncls", [(3, 2), (8, 3), (4, 1)])
@@ -259,3 +284,46 @@ def test_unet3d_full_size_128_properties():
         l1 = float(vol_loss(net(x), mask))
     ratio = (losses[0] - l1) / target
     assert 0.6 < ratio < 1.3, ratio
+
+
+def test_pair_pool_and_pair_upsample_kernels():
+    """the two pair-only memory kernels of the pair forwards: MaxPool3d(2) of the pair VALUES (unet3d.py:37,44) and the bilinear x2
+    interpolation of a pair (unet_parts.py:49-50), against fp32 torch on hi + lo; planes addressed through strides as the engines do"""
+    from semantic_segmentation_amd import ops
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(12)
+    dev = torch.device("cuda:0")
+
+    def pair(t):
+        hi = t.half()
+        return hi, (t - hi.float()).half()
+
+    # ---- max-pool: the residual planes inside a concat buffer [up_h res_h | res_l -]
+    NB, D, H, W, C, cu = 2, 4, 6, 8, 16, 8
+    v = torch.randn(NB * D, H, W, C, generator=g)
+    hi, lo = pair(v)
+    cat = torch.zeros(NB * D, H, W, 2 * (cu + C), dtype=torch.float16, device=dev)
+    cat[..., cu:cu + C] = hi.to(dev)
+    cat[..., cu + C:cu + 2 * C] = lo.to(dev)
+    pooled = torch.empty(NB * D // 2, H // 2, W // 2, 2 * C, dtype=torch.float16, device=dev)
+    ops.maxpool3d_fwd_pair(cat[..., cu:], cat[..., cu + C:], 2 * (cu + C), pooled, pooled[..., C:], 2 * C, NB, D, H, W, C)
+    val = (hi.float() + lo.float()).view(NB, D, H, W, C).permute(0, 4, 1, 2, 3)
+    ref = F.max_pool3d(val, 2).permute(0, 2, 3, 4, 1).reshape(NB * D // 2, H // 2, W // 2, C)
+    got = pooled[..., :C].float().cpu() + pooled[..., C:].float().cpu()
+    assert float((got - ref).abs().max()) < 2e-7 * float(ref.abs().max()) + 1e-9
+    hi_only = torch.empty_like(pooled)
+    ops.maxpool3d_fwd_pair(cat[..., cu:], cat[..., cu + C:], 2 * (cu + C), hi_only, None, 2 * C, NB, D, H, W, C)
+    assert torch.equal(hi_only[..., :C], pooled[..., :C])
+    # ---- bilinear x2 of a pair into the up half of both planes of a 2-D concat buffer, with a pad offset
+    N, h, w, c = 2, 5, 7, 8
+    v = torch.randn(N, h, w, c, generator=g)
+    hi, lo = pair(v)
+    src = torch.cat((hi, lo), 3).to(dev)                                  # [hi | lo]
+    H2, W2 = 2 * h + 1, 2 * w + 1
+    buf = torch.zeros(N, H2, W2, 4 * c, dtype=torch.float16, device=dev)  # [skip_h up_h | skip_l up_l]
+    ops.upsample2x_bilinear_fwd_pair(src, src[..., c:], buf, buf[..., 2 * c:], N, h, w, c, H2, W2, in_stride=2 * c,
+                                     out_stride=4 * c, out_coff=c, ooy=0, oox=1)
+    ref = F.interpolate((hi.float() + lo.float()).permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True)
+    got = (buf[..., c:2 * c].float() + buf[..., 3 * c:].float()).cpu().permute(0, 3, 1, 2)
+    assert float((got[:, :, :2 * h, 1:1 + 2 * w] - ref).abs().max()) < 1e-6
+    assert float(got[:, :, 2 * h:].abs().max()) == 0.0 and float(got[:, :, :, 0].abs().max()) == 0.0       # the pad stays untouched

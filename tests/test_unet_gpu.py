@@ -35,22 +35,29 @@ def _dump():
         json.dump(REPORT, f, indent=1, sort_keys=True)
 
 
-def build_net(n_classes, seed, dtype="f16", bilinear=False):
+def build_net(n_classes, seed, dtype="f16", bilinear=False, precise=False):
+    """precise=False: the FAST 16-bit engine (what most tests of this file were written against, with its bounds); precise=None:
+    what `UNet(n_channels, n_classes)` builds -- the "mixed" pair forward, which must meet the north star's 1e-3 on logits."""
     from semantic_segmentation_amd.unet import UNet
     sd = oracle.unet_state_dict(1, n_classes, seed=seed, bilinear=bilinear)
-    net = UNet(1, n_classes, bilinear=bilinear, compute_dtype=dtype)
+    net = UNet(1, n_classes, bilinear=bilinear, compute_dtype=dtype, precise=precise)
     net.load_state_dict(sd, strict=True)
     return net.cuda(), sd
 
 
+@pytest.mark.parametrize("mode", ["default", "fast"])
 @pytest.mark.parametrize("name", ["unet_c1_64", "unet_c2_64", "unet_c1_odd", "unet_c1_zeros", "unet_c1_ones",
                                   "unet_c2_128_b4", "unet_c1_bilinear_64", "unet_c2_bilinear_odd"])
-def test_unet_step_vs_golden(golden_dir, name):
+def test_unet_step_vs_golden(golden_dir, name, mode):
+    """Every reference fixture in both numerics modes.  "default" = UNet(...) exactly as the reference's scripts build it
+    (train_end2end_jsrt.py:62,67): max |dlogit| < 1e-3, the north star's tolerance (bilinear included).  "fast" =
+    UNet(..., precise=False), the 16-bit engine, asserted at 1.5x its measured error."""
     from semantic_segmentation_amd.losses import seg_loss
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     n_classes, seed = int(z["n_classes"]), int(z["seed"])
     bilinear = bool(int(z["bilinear"])) if "bilinear" in z.files else False
-    net, sd = build_net(n_classes, seed, bilinear=bilinear)
+    net, sd = build_net(n_classes, seed, bilinear=bilinear, precise=None if mode == "default" else False)
+    assert (net.engine.plan is not None) == (mode == "default")
     net.train()
     x = torch.from_numpy(z["x"]).cuda()
     mask = torch.from_numpy(z["mask"].astype(np.int64)).cuda()
@@ -78,27 +85,35 @@ def test_unet_step_vs_golden(golden_dir, name):
             ref = z["buf/" + k]
             bworst = max(bworst, float(np.abs(b.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-6)))
     rep["bn_buffer_rel_err_worst"] = bworst
-    REPORT[name] = rep
+    key = name if mode == "fast" else "default_" + name
+    REPORT[key] = rep
     _dump()
     assert np.isfinite(lg).all()
-    assert abs(rep["loss"] - rep["loss_ref"]) < 1e-3, rep
-    assert abs(rep["dice_loss"] - rep["dice_loss_ref"]) < 1e-3, rep
-    # DEFAULT mode (single 16-bit storage): asserted at 1.5x the worst value measured on MI355X -- max 4.34e-3 / mean 6.0e-4
-    # (bilinear: four more 16-bit roundings and half as many channels to average over: 8.55e-3 / 1.59e-3).  The north star's
-    # 1e-3 on logits is met by precise mode (test_precise_mode_*), not by this mode; loss / Dice meet it in both.
-    assert rep["logit_max_abs"] < (1.3e-2 if bilinear else 6.5e-3) and rep["logit_mean_abs"] < (2.4e-3 if bilinear else 9e-4), rep
-    assert worst < 5e-2, rep                  # gradient norms: measured <= 3.4 %
-    assert bworst < 5e-3, rep
+    if mode == "default":
+        # the north star's bar: measured 5.4e-4 .. 6.7e-4 (bilinear, all stages corrected: 2e-5), loss / Dice <= 1e-5
+        assert abs(rep["loss"] - rep["loss_ref"]) < 2e-5 and abs(rep["dice_loss"] - rep["dice_loss_ref"]) < 2e-5, rep
+        assert rep["logit_max_abs"] < 1e-3 and rep["logit_mean_abs"] < 1.6e-4, rep
+        assert worst < 1.6e-2 and bworst < 6e-4, rep       # gradient norms: measured <= 1.0 %; BN buffers <= 3.8e-4
+    else:
+        assert abs(rep["loss"] - rep["loss_ref"]) < 1e-3, rep
+        assert abs(rep["dice_loss"] - rep["dice_loss_ref"]) < 1e-3, rep
+        # FAST mode (single 16-bit storage): asserted at 1.5x the worst value measured on MI355X -- max 4.12e-3 / mean 5.6e-4
+        # (bilinear: four more 16-bit roundings and half as many channels to average over: 9.94e-3 / 1.57e-3).  OUTSIDE the north
+        # star's 1e-3 on logits (the default mode meets it); loss / Dice meet it in both.
+        assert rep["logit_max_abs"] < (1.5e-2 if bilinear else 6.2e-3) and rep["logit_mean_abs"] < (2.4e-3 if bilinear else 8.5e-4), rep
+        assert worst < 4e-2, rep                  # gradient norms: measured <= 2.7 %
+        assert bworst < 2.6e-3, rep               # measured <= 1.7e-3
     # eval mode with the updated running statistics + evaluate.py Dice
     net.eval()
     with torch.no_grad():
         le = net(x)
     de = np.abs(le.cpu().numpy() - z["logits_eval"])
-    REPORT[name]["eval_logit_max_abs"] = float(de.max())
-    REPORT[name]["eval_dice_delta"] = abs(float(oracle.evaluate_dice(le.cpu(), mask.cpu())) - float(z["eval_dice"]))
+    REPORT[key]["eval_logit_max_abs"] = float(de.max())
+    REPORT[key]["eval_dice_delta"] = abs(float(oracle.evaluate_dice(le.cpu(), mask.cpu())) - float(z["eval_dice"]))
     _dump()
-    assert REPORT[name]["eval_dice_delta"] < 1e-3
-    assert de.max() < 2e-2 * max(1.0, np.abs(z["logits_eval"]).max())
+    assert REPORT[key]["eval_dice_delta"] < 1e-3
+    # (eval mode with barely-moved running statistics squashes the activations: measured 2.6e-5 .. 3.9e-5 in the fast mode)
+    assert de.max() < (1e-5 if mode == "default" else 6e-5) * max(1.0, np.abs(z["logits_eval"]).max())      # measured 2.6e-6 / 3.9e-5
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
@@ -125,10 +140,10 @@ def test_unet_vs_oracle_256(dtype):
                                     "grad_rel_l2_median": float(np.median(list(rel.values())))}
     _dump()
     assert abs(loss.item() - ref_loss.item()) < 1e-3
-    # 1.5x the measured values (f16: max 4.25e-3 / mean 5.7e-4, gradients worst 17 %; bf16: 3.5e-2 / 4.5e-3, 47 %)
-    lim_mean, lim_max = (9e-4, 6.5e-3) if dtype == "f16" else (6.8e-3, 5.3e-2)
+    # 1.5x the measured values (f16: max 3.94e-3 / mean 5.3e-4, gradients worst 16.6 %; bf16: 2.63e-2 / 4.19e-3, 45.8 %)
+    lim_mean, lim_max = (8e-4, 5.9e-3) if dtype == "f16" else (6.3e-3, 4e-2)
     assert d.mean() < lim_mean and d.max() < lim_max, REPORT
-    assert rel[worst_k] < (0.26 if dtype == "f16" else 0.7), (worst_k, rel[worst_k])
+    assert rel[worst_k] < (0.25 if dtype == "f16" else 0.69), (worst_k, rel[worst_k])
 
 
 def test_unet_forward_is_deterministic_and_retain_graph():
@@ -474,13 +489,15 @@ def test_precise_mode_is_deterministic_and_matches_default_backward_path():
     assert (ref(x) - outs[0][0]).abs().max() < 1e-2
 
 
-def test_data_writes_between_training_forwards_are_seen_by_default():
-    """Betty's darts hypergradient perturbs the parameters IN PLACE THROUGH `p.data` between two forward/backward passes
+@pytest.mark.parametrize("precise", [None, False])
+def test_data_writes_between_training_forwards_are_seen_by_default(precise):
+    """(precise=None: the default pair forward -- its segment packs are rebuilt too; False: the fast 16-bit engine.)
+    Betty's darts hypergradient perturbs the parameters IN PLACE THROUGH `p.data` between two forward/backward passes
     (running_files/train_end2end_jsrt.py:287-292, Config(type="darts", roll_back=True)) -- a write no version counter sees.
     With default settings a training forward must use the perturbed weights (the 16-bit packs are rebuilt by every forward
     that keeps a graph), and the gradients must be those of the perturbed network."""
     from semantic_segmentation_amd.losses import seg_loss
-    net, sd = build_net(2, seed=23)
+    net, sd = build_net(2, seed=23, precise=precise)
     net.train()
     x, mask = oracle.synthetic_batch(2, 64, seed=6)
     x, mask = x.cuda(), mask.cuda()
@@ -498,7 +515,7 @@ def test_data_writes_between_training_forwards_are_seen_by_default():
     assert (l1 - l0).abs().max() > 1e-3, "perturbation too small to tell"
     # a fresh module holding the same (perturbed) values
     from semantic_segmentation_amd.unet import UNet
-    ref = UNet(1, 2).cuda()
+    ref = UNet(1, 2, precise=precise).cuda()
     ref.load_state_dict({k: v.detach().clone() for k, v in net.state_dict().items()}, strict=True)
     for k, b in ref.named_buffers():                     # same running statistics as `net` had BEFORE its second pass is irrelevant:
         pass                                             # train-mode logits do not read them
@@ -554,8 +571,8 @@ def test_unet_wide_ends_vs_oracle(n_channels, n_classes, need_dx):
     _dump()
     assert tuple(logits.shape) == (2, n_classes, 48, 64)
     assert abs(loss.item() - ref_loss.item()) < 1e-3
-    assert d.mean() < 1.2e-3 and d.max() < 1e-2, REPORT[f"wide_{n_channels}_{n_classes}"]
-    assert max(rel.values()) < 0.35, (max(rel, key=rel.get), max(rel.values()))
+    assert d.mean() < 9.5e-4 and d.max() < 8.2e-3, REPORT[f"wide_{n_channels}_{n_classes}"]      # 1.5x measured (6.35e-4 / 5.45e-3)
+    assert max(rel.values()) < 0.27, (max(rel, key=rel.get), max(rel.values()))                      # measured 17.7 %
     if need_dx:
         gx, rx = xd.grad.cpu().double(), ref_g[-1].double()
         assert float((gx - rx).norm() / rx.norm()) < 0.35
@@ -602,11 +619,11 @@ def test_mixed_mode_meets_1e3_vs_golden(golden_dir, name):
                                "dice_abs_err": abs(float(parts[2].item()) - float(z["loss_dice"])),
                                "grad_norm_rel_err_worst": worst, "bn_buffer_rel_err_worst": bworst}
     _dump()
-    assert d.max() < 1e-3 and d.mean() < 2e-4, REPORT["mixed_" + name]
+    assert d.max() < 1e-3 and d.mean() < 1.6e-4, REPORT["mixed_" + name]      # measured 5.4e-4 .. 6.7e-4 / 1.05e-4
     assert abs(float(loss.item()) - float(z["loss"])) < 2e-5
     assert abs(float(parts[2].item()) - float(z["loss_dice"])) < 2e-5
-    assert bworst < 1e-3
-    assert worst < 8e-2                      # backward = the default 16-bit one
+    assert bworst < 5.7e-4                   # measured <= 3.8e-4
+    assert worst < 1.5e-2                    # gradient norms, measured <= 1.0 % (backward = the 16-bit one on the hi planes)
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
@@ -630,9 +647,9 @@ def test_mixed_mode_meets_1e3_vs_oracle_256(dtype):
                                           "grad_rel_l2_median": float(np.median(list(rel.values()))),
                                           "grad_rel_l2_worst": max(rel.values())}
     _dump()
-    assert d.max() < 1e-3 and d.mean() < 2e-4, REPORT["mixed_oracle256_" + dtype]
+    assert d.max() < 1e-3 and d.mean() < 1.5e-4, REPORT["mixed_oracle256_" + dtype]
     assert abs(loss.item() - ref_loss.item()) < 2e-5
-    assert max(rel.values()) < (0.15 if dtype == "f16" else 0.25)
+    assert max(rel.values()) < (0.11 if dtype == "f16" else 0.17)      # per-tensor rel-L2, measured 7.3 % / 11.5 %
 
 
 @pytest.mark.parametrize("mode", ["default", "mixed", "full"])
@@ -640,8 +657,9 @@ def test_config2_bs32_256_vs_reference_fixture(golden_dir, mode):
     """BASELINE config 2 AT ITS OWN SIZE -- UNet(1,2), 256x256, batch 32, train mode -- against the compact fixture generated
     from the imported reference (tests/golden/make_golden.py --only unet_b32: logits sub-sampled 8x8 + the 64 largest-|logit|
     positions, the losses, all 118 gradient summaries, the BatchNorm buffers).  The inputs are regenerated from the seed
-    (their checksums are in the fixture).  default: asserted at the default mode's 6.5e-3; mixed: AT the north star's 1e-3;
-    full: 3e-5."""
+    (their checksums are in the fixture).  "default" here = the FAST 16-bit mode (UNet(precise=False)), asserted at 1.5x its measured
+    error; "mixed" = what UNet() builds: AT the north star's 1e-3, over the sub-sample, the 64 largest logits AND the full logits of
+    four images; full: 3e-5."""
     from golden_util import tensor_checksum
     from semantic_segmentation_amd.losses import seg_loss
     z = np.load(os.path.join(golden_dir, "unet_c2_256_b32.npz"))
@@ -678,10 +696,17 @@ def test_config2_bs32_256_vs_reference_fixture(golden_dir, mode):
            "grad_norm_rel_err_worst": worst, "grad_norm_worst_key": wk, "bn_buffer_rel_err_worst": bworst}
     REPORT["config2_bs32_" + mode] = rep
     _dump()
-    lim_max, lim_mean, lim_loss = {"default": (6.5e-3, 9e-4, 1e-3), "mixed": (1e-3, 2e-4, 2e-5), "full": (3e-5, 4e-6, 2e-5)}[mode]
+    # the FULL logits of the first four images: 0.5 M contiguous logits at the size the metric is quoted on
+    d_full = (lg[:4] - torch.from_numpy(z["logits_full4"])).abs()
+    rep["logit_full4_max_abs"], rep["logit_full4_mean_abs"] = float(d_full.max()), float(d_full.mean())
+    _dump()
+    # fast (UNet(precise=False)): 1.5x measured (4.30e-3 over the full logits of four images / 5.5e-4); mixed (what UNet() builds): AT the north star's 1e-3; full: 3e-5
+    lim_max, lim_mean, lim_loss = {"default": (6.5e-3, 8.2e-4, 1e-3), "mixed": (1e-3, 1.5e-4, 2e-5), "full": (3e-5, 4e-6, 2e-5)}[mode]
     assert d_sub.max() < lim_max and d_top.max() < lim_max and d_sub.mean() < lim_mean, rep
+    assert d_full.max() < lim_max and d_full.mean() < lim_mean, rep
     assert rep["loss_abs_err"] < lim_loss and rep["dice_abs_err"] < lim_loss, rep
-    assert worst < 8e-2 and bworst < (5e-3 if mode == "default" else 1e-3), rep
+    # gradient norms: measured 2.3 % / 1.0 % / 0.4 %; BatchNorm buffers 2.8e-4 / 2.8e-4 / 4e-6
+    assert worst < {"default": 3.5e-2, "mixed": 1.5e-2, "full": 6e-3}[mode] and bworst < (1e-5 if mode == "full" else 4.2e-4), rep
     net.eval()
     with torch.no_grad():
         le = net(x.cuda()).cpu()
@@ -690,7 +715,7 @@ def test_config2_bs32_256_vs_reference_fixture(golden_dir, mode):
     REPORT["config2_bs32_" + mode]["eval_dice_delta"] = abs(float(oracle.evaluate_dice(le, mask)) - float(z["eval_dice"]))
     _dump()
     assert REPORT["config2_bs32_" + mode]["eval_dice_delta"] < 1e-3
-    assert de.max() < 2e-2 * max(1.0, float(np.abs(z["logits_eval_sub"]).max()))
+    assert de.max() < 5e-5 * max(1.0, float(np.abs(z["logits_eval_sub"]).max()))      # measured 3.3e-5 (fast) / 2e-6 (mixed)
 
 
 def test_mixed_plan_choices():
@@ -701,6 +726,17 @@ def test_mixed_plan_choices():
     m = ue.resolve_plan("mixed", "f16")
     assert [k for k, v in m.items() if v == "xw"] == [s_ for s_ in ue.STAGES if s_ in ue.MIXED_XW] and len(m) == 22
     assert set(ue.resolve_plan("mixed", "bf16").values()) == {"xw"}
+    assert ue.resolve_plan("auto", "f16") == m                                            # what UNet() builds
+    assert set(ue.resolve_plan("auto", "f16", bilinear=True).values()) == {"xw"}          # bilinear: every stage corrected
+    from semantic_segmentation_amd.unet import UNet
+    assert UNet(1, 2).engine.plan == m and UNet(1, 2).engine.auto and UNet(1, 2, precise=False).engine.plan is None
+    from semantic_segmentation_amd.unet3d import unet3d_engine as u3
+    m3 = u3.resolve_plan3d("auto", "f16")
+    assert [k for k, v in m3.items() if v == "xw"] == [s_ for s_ in u3.STAGES3D if s_ in u3.MIXED3D_XW]
+    assert u3.segs3d("xw", 32) == ([(0, 0, 32), (0, 0, 32), (1, 0, 32), (2, 0, 32)], 128, 64)      # the 32-channel conv: K padded to 128
+    assert u3.segs3d("1", 32) == ([(0, 0, 32), (2, 0, 32)], 64, 64)
+    assert u3.segs3d("xw", 192, lo0=128, lo_len=64) == ([(0, 0, 192), (0, 128, 64), (1, 0, 192)], 448, 256)
+    assert u3.segs3d("1", 768, lo0=512, lo_len=256) == ([(0, 0, 768)], 768, 768)
     assert ue.resolve_plan({"inc.3": "w"}, "f16")["inc.3"] == "w"
     with pytest.raises(ValueError):
         ue.resolve_plan({"inc.7": "w"}, "f16")
@@ -887,7 +923,7 @@ def test_stem_and_head_fusions_match_the_stored_tensor_paths(monkeypatch, N, H, 
     def run(fused):
         for flag in ("FUSED_STEM_FWD", "FUSED_HEAD_FWD", "FUSED_HEAD_BWD", "FUSED_STEM_BWD"):
             monkeypatch.setattr(unet_engine, flag, fused)
-        net = UNet(1, 2).to(dev)
+        net = UNet(1, 2, precise=False).to(dev)          # the fusions of the 16-bit engine (the pair forward has its own forms)
         net.load_state_dict(sd, strict=True)
         net.train()
         xd = x.to(dev).requires_grad_(need_dx)
