@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 44
+#define GS_ABI_VERSION 45
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -484,6 +484,37 @@ int gs_pack_weight_segs(int n, const GsSegPackDesc* descs, int dtype, void* stre
 int gs_conv3x3_precise(const void* x, const void* w, void* y_hi, void* y_lo, const float* bias, float* bn_partials, int N,
                        int H, int W, int K, int in_pix_stride, int in_coff, int in_wrap, int Cout, int out_pix_stride,
                        int out_coff, const int32_t* tap_dy, const int32_t* tap_dx, int act, int dtype, void* stream);
+/* ---- "q" stages: the correction terms of a pair-forward conv as ONE FP8 block-scaled MFMA segment ----------
+ * A conv on hi/lo pairs needs x_hi.w_hi + x_lo.w_hi + x_hi.w_lo to meet 1e-3 on the logits (unet_parts.py:16,19 are plain fp32); the
+ * two correction terms are 2^-11 of the main product, so 4 significant bits suffice for them: they run as e4m3 operands on
+ * v_mfma_scale_f32_32x32x64_f8f6f4 (twice the 16-bit MFMA rate) -- a "q" stage costs 2x the MFMA work of the plain conv, not 3x.
+ * Q PLANE: per 32 channels one 64-byte chunk [lo8: 32 x e4m3(lo * 2^(XH+LS)) | hi8: 32 x e4m3(hi * 2^XH)], XH = -2, LS = 11 (fp16);
+ *   it takes the place of the 16-bit lo plane ([hi plane | q plane] = the same bytes per pixel).
+ * gs_pack_weight_q8: fp32 conv weight [Cout][Cin][taps] -> pack[t][co] = [w_hi 16-bit (Cin) | per 32 channels: w_hi8 (32) | w_lo8 (32)]
+ *   (4*Cin bytes) and wexp[co] = the power-of-two exponent shared by the row's e4m3 planes (from the row's amax); n descriptors, 1 launch.
+ * gs_conv3x3_q8 / gs_conv3d_3x3x3_q8: the conv (forward taps) -> dense pair y_hi / y_lo + BatchNorm partials as gs_conv3x3_precise;
+ *   LDS-DMA kernel only: gs_conv3x3_q8_ok(W, Cin, Cout) (W >= 24, Cin %% 64 == 0, Cout %% 8 == 0), fp16 only.
+ * gs_bn_act_apply_split_q8: gs_bn_act_apply_split writing q planes instead of 16-bit lo planes (z_q8 / zp_q8: which outputs).
+ * gs_stem_fwd_bn_pair_q8: gs_stem_fwd_bn_pair with a q plane.   gs_q8_from_hi: the q plane (lo8 = 0) of channels stored hi-only. */
+typedef struct GsQ8PackDesc {
+    const float* w;     /* fp32 parameter [Cout][Cin][taps] */
+    void* pack;         /* [taps][Cout][4*Cin bytes] */
+    int32_t* wexp;      /* [Cout] */
+    int32_t Cout, Cin, taps;
+} GsQ8PackDesc;
+int gs_pack_weight_q8(int n, const GsQ8PackDesc* descs, int dtype, void* stream);
+int gs_conv3x3_q8_ok(int W, int Cin, int Cout);
+int gs_conv3x3_q8(const void* x, const void* w, const int32_t* wexp, void* y_hi, void* y_lo, float* bn_partials, int N, int H, int W,
+                  int Cin, int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff, int dtype, void* stream);
+int gs_conv3d_3x3x3_q8(const void* x, const void* w, const int32_t* wexp, void* y_hi, void* y_lo, float* bn_partials, int NB, int D,
+                       int H, int W, int Cin, int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff, int dtype,
+                       void* stream);
+int gs_bn_act_apply_split_q8(const void* y_hi, const void* y_lo, const float* scale, const float* shift, int act, void* z_hi,
+                             void* z_lo, int z_q8, int z_pix_stride, int z_coff, void* zp_hi, void* zp_lo, int zp_q8,
+                             int zp_pix_stride, int N, int H, int W, int C, int dtype, void* stream);
+int gs_stem_fwd_bn_pair_q8(const float* x, const float* w, const float* bn_scale, const float* bn_shift, int act, void* z_hi,
+                           void* z_q, int z_pix_stride, int N, int H, int W, int dtype, void* stream);
+int gs_q8_from_hi(const void* x, void* q, int64_t pixels, int C, int pix_stride, int coff, int dtype, void* stream);
 /* gs_conv3d_3x3x3_precise: Conv3d(k3, p1) of the pair forward of UNet3D (GenSeg-3D/UNet3D/unet3d.py:28-31,69-71; BASELINE config 5):
  *   gs_conv3d_3x3x3 with the K extent / in_wrap / [27][Cout][K] segment pack / y pair of gs_conv3x3_precise. */
 int gs_conv3d_3x3x3_precise(const void* x, const void* w, void* y_hi, void* y_lo, const float* bias, float* bn_partials,

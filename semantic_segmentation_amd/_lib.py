@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 GS_F16, GS_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH = 0, 1, 2, 3
 GS_MAX_TAPS = 64
-ABI_VERSION = 44
+ABI_VERSION = 45
 
 
 class GsConvGeom(ctypes.Structure):
@@ -41,6 +41,10 @@ GS_SEG_MAX = 4
 class GsSegPackDesc(ctypes.Structure):
     _fields_ = [("w", c_void_p), ("pack", c_void_p)] + [(n, c_int32) for n in ("Cout", "Cin", "taps", "transposed", "nseg")] + [
         ("kind", c_int32 * GS_SEG_MAX), ("ci0", c_int32 * GS_SEG_MAX), ("len", c_int32 * GS_SEG_MAX)]
+
+
+class GsQ8PackDesc(ctypes.Structure):
+    _fields_ = [("w", c_void_p), ("pack", c_void_p), ("wexp", c_void_p)] + [(n, c_int32) for n in ("Cout", "Cin", "taps")]
 
 
 _P, _F = c_void_p, c_void_p   # device pointers are passed as integers
@@ -153,6 +157,13 @@ PROTOTYPES = {
     "gs_mean_loss_fwd": (c_int, [_F, _F, c_float, c_int, c_int64, _F, _F, c_void_p]),
     "gs_pack_weight_split": (c_int, [_F, _P, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "gs_pack_weight_segs": (c_int, [c_int, POINTER(GsSegPackDesc), c_int, c_void_p]),
+    "gs_pack_weight_q8": (c_int, [c_int, POINTER(GsQ8PackDesc), c_int, c_void_p]),
+    "gs_conv3x3_q8_ok": (c_int, [c_int] * 3),
+    "gs_conv3x3_q8": (c_int, [_P, _P, _P, _P, _P, _F] + [c_int] * 10 + [c_void_p]),
+    "gs_conv3d_3x3x3_q8": (c_int, [_P, _P, _P, _P, _P, _F] + [c_int] * 11 + [c_void_p]),
+    "gs_bn_act_apply_split_q8": (c_int, [_P, _P, _F, _F, c_int, _P, _P, c_int, c_int, c_int, _P, _P, c_int, c_int] + [c_int] * 5 + [c_void_p]),
+    "gs_stem_fwd_bn_pair_q8": (c_int, [_F, _F, _F, _F, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "gs_q8_from_hi": (c_int, [_P, _P, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "gs_conv3d_3x3x3_precise": (c_int, [_P, _P, _P, _P, _F, _F] + [c_int] * 11 + [POINTER(c_int32)] * 3 + [c_int, c_int, c_void_p]),
     "gs_maxpool3d_fwd_pair": (c_int, [_P, _P, c_int, _P, _P] + [c_int] * 7 + [c_void_p]),
     "gs_upsample2x_bilinear_fwd_pair": (c_int, [_P, _P, _P, _P] + [c_int] * 13 + [c_void_p]),

@@ -139,6 +139,47 @@ __device__ __forceinline__ void join8(const uint4& hi, const uint4& lo, float (&
     for (int i = 0; i < 8; ++i) v[i] += l[i];
 }
 
+// ---- FP8 correction planes of the pair forward ("q" stages) ----------------------------------------
+// A "q" conv stage computes x_hi.w_hi on the 16-bit MFMA and the two correction terms x_lo.w_hi + x_hi.w_lo as ONE block-scaled
+// e4m3 MFMA segment (v_mfma_scale_f32_32x32x64_f8f6f4: twice the 16-bit rate).  Its operands travel in "q planes": per 32 channels
+// one 64-byte chunk [lo8 (32 x e4m3 of lo * 2^XL) | hi8 (32 x e4m3 of hi * 2^XH)] for activations and [w_hi8 | w_lo8] for weights
+// -- the same bytes per pixel as the 16-bit lo plane they replace.  In the MFMA the first 16 bytes of a lane's operand belong to
+// K block 0 (scaled by the E8M0 byte of lanes 0..31) and the last 16 to K block 1 (lanes 32..63) [probed: tools/probes/mx_probe2.hip],
+// so a lane that reads the 16-byte slots {h, 2 + h} of a chunk row -- exactly the two reads of the 16-bit stages -- pairs lo8 with
+// w_hi8 in block 0 and hi8 with w_lo8 in block 1.
+// Activation scales are static powers of two: hi * 2^-2 keeps |x| < 1792 in range (e4m3 saturates at 448; a saturated value only
+// degrades the correction term), lo = x - hi is at most 2^-11 |x| in fp16, so lo * 2^9 has the same range.
+constexpr int GS_Q8_XH_EXP = -2;
+constexpr int GS_Q8_LO_SHIFT_F16 = 11, GS_Q8_LO_SHIFT_BF16 = 8;
+template <int DT> struct Q8Shift { static constexpr int v = DT == GS_F16 ? GS_Q8_LO_SHIFT_F16 : GS_Q8_LO_SHIFT_BF16; };
+
+// four floats -> four saturating e4m3 bytes (a in byte 0)
+__device__ __forceinline__ unsigned int cvt4_e4m3(float a, float b, float c, float d) {
+    a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+    c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+    int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (unsigned int)v;
+}
+// the q-plane bytes of 8 consecutive channels whose exact values are v and whose stored hi halves are `hi`: lo8 / hi8 (8 bytes each)
+template <int DT>
+__device__ __forceinline__ void q8_of8(const float (&v)[8], const uint4& hi, float s_lo, float s_hi, uint2& lo8, uint2& hi8) {
+    float h[8];
+    unpack8<DT>(hi, h);
+    lo8.x = cvt4_e4m3((v[0] - h[0]) * s_lo, (v[1] - h[1]) * s_lo, (v[2] - h[2]) * s_lo, (v[3] - h[3]) * s_lo);
+    lo8.y = cvt4_e4m3((v[4] - h[4]) * s_lo, (v[5] - h[5]) * s_lo, (v[6] - h[6]) * s_lo, (v[7] - h[7]) * s_lo);
+    hi8.x = cvt4_e4m3(h[0] * s_hi, h[1] * s_hi, h[2] * s_hi, h[3] * s_hi);
+    hi8.y = cvt4_e4m3(h[4] * s_hi, h[5] * s_hi, h[6] * s_hi, h[7] * s_hi);
+}
+// byte offset, inside a q plane, of the lo8 bytes of channel c (a multiple of 8); the hi8 bytes sit 32 bytes further
+__device__ __forceinline__ int q8_off(int c) { return (c >> 5) * 64 + (c & 31); }
+// e4m3 byte -> float (for the pair max-pool, which reads a q plane back)
+__device__ __forceinline__ float e4m3_to_f(unsigned int b) {
+    const unsigned int e = (b >> 3) & 15u, m = b & 7u;
+    const float f = e == 0 ? (float)m * 0.001953125f : __builtin_bit_cast(float, ((e + 120u) << 23) | (m << 20));
+    return (b & 0x80u) ? -f : f;
+}
+
 __device__ __forceinline__ float act_fwd(float v, int act) {
     switch (act) {
         case GS_ACT_RELU: return v > 0.f ? v : 0.f;

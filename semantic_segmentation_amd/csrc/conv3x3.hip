@@ -1066,7 +1066,10 @@ struct C3DmaPlan { int waves, tiles_x, tiles_y, ntn, nitems, grid; };
 static bool c3_dma_shape_ok(int W, int Cin, int Cout) {
     return c3_variant() == 2 && c3_dma_form.load(std::memory_order_relaxed) != 0 && W >= 24 && Cin % 64 == 0 && Cout % 8 == 0;
 }
-static C3DmaPlan c3_dma_plan(int N, int H, int W, int Cout, bool per_block_rows) {
+// q8_cin: the layer's channels when the launch is a "q" stage (0: not one).  A 64-channel "q" stage -- two 16-bit and two FP8 K stages
+// per item -- runs faster in the 4-wave form: the 8-wave Q8 kernel spills (its epilogue reloads ~90 dwords per lane and item),
+// which the four stages of such an item do not amortise (measured 64->64 @256^2: 409 vs 459 us; from 128 channels on the 8-wave form wins)
+static C3DmaPlan c3_dma_plan(int N, int H, int W, int Cout, bool per_block_rows, int q8_cin = 0) {
     C3DmaPlan p;
     const int blocks = c3_blocks_now();
     p.tiles_x = cdiv(W, 32);
@@ -1077,7 +1080,7 @@ static C3DmaPlan c3_dma_plan(int N, int H, int W, int Cout, bool per_block_rows)
     const double cost4 = 0.98 * (double)((items4 + blocks - 1) / blocks);
     const double cost8 = 0.87 * 2.0 * (double)((items8 + blocks - 1) / blocks);
     const int forced = c3_dma_form.load(std::memory_order_relaxed);
-    p.waves = (forced == 4 || forced == 8) ? forced : (cost8 <= cost4 ? 8 : 4);
+    p.waves = (forced == 4 || forced == 8) ? forced : (q8_cin == 64 ? 4 : (cost8 <= cost4 ? 8 : 4));
     p.tiles_y = cdiv(H, p.waves == 8 ? 16 : 8);
     p.nitems = N * p.tiles_x * p.tiles_y * p.ntn;
     p.grid = per_block_rows ? c3_dma_grid(p.nitems, p.ntn, blocks) : (p.nitems < blocks ? p.nitems : blocks);
@@ -1093,7 +1096,7 @@ static C3DmaPlan c3_dma_plan(int N, int H, int W, int Cout, bool per_block_rows)
 extern "C" int gs_conv3x3_stat_rows(int N, int H, int W, int Cin, int Cout, int pair) {
     static const int prec_dma = getenv("GSSEG_C3_PREC_DMA") ? atoi(getenv("GSSEG_C3_PREC_DMA")) : 1;
     if ((!pair || prec_dma != 0) && c3_dma_shape_ok(W, Cin, Cout)) {
-        const C3DmaPlan p = c3_dma_plan(N, H, W, Cout, true);
+        const C3DmaPlan p = c3_dma_plan(N, H, W, Cout, true, pair == 2 ? Cin / 2 : 0);      // pair == 2: a "q" stage, Cin = its K = 2 * channels
         return p.grid / p.ntn;
     }
     return gs_conv3x3_mtiles(N, H, W, Cout);
@@ -1102,7 +1105,7 @@ extern "C" int gs_conv3x3_stat_rows(int N, int H, int W, int Cin, int Cout, int 
 static int conv3x3_launch(const void* x, const void* w, void* y, const float* bias, float* bn_partials, int N, int H,
                           int W, int Cin, int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff,
                           const int32_t* tap_dy, const int32_t* tap_dx, int act, int dtype, void* stream, int D, int ndz,
-                          const int32_t* tap_dz, void* y_lo = nullptr, int in_wrap = 0) {
+                          const int32_t* tap_dz, void* y_lo = nullptr, int in_wrap = 0, const int* wexp = nullptr) {
     GS_CHECK_ARG(x && w && y && tap_dy && tap_dx, "gs_conv3x3: null pointer");
     GS_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0 && Cout > 0, "gs_conv3x3: bad dims");
     const bool prec = y_lo != nullptr;
@@ -1130,6 +1133,8 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
     }
     a.D = D; a.ndz = ndz;
     a.y_lo = (unsigned short*)y_lo; a.in_wrap = in_wrap / 64; a.xcd_order = 0;
+    // "q" stages (gs_conv3x3_q8): Cin = K = 2 * (the layer's channels): the first half 16-bit stages, the second FP8 correction stages
+    a.q8_c0 = wexp ? Cin / 64 : 0; a.wexp = wexp;
     for (int i = 0; i < 3; ++i) a.tap_dz[i] = (tap_dz && i < ndz) ? tap_dz[i] : 0;
     const C3Plan p = c3_plan(H, W, Cout);
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y;
@@ -1164,8 +1169,10 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
         }
         static const int prec_dma_env = getenv("GSSEG_C3_PREC_DMA") ? atoi(getenv("GSSEG_C3_PREC_DMA")) : 1;
         const bool dma = c3_dma_shape_ok(W, Cin, Cout) && (prec ? (std_taps && prec_dma_env != 0) : (std_taps || flip_taps));
+        GS_CHECK_ARG(wexp == nullptr || (dma && dtype == GS_F16 && Cin % 128 == 0),
+                     "gs_conv3x3_q8: needs the LDS-DMA kernel (W >= 24, channels %% 64 == 0, Cout %% 8 == 0, forward taps) and fp16");
         if (dma) {
-            const C3DmaPlan dp = c3_dma_plan(N, H, W, Cout, true);
+            const C3DmaPlan dp = c3_dma_plan(N, H, W, Cout, true, wexp ? Cin / 2 : 0);
             a.tiles_x = dp.tiles_x; a.tiles_y = dp.tiles_y; a.ntn = dp.ntn; a.nblocks = dp.nitems;
             a.xcd_order = (xcd_env && (dp.grid % 8) == 0 && a.ntn > 1 && (int64_t)N * H * W > (int64_t)18 * Cout) ? 1 : 0;
             c3_dma_launch(a, dp.waves, prec, dtype, dp.grid, bs);
@@ -1209,6 +1216,7 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
     GS_CHECK_ARG(bn_partials == nullptr || !c3_dma_shape_ok(W, Cin, Cout),
                  "gs_conv3x3: BatchNorm partials with channel strides / offsets that are not multiples of 8 (gs_conv3x3_stat_rows would be wrong)");
     GS_CHECK_ARG(!prec, "gs_conv3x3_precise: needs the big-K-step kernel (GSSEG_C3=2, Cout %% 8 == 0, 16-byte aligned output channels)");
+    GS_CHECK_ARG(wexp == nullptr, "gs_conv3x3_q8: shape outside the LDS-DMA kernel");
     static const bool force_v1 = c3_variant() == 0;
     // the persistent kernel stores whole 16-byte channel groups; odd shapes go to the one-patch-per-block kernel
     const bool use_v1 = force_v1 || (Cout % 8) != 0 || (out_pix_stride % 8) != 0 || (out_coff % 8) != 0;
@@ -1276,6 +1284,34 @@ extern "C" int gs_conv3x3_precise(const void* x, const void* w, void* y_hi, void
 // weights of slot dz*9 .. dz*9+8 of the [27][Cout][Cin] pack.  Requires Cin % 8 == 0, Cout % 8 == 0 (a tail channel chunk is zero padded).
 extern "C" int gs_conv3d_3x3x3_mtiles(int NB, int D, int H, int W, int Cout) {
     return gs_conv3x3_mtiles(NB * D, H, W, Cout);
+}
+
+// "q" stage of the pair forward (common.hpp): x holds the hi plane (Cin 16-bit channels) followed by the q plane
+// (per 32 channels 64 bytes: lo8 | hi8) at in_coff of a pixel of in_pix_stride 16-bit elements; w = gs_pack_weight_q8 pack
+// [taps][Cout][4*Cin bytes], wexp = its per-cout exponents.  The kernel runs x_hi.w_hi on the 16-bit MFMA and x_lo.w_hi + x_hi.w_lo as
+// one block-scaled e4m3 MFMA segment (2x the MFMA work of the plain conv instead of 3x).  LDS-DMA kernel only: gs_conv3x3_q8_ok().
+extern "C" int gs_conv3x3_q8_ok(int W, int Cin, int Cout) {
+    return (c3_dma_shape_ok(W, 2 * Cin, Cout) && Cin % 64 == 0) ? 1 : 0;
+}
+extern "C" int gs_conv3x3_q8(const void* x, const void* w, const int32_t* wexp, void* y_hi, void* y_lo, float* bn_partials, int N,
+                             int H, int W, int Cin, int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff,
+                             int dtype, void* stream) {
+    GS_CHECK_ARG(y_lo != nullptr && wexp != nullptr, "gs_conv3x3_q8: y_lo / wexp is NULL");
+    GS_CHECK_ARG(gs_conv3x3_q8_ok(W, Cin, Cout), "gs_conv3x3_q8: shape outside the LDS-DMA kernel (gs_conv3x3_q8_ok)");
+    int32_t dy[9], dx[9];
+    for (int i = 0; i < 9; ++i) { dy[i] = i / 3 - 1; dx[i] = i % 3 - 1; }
+    return conv3x3_launch(x, w, y_hi, nullptr, bn_partials, N, H, W, 2 * Cin, in_pix_stride, in_coff, Cout, out_pix_stride, out_coff,
+                          dy, dx, GS_ACT_NONE, dtype, stream, 1, 1, nullptr, y_lo, 2 * Cin, wexp);
+}
+extern "C" int gs_conv3d_3x3x3_q8(const void* x, const void* w, const int32_t* wexp, void* y_hi, void* y_lo, float* bn_partials,
+                                  int NB, int D, int H, int W, int Cin, int in_pix_stride, int in_coff, int Cout, int out_pix_stride,
+                                  int out_coff, int dtype, void* stream) {
+    GS_CHECK_ARG(y_lo != nullptr && wexp != nullptr && NB > 0 && D > 0, "gs_conv3d_3x3x3_q8: bad arguments");
+    GS_CHECK_ARG(gs_conv3x3_q8_ok(W, Cin, Cout), "gs_conv3d_3x3x3_q8: shape outside the LDS-DMA kernel (gs_conv3x3_q8_ok)");
+    int32_t dy[9], dx[9], dz[3] = {-1, 0, 1};
+    for (int i = 0; i < 9; ++i) { dy[i] = i / 3 - 1; dx[i] = i % 3 - 1; }
+    return conv3x3_launch(x, w, y_hi, nullptr, bn_partials, NB * D, H, W, 2 * Cin, in_pix_stride, in_coff, Cout, out_pix_stride,
+                          out_coff, dy, dx, GS_ACT_NONE, dtype, stream, D, 3, dz, y_lo, 2 * Cin, wexp);
 }
 
 // Conv3d 3x3x3 of the pair forward (UNet3D, BASELINE config 5): as gs_conv3x3_precise -- K = the stage's concatenation of segments

@@ -21,6 +21,11 @@ struct C3Args {
     unsigned short* y_lo;
     int in_wrap;                  // in 64-channel chunks; 0 = no wrap
     int xcd_order;                // big kernel: XCD-aware item order (grid must be a multiple of 8)
+    // "q" stages of the pair forward (conv3x3_dma_kernel<.., Q8>): per depth tap the first q8_c0 32-channel K stages are 16-bit
+    // (x_hi . w_hi), the remaining ones FP8 correction stages reading the q planes of the input / of the pack (common.hpp); wexp[co]
+    // = the power-of-two exponent of cout row co's e4m3 weight planes (gs_pack_weight_q8).  q8_c0 = 0: none.
+    int q8_c0 = 0;
+    const int* wexp = nullptr;
 };
 
 constexpr int C3_LDR = 72;
@@ -31,6 +36,6 @@ __device__ __forceinline__ unsigned int dpp_xor1(unsigned int v) {
 
 // conv3x3_dma.hip: launches conv3x3_dma_kernel.  waves: 4 / 8; prec: pair output (y_lo, in_wrap); per_block_stats: see
 // c3_dma_stat_rows().  The caller has filled every field of `a` except nblocks / tiles_y for the 8-wave form.
-int c3_dma_launch(C3Args& a, int waves, bool prec, int dtype, int grid_blocks, hipStream_t s);
+int c3_dma_launch(C3Args& a, int waves, bool prec, int dtype, int grid_blocks, hipStream_t s);      // (a.q8_c0 > 0: the Q8 form, f16 only)
 // number of BatchNorm partial rows the non-pair DMA kernel writes: one per block and cout tile group (grid / ntn)
 int c3_dma_grid(int nitems, int ntn, int max_blocks);

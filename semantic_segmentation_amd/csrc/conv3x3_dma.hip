@@ -47,10 +47,15 @@ __device__ __forceinline__ void dma_piece16(const __amdgpu_buffer_rsrc_t& rs, un
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)dst, 16, voff, soff, 0, 0);
 }
 
-template <int DT, int NWV, bool STATS, bool PREC, bool DEFER>
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+template <int DT, int NWV, bool STATS, bool PREC, bool DEFER, bool Q8 = false>
 __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a) {
     typedef typename Elem<DT>::V8 V8;
-    static_assert(!(PREC && DEFER), "the pair epilogue is the immediate one");
+    // the pair epilogue is deferred only in the 4-wave form: one wave per SIMD has the 512-register file to itself, so the 64
+    // registers of packed hi + lo results can ride through the next item's first stage (the 8-wave form has 256 per wave)
+    static_assert(!(PREC && DEFER) || NWV == 4, "the deferred pair epilogue needs the 4-wave form's registers");
+    static_assert(!Q8 || PREC, "FP8 correction stages belong to the pair forward");
     constexpr int BN = 64, TW = 32, TH = 2 * NWV, TWS = 5, KC = 32;
     constexpr int HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;
     constexpr int ROWB = KC * 2;                           // bytes per LDS row (one pixel / one cout, KC channels)
@@ -68,7 +73,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
     // staging overlays halo 1 + weights 1 (the last stage of an item always sits in buffer 1, the next item's first stage
     // is on its way into buffer 0)
     constexpr int H0_OFF = W_B, W1_OFF = W_B + 2 * HALO_B;
-    constexpr int PRIV_OFF = 2 * STAGE_B, PRIV_B = DEFER ? NWV * 1024 : 0;
+    constexpr int PRIV_OFF = 2 * STAGE_B, PRIV_B = DEFER ? (PREC ? 2 : 1) * NWV * 1024 : 0;       // (PREC: a second buffer per wave for the lo halves)
     constexpr int LDS_B = 2 * STAGE_B + PRIV_B;
     static_assert(LDS_B <= 160 * 1024, "the stage buffers must fit in LDS");
     // PREC (precise mode): K is a concatenation of segments over the same input channels (stage c reads
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
     // (kept opaque: hipcc otherwise materialises every base + constant combination of both buffers in its own register)
     // (DEFER is short of registers -- 32 of packed results ride through the next item's first stage: the second k half's
     // address is formed at the read, one v_xor each)
-    constexpr int AK = DEFER ? 1 : KSTEPS;
+    constexpr int AK = (DEFER || Q8) ? 1 : KSTEPS;          // (Q8: the FP8 stage's 48 fragment registers leave no room for both sets)
     unsigned aaddr[AK][4][3];                              // [k half][halo row 2*wave + e, e = i + dy + 1][column l31 + dx + 1]
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -216,6 +221,8 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
     // ---- deferred epilogue state (DEFER): the previous item's tile as packed 16-bit pairs, its store base, its image ----
     constexpr int NPK = DEFER ? 8 : 1;
     unsigned pk[2][2][NPK];                                // [i][j][m]: rows 2m, 2m+1 of the lane's cout in tile (i, j)
+    constexpr int NPKL = (DEFER && PREC) ? 8 : 1;
+    unsigned pkl[2][2][NPKL];                              // PREC: the lo halves of the same pairs
     unsigned pend_voff = 0u;                               // lane part of the store offset of the pending tile
     int pend_n = 0;                                        // its image
     bool pend = false;
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
     unsigned char* const priv = smem + PRIV_OFF + wave * 1024;
     const unsigned row_stride_b = (unsigned)a.W * a.out_stride * 2u;          // one image row of the output, bytes
     // pass p (0..7) of the pending tile, three phases: W (4 ds_write_b32), R (ds_read_b128), S (the 16-byte store)
-    u32x4 dsv;                                             // the read-back value in flight
+    u32x4 dsv, dsvl;                                       // the read-back values in flight (PREC: hi and lo)
     auto defer_write = [&](int p) __attribute__((always_inline)) {          // p compile-time
         const int i = p >> 2, m0 = (p & 3) * 2;
 #pragma unroll
@@ -239,6 +246,11 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
                 const unsigned v = __builtin_amdgcn_perm(oth, own, psel);
                 const int slot = (j * 4 + (l31 >> 3)) ^ lr;                  // 16-byte slot (8 couts) of cout pair l31 & ~1
                 *reinterpret_cast<unsigned*>(priv + lr * 128 + slot * 16 + (l31 & 6) * 2) = v;
+                if (PREC) {
+                    const unsigned ownl = pkl[i][j][(DEFER && PREC) ? m : 0];
+                    const unsigned othl = (unsigned)__builtin_amdgcn_mov_dpp((int)ownl, 0xB1, 0xf, 0xf, true);
+                    *reinterpret_cast<unsigned*>(priv + NWV * 1024 + lr * 128 + slot * 16 + (l31 & 6) * 2) = __builtin_amdgcn_perm(othl, ownl, psel);
+                }
             }
         }
     };
@@ -248,6 +260,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
     const unsigned priv_rd = (unsigned)(PRIV_OFF + wave * 1024 + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4));
     auto defer_read = [&](int p) __attribute__((always_inline)) {
         asm volatile("ds_read_b128 %0, %1" : "=v"(dsv) : "v"(priv_rd) : "memory");
+        if (PREC) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dsvl) : "v"(priv_rd), "n"(NWV * 1024) : "memory");
     };
     auto defer_wait = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -259,6 +272,11 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
             (void*)(a.y + (int64_t)pend_n * a.H * a.W * a.out_stride), 0, (unsigned)a.H * a.W * a.out_stride * 2u, 0x00020000);
         const unsigned soff = (unsigned)i * row_stride_b + (unsigned)((p & 3) * 8) * (unsigned)a.out_stride * 2u;
         __builtin_amdgcn_raw_buffer_store_b128(dsv, ry, pend_voff, soff, 0);
+        if (PREC) {
+            const __amdgpu_buffer_rsrc_t ryl = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(a.y_lo + (int64_t)pend_n * a.H * a.W * a.out_stride), 0, (unsigned)a.H * a.W * a.out_stride * 2u, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(dsvl, ryl, pend_voff, soff, 0);
+        }
     };
     // the deferred work of MFMA step `step` of the first stage: pass p = step / 2 writes at step 2p, reads at 2p + 1, stores at 2p + 2
     // (in front of the writes of pass p + 1; LDS operations of a wave execute in order)
@@ -353,6 +371,70 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    // ---- FP8 correction stage (Q8): the same 64-byte rows, now [lo8 (32 ch) | hi8 (32 ch)] pixels against [w_hi8 | w_lo8] couts.
+    // One block-scaled e4m3 MFMA per (tap, 32x32 tile) covers BOTH correction terms of 32 channels: a lane's operand is the 16-byte
+    // slots {h, 2 + h} of its row -- the two addresses of the 16-bit steps -- whose first 16 bytes form K block 0 (x_lo8 . w_hi8,
+    // scaled by the E8M0 bytes of lanes 0..31) and last 16 K block 1 (x_hi8 . w_lo8, lanes 32..63).  9 steps of 4 MFMAs at 64
+    // cycles each = the time of a 16-bit stage; the same eight fragment reads per tap, two DMA pieces per step.
+    int q8_sa = 0, q8_sb[2] = {0, 0};                       // E8M0 scale bytes of this lane's K block: activations / couts j = 0, 1
+    auto run_stage8 = [&](auto buf_tag, const __amdgpu_buffer_rsrc_t& rx_n, const Src& sn, unsigned kill, const Item& itn)
+                          __attribute__((always_inline)) {
+        const unsigned sc_n = sn.sc, wsc_n = sn.wsc, hkill_n = sn.hkill;
+        constexpr int BUF = decltype(buf_tag)::value;
+        constexpr unsigned OBUF = 1 - BUF;
+        // registers: ONE set of fragments (pixel tiles 2 x 8, cout tiles 2 x 8 = 32, what a 16-bit stage holds): a fragment's next
+        // tap is fetched right behind the last MFMA that reads it -- the pixel fragments behind the step's last MFMA, i.e. their
+        // latency is covered by the SIMD's other wave, not by this wave's own MFMAs.  (Double-buffered pixel fragments -- 48
+        // registers -- pushed the 8-wave kernel over its 256 registers: 87 dwords per lane spilled, +6..8 us per item.)
+        typedef __attribute__((ext_vector_type(4))) int i32x4;
+        i32x4 af8[2][2], bf8[2][2];                         // [tile][16-byte half]
+        auto load_a8 = [&](int tap, int i, i32x4 (&fa)[2]) __attribute__((always_inline)) {
+            const int dyi = tap / 3, dxi = tap - 3 * dyi;
+            fa[0] = *reinterpret_cast<const i32x4*>(smem + aaddr[0][dyi + i][dxi] + BUF * HALO_B);
+            fa[1] = *reinterpret_cast<const i32x4*>(smem + (aaddr[0][dyi + i][dxi] ^ 32u) + BUF * HALO_B);
+        };
+        auto load_b8 = [&](int tap, int j, i32x4 (&fb)[2]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                fb[q] = *reinterpret_cast<const i32x4*>(smem + baddr[BUF][q] + tap * (BN * ROWB) + j * 32 * ROWB);
+        };
+        auto mfma8 = [&](int i, int j) __attribute__((always_inline)) {
+            const i32x8 va = __builtin_shufflevector(af8[i][0], af8[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
+            const i32x8 vb = __builtin_shufflevector(bf8[j][0], bf8[j][1], 0, 1, 2, 3, 4, 5, 6, 7);
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, vb, acc[i][j], 0, 0, 0, q8_sa, 0, q8_sb[j]);
+        };
+        load_a8(0, 0, af8[0]);
+        load_b8(0, 0, bf8[0]);
+        load_a8(0, 1, af8[1]);
+        load_b8(0, 1, bf8[1]);
+#pragma unroll
+        for (int step = 0; step < 9; ++step) {
+            const bool more = step + 1 < 9;
+            issue_piece(2 * step, rx_n, sc_n, wsc_n, OBUF, hkill_n, kill);
+            issue_piece(2 * step + 1, rx_n, sc_n, wsc_n, OBUF, hkill_n, kill);
+            // (the next item's piece offsets are formed in the item's first stage, which is always a 16-bit one)
+            // order (i, j): (0,0) (1,0) (1,1) (0,1): after the second MFMA cout fragment 0 is free, after the third pixel fragment 1,
+            // after the fourth pixel fragment 0 and cout fragment 1
+            mfma8(0, 0);
+            mfma8(1, 0);
+            if (more) load_b8(step + 1, 0, bf8[0]);
+            mfma8(1, 1);
+            if (more) load_a8(step + 1, 1, af8[1]);
+            mfma8(0, 1);
+            if (more) load_a8(step + 1, 0, af8[0]);
+            if (more) load_b8(step + 1, 1, bf8[1]);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);           // MFMA (0,0), (1,0)
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);           //   next cout fragment 0
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // MFMA (1,1)
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);           //   next pixel fragment 1
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // MFMA (0,1)
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);           //   next pixel fragment 0, cout fragment 1
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);           // the two DMA pieces of this step
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    static_assert(!Q8 || NWP + HJ <= 18, "two DMA pieces per FP8 step");
+
     // stage hand-over: this wave's pieces have landed; after the barrier everybody's have, and nobody reads the other
     // buffer any more.  (Stores count in vmcnt too: the epilogue's are drained here as well.)
     auto stage_sync = [&]() __attribute__((always_inline)) {
@@ -374,6 +456,12 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
         constexpr bool FULL = decltype(full_tag)::value;
         int e_y0 = itc.y0, e_x0 = itc.x0, e_n = itc.n, e_n0 = itc.n0;
         asm volatile("" : "+s"(e_y0), "+s"(e_x0), "+s"(e_n), "+s"(e_n0));
+        // (Q8: the staging addresses are re-formed per item from an opaque lane offset.  Left alone, hipcc hoists the ~40 per-lane
+        // write / read addresses of both staging areas out of the item loop -- loop invariants -- and, with the FP8 stage's 48 fragment
+        // registers in the same kernel, spills them: 87 dwords per lane, reloaded in every item's epilogue: +6..8 us per item measured)
+        unsigned stg_b = (unsigned)(wave * STG_EL * 2 + ((l31 & ~1) * 2)), stg_rb = (unsigned)(wave * STG_EL * 2 + ((lane >> 3) * C3_LDR + (lane & 7) * 8) * 2);
+        if (Q8) { opaque_vgpr(stg_b); opaque_vgpr(stg_rb); }
+        unsigned char* const stg_base = smem + H0_OFF + HALO_B;
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(a.y + (int64_t)e_n * a.H * a.W * a.out_stride), 0, (unsigned)a.H * a.W * a.out_stride * 2u, 0x00020000);
         const __amdgpu_buffer_rsrc_t ry_lo = __builtin_amdgcn_make_buffer_rsrc(
@@ -421,14 +509,16 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
                     const unsigned int oth = dpp_xor1(own);
                     const unsigned int pkv = __builtin_amdgcn_perm(oth, own, psel);
                     const int row = rowa + (odd ? 1 : 0);
-                    *reinterpret_cast<unsigned int*>(stg + row * C3_LDR + j * 32 + (l31 & ~1)) = pkv;
+                    if (Q8) *reinterpret_cast<unsigned int*>(stg_base + stg_b + (unsigned)((row * C3_LDR + j * 32) * 2)) = pkv;
+                    else *reinterpret_cast<unsigned int*>(stg + row * C3_LDR + j * 32 + (l31 & ~1)) = pkv;
                     if (PREC) {                               // lo = 16-bit(value - hi): the pair carries ~22 bits
                         const float l0 = v0 - Elem<DT>::to_f((unsigned short)(own & 0xffffu));
                         const float l1 = v1 - Elem<DT>::to_f((unsigned short)(own >> 16));
                         const unsigned int own_l = Elem<DT>::pack2(l0, l1);
                         const unsigned int oth_l = dpp_xor1(own_l);
                         const unsigned int pk_l = __builtin_amdgcn_perm(oth_l, own_l, psel);
-                        *reinterpret_cast<unsigned int*>(stg_lo + row * C3_LDR + j * 32 + (l31 & ~1)) = pk_l;
+                        if (Q8) *reinterpret_cast<unsigned int*>(stg_base + stg_b + (unsigned)((NWV * STG_EL + row * C3_LDR + j * 32) * 2)) = pk_l;
+                        else *reinterpret_cast<unsigned int*>(stg_lo + row * C3_LDR + j * 32 + (l31 & ~1)) = pk_l;
                     }
                 }
             }
@@ -436,7 +526,8 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
             uint4 sv[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                sv[q] = *reinterpret_cast<const uint4*>(stg + (q * 8 + (lane >> 3)) * C3_LDR + (lane & 7) * 8);
+                sv[q] = Q8 ? *reinterpret_cast<const uint4*>(stg_base + stg_rb + (unsigned)(q * 8 * C3_LDR * 2))
+                           : *reinterpret_cast<const uint4*>(stg + (q * 8 + (lane >> 3)) * C3_LDR + (lane & 7) * 8);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int p = prow0 + q * 8 + (lane >> 3);
@@ -449,7 +540,8 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
                 if (dbg & 64) asm volatile("" :: "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(off));      // ablation: no global stores
                 else __builtin_amdgcn_raw_buffer_store_b128(d, ry, off, 0, 0);
                 if (PREC) {
-                    const uint4 lv = *reinterpret_cast<const uint4*>(stg_lo + (q * 8 + (lane >> 3)) * C3_LDR + (lane & 7) * 8);
+                    const uint4 lv = Q8 ? *reinterpret_cast<const uint4*>(stg_base + stg_rb + (unsigned)((NWV * STG_EL + q * 8 * C3_LDR) * 2))
+                                        : *reinterpret_cast<const uint4*>(stg_lo + (q * 8 + (lane >> 3)) * C3_LDR + (lane & 7) * 8);
                     u32x4 dl;
                     dl[0] = lv.x; dl[1] = lv.y; dl[2] = lv.z; dl[3] = lv.w;
                     __builtin_amdgcn_raw_buffer_store_b128(dl, ry_lo, off, 0, 0);
@@ -479,7 +571,11 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
                     }
                     v0 += bvb[j];
                     v1 += bvb[j];
-                    pk[i][j][DEFER ? m : 0] = Elem<DT>::pack2(v0, v1);
+                    const unsigned own = Elem<DT>::pack2(v0, v1);
+                    pk[i][j][DEFER ? m : 0] = own;
+                    if (PREC)                                 // lo = 16-bit(value - hi): the pair carries ~22 bits
+                        pkl[i][j][(DEFER && PREC) ? m : 0] = Elem<DT>::pack2(v0 - Elem<DT>::to_f((unsigned short)(own & 0xffffu)),
+                                                                             v1 - Elem<DT>::to_f((unsigned short)(own >> 16)));
                 }
         int e_y0 = itc.y0, e_x0 = itc.x0;
         asm volatile("" : "+s"(e_y0), "+s"(e_x0));
@@ -534,6 +630,16 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
             bvb[j] = co < a.Cout ? a.bias[co] : 0.f;
         }
     }
+    if (Q8) {
+        constexpr int LS = Q8Shift<DT>::v;
+        q8_sa = (127 - GS_Q8_XH_EXP - (h == 0 ? LS : 0)) & 0xff;               // lanes 0..31: x_lo8's block, lanes 32..63: x_hi8's
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int co = block_n0 + j * 32 + l31;
+            const int e = co < a.Cout ? a.wexp[co] : 0;
+            q8_sb[j] = (127 - e - (h == 0 ? 0 : LS)) & 0xff;                  // lanes 0..31: w_hi8's block, lanes 32..63: w_lo8's
+        }
+    }
     // WRES: a 64-channel input is two stages -- the weight slabs of stage 0 / stage 1 of the block's cout tile sit in buffer 0 /
     // buffer 1, and every item would fetch the same 2 x 36 KB again.  The block keeps its cout tile, so they are fetched ONCE:
     // 73 of the 215 KB an item moves through the CU's memory pipe (halo 78 KB in, 64 KB out).  With the immediate epilogue this
@@ -541,7 +647,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
     // weight traffic is what these layers wait for (without epilogue: 171 us -> 138 us with resident weights).
     // (The immediate epilogue's staging overlays halo 1 exactly -- 8 x 4.5 KB + 4 KB of partial sums = 40 KB -- so a partial
     // patch on that path does not disturb the slabs; the pair form overlays weights 1 and never takes this path.)
-    const bool wres = DEFER && nstage == 2 && a.ndz == 1 && st0 == 0 && !(dbg & 32);
+    const bool wres = DEFER && !PREC && nstage == 2 && a.ndz == 1 && st0 == 0 && !(dbg & 32);      // (PREC: the immediate path of partial patches overlays weights 1)
     bool first_item = true;
     setup_item(cur);
     {
@@ -569,6 +675,9 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
                 } else {
                     run_stage(std::integral_constant<int, 0>{}, std::true_type{}, std::false_type{}, image_rsrc(s1.n), s1, 0u, nxt, ws0);
                 }
+            } else if (Q8 && (sp % nchunk) >= a.q8_c0) {
+                run_stage8(std::integral_constant<int, 0>{}, image_rsrc(s1.n), s1, 0u, nxt);
+                PH(6);
             } else {
                 run_stage(std::integral_constant<int, 0>{}, std::false_type{}, std::false_type{}, image_rsrc(s1.n), s1, 0u, nxt);
             }
@@ -581,6 +690,10 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
                 wv = wvn;
             }
             const Src s2 = stage_src(last ? nxt.n : cur.n, last ? 0 : sp + 2);
+            if (Q8 && ((sp + 1) % nchunk) >= a.q8_c0) {
+                run_stage8(std::integral_constant<int, 1>{}, image_rsrc(s2.n), s2, (last && !more_items) ? VOOB : 0u, nxt);
+                PH(7);
+            } else
             run_stage(std::integral_constant<int, 1>{}, std::false_type{}, std::false_type{}, image_rsrc(s2.n), s2,
                       (last && !more_items) ? VOOB : 0u, nxt, wres && last);      // the next item's stage-0 slabs are in buffer 0
             PH(3);
@@ -595,12 +708,15 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int m = 0; m < NPK; ++m) pk[i][j][m] = 0u;
+                        for (int m = 0; m < NPK; ++m) { pk[i][j][m] = 0u; if (PREC) pkl[i][j][m < NPKL ? m : 0] = 0u; }
             }
             __builtin_amdgcn_s_barrier();              // every wave has left the second buffer: staging may overlay it
             asm volatile("" ::: "memory");
             if (!(dbg & 4)) {
-                if (plain && full) epilogue_t(cur, std::true_type{}, std::true_type{});
+                if (Q8) {                                  // (a "q" stage has neither bias nor activation: no code for them in this kernel)
+                    if (full) epilogue_t(cur, std::true_type{}, std::true_type{});
+                    else epilogue_t(cur, std::true_type{}, std::false_type{});
+                } else if (plain && full) epilogue_t(cur, std::true_type{}, std::true_type{});
                 else epilogue_t(cur, std::false_type{}, std::false_type{});
             }
             // (no barrier behind it: the staging area is overwritten by DMA pieces only after the next stage hand-over)
@@ -661,11 +777,22 @@ int c3_dma_grid(int nitems, int ntn, int max_blocks) {
 int c3_dma_launch(C3Args& a, int waves, bool prec, int dtype, int grid_blocks, hipStream_t s) {
     dim3 grid(grid_blocks);
     const bool stats = a.bnp != nullptr;
+    if (a.q8_c0 > 0) {                                     // FP8 correction stages: pair forward, fp16 (the plans use "q" for fp16 only)
+        if (!prec || dtype != GS_F16 || a.wexp == nullptr) return -1;
+        if (waves == 8) {
+            if (stats) conv3x3_dma_kernel<GS_F16, 8, true, true, false, true><<<grid, 512, 0, s>>>(a);
+            else conv3x3_dma_kernel<GS_F16, 8, false, true, false, true><<<grid, 512, 0, s>>>(a);
+        } else {                                           // 4 waves: the deferred pair epilogue
+            if (stats) conv3x3_dma_kernel<GS_F16, 4, true, true, true, true><<<grid, 256, 0, s>>>(a);
+            else conv3x3_dma_kernel<GS_F16, 4, false, true, true, true><<<grid, 256, 0, s>>>(a);
+        }
+        return 0;
+    }
 #define C3_DMA_GO(DT, NWV)                                                                                    \
     do {                                                                                                      \
-        if (prec) {                                                                                           \
-            if (stats) conv3x3_dma_kernel<DT, NWV, true, true, false><<<grid, 64 * NWV, 0, s>>>(a);           \
-            else conv3x3_dma_kernel<DT, NWV, false, true, false><<<grid, 64 * NWV, 0, s>>>(a);                \
+        if (prec) {                                            /* 4 waves: the deferred pair epilogue */      \
+            if (stats) conv3x3_dma_kernel<DT, NWV, true, true, NWV == 4><<<grid, 64 * NWV, 0, s>>>(a);        \
+            else conv3x3_dma_kernel<DT, NWV, false, true, NWV == 4><<<grid, 64 * NWV, 0, s>>>(a);             \
         } else {                                                                                              \
             if (stats) conv3x3_dma_kernel<DT, NWV, true, false, true><<<grid, 64 * NWV, 0, s>>>(a);           \
             else conv3x3_dma_kernel<DT, NWV, false, false, true><<<grid, 64 * NWV, 0, s>>>(a);                \

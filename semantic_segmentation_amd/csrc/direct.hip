@@ -22,6 +22,7 @@ struct SCArgs {
     float* sg;                                         // MODE 1: per-block tap sums + Gram entries [block][54] (may be null)
     unsigned short* y_lo = nullptr;                    // MODE 2: lo half of the output pair (pair forward), same stride
     int ys = 64;                                       // MODE 2: pixel stride of y / y_lo
+    int lo_q8 = 0;                                     // MODE 2: y_lo is a q plane (FP8 correction chunks, common.hpp) of pixel stride ys
 };
 
 template <int DT>
@@ -301,7 +302,13 @@ __global__ __launch_bounds__(256) void smallcin_fwd64_line_kernel(const SCArgs a
                     }
                     const uint4 hi = pack8<DT>(o);
                     *reinterpret_cast<uint4*>(dst + g * 16 + 8 * i) = hi;
-                    if (MODE == 2 && dst_lo) {               // pair forward: lo = 16-bit(value - hi)
+                    if (MODE == 2 && dst_lo && a.lo_q8) {    // pair forward, "q" consumer: the q-plane bytes of these 8 channels
+                        uint2 lo8, hi8;
+                        q8_of8<DT>(o, hi, __builtin_ldexpf(1.f, GS_Q8_XH_EXP + Q8Shift<DT>::v), __builtin_ldexpf(1.f, GS_Q8_XH_EXP), lo8, hi8);
+                        unsigned char* zq = reinterpret_cast<unsigned char*>(dst_lo) + q8_off(g * 16 + 8 * i);
+                        *reinterpret_cast<uint2*>(zq) = lo8;
+                        *reinterpret_cast<uint2*>(zq + 32) = hi8;
+                    } else if (MODE == 2 && dst_lo) {        // pair forward: lo = 16-bit(value - hi)
                         float hf[8];
                         unpack8<DT>(hi, hf);
 #pragma unroll
@@ -1426,14 +1433,26 @@ extern "C" int gs_stem_fwd_bn(const float* x, const float* w, const float* bn_sc
 }
 
 // Pair form (UNet(precise=...)): z_hi / z_lo with pixel stride z_pix_stride (e.g. the two planes of a [hi | lo] buffer); z_lo may be NULL.
+static int stem_fwd_bn_pair_impl(const float* x, const float* w, const float* bn_scale, const float* bn_shift, int act,
+                                 void* z_hi, void* z_lo, int z_pix_stride, int N, int H, int W, int dtype, void* stream, int lo_q8);
 extern "C" int gs_stem_fwd_bn_pair(const float* x, const float* w, const float* bn_scale, const float* bn_shift, int act,
                                    void* z_hi, void* z_lo, int z_pix_stride, int N, int H, int W, int dtype, void* stream) {
+    return stem_fwd_bn_pair_impl(x, w, bn_scale, bn_shift, act, z_hi, z_lo, z_pix_stride, N, H, W, dtype, stream, 0);
+}
+// the same with the lo plane as a Q PLANE (z_q: byte 0 = channel 0; the consumer runs a "q" stage)
+extern "C" int gs_stem_fwd_bn_pair_q8(const float* x, const float* w, const float* bn_scale, const float* bn_shift, int act,
+                                      void* z_hi, void* z_q, int z_pix_stride, int N, int H, int W, int dtype, void* stream) {
+    GS_CHECK_ARG(z_q != nullptr, "gs_stem_fwd_bn_pair_q8: z_q is NULL");
+    return stem_fwd_bn_pair_impl(x, w, bn_scale, bn_shift, act, z_hi, z_q, z_pix_stride, N, H, W, dtype, stream, 1);
+}
+static int stem_fwd_bn_pair_impl(const float* x, const float* w, const float* bn_scale, const float* bn_shift, int act,
+                                 void* z_hi, void* z_lo, int z_pix_stride, int N, int H, int W, int dtype, void* stream, int lo_q8) {
     int rc = stem_check("gs_stem_fwd_bn_pair", x, w, N, H, W, dtype);
     if (rc) return rc;
     GS_CHECK_ARG(bn_scale && bn_shift && z_hi && z_pix_stride >= 64 && z_pix_stride % 8 == 0, "gs_stem_fwd_bn_pair: bad arguments");
     GS_CHECK_ARG(act == GS_ACT_NONE || act == GS_ACT_RELU || act == GS_ACT_LEAKY02, "gs_stem_fwd_bn_pair: activation %d not supported", act);
     SCArgs a{x, w, nullptr, (unsigned short*)z_hi, nullptr, N, 1, H, W, 64, H, W, 3, 1, 1, act};
-    a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.y_lo = (unsigned short*)z_lo; a.ys = z_pix_stride;
+    a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.y_lo = (unsigned short*)z_lo; a.ys = z_pix_stride; a.lo_q8 = lo_q8;
     const int nb = gs_conv_smallcin_mtiles(N, H, W);
     if (dtype == GS_F16) smallcin_fwd64_line_kernel<GS_F16, 2><<<nb, 256, 0, (hipStream_t)stream>>>(a);
     else smallcin_fwd64_line_kernel<GS_BF16, 2><<<nb, 256, 0, (hipStream_t)stream>>>(a);

@@ -77,6 +77,82 @@ __global__ __launch_bounds__(256) void pack_segs_kernel(const SegPackArgs a) {
     }
 }
 
+// ---- weight packs of "q" stages (FP8 correction segment, common.hpp) ------------------------------------------------------
+// out[t][co] = one row of 4*Cin bytes: [w_hi 16-bit (Cin) | per 32 channels a 64-byte chunk: w_hi8 (32 x e4m3) | w_lo8 (32 x e4m3)].
+// Both e4m3 planes of a cout row share ONE power-of-two scale derived from the row's own amax (all taps): w_hi8 = e4m3(hi * 2^e),
+// w_lo8 = e4m3(lo * 2^(e + LS)) with amax * 2^e in [64, 128); e goes to wexp[co] (the conv kernel turns it into the E8M0 scale bytes
+// of its B operand: per-lane = per cout).  One wave per cout row: amax pass + pack pass over Cin * taps fp32 values.
+constexpr int Q8PACK_MAX = 24;
+struct Q8PackArgs {
+    const float* w[Q8PACK_MAX];
+    unsigned char* out[Q8PACK_MAX];
+    int* wexp[Q8PACK_MAX];
+    int Cout[Q8PACK_MAX], Cin[Q8PACK_MAX], taps[Q8PACK_MAX];
+    int first[Q8PACK_MAX + 1];           // first block of each descriptor (4 rows per block)
+    int n;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void pack_q8_kernel(const Q8PackArgs a) {
+    int d = 0;
+    while (d + 1 < a.n && (int)blockIdx.x >= a.first[d + 1]) ++d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int co = (blockIdx.x - a.first[d]) * 4 + wave;
+    const int Cout = a.Cout[d], Cin = a.Cin[d], taps = a.taps[d];
+    if (co >= Cout) return;
+    const float* __restrict__ src = a.w[d] + (int64_t)co * Cin * taps;
+    const int n = Cin * taps;
+    float amax = 0.f;
+    for (int i = lane; i < n; i += 64) amax = fmaxf(amax, fabsf(src[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    int e = 0;
+    if (amax > 0.f && amax < INFINITY) {
+        int ex;
+        frexpf(amax, &ex);                              // amax = m * 2^ex, m in [0.5, 1)
+        e = 7 - ex;                                      // amax * 2^e in [64, 128)
+    }
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    if (lane == 0) a.wexp[d][co] = e;
+    const float s_hi = __builtin_ldexpf(1.f, e), s_lo = __builtin_ldexpf(1.f, e + Q8Shift<DT>::v);
+    const int64_t rowb = (int64_t)4 * Cin;
+    for (int ci = lane; ci < Cin; ci += 64) {
+        const int qoff = 2 * Cin + q8_off(ci);
+        for (int t = 0; t < taps; ++t) {
+            const float v = src[ci * taps + t];
+            const unsigned short hi = Elem<DT>::from_f(v);
+            const float hf = Elem<DT>::to_f(hi);
+            unsigned char* row = a.out[d] + ((int64_t)t * Cout + co) * rowb;
+            reinterpret_cast<unsigned short*>(row)[ci] = hi;
+            row[qoff] = (unsigned char)(cvt4_e4m3(hf * s_hi, 0.f, 0.f, 0.f) & 0xffu);
+            row[qoff + 32] = (unsigned char)(cvt4_e4m3((v - hf) * s_lo, 0.f, 0.f, 0.f) & 0xffu);
+        }
+    }
+}
+
+// ---- q plane of a tensor that was written hi-only (the transposed conv's half of a concat buffer): hi8 from the stored hi plane,
+// lo8 = 0 (the stage's x_lo . w_hi term then covers the other channels only -- exactly what the 16-bit "lo_len" segment did)
+template <int DT>
+__global__ __launch_bounds__(256) void q8_from_hi_kernel(const unsigned short* __restrict__ x, unsigned char* __restrict__ q, int64_t P,
+                                                         int C, int xs, int xc) {
+    const int nch = C >> 3;
+    const float s_hi = __builtin_ldexpf(1.f, GS_Q8_XH_EXP);
+    const int64_t total = P * nch;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(i % nch);
+        const int64_t p = i / nch;
+        const int c = xc + ch * 8;
+        float h[8];
+        unpack8<DT>(*reinterpret_cast<const uint4*>(x + p * xs + c), h);
+        uint2 hi8;
+        hi8.x = cvt4_e4m3(h[0] * s_hi, h[1] * s_hi, h[2] * s_hi, h[3] * s_hi);
+        hi8.y = cvt4_e4m3(h[4] * s_hi, h[5] * s_hi, h[6] * s_hi, h[7] * s_hi);
+        unsigned char* dst = q + p * xs * 2 + q8_off(c);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(0u, 0u);
+        *reinterpret_cast<uint2*>(dst + 32) = hi8;
+    }
+}
+
 // ---- first conv: fp32 NCHW image, fp32 weights, VALU; one thread per (pixel, 8-channel chunk) ----------------------
 constexpr int SCP_TILE = 1024;      // output pixels per block = per BatchNorm tile (== gs_conv_smallcin_mtiles)
 constexpr int SCP_MAX_W = 8192;
@@ -160,15 +236,18 @@ struct ApplySArgs {
     unsigned short* z_hi; unsigned short* z_lo;       // both with (zs, zc)
     unsigned short* zp_hi; unsigned short* zp_lo;     // pooled pair, both with pixel stride zps (channel offset 0)
     int act, N, H, W, C, zs, zc, zps;
+    int zp_q8 = 0;                                    // the pooled lo plane is a q plane (FP8 correction chunks, common.hpp)
 };
 
 // Plain form: a thread owns ONE 8-channel chunk for the whole launch (scale / shift live in registers, no index divisions:
 // pixels are a flat range, y dense with stride C, z with stride zs) and keeps UNR pixels in flight -- 2 x UNR 16-byte loads
 // issued before the first use.  The first version (one element per grid-stride iteration, 64-bit div / mod per element,
 // coefficients re-loaded) ran the level-0 tensors at 3.1 TB/s of its four streams.  z_lo may be NULL (no consumer reads it).
-template <int DT, bool LO>
+template <int DT, int LOF>
 __global__ __launch_bounds__(256) void bn_act_apply_split_kernel(const ApplySArgs a) {
     constexpr int UNR = 4;
+    constexpr bool LO = LOF == 1;
+    const float q_slo = __builtin_ldexpf(1.f, GS_Q8_XH_EXP + Q8Shift<DT>::v), q_shi = __builtin_ldexpf(1.f, GS_Q8_XH_EXP);
     const float slope = a.act == GS_ACT_RELU ? 0.f : (a.act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
     const int nch = a.C >> 3;                              // a power-of-two-free divisor of the thread count (host-checked)
     const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -183,6 +262,7 @@ __global__ __launch_bounds__(256) void bn_act_apply_split_kernel(const ApplySArg
     const unsigned short* yl = a.y_lo + c0;
     unsigned short* zh = a.z_hi + a.zc + c0;
     unsigned short* zl = LO ? a.z_lo + a.zc + c0 : nullptr;
+    unsigned char* zq = LOF == 2 ? reinterpret_cast<unsigned char*>(a.z_lo) + q8_off(a.zc + c0) : nullptr;
     for (int64_t p0 = pl; p0 < P; p0 += npl * UNR) {
         uint4 vh[UNR], vl[UNR];
 #pragma unroll
@@ -209,6 +289,13 @@ __global__ __launch_bounds__(256) void bn_act_apply_split_kernel(const ApplySArg
                     split8<DT>(v, hi, lo);
                     *reinterpret_cast<uint4*>(zh + p * a.zs) = hi;
                     *reinterpret_cast<uint4*>(zl + p * a.zs) = lo;
+                } else if (LOF == 2) {
+                    const uint4 hi = pack8<DT>(v);
+                    uint2 lo8, hi8;
+                    q8_of8<DT>(v, hi, q_slo, q_shi, lo8, hi8);
+                    *reinterpret_cast<uint4*>(zh + p * a.zs) = hi;
+                    *reinterpret_cast<uint2*>(zq + p * a.zs * 2) = lo8;
+                    *reinterpret_cast<uint2*>(zq + p * a.zs * 2 + 32) = hi8;
                 } else {
                     *reinterpret_cast<uint4*>(zh + p * a.zs) = pack8<DT>(v);
                 }
@@ -219,8 +306,10 @@ __global__ __launch_bounds__(256) void bn_act_apply_split_kernel(const ApplySArg
 
 // Pooled form: a thread owns one chunk; units are 2x2 windows (32-bit index arithmetic), the four pixels of a window are
 // loaded before the first use.  The pooled pair is the maximum of the STORED pair values.
-template <int DT, bool LO>
+template <int DT, int LOF>
 __global__ __launch_bounds__(256) void bn_act_apply_split_pool_kernel(const ApplySArgs a) {
+    constexpr bool LO = LOF == 1;
+    const float q_slo = __builtin_ldexpf(1.f, GS_Q8_XH_EXP + Q8Shift<DT>::v), q_shi = __builtin_ldexpf(1.f, GS_Q8_XH_EXP);
     const float slope = a.act == GS_ACT_RELU ? 0.f : (a.act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
     const int nch = a.C >> 3;
     const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -267,8 +356,15 @@ __global__ __launch_bounds__(256) void bn_act_apply_split_pool_kernel(const Appl
             split8<DT>(v, hi, lo);
             *reinterpret_cast<uint4*>(a.z_hi + pix * a.zs + a.zc + c0) = hi;
             if (LO) *reinterpret_cast<uint4*>(a.z_lo + pix * a.zs + a.zc + c0) = lo;
+            if (LOF == 2) {
+                uint2 lo8, hi8;
+                q8_of8<DT>(v, hi, q_slo, q_shi, lo8, hi8);
+                unsigned char* zq = reinterpret_cast<unsigned char*>(a.z_lo) + pix * a.zs * 2 + q8_off(a.zc + c0);
+                *reinterpret_cast<uint2*>(zq) = lo8;
+                *reinterpret_cast<uint2*>(zq + 32) = hi8;
+            }
             float rr[8];
-            if (LO) join8<DT>(hi, lo, rr);
+            if (LOF != 0) join8<DT>(hi, lo, rr);             // the pooled value: the maximum of the pair values (16-bit lo precision)
             else unpack8<DT>(hi, rr);
 #pragma unroll
             for (int i = 0; i < 8; ++i) mx[i] = fmaxf(mx[i], rr[i]);
@@ -278,7 +374,14 @@ __global__ __launch_bounds__(256) void bn_act_apply_split_pool_kernel(const Appl
             uint4 hi, lo;
             split8<DT>(mx, hi, lo);
             *reinterpret_cast<uint4*>(a.zp_hi + pp * a.zps + c0) = hi;
-            if (a.zp_lo) *reinterpret_cast<uint4*>(a.zp_lo + pp * a.zps + c0) = lo;
+            if (a.zp_lo && !a.zp_q8) *reinterpret_cast<uint4*>(a.zp_lo + pp * a.zps + c0) = lo;
+            if (a.zp_lo && a.zp_q8) {
+                uint2 lo8, hi8;
+                q8_of8<DT>(mx, hi, q_slo, q_shi, lo8, hi8);
+                unsigned char* zq = reinterpret_cast<unsigned char*>(a.zp_lo) + pp * a.zps * 2 + q8_off(c0);
+                *reinterpret_cast<uint2*>(zq) = lo8;
+                *reinterpret_cast<uint2*>(zq + 32) = hi8;
+            }
         }
     }
 }
@@ -391,6 +494,44 @@ extern "C" int gs_pack_weight_segs(int n, const GsSegPackDesc* descs, int dtype,
     return GS_OK;
 }
 
+extern "C" int gs_pack_weight_q8(int n, const GsQ8PackDesc* descs, int dtype, void* stream) {
+    GS_CHECK_ARG(n > 0 && descs != nullptr, "gs_pack_weight_q8: no descriptors");
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_pack_weight_q8: bad dtype");
+    hipStream_t s = (hipStream_t)stream;
+    for (int base = 0; base < n; base += Q8PACK_MAX) {
+        Q8PackArgs a;
+        a.n = n - base < Q8PACK_MAX ? n - base : Q8PACK_MAX;
+        int blocks = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const GsQ8PackDesc& d = descs[base + i];
+            GS_CHECK_ARG(d.w && d.pack && d.wexp && d.Cout > 0 && d.Cin > 0 && d.Cin % 32 == 0 && d.taps > 0,
+                         "gs_pack_weight_q8: descriptor %d: needs w, pack, wexp and Cin %% 32 == 0", base + i);
+            a.w[i] = d.w; a.out[i] = (unsigned char*)d.pack; a.wexp[i] = d.wexp;
+            a.Cout[i] = d.Cout; a.Cin[i] = d.Cin; a.taps[i] = d.taps;
+            a.first[i] = blocks;
+            blocks += cdiv(d.Cout, 4);
+        }
+        a.first[a.n] = blocks;
+        if (dtype == GS_F16) pack_q8_kernel<GS_F16><<<blocks, 256, 0, s>>>(a);
+        else pack_q8_kernel<GS_BF16><<<blocks, 256, 0, s>>>(a);
+        GS_CHECK_LAUNCH("gs_pack_weight_q8");
+    }
+    return GS_OK;
+}
+
+extern "C" int gs_q8_from_hi(const void* x, void* q, int64_t pixels, int C, int pix_stride, int coff, int dtype, void* stream) {
+    GS_CHECK_ARG(x && q && pixels > 0 && C > 0 && C % 32 == 0 && coff % 32 == 0 && pix_stride % 8 == 0 && pix_stride >= coff + C,
+                 "gs_q8_from_hi: C and coff must be multiples of 32 inside the pixel stride");
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_q8_from_hi: bad dtype");
+    int64_t nb = cdiv64(pixels * (C / 8), 256 * 4);
+    if (nb > 8192) nb = 8192;
+    if (nb < 1) nb = 1;
+    if (dtype == GS_F16) q8_from_hi_kernel<GS_F16><<<(int)nb, 256, 0, (hipStream_t)stream>>>((const unsigned short*)x, (unsigned char*)q, pixels, C, pix_stride, coff);
+    else q8_from_hi_kernel<GS_BF16><<<(int)nb, 256, 0, (hipStream_t)stream>>>((const unsigned short*)x, (unsigned char*)q, pixels, C, pix_stride, coff);
+    GS_CHECK_LAUNCH("gs_q8_from_hi");
+    return GS_OK;
+}
+
 extern "C" int gs_conv_smallcin_fwd_split(const float* x, const float* w, void* y_hi, void* y_lo, float* bn_partials, int N,
                                           int Cin, int H, int W, int Cout, int k, int pad, int dtype, void* stream) {
     GS_CHECK_ARG(x && w && y_hi && y_lo, "gs_conv_smallcin_fwd_split: null pointer");
@@ -408,9 +549,29 @@ extern "C" int gs_conv_smallcin_fwd_split(const float* x, const float* w, void* 
     return GS_OK;
 }
 
+static int bn_act_apply_split_impl(const void* y_hi, const void* y_lo, const float* scale, const float* shift, int act,
+                                   void* z_hi, void* z_lo, int z_pix_stride, int z_coff, void* zp_hi, void* zp_lo,
+                                   int zp_pix_stride, int N, int H, int W, int C, int dtype, void* stream, int z_q8, int zp_q8);
 extern "C" int gs_bn_act_apply_split(const void* y_hi, const void* y_lo, const float* scale, const float* shift, int act,
                                      void* z_hi, void* z_lo, int z_pix_stride, int z_coff, void* zp_hi, void* zp_lo,
                                      int zp_pix_stride, int N, int H, int W, int C, int dtype, void* stream) {
+    return bn_act_apply_split_impl(y_hi, y_lo, scale, shift, act, z_hi, z_lo, z_pix_stride, z_coff, zp_hi, zp_lo, zp_pix_stride, N, H, W,
+                                   C, dtype, stream, 0, 0);
+}
+// the same with the lo planes as Q PLANES (FP8 correction chunks, common.hpp): z_q8 / zp_q8 != 0 -> z_lo / zp_lo point at the q
+// plane of their buffer (its byte 0 = channel 0 of the buffer; z_coff selects the chunk), which takes the place of the 16-bit lo
+// plane for consumers that run a "q" stage.  Channel offsets and C must be multiples of 32 for a q plane.
+extern "C" int gs_bn_act_apply_split_q8(const void* y_hi, const void* y_lo, const float* scale, const float* shift, int act,
+                                        void* z_hi, void* z_lo, int z_q8, int z_pix_stride, int z_coff, void* zp_hi, void* zp_lo,
+                                        int zp_q8, int zp_pix_stride, int N, int H, int W, int C, int dtype, void* stream) {
+    GS_CHECK_ARG((!z_q8 || (z_lo && z_coff % 32 == 0 && C % 32 == 0)) && (!zp_q8 || (zp_lo && C % 32 == 0)),
+                 "gs_bn_act_apply_split_q8: a q plane needs its pointer and channel counts / offsets that are multiples of 32");
+    return bn_act_apply_split_impl(y_hi, y_lo, scale, shift, act, z_hi, z_lo, z_pix_stride, z_coff, zp_hi, zp_lo, zp_pix_stride, N, H, W,
+                                   C, dtype, stream, z_q8 ? 1 : 0, zp_q8 ? 1 : 0);
+}
+static int bn_act_apply_split_impl(const void* y_hi, const void* y_lo, const float* scale, const float* shift, int act,
+                                   void* z_hi, void* z_lo, int z_pix_stride, int z_coff, void* zp_hi, void* zp_lo,
+                                   int zp_pix_stride, int N, int H, int W, int C, int dtype, void* stream, int z_q8, int zp_q8) {
     GS_CHECK_ARG(y_hi && y_lo && z_hi && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "gs_bn_act_apply_split: bad arguments");
     GS_CHECK_ARG(z_pix_stride >= z_coff + C && z_pix_stride % 8 == 0 && z_coff % 8 == 0, "gs_bn_act_apply_split: bad z stride");
     GS_CHECK_ARG((scale == nullptr) == (shift == nullptr), "gs_bn_act_apply_split: scale/shift must both be given or NULL");
@@ -422,7 +583,9 @@ extern "C" int gs_bn_act_apply_split(const void* y_hi, const void* y_lo, const f
     ApplySArgs a{(const unsigned short*)y_hi, (const unsigned short*)y_lo, scale, shift, (unsigned short*)z_hi,
                  (unsigned short*)z_lo, (unsigned short*)zp_hi, (unsigned short*)zp_lo, act, N, H, W, C, z_pix_stride, z_coff,
                  zp_pix_stride};
-    const bool pool = zp_hi != nullptr, lo = z_lo != nullptr;
+    a.zp_q8 = zp_q8;
+    const bool pool = zp_hi != nullptr;
+    const int lof = z_lo == nullptr ? 0 : (z_q8 ? 2 : 1);
     const int nch = C / 8;
     // the grid's thread count must be a multiple of the chunk count (a thread keeps its chunk): blocks of 256 threads,
     // nch | 256 * blocks
@@ -437,11 +600,13 @@ extern "C" int gs_bn_act_apply_split(const void* y_hi, const void* y_lo, const f
 #define GS_APPLY_SPLIT(DT)                                                                         \
     do {                                                                                           \
         if (pool) {                                                                                \
-            if (lo) bn_act_apply_split_pool_kernel<DT, true><<<(int)blocks, 256, 0, s>>>(a);       \
-            else bn_act_apply_split_pool_kernel<DT, false><<<(int)blocks, 256, 0, s>>>(a);         \
+            if (lof == 1) bn_act_apply_split_pool_kernel<DT, 1><<<(int)blocks, 256, 0, s>>>(a);    \
+            else if (lof == 2) bn_act_apply_split_pool_kernel<DT, 2><<<(int)blocks, 256, 0, s>>>(a); \
+            else bn_act_apply_split_pool_kernel<DT, 0><<<(int)blocks, 256, 0, s>>>(a);             \
         } else {                                                                                   \
-            if (lo) bn_act_apply_split_kernel<DT, true><<<(int)blocks, 256, 0, s>>>(a);            \
-            else bn_act_apply_split_kernel<DT, false><<<(int)blocks, 256, 0, s>>>(a);              \
+            if (lof == 1) bn_act_apply_split_kernel<DT, 1><<<(int)blocks, 256, 0, s>>>(a);         \
+            else if (lof == 2) bn_act_apply_split_kernel<DT, 2><<<(int)blocks, 256, 0, s>>>(a);    \
+            else bn_act_apply_split_kernel<DT, 0><<<(int)blocks, 256, 0, s>>>(a);                  \
         }                                                                                          \
     } while (0)
     if (dtype == GS_F16) GS_APPLY_SPLIT(GS_F16);

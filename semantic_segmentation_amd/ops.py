@@ -289,11 +289,12 @@ def conv3x3_mtiles(N, H, W, Cout) -> int:
     return _lib.load().gs_conv3x3_mtiles(N, H, W, Cout)
 
 
-def conv3x3_stat_rows(N, H, W, Cin, Cout, pair: bool = False) -> int:
+def conv3x3_stat_rows(N, H, W, Cin, Cout, pair=False) -> int:
     """Rows of BatchNorm partial sums a conv3x3 launch of these dimensions WRITES (what bn_finalize / bn_partials_colsum must
     be told): one per block and cout-tile group on the LDS-DMA kernel, one per patch otherwise and in the pair forward.  A
     buffer of conv3x3_mtiles() rows always suffices."""
-    return int(_lib.load().gs_conv3x3_stat_rows(N, H, W, Cin, Cout, 1 if pair else 0))
+    # pair: False / True (the pair forward: Cin = its K extent) / "q" (a "q" stage: Cin = K = 2 * channels; its form is chosen per shape)
+    return int(_lib.load().gs_conv3x3_stat_rows(N, H, W, Cin, Cout, 2 if pair == "q" else (1 if pair else 0)))
 
 
 def conv3d3_stat_rows(NB, D, H, W, Cin, Cout) -> int:
@@ -1362,3 +1363,97 @@ def head1x1_fwd_split(x_hi, x_lo, w, bias, y):
         raise ValueError("head1x1_fwd_split: x_hi / x_lo must be dense NHWC of one shape")
     _lib.call("gs_head1x1_fwd_split", _p(x_hi), _p(x_lo), _p(w), _p(bias), _p(y), N, H, W, Cin, y.shape[1], dt_code(x_hi),
               _stream())
+
+
+# ---------------------------------------------------------------------------- "q" stages: FP8 correction segment of the pair forward
+# (include/gsseg.h, csrc/common.hpp): the lo plane of a pair travels as a Q PLANE -- per 32 channels 64 bytes [lo8 | hi8] of e4m3 --
+# and a conv stage runs x_hi.w_hi on the 16-bit MFMA plus ONE block-scaled e4m3 segment for x_lo.w_hi + x_hi.w_lo.
+def conv3x3_q8_ok(W, Cin, Cout) -> bool:
+    """does the "q" form of a 3x3 / 3x3x3 conv exist for this shape (LDS-DMA kernel: W >= 24, Cin % 64 == 0, Cout % 8 == 0)?"""
+    return USE_HALO_CONV and bool(_lib.load().gs_conv3x3_q8_ok(W, Cin, Cout))
+
+
+def pack_weight_q8(items):
+    """items: (w fp32 [Cout][Cin][taps...], pack [taps][Cout][2*Cin] 16-bit elements = 4*Cin bytes per row, wexp int32 [Cout]); one launch."""
+    if not items:
+        return
+    descs = (_lib.GsQ8PackDesc * len(items))()
+    ref = items[0][1]
+    for d, (w, pack, wexp) in zip(descs, items):
+        _dev(w)
+        _f32(w, "weight")
+        cout, cin = w.shape[0], w.shape[1]
+        taps = w.numel() // (cout * cin)
+        if pack.numel() != taps * cout * 2 * cin or not pack.is_contiguous() or pack.dtype != ref.dtype:
+            raise ValueError("pack_weight_q8: pack must be contiguous [taps][Cout][2*Cin] of the engine's 16-bit dtype")
+        if wexp.dtype != torch.int32 or wexp.numel() != cout or not wexp.is_contiguous():
+            raise ValueError("pack_weight_q8: wexp must be int32 [Cout]")
+        d.w, d.pack, d.wexp, d.Cout, d.Cin, d.taps = _p(w), _p(pack), _p(wexp), cout, cin, taps
+    _lib.call("gs_pack_weight_q8", len(items), descs, dt_code(ref), _stream())
+
+
+def conv3x3_q8(x, w, wexp, y_hi, y_lo, N, H, W, Cin, Cout, in_stride, in_coff=0, bn_partials=None):
+    """3x3/s1/p1 conv as a "q" stage: x = [hi plane (Cin) | q plane] at in_coff (pixel stride in_stride), w / wexp from pack_weight_q8;
+    result: dense pair y_hi / y_lo [N,H,W,Cout]."""
+    _dev(x)
+    _f32(bn_partials, "bn_partials")
+    if not (x.dtype == w.dtype == y_hi.dtype == y_lo.dtype == torch.float16):
+        raise TypeError("conv3x3_q8: fp16 tensors only")
+    if w.numel() != 9 * Cout * 2 * Cin:
+        raise ValueError("conv3x3_q8: w must be the [9][Cout][2*Cin] q pack")
+    if bn_partials is not None and bn_partials.numel() < bn_partials_numel(conv3x3_stat_rows(N, H, W, 2 * Cin, Cout, pair="q"), Cout):
+        raise ValueError("conv3x3_q8: bn_partials too small")
+    ev = TIMER.start() if TIMER is not None else None
+    _lib.call("gs_conv3x3_q8", _p(x), _p(w), _p(wexp), _p(y_hi), _p(y_lo), _p(bn_partials), N, H, W, Cin, in_stride, in_coff,
+              Cout, Cout, 0, dt_code(x), _stream())
+    if ev is not None:
+        TIMER.stop("conv3x3_halo_precise", ev, 2.0 * N * H * W * Cout * 9 * Cin,
+                   2.0 * (N * H * W * 2 * (Cin + Cout) + 9 * 2 * Cin * Cout))
+
+
+def conv3d3_q8(x, w, wexp, y_hi, y_lo, NB, D, H, W, Cin, Cout, in_stride, in_coff=0, bn_partials=None):
+    """Conv3d(k3, p1) as a "q" stage (see conv3x3_q8); w = [27][Cout][2*Cin] q pack."""
+    _dev(x)
+    _f32(bn_partials, "bn_partials")
+    if not (x.dtype == w.dtype == y_hi.dtype == y_lo.dtype == torch.float16):
+        raise TypeError("conv3d3_q8: fp16 tensors only")
+    if w.numel() != 27 * Cout * 2 * Cin:
+        raise ValueError("conv3d3_q8: w must be the [27][Cout][2*Cin] q pack")
+    if bn_partials is not None and bn_partials.numel() < bn_partials_numel(conv3x3_stat_rows(NB * D, H, W, 2 * Cin, Cout, pair="q"), Cout):
+        raise ValueError("conv3d3_q8: bn_partials too small")
+    ev = TIMER.start() if TIMER is not None else None
+    _lib.call("gs_conv3d_3x3x3_q8", _p(x), _p(w), _p(wexp), _p(y_hi), _p(y_lo), _p(bn_partials), NB, D, H, W, Cin, in_stride,
+              in_coff, Cout, Cout, 0, dt_code(x), _stream())
+    if ev is not None:
+        TIMER.stop("conv3x3_halo_precise", ev, 2.0 * NB * D * H * W * Cout * 27 * Cin,
+                   2.0 * (NB * D * H * W * 2 * (Cin + Cout) + 27 * 2 * Cin * Cout))
+
+
+def bn_act_apply_split_q8(y_hi, y_lo, scale, shift, act, z_hi, z_lo, z_q8, z_stride, z_coff, zp_hi=None, zp_lo=None, zp_q8=False,
+                          zp_stride=0):
+    """bn_act_apply_split with q planes: z_q8 / zp_q8 say whether z_lo / zp_lo are q planes (pointers at the plane's byte 0; z_coff
+    selects the chunk) or 16-bit lo planes."""
+    N, H, W, C = y_hi.shape
+    if not (y_hi.is_contiguous() and y_lo.is_contiguous()) or y_lo.shape != y_hi.shape:
+        raise ValueError("bn_act_apply_split_q8: y_hi / y_lo must be dense NHWC of one shape")
+    _f32(scale, "scale"); _f32(shift, "shift")
+    _lib.call("gs_bn_act_apply_split_q8", _p(y_hi), _p(y_lo), _p(scale), _p(shift), act, _p(z_hi), _p(z_lo), int(bool(z_q8)), z_stride,
+              z_coff, _p(zp_hi), _p(zp_lo), int(bool(zp_q8)), zp_stride, N, H, W, C, dt_code(y_hi), _stream())
+
+
+def stem_fwd_bn_pair_q8(x, w, scale, shift, act, zpair):
+    """stem_fwd_bn_pair writing [hi plane (64) | q plane] into zpair [N,H,W,128]."""
+    _stem_check(x, w, "stem_fwd_bn_pair_q8")
+    _f32(scale, "scale"); _f32(shift, "shift")
+    N, _, H, W = x.shape
+    if tuple(zpair.shape) != (N, H, W, 128) or not zpair.is_contiguous():
+        raise ValueError("stem_fwd_bn_pair_q8: zpair must be dense [N,H,W,128]")
+    _lib.call("gs_stem_fwd_bn_pair_q8", _p(x), _p(w), _p(scale), _p(shift), act, _p(zpair), _p(zpair[..., 64:]), 128, N, H, W,
+              dt_code(zpair), _stream())
+
+
+def q8_from_hi(buf, q_plane, pixels, C, pix_stride, coff):
+    """q plane (hi8 from the stored hi plane, lo8 = 0) of channels [coff, coff + C) of a buffer whose hi plane starts at `buf` and
+    whose q plane starts at `q_plane` (both with pixel stride pix_stride 16-bit elements)."""
+    _dev(buf)
+    _lib.call("gs_q8_from_hi", _p(buf), _p(q_plane), int(pixels), C, pix_stride, coff, dt_code(buf), _stream())

@@ -106,7 +106,16 @@ def pack_reuse_allowed(need_grad: bool, trust_versions: bool = False) -> bool:
 STAGES = (["inc.0", "inc.3"] + [f"down{i}.{k}" for i in range(1, 5) for k in (0, 3)] +
           [s_ for j in range(1, 5) for s_ in (f"up{j}.up", f"up{j}.conv.0", f"up{j}.conv.3")])
 # MFMA segments of one stage of the pair forward: "1" = x_hi.w_hi, "x" = + x_lo.w_hi, "w" = + x_hi.w_lo, "xw" = all three
-_SEG_MODES = ("1", "x", "w", "xw")
+# "q" = x_hi.w_hi on the 16-bit MFMA + the two correction terms as ONE FP8 block-scaled segment (csrc/common.hpp): 2x the MFMA work of
+# "1" instead of the 3x of "xw"; the lo plane of its input travels as a q plane.  Shapes outside the LDS-DMA kernel run it as "xw".
+_SEG_MODES = ("1", "x", "w", "xw", "q")
+# The correction form of the "mixed" plan's MIXED_XW stages: "xw" (default: 16-bit correction segments) or "q" (GSSEG_MIXED_SEG=q).
+# Round-4 experiment with a stated kill criterion (VERDICT r3 item 2 ii: keep "q" only if every fixture stays < 8.5e-4 AND the bs=32
+# step gains >= 1 ms): fixtures 5.7e-4 .. 7.7e-4 (xw: 5.4e-4 .. 6.7e-4) -- met; step 14.98 -> 14.69 ms = -0.3 ms -- NOT met, so "q" is
+# not the default.  The FP8 stage itself runs at 0.85x the time of a 16-bit stage (in-kernel stamps, profiles/r04_q8_phase.txt) and
+# the 4-wave form reaches the ideal q/xw = 0.67, but the 8-wave kernel that the large layers need has no registers left for it:
+# 66 VGPRs + 59 SGPRs spilled, its epilogue takes 1.8x as long.
+MIXED_SEG = os.environ.get("GSSEG_MIXED_SEG", "xw")
 # Where the 16-bit error of the logits is made (tools/parity_attribution.py, profiles/r03_parity_attribution_wyz.json): the
 # 256^2 / 128^2 / 64^2 stages of the encoder and the last two decoder levels; everything at 32^2 and below contributes
 # < 5e-5 each.  "mixed" keeps all three MFMA segments there and one segment elsewhere -- every tensor still travels as a
@@ -128,7 +137,7 @@ def resolve_plan(precise, dtype: str, bilinear: bool = False):
     if precise == "mixed" or precise == "auto":
         if dtype != "f16" or bilinear:
             return {s_: "xw" for s_ in STAGES}
-        return {s_: ("xw" if s_ in MIXED_XW else "1") for s_ in STAGES}
+        return {s_: (MIXED_SEG if s_ in MIXED_XW else "1") for s_ in STAGES}
     if isinstance(precise, dict):
         bad = [k for k, v in precise.items() if k not in STAGES or v not in _SEG_MODES]
         if bad:
@@ -547,13 +556,14 @@ class UNetEngine:
         return logits, ctx
 
     # ------------------------------------------------------------------ precise forward
-    def _prepack_segs(self, params: Dict[str, torch.Tensor]):
-        """Segment packs of the pair forward ([taps][Cout][K], K = the stage's concatenation of hi / lo segments), every
-        stale one re-packed in ONE launch; cached until the Parameter is modified."""
-        items, fresh = [], []
+    def _prepack_segs(self, params: Dict[str, torch.Tensor], eff: Dict[str, str]):
+        """Segment packs of the pair forward ([taps][Cout][K], K = the stage's concatenation of hi / lo segments; "q" stages: the
+        q pack [taps][Cout][2*Cin] + per-cout exponents), every stale one re-packed in ONE launch per kind; cached until the
+        Parameter is modified.  eff: the plan with "q" replaced by "xw" where this input size has no "q" kernel."""
+        items, fresh, qitems, qfresh = [], [], [], []
         full = all(v == "xw" for v in self.plan.values())
         for st in STAGES:
-            mode = self.plan[st]
+            mode = eff[st]
             if st.endswith(".up"):
                 wkey, transposed = st + ".weight", True
             else:
@@ -570,11 +580,17 @@ class UNetEngine:
             if not full:
                 if transposed and mode == "1":
                     continue                               # runs on the default LDS-DMA GEMM with the ordinary pack
-                if st.endswith(".conv.0") and self.plan[st[:-len(".conv.0")] + ".up"] == "1" and not self.net.bilinear:
+                if st.endswith(".conv.0") and eff[st[:-len(".conv.0")] + ".up"] == "1" and not self.net.bilinear:
                     lo_len = cin // 2                      # the up half of the concat buffer carries no lo plane
             key = (_pack_key(w), mode, lo_len)
             ent = self._packs.get(wkey + "|segs")
             if ent is not None and ent[0] == key:
+                continue
+            if mode == "q":
+                pack = torch.empty((w.shape[2] * w.shape[3], cout, 2 * cin), dtype=self.tdt, device=w.device)
+                wexp = torch.empty(cout, dtype=torch.int32, device=w.device)
+                qitems.append((w.detach().contiguous(), pack, wexp))
+                qfresh.append((wkey, key, (pack, wexp)))
                 continue
             segs, K, _ = _segs(mode, cin, lo_len)
             pack = torch.empty((w.shape[2] * w.shape[3], cout, K), dtype=self.tdt, device=w.device)
@@ -582,11 +598,22 @@ class UNetEngine:
             fresh.append((wkey, key, pack))
         if items:
             ops.pack_weight_segs(items)
-            for wkey, key, pack in fresh:
-                self._packs[wkey + "|segs"] = (key, pack)
+        if qitems:
+            ops.pack_weight_q8(qitems)
+        for wkey, key, pack in fresh + qfresh:
+            self._packs[wkey + "|segs"] = (key, pack)
 
     def _seg_pack(self, wkey: str):
         return self._packs[wkey + "|segs"][1]
+
+    @staticmethod
+    def _wkey_of(st: str) -> str:
+        """state-dict key of the weight of plan stage `st` ("down2.3" -> "down2.maxpool_conv.1.double_conv.3.weight")"""
+        if st.endswith(".up"):
+            return st + ".weight"
+        blk, idx = st.rsplit(".", 1)
+        prefix = blk if (blk == "inc" or blk.endswith(".conv")) else blk + ".maxpool_conv.1"
+        return f"{prefix}.double_conv.{idx}.weight"
 
     def forward_precise(self, x: torch.Tensor, params: Dict[str, torch.Tensor], training: bool, need_grad: bool):
         """The pair forward: every activation and conv output travels as a PAIR of 16-bit values v = hi + lo (hi = 16-bit(v),
@@ -621,9 +648,21 @@ class UNetEngine:
         full = all(v == "xw" for v in plan.values())
         if not pack_reuse_allowed(need_grad, self.trust_versions):
             self._packs.clear()                            # `.data` writes are invisible to the version keys
+        # "q" stages exist on the LDS-DMA kernel only (W >= 24, channels % 64 == 0, fp16): elsewhere they run as "xw"
+        lvl_of = {"inc": 0, "down1": 1, "down2": 2, "down3": 3, "down4": 4, "up1": 3, "up2": 2, "up3": 1, "up4": 0}
+        eff = dict(plan)
+        for st_, m_ in plan.items():
+            if m_ == "q":
+                w_ = params.get(self._wkey_of(st_))
+                lv = lvl_of[st_.split(".")[0]]
+                ok = (not st_.endswith(".up") and w_ is not None and self.dtype == "f16"
+                      and ops.conv3x3_q8_ok(ws_[lv], w_.shape[1], w_.shape[0]))
+                if not ok:
+                    eff[st_] = "xw"
+        plan = eff
         if need_grad or not full:
             self._prepack(params, need_grad)               # the backward's data-gradient packs / the "1" up-convs' packs, one launch
-        self._prepack_segs(params)                         # the forward's segment packs, one launch
+        self._prepack_segs(params, eff)                    # the forward's segment packs, one launch per kind
 
         def empty(*shape, dtype=tdt):
             return torch.empty(shape, dtype=dtype, device=dev)
@@ -671,8 +710,10 @@ class UNetEngine:
             rec.cin, rec.cout, rec.h, rec.w, rec.inp_is_image = cin, cout, h, w, image
             rec.inp, rec.train_stats, rec.geom, rec.z, rec.tap_sums = inp, batch_stats, None, None, None
             rec.inp_stride = None if image else 2 * cin
-            ntiles = ops.conv_smallcin_mtiles(N, h, w) if image else ops.conv3x3_stat_rows(N, h, w, cin, cout, pair=True)
+            ntiles = ops.conv_smallcin_mtiles(N, h, w) if image else (
+                ops.conv3x3_stat_rows(N, h, w, 2 * cin, cout, pair="q") if plan[short] == "q" else ops.conv3x3_stat_rows(N, h, w, cin, cout, pair=True))
             partials = empty(ops.bn_partials_numel(ntiles, cout), dtype=torch.float32) if batch_stats else None
+            want_lo, zp_want_lo = int(want_lo), int(zp_want_lo)     # 0 none / 1 16-bit lo plane / 2 q plane (lo_fmt below)
             z_lo = zbuf[..., z_stride // 2:] if (zbuf is not None and want_lo) else None
             if (image and not full and FUSED_STEM_FWD and cin == 1 and cout == 64 and zp is None and z_stride == 2 * cout
                     and inp.is_contiguous()):
@@ -684,7 +725,10 @@ class UNetEngine:
                 if batch_stats:
                     ops.stem_stats(inp, wst, partials, rec.tap_sums)
                 coef = bn_coef(bnkey, partials, ntiles, cout, N * h * w, batch_stats)
-                ops.stem_fwd_bn_pair(inp, wst, coef[0], coef[1], ACT_RELU, zbuf, write_lo=want_lo)
+                if want_lo == 2:
+                    ops.stem_fwd_bn_pair_q8(inp, wst, coef[0], coef[1], ACT_RELU, zbuf)
+                else:
+                    ops.stem_fwd_bn_pair(inp, wst, coef[0], coef[1], ACT_RELU, zbuf, write_lo=bool(want_lo))
                 rec.y, rec.coef, rec.z, rec.wd = None, coef, zbuf, None
                 if need_grad:
                     recs.append(rec)
@@ -692,6 +736,9 @@ class UNetEngine:
             y_hi, y_lo = empty(N, h, w, cout), empty(N, h, w, cout)
             if image:
                 ops.conv_smallcin_fwd_split(inp, wparam.detach().contiguous(), y_hi, y_lo, partials, 3, 1)
+            elif plan[short] == "q":
+                qpack, wexp = self._seg_pack(wkey)
+                ops.conv3x3_q8(inp, qpack, wexp, y_hi, y_lo, N, h, w, cin, cout, in_stride=2 * cin, bn_partials=partials)
             else:
                 _, K, wrap = _segs(plan[short], cin, lo_len)
                 ops.conv3x3_segs(inp, self._seg_pack(wkey), y_hi, y_lo, N, h, w, K, wrap, cin, cout, in_stride=2 * cin,
@@ -705,12 +752,18 @@ class UNetEngine:
                 return rec, y_lo
             zp_hi = zp if zp is not None else None
             zp_lo = zp[..., zp.shape[3] // 2:] if (zp is not None and zp_want_lo) else None
-            ops.bn_act_apply_split(y_hi, y_lo, coef[0], coef[1], ACT_RELU, zbuf, z_lo, z_stride, 0, zp_hi, zp_lo,
-                                   0 if zp is None else zp.shape[3])
+            if want_lo == 2 or zp_want_lo == 2:
+                ops.bn_act_apply_split_q8(y_hi, y_lo, coef[0], coef[1], ACT_RELU, zbuf, z_lo, want_lo == 2, z_stride, 0, zp_hi, zp_lo,
+                                          zp_want_lo == 2, 0 if zp is None else zp.shape[3])
+            else:
+                ops.bn_act_apply_split(y_hi, y_lo, coef[0], coef[1], ACT_RELU, zbuf, z_lo, z_stride, 0, zp_hi, zp_lo,
+                                       0 if zp is None else zp.shape[3])
             return rec
 
-        def reads_lo(st):                                   # does stage `st` run an x_lo segment?
-            return "x" in plan[st]
+        def reads_lo(st):
+            """the form in which consumer stage `st` reads the lo plane of its input: 0 not at all, 1 a 16-bit lo plane (an x_lo
+            segment), 2 a q plane (FP8 correction chunks)"""
+            return 2 if plan[st] == "q" else (1 if "x" in plan[st] else 0)
 
         # ---- encoder ----
         cats = [None] * 4
@@ -753,6 +806,8 @@ class UNetEngine:
                 # nn.Upsample(scale_factor=2, bilinear, align_corners=True) of the PAIR (unet_parts.py:49-50), straight into the up
                 # half of both planes of the concat buffer; the lo plane only when the consumer runs an x_lo segment
                 want = reads_lo(prefix + ".conv.0")
+                if want == 2:
+                    raise NotImplementedError("a 'q' stage behind the bilinear up-sampling (its pair kernel writes 16-bit lo planes)")
                 ops.upsample2x_bilinear_fwd_pair(inp, inp[..., cin_t:], cat, cat[..., 2 * cout_t:] if want else None, N, h, w,
                                                  cin_t, H2, W2, in_stride=2 * cin_t, out_stride=4 * cout_t, out_coff=cout_t,
                                                  ooy=pt, oox=pl)
@@ -763,7 +818,13 @@ class UNetEngine:
                 ops.upconv2x2_fwd(inp, wf, params[prefix + ".up.bias"].detach(), cat, N, 1, h, w, cin_t, cout_t, 1, H2, W2,
                                   in_stride=2 * cin_t, out_stride=4 * cout_t, out_coff=cout_t, ooy=pt, oox=pl)
                 up_lo_valid = False
+                if reads_lo(prefix + ".conv.0") == 2:
+                    # the consumer is a "q" stage: the q chunks of the up half -- hi8 from the hi plane just written, lo8 = 0 (its
+                    # x_lo . w_hi term then covers the skip channels only, exactly like the 16-bit "lo_len" segment)
+                    ops.q8_from_hi(cat, cat[..., 2 * cout_t:], N * H2 * W2, cout_t, 4 * cout_t, cout_t)
             else:
+                if reads_lo(prefix + ".conv.0") == 2:
+                    raise NotImplementedError("a 'q' stage behind a pair transposed conv (it writes 16-bit lo planes)")
                 _, K, wrap = _segs(up_mode, cin_t)
                 ops.upconv2x2_fwd_segs(inp, self._seg_pack(wkey), params[prefix + ".up.bias"].detach(),
                                        cat[..., cout_t:], cat[..., 3 * cout_t:], N, h, w, K, wrap, cin_t, cout_t, H2, W2,

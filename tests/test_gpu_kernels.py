@@ -1403,3 +1403,101 @@ def test_pack_weight_multi_matches_single(dtn, dt):
         assert torch.equal(wf, wf1)
         if wd is not None:
             assert torch.equal(wd, wd1)
+
+
+# ------------------------------------------------------------------------------------------------ "q" stages (FP8 correction segment)
+@pytest.mark.parametrize("N,H,W,cin,cout,form", [(2, 32, 32, 64, 64, -1), (1, 24, 40, 128, 64, 8), (2, 16, 32, 64, 128, 4), (1, 16, 64, 256, 128, -1)])
+def test_conv3x3_q8_matches_its_arithmetic(N, H, W, cin, cout, form):
+    """gs_conv3x3_q8 (x_hi.w_hi on the 16-bit MFMA + ONE block-scaled e4m3 segment for x_lo.w_hi + x_hi.w_lo) against the SAME
+    arithmetic in fp32 torch: q planes written by gs_bn_act_apply_split_q8, q pack + per-cout exponents by gs_pack_weight_q8,
+    e4m3 values emulated with torch.float8_e4m3fn (saturating).  The result must also be >= 10x closer to the exact fp32
+    convolution than the plain 16-bit product; BatchNorm partial rows sum to the column sums.  8- and 4-wave forms."""
+    import torch.nn.functional as F
+    from semantic_segmentation_amd import ops
+    dev = torch.device("cuda:0")
+    E4 = torch.float8_e4m3fn
+    g = torch.Generator().manual_seed(cin + cout + H)
+    v = torch.randn(N, H, W, cin, generator=g).abs() * 1.5
+    v[0, 0, 0, :4] = torch.tensor([3000.0, 1e-4, 0.0, 500.0])                   # saturating / tiny / zero activations
+    wt = (torch.rand(cout, cin, 3, 3, generator=g) * 2 - 1) * (1.0 / (cin * 9) ** 0.5)
+    wt[3] *= 40.0                                                                # rows of very different magnitude: per-cout exponents
+    wt[5] *= 1e-3
+    yh = v.half().to(dev).contiguous()
+    yl = (v - v.half().float()).half().to(dev).contiguous()
+    one, zero = torch.ones(cin, device=dev), torch.zeros(cin, device=dev)
+    xbuf = torch.zeros(N, H, W, 2 * cin, dtype=torch.float16, device=dev)
+    ops.bn_act_apply_split_q8(yh, yl, one, zero, 0, xbuf, xbuf[..., cin:], True, 2 * cin, 0)
+    pack = torch.empty(9, cout, 2 * cin, dtype=torch.float16, device=dev)
+    wexp = torch.empty(cout, dtype=torch.int32, device=dev)
+    ops.pack_weight_q8([(wt.to(dev).contiguous(), pack, wexp)])
+    y_hi = torch.empty(N, H, W, cout, dtype=torch.float16, device=dev)
+    y_lo = torch.empty_like(y_hi)
+    ops.conv3x3_set_kernel_form(form)
+    try:
+        nt = ops.conv3x3_stat_rows(N, H, W, 2 * cin, cout, pair="q")
+        part = torch.zeros(ops.bn_partials_numel(nt, cout), dtype=torch.float32, device=dev)
+        ops.conv3x3_q8(xbuf, pack, wexp, y_hi, y_lo, N, H, W, cin, cout, 2 * cin, 0, part)
+        torch.cuda.synchronize()
+    finally:
+        ops.conv3x3_set_kernel_form(-1)
+    got = (y_hi.float() + y_lo.float()).cpu().permute(0, 3, 1, 2)
+
+    def q8(t, k):
+        s = 2.0 ** k
+        return (t * s).clamp(-448, 448).to(E4).float() / s
+    vv = (yh.float() + yl.float()).cpu()
+    hi2 = vv.half().float()
+    xh, xl = hi2.permute(0, 3, 1, 2), (vv - hi2).permute(0, 3, 1, 2)
+    wh = wt.half().float()
+    wl = wt - wh
+    e = wexp.cpu().view(-1, 1, 1, 1).double()
+    amax = wt.abs().flatten(1).amax(1)
+    assert torch.all((amax * 2.0 ** wexp.cpu().float() >= 64) & (amax * 2.0 ** wexp.cpu().float() < 128)), "per-cout exponents"
+    wh8 = ((wh.double() * 2 ** e).clamp(-448, 448).float().to(E4).double() / 2 ** e).float()
+    wl8 = ((wl.double() * 2 ** (e + 11)).clamp(-448, 448).float().to(E4).double() / 2 ** (e + 11)).float()
+    ref = F.conv2d(xh, wh, padding=1) + F.conv2d(q8(xl, 9), wh8, padding=1) + F.conv2d(q8(xh, -2), wl8, padding=1)
+    exact = F.conv2d(vv.permute(0, 3, 1, 2), wt, padding=1)
+    plain = F.conv2d(xh, wh, padding=1)
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) < 3e-6 * scale + 2e-6, float((got - ref).abs().max())
+    # away from the saturated pixel the correction segment recovers the fp32 product to ~2^-15
+    m = torch.ones_like(exact, dtype=torch.bool)
+    m[0, :, :2, :2] = False
+    assert float((got - exact)[m].abs().max()) * 10 < float((plain - exact)[m].abs().max())
+    s1 = part[:nt * 2 * cout].view(nt, 2, cout)[:, 0].sum(0).cpu()
+    assert float((s1 - got.sum((0, 2, 3))).abs().max()) < 1e-5 * float(got.abs().sum((0, 2, 3)).max())
+
+
+def test_q8_from_hi_and_stem_q8_planes():
+    """the two other producers of q planes: gs_q8_from_hi (hi8 from a stored hi plane, lo8 = 0) and gs_stem_fwd_bn_pair_q8"""
+    from semantic_segmentation_amd import ops
+    from semantic_segmentation_amd._lib import ACT_RELU
+    dev = torch.device("cuda:0")
+    E4 = torch.float8_e4m3fn
+    g = torch.Generator().manual_seed(3)
+    N, H, W, C = 2, 6, 10, 64
+    buf = torch.zeros(N, H, W, 4 * C, dtype=torch.float16, device=dev)              # [skip_h up_h | q plane]
+    up = torch.randn(N, H, W, C, generator=g).half()
+    buf[..., C:2 * C] = up.to(dev)
+    ops.q8_from_hi(buf, buf[..., 2 * C:], N * H * W, C, 4 * C, C)
+    q = buf[..., 2 * C:].contiguous().view(torch.uint8).view(N, H, W, 4 * C)           # bytes of the q plane: chunks of 64 per 32 channels
+    chunks = q.view(N, H, W, 4, 64).cpu()
+    assert int(chunks[..., :2, :].abs().sum()) == 0                                   # the skip half was not touched
+    hi8 = chunks[..., 2:, 32:].reshape(N, H, W, C).view(E4).float()
+    lo8 = chunks[..., 2:, :32].reshape(N, H, W, C)
+    assert int(lo8.abs().sum()) == 0
+    assert torch.equal(hi8, (up.float() * 0.25).clamp(-448, 448).to(E4).float())
+    # stem: [hi | q plane] against the 16-bit pair form
+    x = torch.randn(2, 1, 32, 40, generator=g).to(dev)
+    w = (torch.randn(64, 1, 3, 3, generator=g) * 0.3).to(dev)
+    sc, sh = (torch.rand(64, generator=g) + 0.5).to(dev), torch.randn(64, generator=g).to(dev)
+    zq = torch.empty(2, 32, 40, 128, dtype=torch.float16, device=dev)
+    zp = torch.empty_like(zq)
+    ops.stem_fwd_bn_pair_q8(x, w, sc, sh, ACT_RELU, zq)
+    ops.stem_fwd_bn_pair(x, w, sc, sh, ACT_RELU, zp, write_lo=True)
+    assert torch.equal(zq[..., :64], zp[..., :64])
+    hi, lo = zp[..., :64].float().cpu(), zp[..., 64:].float().cpu()
+    ch = zq[..., 64:].contiguous().view(torch.uint8).view(2, 32, 40, 2, 64).cpu()
+    assert torch.equal(ch[..., 32:].reshape(2, 32, 40, 64).view(E4).float(), (hi * 0.25).clamp(-448, 448).to(E4).float())
+    got_lo = ch[..., :32].reshape(2, 32, 40, 64).view(E4).float() / 512.0
+    assert float((got_lo - lo).abs().max()) <= float(lo.abs().max()) / 16 + 2.0 ** -18          # e4m3 of (value - hi) * 2^9
