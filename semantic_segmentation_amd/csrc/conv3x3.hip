@@ -1017,8 +1017,8 @@ C3Plan c3_plan(int H, int W, int Cout) {
 static std::atomic<int> c3_dma_form{getenv("GSSEG_C3_DMA") ? atoi(getenv("GSSEG_C3_DMA")) : -1};
 
 extern "C" int gs_conv3x3_set_kernel_form(int form) {
-    GS_CHECK_ARG(form == -1 || form == 0 || form == 4 || form == 8,
-                 "gs_conv3x3_set_kernel_form: form must be -1 (automatic), 0 (big K-step kernel), 4 or 8 (waves of the LDS-DMA kernel)");
+    GS_CHECK_ARG(form == -1 || form == 0 || form == 4 || form == 8 || form == 44,
+                 "gs_conv3x3_set_kernel_form: form must be -1 (automatic), 0 (big K-step kernel), 4 / 8 (waves of the LDS-DMA kernel) or 44 (its quad form)");
     c3_dma_form.store(form, std::memory_order_relaxed);
     return GS_OK;
 }
@@ -1069,7 +1069,7 @@ static bool c3_dma_shape_ok(int W, int Cin, int Cout) {
 // q8_cin: the layer's channels when the launch is a "q" stage (0: not one).  A 64-channel "q" stage -- two 16-bit and two FP8 K stages
 // per item -- runs faster in the 4-wave form: the 8-wave Q8 kernel spills (its epilogue reloads ~90 dwords per lane and item),
 // which the four stages of such an item do not amortise (measured 64->64 @256^2: 409 vs 459 us; from 128 channels on the 8-wave form wins)
-static C3DmaPlan c3_dma_plan(int N, int H, int W, int Cout, bool per_block_rows, int q8_cin = 0) {
+static C3DmaPlan c3_dma_plan(int N, int H, int W, int Cout, bool per_block_rows, int q8_cin = 0, bool pair_form = false) {
     C3DmaPlan p;
     const int blocks = c3_blocks_now();
     p.tiles_x = cdiv(W, 32);
@@ -1081,7 +1081,8 @@ static C3DmaPlan c3_dma_plan(int N, int H, int W, int Cout, bool per_block_rows,
     const double cost8 = 0.87 * 2.0 * (double)((items8 + blocks - 1) / blocks);
     const int forced = c3_dma_form.load(std::memory_order_relaxed);
     p.waves = (forced == 4 || forced == 8) ? forced : (q8_cin == 64 ? 4 : (cost8 <= cost4 ? 8 : 4));
-    p.tiles_y = cdiv(H, p.waves == 8 ? 16 : 8);
+    if (forced == 44 && !pair_form) p.waves = 44;          // the quad form: 4 waves x 4 pixel rows (16-bit forward / data gradient only)
+    p.tiles_y = cdiv(H, p.waves == 4 ? 8 : 16);
     p.nitems = N * p.tiles_x * p.tiles_y * p.ntn;
     p.grid = per_block_rows ? c3_dma_grid(p.nitems, p.ntn, blocks) : (p.nitems < blocks ? p.nitems : blocks);
     return p;
@@ -1096,7 +1097,7 @@ static C3DmaPlan c3_dma_plan(int N, int H, int W, int Cout, bool per_block_rows,
 extern "C" int gs_conv3x3_stat_rows(int N, int H, int W, int Cin, int Cout, int pair) {
     static const int prec_dma = getenv("GSSEG_C3_PREC_DMA") ? atoi(getenv("GSSEG_C3_PREC_DMA")) : 1;
     if ((!pair || prec_dma != 0) && c3_dma_shape_ok(W, Cin, Cout)) {
-        const C3DmaPlan p = c3_dma_plan(N, H, W, Cout, true, pair == 2 ? Cin / 2 : 0);      // pair == 2: a "q" stage, Cin = its K = 2 * channels
+        const C3DmaPlan p = c3_dma_plan(N, H, W, Cout, true, pair == 2 ? Cin / 2 : 0, pair != 0);      // pair == 2: a "q" stage, Cin = its K = 2 * channels
         return p.grid / p.ntn;
     }
     return gs_conv3x3_mtiles(N, H, W, Cout);
@@ -1172,7 +1173,7 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
         GS_CHECK_ARG(wexp == nullptr || (dma && dtype == GS_F16 && Cin % 128 == 0),
                      "gs_conv3x3_q8: needs the LDS-DMA kernel (W >= 24, channels %% 64 == 0, Cout %% 8 == 0, forward taps) and fp16");
         if (dma) {
-            const C3DmaPlan dp = c3_dma_plan(N, H, W, Cout, true, wexp ? Cin / 2 : 0);
+            const C3DmaPlan dp = c3_dma_plan(N, H, W, Cout, true, wexp ? Cin / 2 : 0, prec);
             a.tiles_x = dp.tiles_x; a.tiles_y = dp.tiles_y; a.ntn = dp.ntn; a.nblocks = dp.nitems;
             a.xcd_order = (xcd_env && (dp.grid % 8) == 0 && a.ntn > 1 && (int64_t)N * H * W > (int64_t)18 * Cout) ? 1 : 0;
             c3_dma_launch(a, dp.waves, prec, dtype, dp.grid, bs);

@@ -49,14 +49,19 @@ __device__ __forceinline__ void dma_piece16(const __amdgpu_buffer_rsrc_t& rs, un
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
-template <int DT, int NWV, bool STATS, bool PREC, bool DEFER, bool Q8 = false>
+// MI = 32-pixel rows per wave: 2 (the 4- and 8-wave forms) or 4 -- the "quad" form: 4 waves, ONE per SIMD, each with a 128-pixel x 64-cout
+// tile (eight 32x32 MFMA tiles, 128 accumulator registers): the 16x32-pixel items of the 8-wave form -- the same DMA bytes per MFMA --
+// with half the fragment reads per MFMA (6 per 8 instead of 4 per 4) and the whole 512-register file of the SIMD for one wave
+// (double-buffered fragments, the deferred epilogue's packed tile, no spills).
+template <int DT, int NWV, bool STATS, bool PREC, bool DEFER, bool Q8 = false, int MI = 2>
 __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a) {
     typedef typename Elem<DT>::V8 V8;
     // the pair epilogue is deferred only in the 4-wave form: one wave per SIMD has the 512-register file to itself, so the 64
     // registers of packed hi + lo results can ride through the next item's first stage (the 8-wave form has 256 per wave)
     static_assert(!(PREC && DEFER) || NWV == 4, "the deferred pair epilogue needs the 4-wave form's registers");
+    static_assert(MI == 2 || (MI == 4 && NWV == 4 && DEFER), "the quad form: 4 waves, deferred epilogue");
     static_assert(!Q8 || PREC, "FP8 correction stages belong to the pair forward");
-    constexpr int BN = 64, TW = 32, TH = 2 * NWV, TWS = 5, KC = 32;
+    constexpr int BN = 64, TW = 32, TH = MI * NWV, TWS = 5, KC = 32;
     constexpr int HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;
     constexpr int ROWB = KC * 2;                           // bytes per LDS row (one pixel / one cout, KC channels)
     constexpr int SPR = ROWB / 16, RPP = 64 / SPR;         // 16-byte slots per row, rows per 1-KiB piece
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
     // PREC (precise mode): K is a concatenation of segments over the same input channels (stage c reads
     // input chunk c mod wrap) and the result leaves as a hi / lo pair (a second staging area and store stream)
     static_assert((PREC ? 2 : 1) * NWV * STG_EL * 2 + NWV * 2 * BN * 4 <= HALO_B + W_B, "epilogue staging overlays the second stage buffer");
-    static_assert(NWP + HJ <= NSTEP && HJ + 1 <= NSTEP, "one DMA piece / one next-item offset per MFMA step");
+    static_assert(NWP + HJ <= NSTEP + 1 && HJ + 1 <= NSTEP, "one DMA piece (two in step 0 of the quad form) / one next-item offset per MFMA step");
     static_assert(NWV % WG == 0, "a wave's weight pieces all belong to one row group");
     static_assert(WP % NWV == 0 || HI < HJ * NWV, "a surplus weight slot parks its (empty) piece in the spare halo piece");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_B];
@@ -184,12 +189,12 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
     // (DEFER is short of registers -- 32 of packed results ride through the next item's first stage: the second k half's
     // address is formed at the read, one v_xor each)
     constexpr int AK = (DEFER || Q8) ? 1 : KSTEPS;          // (Q8: the FP8 stage's 48 fragment registers leave no room for both sets)
-    unsigned aaddr[AK][4][3];                              // [k half][halo row 2*wave + e, e = i + dy + 1][column l31 + dx + 1]
+    unsigned aaddr[AK][MI + 2][3];                              // [k half][halo row 2*wave + e, e = i + dy + 1][column l31 + dx + 1]
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int e = 0; e < MI + 2; ++e)
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const int r = (2 * wave + e) * HWD + l31 + d;
+            const int r = (MI * wave + e) * HWD + l31 + d;
             const int key = (r >> 2) & 3;
             aaddr[0][e][d] = (unsigned)(H0_OFF + r * ROWB + ((h ^ key) << 4));
             opaque_vgpr(aaddr[0][e][d]);
@@ -208,10 +213,10 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
         opaque_vgpr(baddr[b][1]);
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
     auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -220,12 +225,12 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
 
     // ---- deferred epilogue state (DEFER): the previous item's tile as packed 16-bit pairs, its store base, its image ----
     constexpr int NPK = DEFER ? 8 : 1;
-    unsigned pk[2][2][NPK];                                // [i][j][m]: rows 2m, 2m+1 of the lane's cout in tile (i, j)
+    unsigned pk[MI][2][NPK];                                // [i][j][m]: rows 2m, 2m+1 of the lane's cout in tile (i, j)
     constexpr int NPKL = (DEFER && PREC) ? 8 : 1;
-    unsigned pkl[2][2][NPKL];                              // PREC: the lo halves of the same pairs
-    unsigned pend_voff = 0u;                               // lane part of the store offset of the pending tile
+    unsigned pkl[MI][2][NPKL];                              // PREC: the lo halves of the same pairs
+    unsigned pend_voff = MI == 4 ? 0x80000000u : 0u;       // lane part of the store offset of the pending tile (quad form: out of range = nothing pending)
     int pend_n = 0;                                        // its image
-    bool pend = false;
+    bool pend = false, pend2 = false;                      // (pend2: the quad form's second eight passes are still to come)
     const bool odd = lane & 1;
     const unsigned int psel = odd ? 0x03020706u : 0x05040100u;
     // private transposition buffer of the wave: 8 pixel rows x 128 B (64 couts), 16-byte slot s of row r at s ^ r
@@ -280,10 +285,11 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
     };
     // the deferred work of MFMA step `step` of the first stage: pass p = step / 2 writes at step 2p, reads at 2p + 1, stores at 2p + 2
     // (in front of the writes of pass p + 1; LDS operations of a wave execute in order)
-    auto defer_step = [&](int step) __attribute__((always_inline)) {
-        if (step >= 2 && step % 2 == 0 && (step - 2) / 2 < 8) defer_store((step - 2) / 2);
-        if (step % 2 == 0 && step / 2 < 8) defer_write(step / 2);
-        if (step % 2 == 1 && step / 2 < 8) defer_read(step / 2);
+    // (quad form: 16 passes -- the first eight on the item's first stage, pb = 0, the other eight on its second stage, pb = 8)
+    auto defer_step = [&](int step, int pb) __attribute__((always_inline)) {
+        if (step >= 2 && step % 2 == 0 && (step - 2) / 2 < 8) defer_store(pb + (step - 2) / 2);
+        if (step % 2 == 0 && step / 2 < 8) defer_write(pb + step / 2);
+        if (step % 2 == 1 && step / 2 < 8) defer_read(pb + step / 2);
     };
     auto defer_step_head = [&](int step) __attribute__((always_inline)) {     // top of a step that stores: the read-back has landed
         if (step >= 2 && step % 2 == 0 && (step - 2) / 2 < 8) defer_wait();
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
     static_assert(NSTEP >= 17, "eight passes need steps 0..16 of one stage");
     auto defer_flush = [&]() __attribute__((always_inline)) {               // everything at once (after the last item)
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
+        for (int p = 0; p < 4 * MI; ++p) {
             defer_write(p);
             defer_read(p);
             defer_wait();
@@ -308,7 +314,8 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
         const unsigned sc_n = sn.sc, wsc_n = sn.wsc, hkill_n = sn.hkill;
         constexpr int BUF = decltype(buf_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value;
-        constexpr bool PEND = decltype(pend_tag)::value;
+        constexpr int PENDV = (int)decltype(pend_tag)::value;      // 0: nothing pending; 1: deferred passes 0..7 ride here; 2: passes 8..15
+        constexpr bool PEND = PENDV != 0;
         constexpr unsigned OBUF = 1 - BUF;           // the buffer the next stage is fetched into
         if (dbg & 2) {                                     // ablation: DMA traffic only
 #pragma unroll
@@ -322,16 +329,19 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
             if (PEND) defer_flush();
             return;
         }
-        V8 af[2][2], bf[2][2];
-        auto frag_load = [&](int step, V8 (&fa)[2], V8 (&fb)[2]) __attribute__((always_inline)) {
+        V8 af[2][MI], bf[2][2];
+        auto frag_load = [&](int step, V8 (&fa)[MI], V8 (&fb)[2]) __attribute__((always_inline)) {
             const int tap = step / KSTEPS, kh = step % KSTEPS;
             const int dyi = tap / 3, dxi = tap - 3 * dyi;
-            const unsigned a0 = (AK == 1 && kh == 1) ? (aaddr[0][dyi][dxi] ^ 32u) : aaddr[AK == 1 ? 0 : kh][dyi][dxi];
-            const unsigned a1 = (AK == 1 && kh == 1) ? (aaddr[0][dyi + 1][dxi] ^ 32u) : aaddr[AK == 1 ? 0 : kh][dyi + 1][dxi];
-            fa[0] = *reinterpret_cast<const V8*>(smem + a0 + BUF * HALO_B);
+            auto aof = [&](int i) __attribute__((always_inline)) {
+                return (AK == 1 && kh == 1) ? (aaddr[0][dyi + i][dxi] ^ 32u) : aaddr[AK == 1 ? 0 : kh][dyi + i][dxi];
+            };
+            fa[0] = *reinterpret_cast<const V8*>(smem + aof(0) + BUF * HALO_B);
             fb[0] = *reinterpret_cast<const V8*>(smem + baddr[BUF][kh] + tap * (BN * ROWB));
-            fa[1] = *reinterpret_cast<const V8*>(smem + a1 + BUF * HALO_B);
+            fa[1] = *reinterpret_cast<const V8*>(smem + aof(1) + BUF * HALO_B);
             fb[1] = *reinterpret_cast<const V8*>(smem + baddr[BUF][kh] + tap * (BN * ROWB) + 32 * ROWB);
+#pragma unroll
+            for (int i = 2; i < MI; ++i) fa[i] = *reinterpret_cast<const V8*>(smem + aof(i) + BUF * HALO_B);
         };
         frag_load(0, af[0], bf[0]);
 #pragma unroll
@@ -342,6 +352,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
             // (two pieces per step, i.e. everything issued in the first half of the stage, measured the same or 1 % slower
             // on the deep layers: the pieces are not late)
             issue_piece(step, rx_n, sc_n, wsc_n, OBUF, hkill_n, kill, wskip);
+            if (NWP + HJ > NSTEP && step == 0) issue_piece(NSTEP, rx_n, sc_n, wsc_n, OBUF, hkill_n, kill, wskip);      // quad form: 19 pieces
             if (BUF == 0 && step <= HJ) {                  // the next item's piece offsets, one slot per step
                 int py0 = itn.y0, px0 = itn.x0, pn0 = itn.n0;
                 asm volatile("" : "+s"(py0), "+s"(px0), "+s"(pn0));      // keeps this arithmetic in the step (else hoisted to the item boundary)
@@ -351,7 +362,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < MI; ++i) {
                     if (FIRST && step == 0) {
                         f32x16 z;
 #pragma unroll
@@ -361,13 +372,25 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
                         acc[i][j] = Elem<DT>::mfma32(af[cur][i], bf[cur][j], acc[i][j]);
                     }
                 }
-            if (PEND) defer_step(step);
+            if (PEND) defer_step(step, PENDV == 2 ? 8 : 0);
+            if (MI == 2) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // one LDS fragment read in its shadow
+                for (int q = 0; q < 4; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // one LDS fragment read in its shadow
+                }
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);           // the DMA piece of this step
+            } else {                                       // quad form: eight MFMAs, six fragment reads, one or two DMA pieces
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (step == 0) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);           // the DMA piece of this step
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -476,8 +499,8 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
             }
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int prow0 = (wave * 2 + i) * 32;
+        for (int i = 0; i < MI; ++i) {
+            const int prow0 = (wave * MI + i) * 32;
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 const int r0 = 2 * m;
@@ -558,7 +581,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
     float bvb[2] = {0.f, 0.f};
     auto convert_item = [&](const Item& itc) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int m = 0; m < 8; ++m)
 #pragma unroll
@@ -571,7 +594,10 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
                     }
                     v0 += bvb[j];
                     v1 += bvb[j];
-                    const unsigned own = Elem<DT>::pack2(v0, v1);
+                    unsigned own = Elem<DT>::pack2(v0, v1);
+                    // (quad form: pinned here -- hipcc otherwise sinks the conversions to their uses in the next item's stages and
+                    // carries the 128 fp32 values there in a second accumulator set: 560 registers)
+                    if (MI == 4) opaque_vgpr(own);
                     pk[i][j][DEFER ? m : 0] = own;
                     if (PREC)                                 // lo = 16-bit(value - hi): the pair carries ~22 bits
                         pkl[i][j][(DEFER && PREC) ? m : 0] = Elem<DT>::pack2(v0 - Elem<DT>::to_f((unsigned short)(own & 0xffffu)),
@@ -582,7 +608,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
         // pixel (patch row 2*wave + i, column 8*(p & 3) + lane / 8), couts n0 + 8*(lane & 7): i and p ride in the scalar offset
         // (a partial cout tile: the lanes beyond Cout carry the out-of-range offset, their stores are dropped)
         pend_voff = (itc.n0 + (lane & 7) * 8 < a.Cout)
-                        ? (unsigned)((((e_y0 + 2 * wave) * a.W + e_x0 + (lane >> 3)) * a.out_stride + a.out_coff + itc.n0 + (lane & 7) * 8) * 2)
+                        ? (unsigned)((((e_y0 + MI * wave) * a.W + e_x0 + (lane >> 3)) * a.out_stride + a.out_coff + itc.n0 + (lane & 7) * 8) * 2)
                         : VOOB;
         pend_n = itc.n;
         pend = true;
@@ -662,6 +688,49 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
         Item nxt = cur;
         if (more_items) nxt = advance_item();
         PH(5);
+        if (MI == 4) {
+            // Quad form: the item's first stage pair is peeled and ALWAYS carries the deferred passes (with nothing pending the
+            // stores go to the out-of-range offset and are dropped): one straight line of stage bodies and one plain loop -- with
+            // the 2-tile forms' runtime choice between pending / not-pending bodies hipcc assigned the 128 accumulator registers
+            // differently per body and reconciled them with 128 moves at every join (a second accumulator set: 560 registers).
+            const bool last0 = nstage <= 2;
+            stage_sync();
+            {
+                const Src s1 = stage_src(cur.n, 1);
+                run_stage(std::integral_constant<int, 0>{}, std::true_type{}, std::integral_constant<int, 1>{}, image_rsrc(s1.n), s1, 0u, nxt,
+                          wres && !first_item);
+            }
+            stage_sync();
+            if (last0) {
+#pragma unroll
+                for (int j = 0; j < HJ; ++j) hv[j] = hvn[j];
+                wv = wvn;
+            }
+            {
+                const Src s2 = stage_src(last0 ? nxt.n : cur.n, last0 ? 0 : 2);
+                run_stage(std::integral_constant<int, 1>{}, std::false_type{}, std::integral_constant<int, 2>{}, image_rsrc(s2.n), s2,
+                          (last0 && !more_items) ? VOOB : 0u, nxt, wres && last0);
+            }
+            pend = false;
+            pend_voff = VOOB;
+            for (int sp = 2; sp < nstage; sp += 2) {
+                const bool last = sp + 2 >= nstage;
+                stage_sync();
+                {
+                    const Src s1 = stage_src(cur.n, sp + 1);
+                    run_stage(std::integral_constant<int, 0>{}, std::false_type{}, std::integral_constant<int, 0>{}, image_rsrc(s1.n), s1, 0u, nxt);
+                }
+                stage_sync();
+                if (last) {
+#pragma unroll
+                    for (int j = 0; j < HJ; ++j) hv[j] = hvn[j];
+                    wv = wvn;
+                }
+                const Src s2 = stage_src(last ? nxt.n : cur.n, last ? 0 : sp + 2);
+                run_stage(std::integral_constant<int, 1>{}, std::false_type{}, std::integral_constant<int, 0>{}, image_rsrc(s2.n), s2,
+                          (last && !more_items) ? VOOB : 0u, nxt);
+            }
+        } else
         for (int sp = 0; sp < nstage; sp += 2) {
             const bool last = sp + 2 >= nstage;
             stage_sync();
@@ -670,16 +739,17 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
             if (sp == 0) {
                 const bool ws0 = wres && !first_item;      // stage 1's slabs are in buffer 1 since the first item
                 if (DEFER && pend) {
-                    run_stage(std::integral_constant<int, 0>{}, std::true_type{}, std::true_type{}, image_rsrc(s1.n), s1, 0u, nxt, ws0);
+                    run_stage(std::integral_constant<int, 0>{}, std::true_type{}, std::integral_constant<int, 1>{}, image_rsrc(s1.n), s1, 0u, nxt, ws0);
                     pend = false;
+                    pend2 = MI == 4;                       // quad form: passes 8..15 ride on the item's second stage
                 } else {
-                    run_stage(std::integral_constant<int, 0>{}, std::true_type{}, std::false_type{}, image_rsrc(s1.n), s1, 0u, nxt, ws0);
+                    run_stage(std::integral_constant<int, 0>{}, std::true_type{}, std::integral_constant<int, 0>{}, image_rsrc(s1.n), s1, 0u, nxt, ws0);
                 }
             } else if (Q8 && (sp % nchunk) >= a.q8_c0) {
                 run_stage8(std::integral_constant<int, 0>{}, image_rsrc(s1.n), s1, 0u, nxt);
                 PH(6);
             } else {
-                run_stage(std::integral_constant<int, 0>{}, std::false_type{}, std::false_type{}, image_rsrc(s1.n), s1, 0u, nxt);
+                run_stage(std::integral_constant<int, 0>{}, std::false_type{}, std::integral_constant<int, 0>{}, image_rsrc(s1.n), s1, 0u, nxt);
             }
             PH(1);
             stage_sync();
@@ -693,8 +763,12 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
             if (Q8 && ((sp + 1) % nchunk) >= a.q8_c0) {
                 run_stage8(std::integral_constant<int, 1>{}, image_rsrc(s2.n), s2, (last && !more_items) ? VOOB : 0u, nxt);
                 PH(7);
+            } else if (MI == 4 && pend2) {
+                run_stage(std::integral_constant<int, 1>{}, std::false_type{}, std::integral_constant<int, 2>{}, image_rsrc(s2.n), s2,
+                          (last && !more_items) ? VOOB : 0u, nxt, wres && last);
+                pend2 = false;
             } else
-            run_stage(std::integral_constant<int, 1>{}, std::false_type{}, std::false_type{}, image_rsrc(s2.n), s2,
+            run_stage(std::integral_constant<int, 1>{}, std::false_type{}, std::integral_constant<int, 0>{}, image_rsrc(s2.n), s2,
                       (last && !more_items) ? VOOB : 0u, nxt, wres && last);      // the next item's stage-0 slabs are in buffer 0
             PH(3);
         }
@@ -704,7 +778,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
         } else {
             if (DEFER) {                                   // (nothing is pending here; tells the register allocator so)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -777,6 +851,17 @@ int c3_dma_grid(int nitems, int ntn, int max_blocks) {
 int c3_dma_launch(C3Args& a, int waves, bool prec, int dtype, int grid_blocks, hipStream_t s) {
     dim3 grid(grid_blocks);
     const bool stats = a.bnp != nullptr;
+    if (waves == 44) {                                     // the quad form (4 waves x 4 pixel rows: 16x32-pixel items): 16-bit forward / data gradient
+        if (prec || a.q8_c0 > 0) return -1;
+        if (dtype == GS_F16) {
+            if (stats) conv3x3_dma_kernel<GS_F16, 4, true, false, true, false, 4><<<grid, 256, 0, s>>>(a);
+            else conv3x3_dma_kernel<GS_F16, 4, false, false, true, false, 4><<<grid, 256, 0, s>>>(a);
+        } else {
+            if (stats) conv3x3_dma_kernel<GS_BF16, 4, true, false, true, false, 4><<<grid, 256, 0, s>>>(a);
+            else conv3x3_dma_kernel<GS_BF16, 4, false, false, true, false, 4><<<grid, 256, 0, s>>>(a);
+        }
+        return 0;
+    }
     if (a.q8_c0 > 0) {                                     // FP8 correction stages: pair forward, fp16 (the plans use "q" for fp16 only)
         if (!prec || dtype != GS_F16 || a.wexp == nullptr) return -1;
         if (waves == 8) {

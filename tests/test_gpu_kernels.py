@@ -1176,7 +1176,7 @@ def _unpack_merged(pf, cin, cout):
 
 
 @pytest.mark.parametrize("dtn,dt", DTS)
-@pytest.mark.parametrize("form", [0, 4, 8])
+@pytest.mark.parametrize("form", [0, 4, 8, 44])
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 37, 41, 64, 64), (1, 17, 33, 128, 72), (3, 9, 100, 64, 128), (2, 48, 32, 192, 64),
                                             (2, 33, 40, 128, 256),
                                             # several items per block (the persistent grid is 256 blocks): the deferred epilogue's
