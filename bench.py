@@ -377,6 +377,15 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # N > 1: the same K steps once more WITHOUT the gradient exchange (reducer detached: every rank steps on its own shard), same
+    # barrier + max-over-ranks timing: ms_per_step - ms_per_step_no_exchange = what the exchange costs after overlap ("exposed"),
+    # next to `allreduce_ms_per_step_unoverlapped` (all buckets back to back with nothing to hide behind)
+    no_exchange_ms = None
+    if world > 1:
+        ne_elapsed, _, _, _, _ = timed_leg(args.precise, False)
+        t = torch.tensor([ne_elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        no_exchange_ms = float(t.item()) / args.steps * 1e3
     # second leg, N = 1 only (like the CPU baseline): the fast 16-bit mode, whose logits are OUTSIDE the north star's tolerance
     fast = None
     if world == 1 and args.fast_leg != "none" and args.precise == "mixed":
@@ -430,6 +439,8 @@ def main():
         "rccl_ranks": dist.get_world_size() if world > 1 else 1,
         "allreduce_ms_per_step_unoverlapped": None if allreduce_ms is None else round(allreduce_ms, 3),
         "grad_buckets": None if reducer is None else len(reducer.buckets),
+        "ms_per_step_no_exchange": None if no_exchange_ms is None else round(no_exchange_ms, 3),
+        "exposed_exchange_ms_per_step": None if no_exchange_ms is None else round(ms - no_exchange_ms, 3),
         "whole_step_tflops": round(value * gf / 1e3, 1),
         "whole_step_frac_of_mfma_peak": round(value * gf / 1e3 / (MFMA_PEAK_TFLOPS * world), 4),
         "roofline": roof, "kernels": kern,

@@ -143,3 +143,91 @@ def test_grad_reducer_on_unet_engine_rccl_single_rank():
         assert tr.global_step == 5 and all(torch.isfinite(v).all() for rec in tr.history for v in rec.values())
     finally:
         dist.destroy_process_group()
+
+
+def test_unet3d_and_pix2pix_steps_replayed_from_hipgraphs_then_exchanged_over_rccl():
+    """UNet3D and the Pix2Pix generator / discriminator steps captured into hipGraphs (graphs.capture_step) and replayed inside a
+    1-rank RCCL group; the gradient exchange (parallel.all_reduce_gradients, what harness.EndToEndTrainer runs between a replay and
+    the optimiser step) goes through RCCL on the tensors the graph wrote.  Replays must reproduce the eager step bit for bit --
+    before and after the exchange touched the gradient buffers -- for new inputs copied into the static tensors."""
+    from oracle import oracle
+    from semantic_segmentation_amd.graphs import capture_step
+    from semantic_segmentation_amd.losses import seg_loss
+    from semantic_segmentation_amd.models_pix2pix import networks as nw
+    from semantic_segmentation_amd.parallel import all_reduce_gradients, broadcast_module_state
+    from semantic_segmentation_amd.unet3d import UNet3D
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(_free_port())
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        g = torch.Generator().manual_seed(8)
+
+        def check(net, make_inputs, loss_of):
+            """eager reference on input set 1, capture on set 0, replay on set 1 == eager; exchange; replay again == eager"""
+            net = net.to(dev).train()
+            broadcast_module_state(net)
+            sets = [make_inputs(), make_inputs()]
+            static = [t.clone() for t in sets[0]]
+
+            def step():
+                loss = loss_of(net, *static)
+                loss.backward()
+                return loss.detach()
+
+            def prepare():
+                for p in net.parameters():
+                    p.grad = None
+                eng = getattr(net, "engine", None)
+                if eng is not None and hasattr(eng, "invalidate_packs"):
+                    eng.invalidate_packs()
+
+            sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+            for s_, t in zip(static, sets[1]):
+                s_.copy_(t)
+            prepare()
+            l_ref = float(step())
+            g_ref = [p.grad.clone() for p in net.parameters()]
+            net.load_state_dict(sd0)                               # undo the BatchNorm running-statistics updates
+            for s_, t in zip(static, sets[0]):
+                s_.copy_(t)
+            cap = capture_step(step, prepare=prepare, warmup=1)
+            for rep in range(2):
+                net.load_state_dict(sd0)
+                for s_, t in zip(static, sets[1]):
+                    s_.copy_(t)
+                with torch.cuda.stream(cap.stream):
+                    l_got = float(cap.replay())
+                    all_reduce_gradients(net.parameters())         # (1-rank group: returns early; the multi-rank arithmetic is the gloo test's)
+                    for b in (dist.all_reduce(p.grad, op=dist.ReduceOp.AVG, async_op=True) for p in list(net.parameters())[:3]):
+                        b.wait()                                   # RCCL collectives on tensors that live in the graph's pool
+                torch.cuda.synchronize()
+                assert l_got == l_ref, (rep, l_got, l_ref)
+                for p, gr in zip(net.parameters(), g_ref):
+                    assert torch.equal(p.grad, gr)
+
+        # UNet3D (default numerics mode = the pair forward)
+        sd3 = oracle.unet3d_state_dict(1, 2, seed=4)
+        m3 = UNet3D(1, 2)
+        m3.load_state_dict(sd3, strict=True)
+
+        def in3():
+            return [torch.randn(1, 1, 16, 32, 32, generator=g).to(dev), (torch.rand(1, 16, 32, 32, generator=g) > 0.5).long().to(dev)]
+
+        def loss3(net, vol, vmask):
+            lg = net(vol)
+            n, c, d, h, w = lg.shape
+            return seg_loss(lg.reshape(n, c, d * h, w), vmask.reshape(n, d * h, w))
+        check(m3, in3, loss3)
+        # Pix2Pix generator (eval-mode dropout so that eager and replay draw no random numbers) and discriminator
+        nw.upconv_arch.data.zero_()
+        G = nw.define_G(1, 1, 64, "unet_256", "batch", False, "normal", 0.02, [0])
+        D = nw.define_D(2, 64, "basic", 3, "batch", "normal", 0.02, [0])
+
+        def in2():
+            return [(torch.rand(2, 1, 256, 256, generator=g) > 0.5).float().to(dev), torch.rand(2, 1, 256, 256, generator=g).to(dev)]
+        check(G, in2, lambda net, m, r: (net(m) - r).abs().mean())
+        check(D, in2, lambda net, m, r: net(torch.cat((m, r), 1)).square().mean())
+    finally:
+        dist.destroy_process_group()
