@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 45
+#define GS_ABI_VERSION 46
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -280,6 +280,10 @@ int gs_maxpool3d_fwd(const void* z, int z_pix_stride, int z_coff, void* zp, int 
  * z_hi / z_lo point at the first channel of their planes inside a buffer of pixel stride z_pix_stride (unet3d.py:37,44). */
 int gs_maxpool3d_fwd_pair(const void* z_hi, const void* z_lo, int z_pix_stride, void* zp_hi, void* zp_lo, int zp_pix_stride,
                           int NB, int D, int H, int W, int C, int dtype, void* stream);
+/* ... with q planes (see gs_conv3x3_q8): z_q8 -> z_lo = byte 0 of the input buffer's q plane, the pooled channels start at its channel
+ * zq_coff; zp_q8 -> zp_lo = byte 0 of the pooled buffer's q plane. */
+int gs_maxpool3d_fwd_pair_q8(const void* z_hi, const void* z_lo, int z_q8, int zq_coff, int z_pix_stride, void* zp_hi, void* zp_lo,
+                             int zp_q8, int zp_pix_stride, int NB, int D, int H, int W, int C, int dtype, void* stream);
 int gs_maxpool3d_bwd(const void* z, int z_pix_stride, int z_coff, const void* dzp, const void* dres,
                      int res_pix_stride, int res_coff, void* dz, int NB, int D, int H, int W, int C, int dtype,
                      void* stream);

@@ -93,6 +93,8 @@ __global__ __launch_bounds__(256) void maxpool3d_kernel(const P3Args a) {
 struct P3PairArgs {
     const unsigned short* z_hi; const unsigned short* z_lo; unsigned short* zp_hi; unsigned short* zp_lo;
     int zs, zps, NB, D, H, W, C;
+    int z_q8, zq_coff, zp_q8;      // z_lo / zp_lo are Q PLANES (common.hpp): z_lo points at byte 0 of the buffer's q plane and the pooled
+                                   // tensor's channels start at channel zq_coff of it; zp_lo at byte 0 of the pooled buffer's q plane
 };
 
 template <int DT>
@@ -109,19 +111,29 @@ __global__ __launch_bounds__(256) void maxpool3d_pair_kernel(const P3PairArgs a)
         const int nb = (int)(r / PD);
         const int c0 = ch * 8;
         uint4 vh[8], vl[8];
+        uint2 vq[8];
+        const float inv_slo = __builtin_ldexpf(1.f, -(GS_Q8_XH_EXP + Q8Shift<DT>::v));
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int dd = 2 * pd + (k >> 2), yy = 2 * py + ((k >> 1) & 1), xx = 2 * px + (k & 1);
             const int64_t pix = (((int64_t)nb * a.D + dd) * a.H + yy) * a.W + xx;
             vh[k] = *reinterpret_cast<const uint4*>(a.z_hi + pix * a.zs + c0);
-            vl[k] = *reinterpret_cast<const uint4*>(a.z_lo + pix * a.zs + c0);
+            if (a.z_q8) vq[k] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(a.z_lo) + pix * a.zs * 2 + q8_off(a.zq_coff + c0));
+            else vl[k] = *reinterpret_cast<const uint4*>(a.z_lo + pix * a.zs + c0);
         }
         float m[8];
-        join8<DT>(vh[0], vl[0], m);
 #pragma unroll
-        for (int k = 1; k < 8; ++k) {
+        for (int i = 0; i < 8; ++i) m[i] = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
             float v[8];
-            join8<DT>(vh[k], vl[k], v);
+            if (a.z_q8) {                                  // the pair value as the q plane holds it: hi + e4m3(lo * 2^s) / 2^s
+                unpack8<DT>(vh[k], v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] += e4m3_to_f(((i < 4 ? vq[k].x : vq[k].y) >> (8 * (i & 3))) & 0xffu) * inv_slo;
+            } else {
+                join8<DT>(vh[k], vl[k], v);
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], v[i]);
         }
@@ -129,7 +141,14 @@ __global__ __launch_bounds__(256) void maxpool3d_pair_kernel(const P3PairArgs a)
         uint4 hi, lo;
         split8<DT>(m, hi, lo);
         *reinterpret_cast<uint4*>(a.zp_hi + pp * a.zps + c0) = hi;
-        if (a.zp_lo) *reinterpret_cast<uint4*>(a.zp_lo + pp * a.zps + c0) = lo;
+        if (a.zp_lo && !a.zp_q8) *reinterpret_cast<uint4*>(a.zp_lo + pp * a.zps + c0) = lo;
+        if (a.zp_lo && a.zp_q8) {
+            uint2 lo8, hi8;
+            q8_of8<DT>(m, hi, __builtin_ldexpf(1.f, GS_Q8_XH_EXP + Q8Shift<DT>::v), __builtin_ldexpf(1.f, GS_Q8_XH_EXP), lo8, hi8);
+            unsigned char* zq = reinterpret_cast<unsigned char*>(a.zp_lo) + pp * a.zps * 2 + q8_off(c0);
+            *reinterpret_cast<uint2*>(zq) = lo8;
+            *reinterpret_cast<uint2*>(zq + 32) = hi8;
+        }
     }
 }
 
@@ -208,8 +227,21 @@ extern "C" int gs_maxpool3d_fwd(const void* z, int z_pix_stride, int z_coff, voi
     return GS_OK;
 }
 
+static int maxpool3d_pair_impl(const void* z_hi, const void* z_lo, int z_pix_stride, void* zp_hi, void* zp_lo, int zp_pix_stride, int NB,
+                               int D, int H, int W, int C, int dtype, void* stream, int z_q8, int zq_coff, int zp_q8);
 extern "C" int gs_maxpool3d_fwd_pair(const void* z_hi, const void* z_lo, int z_pix_stride, void* zp_hi, void* zp_lo,
                                      int zp_pix_stride, int NB, int D, int H, int W, int C, int dtype, void* stream) {
+    return maxpool3d_pair_impl(z_hi, z_lo, z_pix_stride, zp_hi, zp_lo, zp_pix_stride, NB, D, H, W, C, dtype, stream, 0, 0, 0);
+}
+// the same with q planes (FP8 correction chunks): z_q8: z_lo = byte 0 of the input buffer's q plane, the pooled channels start at its
+// channel zq_coff; zp_q8: zp_lo = byte 0 of the pooled buffer's q plane
+extern "C" int gs_maxpool3d_fwd_pair_q8(const void* z_hi, const void* z_lo, int z_q8, int zq_coff, int z_pix_stride, void* zp_hi, void* zp_lo,
+                                        int zp_q8, int zp_pix_stride, int NB, int D, int H, int W, int C, int dtype, void* stream) {
+    GS_CHECK_ARG((!z_q8 || (zq_coff % 32 == 0 && C % 32 == 0)) && (!zp_q8 || C % 32 == 0), "gs_maxpool3d_fwd_pair_q8: q planes need multiples of 32 channels");
+    return maxpool3d_pair_impl(z_hi, z_lo, z_pix_stride, zp_hi, zp_lo, zp_pix_stride, NB, D, H, W, C, dtype, stream, z_q8 ? 1 : 0, zq_coff, zp_q8 ? 1 : 0);
+}
+static int maxpool3d_pair_impl(const void* z_hi, const void* z_lo, int z_pix_stride, void* zp_hi, void* zp_lo, int zp_pix_stride, int NB,
+                               int D, int H, int W, int C, int dtype, void* stream, int z_q8, int zq_coff, int zp_q8) {
     GS_CHECK_ARG(z_hi && z_lo && zp_hi && NB > 0 && D > 1 && H > 1 && W > 1 && C > 0 && C % 8 == 0, "gs_maxpool3d_fwd_pair: bad arguments");
     GS_CHECK_ARG(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "gs_maxpool3d_fwd_pair: even volume dims only");
     GS_CHECK_ARG(z_pix_stride >= C && z_pix_stride % 8 == 0 && zp_pix_stride >= C && zp_pix_stride % 8 == 0,
@@ -217,7 +249,7 @@ extern "C" int gs_maxpool3d_fwd_pair(const void* z_hi, const void* z_lo, int z_p
     GS_CHECK_ARG(((uintptr_t)z_hi | (uintptr_t)z_lo | (uintptr_t)zp_hi | (uintptr_t)zp_lo) % 16 == 0, "gs_maxpool3d_fwd_pair: planes must be 16-byte aligned");
     GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_maxpool3d_fwd_pair: bad dtype");
     P3PairArgs a{(const unsigned short*)z_hi, (const unsigned short*)z_lo, (unsigned short*)zp_hi, (unsigned short*)zp_lo,
-                 z_pix_stride, zp_pix_stride, NB, D, H, W, C};
+                 z_pix_stride, zp_pix_stride, NB, D, H, W, C, z_q8, zq_coff, zp_q8};
     int64_t nb = cdiv64((int64_t)NB * (D / 2) * (H / 2) * (W / 2) * (C / 8), 256);
     if (nb > 8192) nb = 8192;
     if (dtype == GS_F16) maxpool3d_pair_kernel<GS_F16><<<(int)nb, 256, 0, (hipStream_t)stream>>>(a);

@@ -1457,3 +1457,10 @@ def q8_from_hi(buf, q_plane, pixels, C, pix_stride, coff):
     whose q plane starts at `q_plane` (both with pixel stride pix_stride 16-bit elements)."""
     _dev(buf)
     _lib.call("gs_q8_from_hi", _p(buf), _p(q_plane), int(pixels), C, pix_stride, coff, dt_code(buf), _stream())
+
+
+def maxpool3d_fwd_pair_q8(z_hi, z_lo, z_q8, zq_coff, z_stride, zp_hi, zp_lo, zp_q8, zp_stride, NB, D, H, W, C):
+    """maxpool3d_fwd_pair with q planes: z_q8 -> z_lo is the input buffer's q plane (byte 0), the pooled channels start at its channel
+    zq_coff; zp_q8 -> zp_lo is the pooled buffer's q plane."""
+    _lib.call("gs_maxpool3d_fwd_pair_q8", _p(z_hi), _p(z_lo), int(bool(z_q8)), zq_coff, z_stride, _p(zp_hi), _p(zp_lo), int(bool(zp_q8)),
+              zp_stride, NB, D, H, W, C, dt_code(z_hi), _stream())

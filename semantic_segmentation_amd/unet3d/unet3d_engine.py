@@ -41,9 +41,10 @@ def resolve_plan3d(precise, dtype: str):
     if precise is True or precise == 1 or precise == "1" or precise == "full":
         plan = {s_: "xw" for s_ in convs}
     elif precise in ("mixed", "auto"):
-        plan = {s_: ("xw" if (s_ in MIXED3D_XW or dtype != "f16") else "1") for s_ in convs}
+        from ..unet.unet_engine import MIXED_SEG      # "xw" (default) or "q": the FP8 correction segment (GSSEG_MIXED_SEG)
+        plan = {s_: ("xw" if dtype != "f16" else (MIXED_SEG if s_ in MIXED3D_XW else "1")) for s_ in convs}
     elif isinstance(precise, dict):
-        bad = [k for k, v in precise.items() if k not in STAGES3D or v not in ("1", "x", "w", "xw")]
+        bad = [k for k, v in precise.items() if k not in STAGES3D or v not in ("1", "x", "w", "xw", "q")]
         if bad:
             raise ValueError(f"precise plan: unknown stages / modes {bad}")
         plan = {s_: precise.get(s_, "1") for s_ in convs}
@@ -127,7 +128,7 @@ class UNet3DEngine:
         if self.plan is not None:
             if self.auto:
                 try:
-                    self._pair_layout()
+                    self._pair_layout(W0)
                     covered = net.in_channels == 1 and net.num_classes <= 4 and ops.USE_HALO_CONV
                 except NotImplementedError:
                     covered = False
@@ -293,29 +294,43 @@ class UNet3DEngine:
         return logits, ctx
 
     # ------------------------------------------------------------------------------------------------
-    def _pair_layout(self):
+    def _pair_layout(self, W0: int = 128):
         """segment layouts of every conv stage under self.plan (raises NotImplementedError for channel counts the pair forward
-        cannot lay out): {stage: (segs, K, wrap)}; cached per plan"""
-        lay = self.__dict__.get("_lay")
-        if lay is not None:
-            return lay
-        net, plan = self.net, self.plan
+        cannot lay out): ({stage: (segs, K, wrap)}, the effective plan); cached per (plan, volume width).  A "q" stage (FP8
+        correction segment) needs the LDS-DMA kernel -- level width >= 24, channels % 64 == 0, fp16 -- and runs as "xw" elsewhere;
+        its entry is ("q", 2 * cin, 2 * cin)."""
+        cache = self.__dict__.setdefault("_lay", {})
+        if W0 in cache:
+            return cache[W0]
+        net = self.net
+        plan = dict(self.plan)
+        level = {"a_block1": 0, "a_block2": 1, "a_block3": 2, "bottleNeck": 3, "s_block3": 2, "s_block2": 1, "s_block1": 0}
+        for st_, m_ in self.plan.items():
+            if m_ == "q":
+                conv = net.get_submodule(st_)
+                ok = (not st_.endswith("upconv1") and self.dtype == "f16"
+                      and ops.conv3x3_q8_ok(W0 >> level[st_.split(".")[0]], conv.in_channels, conv.out_channels))
+                if not ok:
+                    plan[st_] = "xw"
         lay = {}
         for k, blk in (("a_block1", net.a_block1), ("a_block2", net.a_block2), ("a_block3", net.a_block3), ("bottleNeck", net.bottleNeck)):
+            def seg_or_q(name, cin, **kw):
+                return ("q", 2 * cin, 2 * cin) if plan[name] == "q" else segs3d(plan[name], cin, **kw)
             if k != "a_block1":
-                lay[k + ".conv1"] = segs3d(plan[k + ".conv1"], blk.conv1.in_channels)
+                lay[k + ".conv1"] = seg_or_q(k + ".conv1", blk.conv1.in_channels)
             elif net.in_channels != 1:
                 raise NotImplementedError("pair forward: one input channel (the direct first-layer kernel)")
-            lay[k + ".conv2"] = segs3d(plan[k + ".conv2"], blk.conv2.in_channels)
+            lay[k + ".conv2"] = seg_or_q(k + ".conv2", blk.conv2.in_channels)
         for k, sb, ab in (("s_block3", net.s_block3, net.a_block3), ("s_block2", net.s_block2, net.a_block2),
                           ("s_block1", net.s_block1, net.a_block1)):
             cu, cr = sb.upconv1.out_channels, ab.conv2.out_channels
-            lay[k + ".conv1"] = segs3d(plan[k + ".conv1"], cu + cr, lo0=cu, lo_len=cr)
-            lay[k + ".conv2"] = segs3d(plan[k + ".conv2"], sb.conv2.in_channels)
+            lay[k + ".conv1"] = ("q", 2 * (cu + cr), 2 * (cu + cr)) if plan[k + ".conv1"] == "q" else segs3d(plan[k + ".conv1"], cu + cr, lo0=cu, lo_len=cr)
+            lay[k + ".conv2"] = ("q", 2 * sb.conv2.in_channels, 2 * sb.conv2.in_channels) if plan[k + ".conv2"] == "q" else \
+                segs3d(plan[k + ".conv2"], sb.conv2.in_channels)
         if net.s_block1.conv2.out_channels != 64:
             raise NotImplementedError("pair forward: the pointwise head kernel reads 64 channels")
-        self.__dict__["_lay"] = lay
-        return lay
+        cache[W0] = (lay, plan)
+        return cache[W0]
 
     def forward_pair(self, x, training, need_grad):
         """The pair forward of UNet3D (BASELINE config 5 at the north star's 1e-3 on logits; GenSeg-3D/UNet3D/unet3d.py:89-126 is
@@ -325,11 +340,15 @@ class UNet3DEngine:
         HBM layout: pair buffers [NB*D, H, W, 2*C] = [hi (C) | lo (C)]; concat buffers [.., 2*(cup + cres)] =
         [up_h res_h | res_l -] -- the residual's lo plane FIRST, so that the consumer's x_lo segment (residual channels only) is
         contiguous behind the hi plane.  The backward pass is the default one: it reads the hi planes through strides."""
-        net, tdt, plan = self.net, self.tdt, self.plan
+        net, tdt = self.net, self.tdt
         if not ops.USE_HALO_CONV:
             raise RuntimeError("the pair forward needs the halo-reuse conv kernels (GSSEG_CONV3X3=halo)")
-        lay = self._pair_layout()
         NB, _, D0, H0, W0 = x.shape
+        lay, plan = self._pair_layout(W0)              # plan: "q" stages this volume size has no kernel for run as "xw"
+
+        def lo_fmt(st_name):
+            """form in which conv stage st_name reads the lo plane of its input: 1 = 16-bit lo plane, 2 = q plane (FP8 chunks)"""
+            return 2 if plan[st_name] == "q" else 1
         dev = x.device
         x = x.contiguous().float()
         names = {id(m): n for n, m in net.named_modules()}
@@ -338,14 +357,22 @@ class UNet3DEngine:
             return torch.empty(shape, dtype=dtype, device=dev)
 
         # every stale segment pack in ONE launch
-        items, packs = [], {}
+        items, qitems, packs = [], [], {}
         for st_name, (segs, K, _) in lay.items():
             conv = net.get_submodule(st_name)
             cout, cin = conv.out_channels, conv.in_channels
             pack = empty(27, cout, K)
-            items.append((conv.weight.detach().reshape(cout, cin, 27, 1), pack, False, segs))
-            packs[st_name] = pack
-        ops.pack_weight_segs(items)
+            if segs == "q":
+                wexp = torch.empty(cout, dtype=torch.int32, device=dev)
+                qitems.append((conv.weight.detach().reshape(cout, cin, 27, 1), pack, wexp))
+                packs[st_name] = (pack, wexp)
+            else:
+                items.append((conv.weight.detach().reshape(cout, cin, 27, 1), pack, False, segs))
+                packs[st_name] = pack
+        if items:
+            ops.pack_weight_segs(items)
+        if qitems:
+            ops.pack_weight_q8(qitems)
         dpacks = {}
         if need_grad:                              # the backward's data-gradient packs (16-bit, as the default engine): one launch
             ditems = []
@@ -377,9 +404,9 @@ class UNet3DEngine:
                                    coef[0], coef[1], coef[2], coef[3])
             return coef, batch
 
-        def stage(conv, bn, inp, in_stride, cin, D, H, W, z_hi, z_lo, z_stride, z_coff, first=False):
+        def stage(conv, bn, inp, in_stride, cin, D, H, W, z_hi, z_lo, z_stride, z_coff, first=False, z_q8=False):
             """conv (+ bias folded into BatchNorm) -> BN -> ReLU on pairs; the z pair goes to z_hi / z_lo (views; both take
-            z_coff) with pixel stride z_stride; z_lo None: not stored."""
+            z_coff) with pixel stride z_stride; z_lo None: not stored; z_q8: z_lo is the buffer's q plane (its byte 0)."""
             cout = conv.out_channels
             st = _Stage()
             st.conv, st.bn, st.cin, st.cout, st.D, st.H, st.W, st.first = conv, bn, cin, cout, D, H, W, first
@@ -395,14 +422,21 @@ class UNet3DEngine:
                 ops.conv_smallcin_fwd_split(x3, conv.weight.detach().reshape(cout, 3, 3, 3).contiguous(), y_hi, y_lo, part, 3, 1)
                 st.wd, st.halo = None, False
             else:
-                _, K, wrap = lay[names[id(conv)]]
-                nt = ops.conv3x3_stat_rows(NB * D, H, W, K, cout, pair=True)
+                segs_, K, wrap = lay[names[id(conv)]]
+                nt = ops.conv3x3_stat_rows(NB * D, H, W, K, cout, pair="q" if segs_ == "q" else True)
                 part = empty(ops.bn_partials_numel(nt, cout), dtype=torch.float32) if batch else None
-                ops.conv3d3_segs(inp, packs[names[id(conv)]], y_hi, y_lo, NB, D, H, W, K, wrap, cin, cout, in_stride, 0, part)
+                if segs_ == "q":
+                    qpack, wexp = packs[names[id(conv)]]
+                    ops.conv3d3_q8(inp, qpack, wexp, y_hi, y_lo, NB, D, H, W, cin, cout, in_stride, 0, part)
+                else:
+                    ops.conv3d3_segs(inp, packs[names[id(conv)]], y_hi, y_lo, NB, D, H, W, K, wrap, cin, cout, in_stride, 0, part)
                 st.halo = True
                 st.wd = dpacks.get(names[id(conv)])
             st.coef, st.stats = bn_coeffs(bn, conv.bias, part, nt, cout, NB * D * H * W)
-            ops.bn_act_apply_split(y_hi, y_lo, st.coef[0], st.coef[1], ACT_RELU, z_hi, z_lo, z_stride, z_coff)
+            if z_q8:
+                ops.bn_act_apply_split_q8(y_hi, y_lo, st.coef[0], st.coef[1], ACT_RELU, z_hi, z_lo, True, z_stride, z_coff)
+            else:
+                ops.bn_act_apply_split(y_hi, y_lo, st.coef[0], st.coef[1], ACT_RELU, z_hi, z_lo, z_stride, z_coff)
             st.y = y_hi
             if need_grad:
                 stages.append(st)
@@ -426,21 +460,28 @@ class UNet3DEngine:
             D, H, W = dims[k - 1]
             cmid, cout = blk.conv1.out_channels, blk.conv2.out_channels
             z1 = empty(NB * D, H, W, 2 * cmid)
-            s1 = stage(blk.conv1, blk.bn1, inp, in_stride, cin, D, H, W, z1, z1[..., cmid:], 2 * cmid, 0, first=(k == 1))
+            s1 = stage(blk.conv1, blk.bn1, inp, in_stride, cin, D, H, W, z1, z1[..., cmid:], 2 * cmid, 0, first=(k == 1),
+                       z_q8=lo_fmt(f"a_block{k}.conv2") == 2)
             ctot = cup[k] + cout
             cat = cats[k]
-            # residual: hi plane at channels [cup, ctot), lo plane at [ctot, ctot + cout)
-            s2 = stage(blk.conv2, blk.bn2, z1, 2 * cmid, cmid, D, H, W, cat, cat[..., ctot - cup[k]:], 2 * ctot, cup[k])
+            cat_q8 = lo_fmt(f"s_block{k}.conv1") == 2
+            if cat_q8:
+                # residual: hi plane at channels [cup, ctot); the buffer's second half is the q plane of ALL ctot channels
+                s2 = stage(blk.conv2, blk.bn2, z1, 2 * cmid, cmid, D, H, W, cat, cat[..., ctot:], 2 * ctot, cup[k], z_q8=True)
+            else:
+                # residual: hi plane at channels [cup, ctot), 16-bit lo plane at [ctot, ctot + cout)
+                s2 = stage(blk.conv2, blk.bn2, z1, 2 * cmid, cmid, D, H, W, cat, cat[..., ctot - cup[k]:], 2 * ctot, cup[k])
             pooled = empty(NB * (D // 2), H // 2, W // 2, 2 * cout)
-            ops.maxpool3d_fwd_pair(cat[..., cup[k]:], cat[..., ctot:], 2 * ctot, pooled, pooled[..., cout:], 2 * cout,
-                                   NB, D, H, W, cout)
+            nxt_conv = f"a_block{k + 1}.conv1" if k < 3 else "bottleNeck.conv1"
+            ops.maxpool3d_fwd_pair_q8(cat[..., cup[k]:], cat[..., ctot:], cat_q8, cup[k], 2 * ctot, pooled, pooled[..., cout:],
+                                      lo_fmt(nxt_conv) == 2, 2 * cout, NB, D, H, W, cout)
             enc.append((s1, s2, pooled))
             inp, in_stride, cin = pooled, 2 * cout, cout
         D, H, W = dims[3]
         bb = net.bottleNeck
         c1, c2 = bb.conv1.out_channels, bb.conv2.out_channels
         zb1 = empty(NB * D, H, W, 2 * c1)
-        sb1 = stage(bb.conv1, bb.bn1, inp, in_stride, cin, D, H, W, zb1, zb1[..., c1:], 2 * c1, 0)
+        sb1 = stage(bb.conv1, bb.bn1, inp, in_stride, cin, D, H, W, zb1, zb1[..., c1:], 2 * c1, 0, z_q8=lo_fmt("bottleNeck.conv2") == 2)
         zb = empty(NB * D, H, W, 2 * c2)
         sb2 = stage(bb.conv2, bb.bn2, zb1, 2 * c1, c1, D, H, W, zb, None, 2 * c2, 0)       # one reader: the hi-only transposed conv
 
@@ -461,6 +502,8 @@ class UNet3DEngine:
             # x_hi . w_hi on the LDS-DMA pointwise GEMM, hi plane only (all eight sub-voxel classes in one launch)
             ops.upconv2x2_fwd(cur, wf, sb.upconv1.bias.detach(), cats[k], NB, d, h, w, ccur, cu, D, H, W, in_stride=2 * ccur,
                               out_stride=2 * ctot, out_coff=0)
+            if lo_fmt(f"s_block{k}.conv1") == 2:       # a "q" consumer: the q chunks of the up channels (hi8 from the hi plane, lo8 = 0)
+                ops.q8_from_hi(cats[k], cats[k][..., ctot:], NB * D * H * W, cu, 2 * ctot, 0)
             if need_grad:
                 taps = [((c >> 1) & 1, c & 1) for c in range(8)]
                 tdz = [c >> 2 for c in range(8)]
@@ -473,7 +516,7 @@ class UNet3DEngine:
                 ups[k] = dict(zin=cur, wd=wd, geom=gb, geom_wg=gw, cin=ccur, cup=cu, ctot=ctot, dims=(d, h, w, D, H, W))
             cmid = sb.conv1.out_channels
             z1 = empty(NB * D, H, W, 2 * cmid)
-            stage(sb.conv1, sb.bn, cats[k], 2 * ctot, ctot, D, H, W, z1, z1[..., cmid:], 2 * cmid, 0)
+            stage(sb.conv1, sb.bn, cats[k], 2 * ctot, ctot, D, H, W, z1, z1[..., cmid:], 2 * cmid, 0, z_q8=lo_fmt(f"s_block{k}.conv2") == 2)
             if k > 1:
                 z2 = empty(NB * D, H, W, 2 * cmid)
                 stage(sb.conv2, sb.bn, z1, 2 * cmid, cmid, D, H, W, z2, None, 2 * cmid, 0)  # one reader: the next transposed conv

@@ -327,3 +327,38 @@ def test_pair_pool_and_pair_upsample_kernels():
     got = (buf[..., c:2 * c].float() + buf[..., 3 * c:].float()).cpu().permute(0, 3, 1, 2)
     assert float((got[:, :, :2 * h, 1:1 + 2 * w] - ref).abs().max()) < 1e-6
     assert float(got[:, :, 2 * h:].abs().max()) == 0.0 and float(got[:, :, :, 0].abs().max()) == 0.0       # the pad stays untouched
+
+
+def test_unet3d_q_plan_fp8_correction_segment_vs_oracle():
+    """the opt-in "q" form of the 3-D mixed plan (GSSEG_MIXED_SEG=q): FP8 correction segments on the stages the volume size has an
+    LDS-DMA kernel for (32^3: level 0; the 16-wide level runs them as "xw"), q planes through BatchNorm / max-pool / the concat
+    buffers; logits within 8.5e-4 of the fp32 oracle (measured 6.3e-4; "xw": 5.1e-4), gradients as the default mode"""
+    from semantic_segmentation_amd.unet3d import UNet3D, unet3d_engine as u3
+    sd = oracle.unet3d_state_dict(1, 2, seed=5)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 1, 32, 32, 32, generator=g)
+    mask = (torch.rand(1, 32, 32, 32, generator=g) > 0.5).long()
+    ref_p = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
+    ref = oracle.unet3d_forward(ref_p, x, train=True)
+    n, c, dd, hh, ww = ref.shape
+    oracle.seg_loss(ref.reshape(n, c, dd * hh, ww), mask.reshape(n, dd * hh, ww)).backward()
+    convs = [s for s in u3.STAGES3D if not s.endswith("upconv1")]
+    net = UNet3D(1, 2, precise={s: ("q" if s in u3.MIXED3D_XW else "1") for s in convs})
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    eff = net.engine._pair_layout(32)[1]
+    assert eff["s_block1.conv1"] == "q" and eff["s_block1.conv2"] == "q" and eff["a_block2.conv1"] == "xw" and eff["a_block1.conv2"] == "xw"
+    logits = net(x.cuda())
+    vol_loss(logits, mask.cuda()).backward()
+    torch.cuda.synchronize()
+    d = (logits.detach().cpu() - ref.detach()).abs()
+    REPORT["q_32"] = {"logit_max_abs": float(d.max()), "logit_mean_abs": float(d.mean())}
+    _dump()
+    assert float(d.max()) < 8.5e-4 and float(d.mean()) < 1.2e-4, REPORT["q_32"]
+    errs = []
+    for k, p in net.named_parameters():
+        r = ref_p[k].grad
+        if k.endswith(".bias") and ".conv" in k and "conv3" not in k:
+            continue
+        errs.append(abs(float(p.grad.norm()) - float(r.norm())) / max(float(r.norm()), 1e-12))
+    assert max(errs) < 2e-2, max(errs)
