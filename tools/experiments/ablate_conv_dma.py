@@ -1,7 +1,7 @@
 """ablation timing of the conv3x3 kernel on selected layers (GSSEG_C3_DEBUG=1)."""
 import os, sys
 os.environ["GSSEG_C3_DEBUG"] = "1"
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from semantic_segmentation_amd import ops
 LAYERS = [("inc.3", 256, 64, 64), ("d1.3", 128, 128, 128), ("u4.0", 256, 128, 64), ("d2.3", 64, 256, 256), ("u2.0", 64, 512, 256), ("d3.3", 32, 512, 512), ("u1.0", 32, 1024, 512)]

@@ -3,7 +3,7 @@
 LDS transpose, statistics all run) / no epilogue at all (dbg 4), interleaved rounds in one process."""
 import os, sys, statistics
 os.environ["GSSEG_C3_DEBUG"] = "1"
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from semantic_segmentation_amd import ops
 LAYERS = [("inc.3 fwd", 256, 64, 64, True), ("inc.3 nostat", 256, 64, 64, False), ("u4.0 fwd", 256, 128, 64, True), ("d1.3 fwd", 128, 128, 128, True),

@@ -3,7 +3,7 @@
 capped at 256 / 248 / 240 / 224 blocks (gs_set_persistent_grid), interleaved rounds in one process.  parallel.GradReducer
 caps them at 256 - GSSEG_RCCL_CUS (default 8) when world > 1."""
 import os, sys, statistics
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from semantic_segmentation_amd import ops
 from semantic_segmentation_amd.harness import synthetic_batch

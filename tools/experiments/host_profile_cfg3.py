@@ -1,6 +1,6 @@
 """cProfile of the eager config-3 steps at batch 2 (host side: where the ~16 us per launch go)"""
 import cProfile, os, pstats, sys, io
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from semantic_segmentation_amd import steps
 from semantic_segmentation_amd.harness import synthetic_batch

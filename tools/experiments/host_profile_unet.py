@@ -1,7 +1,7 @@
 """cProfile of the U-Net engine's forward + backward called directly (autograd runs backward on its own thread, invisible to
 cProfile): where the host time of a small-batch step goes"""
 import cProfile, io, os, pstats, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from semantic_segmentation_amd.harness import synthetic_batch
 from semantic_segmentation_amd.unet import UNet

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Run a few isolated conv launches (for rocprofv3 --pmc collection): python tools/pmc_conv.py [layer]"""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from semantic_segmentation_amd import ops
 dev = torch.device("cuda:0"); dt = torch.float16; N = 32
 LAY = {"inc.3": (256, 64, 64), "d2.3": (64, 256, 256), "d4.3": (16, 1024, 1024), "u4.0": (256, 128, 64)}

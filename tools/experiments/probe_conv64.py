@@ -1,7 +1,7 @@
 """64->64 layer at 256^2: forward vs data gradient, with / without statistics, with / without resident weights (ablation bit 32)."""
 import os, sys
 os.environ["GSSEG_C3_DEBUG"] = "1"
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from semantic_segmentation_amd import ops
 def timeit(fn, iters=20):

@@ -1,7 +1,7 @@
 """Feasibility probe: the three config-3 training steps (forward + backward) captured into HIP graphs (torch.cuda.CUDAGraph) and
 replayed, against the eager loop.  Weights are not updated (timing only); gradients of eager and replay are compared."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from semantic_segmentation_amd import steps
 from semantic_segmentation_amd.harness import synthetic_batch

@@ -1,7 +1,7 @@
 """2-D weight gradient (the per-depth-tap launch of the 3-D net's s_block1.conv1: 128 slices of 128x128, 192 -> 64) in variants:
 dense 192-channel input, 64-channel slices of a 192-wide buffer, other Cin / sizes -- to locate the 0.72 PF of that layer"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from semantic_segmentation_amd import ops
 def timeit(fn, iters=10):

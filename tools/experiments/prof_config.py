@@ -9,7 +9,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from semantic_segmentation_amd import steps  # noqa: E402
 from semantic_segmentation_amd.harness import synthetic_batch  # noqa: E402
 from semantic_segmentation_amd.losses import seg_loss  # noqa: E402

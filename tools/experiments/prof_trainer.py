@@ -2,7 +2,7 @@
 """harness.EndToEndTrainer iterations (config 3, batches resident on the device, no arch step / validation / augmentation) for
 rocprofv3:  python tools/prof_trainer.py <batch> <iters> <graphs 0|1>"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from semantic_segmentation_amd.harness import EndToEndTrainer, SyntheticLungDataset
 from semantic_segmentation_amd.models_pix2pix import networks
