@@ -23,6 +23,7 @@ struct SCArgs {
     unsigned short* y_lo = nullptr;                    // MODE 2: lo half of the output pair (pair forward), same stride
     int ys = 64;                                       // MODE 2: pixel stride of y / y_lo
     int lo_q8 = 0;                                     // MODE 2: y_lo is a q plane (FP8 correction chunks, common.hpp) of pixel stride ys
+    int rows256 = 0;                                   // MODE 2: y_lo == y + 64 and ys == 128 (one 256-byte row per pixel), staged through LDS
 };
 
 template <int DT>
@@ -206,6 +207,7 @@ __device__ __forceinline__ int sc_opaque(int x) { asm volatile("" : "+v"(x)); re
 // MODE 1: the partials ALONE -- they depend on the image and the weights only (tap sums + Gram matrix), y is not formed.
 // MODE 2: y * bn_scale + bn_shift, activation, stored: with MODE 1 in front (and gs_bn_finalize between) the stem's
 //         convolution output is never written -- train-mode BatchNorm without the 2 x 268 MB round trip of y at batch 32.
+extern __shared__ uint4 sc_line_stage[];            // MODE 2 with a.rows256: [4 waves][64 rows][256 B]
 template <int DT, int MODE>
 __global__ __launch_bounds__(256) void smallcin_fwd64_line_kernel(const SCArgs a) {
     constexpr int TT = 9, NG = TT * (TT + 1) / 2;
@@ -260,6 +262,13 @@ __global__ __launch_bounds__(256) void smallcin_fwd64_line_kernel(const SCArgs a
         }
         unsigned short* dst = a.y + (int64_t)mm * (MODE == 2 ? a.ys : 64);
         unsigned short* dst_lo = (MODE == 2 && a.y_lo) ? a.y_lo + (int64_t)mm * a.ys : nullptr;
+        // MODE 2, [hi(64) | lo(64)] pair rows of 256 contiguous bytes (a.rows256): the wave's 64 rows are assembled in its 16 KB of
+        // LDS (16-byte slot s of row r at s ^ (r & 15): conflict-free both ways) and leave as sixteen 1 KB stores of complete lines.
+        // Written lane by lane, a row's two 128-byte lines receive sixteen 16-byte pieces spread over the whole channel loop and L2
+        // evicts them half written: 1.15 GB of HBM writes for 0.54 GB of pairs at batch 32 (profiles/r04_v2_mixed_pmc_traffic.json).
+        const bool rows256 = MODE == 2 && a.rows256;
+        unsigned char* const stg = reinterpret_cast<unsigned char*>(sc_line_stage) + (threadIdx.x >> 6) * (64 * 256) + (threadIdx.x & 63) * 256;
+        const int swz = threadIdx.x & 15;
 #pragma unroll 1
         for (int g = 0; g < (MODE == 1 ? 0 : 4); ++g) {     // 16 channels at a time, a runtime loop: unrolled, the compiler hoists all
             const float* wk = wl + sc_opaque(g * 16);       // 144 weight reads above the FMAs and spills the accumulators
@@ -301,22 +310,44 @@ __global__ __launch_bounds__(256) void smallcin_fwd64_line_kernel(const SCArgs a
                         o[c] = v > 0.f ? v : v * slope;
                     }
                     const uint4 hi = pack8<DT>(o);
-                    *reinterpret_cast<uint4*>(dst + g * 16 + 8 * i) = hi;
+                    if (rows256) *reinterpret_cast<uint4*>(stg + (((g * 2 + i) ^ swz) << 4)) = hi;
+                    else *reinterpret_cast<uint4*>(dst + g * 16 + 8 * i) = hi;
                     if (MODE == 2 && dst_lo && a.lo_q8) {    // pair forward, "q" consumer: the q-plane bytes of these 8 channels
                         uint2 lo8, hi8;
                         q8_of8<DT>(o, hi, __builtin_ldexpf(1.f, GS_Q8_XH_EXP + Q8Shift<DT>::v), __builtin_ldexpf(1.f, GS_Q8_XH_EXP), lo8, hi8);
-                        unsigned char* zq = reinterpret_cast<unsigned char*>(dst_lo) + q8_off(g * 16 + 8 * i);
-                        *reinterpret_cast<uint2*>(zq) = lo8;
-                        *reinterpret_cast<uint2*>(zq + 32) = hi8;
+                        const int qo = q8_off(g * 16 + 8 * i);
+                        if (rows256) {
+                            *reinterpret_cast<uint2*>(stg + ((((128 + qo) >> 4) ^ swz) << 4) + (qo & 8)) = lo8;
+                            *reinterpret_cast<uint2*>(stg + ((((160 + qo) >> 4) ^ swz) << 4) + (qo & 8)) = hi8;
+                        } else {
+                            unsigned char* zq = reinterpret_cast<unsigned char*>(dst_lo) + qo;
+                            *reinterpret_cast<uint2*>(zq) = lo8;
+                            *reinterpret_cast<uint2*>(zq + 32) = hi8;
+                        }
                     } else if (MODE == 2 && dst_lo) {        // pair forward: lo = 16-bit(value - hi)
                         float hf[8];
                         unpack8<DT>(hi, hf);
 #pragma unroll
                         for (int c = 0; c < 8; ++c) o[c] -= hf[c];
-                        *reinterpret_cast<uint4*>(dst_lo + g * 16 + 8 * i) = pack8<DT>(o);
+                        if (rows256) *reinterpret_cast<uint4*>(stg + (((8 + g * 2 + i) ^ swz) << 4)) = pack8<DT>(o);
+                        else *reinterpret_cast<uint4*>(dst_lo + g * 16 + 8 * i) = pack8<DT>(o);
                     }
                 }
             }
+        }
+        if (rows256) {                                   // (a wave's LDS accesses execute in order: no barrier between its lanes' rows)
+            __builtin_amdgcn_wave_barrier();
+            const int lane = threadIdx.x & 63;
+            const int m_w = m - lane;                    // the wave's first pixel
+            const unsigned char* wst = reinterpret_cast<const unsigned char*>(sc_line_stage) + (threadIdx.x >> 6) * (64 * 256);
+            unsigned char* gw = reinterpret_cast<unsigned char*>(a.y) + (int64_t)m_w * 256;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int row = it * 4 + (lane >> 4);
+                const uint4 v = *reinterpret_cast<const uint4*>(wst + row * 256 + (((lane & 15) ^ (row & 15)) << 4));
+                if (m_w + row < M) *reinterpret_cast<uint4*>(gw + it * 1024 + lane * 16) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
     if (MODE != 2 && a.bnp) {
@@ -1454,8 +1485,19 @@ static int stem_fwd_bn_pair_impl(const float* x, const float* w, const float* bn
     SCArgs a{x, w, nullptr, (unsigned short*)z_hi, nullptr, N, 1, H, W, 64, H, W, 3, 1, 1, act};
     a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.y_lo = (unsigned short*)z_lo; a.ys = z_pix_stride; a.lo_q8 = lo_q8;
     const int nb = gs_conv_smallcin_mtiles(N, H, W);
-    if (dtype == GS_F16) smallcin_fwd64_line_kernel<GS_F16, 2><<<nb, 256, 0, (hipStream_t)stream>>>(a);
-    else smallcin_fwd64_line_kernel<GS_BF16, 2><<<nb, 256, 0, (hipStream_t)stream>>>(a);
+    a.rows256 = z_lo != nullptr && z_pix_stride == 128 && (unsigned short*)z_lo == (unsigned short*)z_hi + 64 &&
+                ((uintptr_t)z_hi & 15) == 0 && getenv("GSSEG_STEM_ROWS256_OFF") == nullptr;
+    const size_t lds = a.rows256 ? 4 * 64 * 256 : 0;
+    if (a.rows256) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)smallcin_fwd64_line_kernel<GS_F16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 256);
+            (void)hipFuncSetAttribute((const void*)smallcin_fwd64_line_kernel<GS_BF16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 256);
+            attr_done = true;
+        }
+    }
+    if (dtype == GS_F16) smallcin_fwd64_line_kernel<GS_F16, 2><<<nb, 256, lds, (hipStream_t)stream>>>(a);
+    else smallcin_fwd64_line_kernel<GS_BF16, 2><<<nb, 256, lds, (hipStream_t)stream>>>(a);
     GS_CHECK_LAUNCH("gs_stem_fwd_bn_pair");
     return GS_OK;
 }
