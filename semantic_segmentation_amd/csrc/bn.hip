@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(const ApplyArgs a) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] *= ((kw[i >> 2] >> (8 * (i & 3))) & 0xffu) ? a.keep_scale : 0.f;
             }
-            *reinterpret_cast<uint4*>(a.z + pix * a.zs + a.zc + c0) = pack8<DT>(v);
+            st16(a.z + pix * a.zs + a.zc + c0, pack8<DT>(v));
         } else {
             float mx[8];
 #pragma unroll
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(const ApplyArgs a) {
 #pragma unroll
                         for (int i = 0; i < 8; ++i) v[i] = fwd_a(v[i] * sc[i] + sh[i]);
                         const uint4 pk = pack8<DT>(v);
-                        *reinterpret_cast<uint4*>(a.z + pix * a.zs + a.zc + c0) = pk;
+                        st16(a.z + pix * a.zs + a.zc + c0, pk);
                         // pool the ROUNDED values: the next layer sees exactly max over the stored z
                         float r[8];
                         unpack8<DT>(pk, r);
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(const ApplyArgs a) {
                 }
             if (py < a.H / 2 && px < a.W / 2) {
                 const int64_t pp = ((int64_t)n * (a.H / 2) + py) * (a.W / 2) + px;
-                *reinterpret_cast<uint4*>(a.zp + pp * a.C + c0) = pack8<DT>(mx);
+                st16(a.zp + pp * a.C + c0, pack8<DT>(mx));
             }
         }
     }
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
                         if (APPLY) out[i] = a.bn ? sc[i] * (gh - k1[i] - xh * k2[i]) : gh;
                         else { s1[i] += gh; s2[i] += gh * xh; }
                     }
-                    if (APPLY) *reinterpret_cast<uint4*>(a.dy + pix * a.C + c0) = pack8<DT>(out);
+                    if (APPLY) st16(a.dy + pix * a.C + c0, pack8<DT>(out));
                 }
             }
             }       // chunks
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BwdArgs a) {
                         if (APPLY) out[i] = a.bn ? sc[i] * (gh - k1[i] - xh * k2[i]) : gh;
                         else { s1[i] += gh; s2[i] += gh * xh; }
                     }
-                    if (APPLY) *reinterpret_cast<uint4*>(a.dy + pixk[k] * a.C + c0) = pack8<DT>(out);
+                    if (APPLY) st16(a.dy + pixk[k] * a.C + c0, pack8<DT>(out));
                 }
             }
         }

@@ -18,6 +18,26 @@ typedef __attribute__((ext_vector_type(8))) short i16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
+// Output stores of the streaming kernels.  GS_OUT_AUX = 16 (`sc1`, write-through) on the buffer stores of the conv / up-conv
+// epilogues: the line leaves the XCD's L2 at once instead of staying dirty until the kernel boundary writes the L2 back
+// (MI355X_MICROARCH.md, "boundary").  Measured on the bs 32 step, three alternating rounds on one box: plain 15.29 ms, conv /
+// up-conv stores sc1 15.25 ms, these AND the 16-byte stores of the BatchNorm / stem passes (st16 as inline-asm
+// `global_store_dwordx4 ... sc1`, GS_ST16_WT = 1) 15.28 ms: kept for the buffer stores, not for st16.
+#ifndef GS_OUT_AUX
+#define GS_OUT_AUX 16
+#endif
+#ifndef GS_ST16_WT
+#define GS_ST16_WT 0
+#endif
+__device__ __forceinline__ void st16(void* p, const uint4& v) {
+#if GS_ST16_WT
+    const u32x4 t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(t) : "memory");
+#else
+    *reinterpret_cast<uint4*>(p) = v;
+#endif
+}
+
 #define LDS_AS __attribute__((address_space(3)))
 
 void gs_set_error(const char* fmt, ...);

@@ -276,11 +276,11 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(a.y + (int64_t)pend_n * a.H * a.W * a.out_stride), 0, (unsigned)a.H * a.W * a.out_stride * 2u, 0x00020000);
         const unsigned soff = (unsigned)i * row_stride_b + (unsigned)((p & 3) * 8) * (unsigned)a.out_stride * 2u;
-        __builtin_amdgcn_raw_buffer_store_b128(dsv, ry, pend_voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(dsv, ry, pend_voff, soff, GS_OUT_AUX);
         if (PREC) {
             const __amdgpu_buffer_rsrc_t ryl = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(a.y_lo + (int64_t)pend_n * a.H * a.W * a.out_stride), 0, (unsigned)a.H * a.W * a.out_stride * 2u, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b128(dsvl, ryl, pend_voff, soff, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(dsvl, ryl, pend_voff, soff, GS_OUT_AUX);
         }
     };
     // the deferred work of MFMA step `step` of the first stage: pass p = step / 2 writes at step 2p, reads at 2p + 1, stores at 2p + 2
@@ -561,13 +561,13 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
                 u32x4 d;
                 d[0] = sv[q].x; d[1] = sv[q].y; d[2] = sv[q].z; d[3] = sv[q].w;
                 if (dbg & 64) asm volatile("" :: "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(off));      // ablation: no global stores
-                else __builtin_amdgcn_raw_buffer_store_b128(d, ry, off, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(d, ry, off, 0, GS_OUT_AUX);
                 if (PREC) {
                     const uint4 lv = Q8 ? *reinterpret_cast<const uint4*>(stg_base + stg_rb + (unsigned)((NWV * STG_EL + q * 8 * C3_LDR) * 2))
                                         : *reinterpret_cast<const uint4*>(stg_lo + (q * 8 + (lane >> 3)) * C3_LDR + (lane & 7) * 8);
                     u32x4 dl;
                     dl[0] = lv.x; dl[1] = lv.y; dl[2] = lv.z; dl[3] = lv.w;
-                    __builtin_amdgcn_raw_buffer_store_b128(dl, ry_lo, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(dl, ry_lo, off, 0, GS_OUT_AUX);
                 }
             }
             __builtin_amdgcn_wave_barrier();

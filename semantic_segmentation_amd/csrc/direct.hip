@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void smallcin_fwd64_line_kernel(const SCArgs a
             for (int it = 0; it < 16; ++it) {
                 const int row = it * 4 + (lane >> 4);
                 const uint4 v = *reinterpret_cast<const uint4*>(wst + row * 256 + (((lane & 15) ^ (row & 15)) << 4));
-                if (m_w + row < M) *reinterpret_cast<uint4*>(gw + it * 1024 + lane * 16) = v;
+                if (m_w + row < M) st16(gw + it * 1024 + lane * 16, v);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -465,8 +465,8 @@ __global__ __launch_bounds__(256) void smallcin_fwd64x4_kernel(const SCArgs a) {
                     o[c >> 3][c & 7] = v > 0.f ? v : v * slope;
                 }
                 unsigned short* dst = a.y + (int64_t)m * 64 + g * 16;
-                *reinterpret_cast<uint4*>(dst) = pack8<DT>(o[0]);
-                *reinterpret_cast<uint4*>(dst + 8) = pack8<DT>(o[1]);
+                st16(dst, pack8<DT>(o[0]));
+                st16(dst + 8, pack8<DT>(o[1]));
             }
         }
         if (a.bnp) {

@@ -287,17 +287,17 @@ __global__ __launch_bounds__(256) void bn_act_apply_split_kernel(const ApplySArg
                 if (LO) {
                     uint4 hi, lo;
                     split8<DT>(v, hi, lo);
-                    *reinterpret_cast<uint4*>(zh + p * a.zs) = hi;
-                    *reinterpret_cast<uint4*>(zl + p * a.zs) = lo;
+                    st16(zh + p * a.zs, hi);
+                    st16(zl + p * a.zs, lo);
                 } else if (LOF == 2) {
                     const uint4 hi = pack8<DT>(v);
                     uint2 lo8, hi8;
                     q8_of8<DT>(v, hi, q_slo, q_shi, lo8, hi8);
-                    *reinterpret_cast<uint4*>(zh + p * a.zs) = hi;
+                    st16(zh + p * a.zs, hi);
                     *reinterpret_cast<uint2*>(zq + p * a.zs * 2) = lo8;
                     *reinterpret_cast<uint2*>(zq + p * a.zs * 2 + 32) = hi8;
                 } else {
-                    *reinterpret_cast<uint4*>(zh + p * a.zs) = pack8<DT>(v);
+                    st16(zh + p * a.zs, pack8<DT>(v));
                 }
             }
         }
@@ -354,8 +354,8 @@ __global__ __launch_bounds__(256) void bn_act_apply_split_pool_kernel(const Appl
             }
             uint4 hi, lo;
             split8<DT>(v, hi, lo);
-            *reinterpret_cast<uint4*>(a.z_hi + pix * a.zs + a.zc + c0) = hi;
-            if (LO) *reinterpret_cast<uint4*>(a.z_lo + pix * a.zs + a.zc + c0) = lo;
+            st16(a.z_hi + pix * a.zs + a.zc + c0, hi);
+            if (LO) st16(a.z_lo + pix * a.zs + a.zc + c0, lo);
             if (LOF == 2) {
                 uint2 lo8, hi8;
                 q8_of8<DT>(v, hi, q_slo, q_shi, lo8, hi8);
@@ -373,8 +373,8 @@ __global__ __launch_bounds__(256) void bn_act_apply_split_pool_kernel(const Appl
             const int64_t pp = ((int64_t)n * (a.H / 2) + py) * (a.W / 2) + px;
             uint4 hi, lo;
             split8<DT>(mx, hi, lo);
-            *reinterpret_cast<uint4*>(a.zp_hi + pp * a.zps + c0) = hi;
-            if (a.zp_lo && !a.zp_q8) *reinterpret_cast<uint4*>(a.zp_lo + pp * a.zps + c0) = lo;
+            st16(a.zp_hi + pp * a.zps + c0, hi);
+            if (a.zp_lo && !a.zp_q8) st16(a.zp_lo + pp * a.zps + c0, lo);
             if (a.zp_lo && a.zp_q8) {
                 uint2 lo8, hi8;
                 q8_of8<DT>(mx, hi, q_slo, q_shi, lo8, hi8);

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(512, 1) void upconv2x2_dma_kernel(const PwArgs a) {
                 for (int q = 0; q < 4; ++q) {
                     u32x4 d;
                     d[0] = sv[q].x; d[1] = sv[q].y; d[2] = sv[q].z; d[3] = sv[q].w;
-                    __builtin_amdgcn_raw_buffer_store_b128(d, y_rsrc, dead ? VOOB : pixoff[i][q] + clsoff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(d, y_rsrc, dead ? VOOB : pixoff[i][q] + clsoff, 0, GS_OUT_AUX);
                 }
                 __builtin_amdgcn_wave_barrier();
             }
