@@ -136,6 +136,10 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only with --dry")
+    ap.add_argument("--rehearse-dp", action="store_true",
+                    help="N = 1 only: run the N > 1 code path on ONE rank (a 1-rank RCCL process group, reducer attached and detached "
+                         "legs, the back-to-back bucket all-reduce) -- a rehearsal of what the driver's scaling run executes, on a "
+                         "one-GPU box; the JSON line carries \"rehearse_dp\": true")
     ap.add_argument("--dry", action="store_true",
                     help="plumbing rehearsal without kernels: launcher, rendezvous, barrier/max-over-ranks timing and the "
                          "bucketed GradReducer on a small CPU stand-in model; the JSON line says \"dry\": true and is NOT a "
@@ -174,13 +178,17 @@ def cpu_baseline(args):
             "gflops": round(ips * GF_PER_IMG_FWDBWD.get(args.classes, 288.5) * (args.size / 256.0) ** 2, 1)}
 
 
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this script (one per GPU) with the
     torch.distributed environment, relay rank 0's JSON line, fail if any rank fails.  This parent never initialises a
     GPU (no HIP call, no torch.cuda.is_available()), and nothing is exec'ed: children are ordinary subprocesses."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = free_port()
     import tempfile
     procs = []
     with tempfile.TemporaryFile("w+") as out0:
@@ -288,9 +296,15 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.rehearse_dp          # the data-parallel code path (rehearsal: one rank, the same calls)
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from semantic_segmentation_amd import ops
     from semantic_segmentation_amd.harness import synthetic_batch
@@ -311,7 +325,7 @@ def main():
         net.train()
         broadcast_module_state(net)
         reducer = None
-        if world > 1 and with_reducer:
+        if multi and with_reducer:
             reducer = GradReducer(net.named_parameters()).attach(net.engine)
 
         def step():
@@ -321,7 +335,7 @@ def main():
             xs, ms_ = x, mask
             if args.host_input:
                 xs, ms_ = x_host.to(dev, non_blocking=True), mask_host.to(dev, non_blocking=True)
-            loss = seg_loss(net(xs), ms_, global_dice=True if (args.global_dice and world > 1) else None)
+            loss = seg_loss(net(xs), ms_, global_dice=True if (args.global_dice and multi) else None)
             loss.backward()
             return loss
 
@@ -338,7 +352,7 @@ def main():
             step()
         torch.cuda.synchronize()
         timer.reset()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]    # on the launch (= current) stream
@@ -347,7 +361,7 @@ def main():
         for i in range(args.steps):
             loss = step()
             marks[i + 1].record()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
@@ -373,7 +387,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         allreduce_ms = e0.elapsed_time(e1) / reps
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -381,14 +395,14 @@ def main():
     # barrier + max-over-ranks timing: ms_per_step - ms_per_step_no_exchange = what the exchange costs after overlap ("exposed"),
     # next to `allreduce_ms_per_step_unoverlapped` (all buckets back to back with nothing to hide behind)
     no_exchange_ms = None
-    if world > 1:
+    if multi:
         ne_elapsed, _, _, _, _ = timed_leg(args.precise, False)
         t = torch.tensor([ne_elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         no_exchange_ms = float(t.item()) / args.steps * 1e3
     # second leg, N = 1 only (like the CPU baseline): the fast 16-bit mode, whose logits are OUTSIDE the north star's tolerance
     fast = None
-    if world == 1 and args.fast_leg != "none" and args.precise == "mixed":
+    if world == 1 and not multi and args.fast_leg != "none" and args.precise == "mixed":
         p_elapsed, p_step_ms, p_ksum, p_loss, _ = timed_leg("fast", False)
         fast = {"mode": PARITY_MODES["fast"][0], "value": round(args.batch * args.steps / p_elapsed, 2),
                 "unit": "images/sec", "ms_per_step": round(p_elapsed / args.steps * 1e3, 3),
@@ -398,7 +412,7 @@ def main():
                 "loss": float(p_loss.item()), "steps": args.steps, "warmup": args.warmup,
                 "conv3x3_family": family_summary(p_ksum, args.steps)}
     if rank != 0:
-        if world > 1:
+        if multi:
             dist.destroy_process_group()
         return
 
@@ -436,7 +450,7 @@ def main():
         "ms_per_step_median": round(statistics.median(step_ms), 3),
         "ms_per_step_min_max": [round(min(step_ms), 3), round(max(step_ms), 3)],
         "value_at_median_step": round(world * args.batch / statistics.median(step_ms) * 1e3, 2),
-        "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+        "rccl_ranks": dist.get_world_size() if multi else 1, "rehearse_dp": bool(args.rehearse_dp and world == 1),
         "allreduce_ms_per_step_unoverlapped": None if allreduce_ms is None else round(allreduce_ms, 3),
         "grad_buckets": None if reducer is None else len(reducer.buckets),
         "ms_per_step_no_exchange": None if no_exchange_ms is None else round(no_exchange_ms, 3),
@@ -445,12 +459,12 @@ def main():
         "whole_step_frac_of_mfma_peak": round(value * gf / 1e3 / (MFMA_PEAK_TFLOPS * world), 4),
         "roofline": roof, "kernels": kern,
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not multi and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

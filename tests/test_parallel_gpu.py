@@ -231,3 +231,24 @@ def test_unet3d_and_pix2pix_steps_replayed_from_hipgraphs_then_exchanged_over_rc
         check(D, in2, lambda net, m, r: net(torch.cat((m, r), 1)).square().mean())
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_bench_data_parallel_path_rehearsal_on_one_rank():
+    """`bench.py --rehearse-dp`: the code path of `bench.py --gpus N` (N > 1) on ONE rank -- a 1-rank RCCL process group, the timed leg
+    with the bucketed GradReducer attached, the back-to-back bucket all-reduce, the timed leg with the reducer detached -- so that
+    the path the driver's scaling run executes has run on a GPU before.  (A subprocess: bench.py owns its process group.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rehearse-dp", "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--size", "128"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["rehearse_dp"] is True and d["rccl_ranks"] == 1 and d["n_gpus"] == 1
+    assert d["grad_buckets"] >= 1 and d["allreduce_ms_per_step_unoverlapped"] > 0
+    assert d["ms_per_step_no_exchange"] > 0 and d["exposed_exchange_ms_per_step"] is not None
+    assert d["meets_north_star_tolerance"] is True and d["value"] > 0
