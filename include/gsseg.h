@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 46
+#define GS_ABI_VERSION 47
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -293,6 +293,11 @@ int gs_maxpool3d_bwd(const void* z, int z_pix_stride, int z_coff, const void* dz
  * conv + folded BatchNorm + ReLU is ONE gs_conv3x3 call (bias + activation epilogue) and gs_bn_act_apply is not run. */
 int gs_maxpool2x2_fwd(const void* z, int z_pix_stride, int z_coff, void* zp, int N, int H, int W, int C, int dtype,
                       void* stream);
+/* The same on hi/lo pairs (folded-BatchNorm inference of the pair forward: conv + bias + ReLU leave the z pair, nn.MaxPool2d(2) of
+ * `Down`, unet/unet_parts.py:34): the pooled pair = the maximum of the window's pair VALUES hi + lo, split again.  z_hi / z_lo: two
+ * planes with pixel stride z_pix_stride (16-bit elements); zp_hi / zp_lo (zp_lo may be NULL) with zp_pix_stride. */
+int gs_maxpool2x2_fwd_pair(const void* z_hi, const void* z_lo, int z_pix_stride, void* zp_hi, void* zp_lo, int zp_pix_stride, int N, int H,
+                           int W, int C, int dtype, void* stream);
 
 /* per-channel column sums over the sub-rectangle [y0,y0+h) x [x0,x0+w) of a (strided) NHWC tensor
  * [N,H,W,*]: out[c] (OVERWRITE) = gscale * sum t[pix*s + coff + c]  (bias gradient of ConvTranspose2d,

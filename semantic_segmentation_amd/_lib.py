@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 GS_F16, GS_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH = 0, 1, 2, 3
 GS_MAX_TAPS = 64
-ABI_VERSION = 46
+ABI_VERSION = 47
 
 
 class GsConvGeom(ctypes.Structure):
@@ -112,6 +112,7 @@ PROTOTYPES = {
                             + [c_int] * 5 + [c_void_p]),
     "gs_maxpool3d_fwd": (c_int, [_P, c_int, c_int, _P] + [c_int] * 6 + [c_void_p]),
     "gs_maxpool2x2_fwd": (c_int, [_P, c_int, c_int, _P] + [c_int] * 5 + [c_void_p]),
+    "gs_maxpool2x2_fwd_pair": (c_int, [_P, _P, c_int, _P, _P, c_int] + [c_int] * 5 + [c_void_p]),
     "gs_maxpool3d_bwd": (c_int, [_P, c_int, c_int, _P, _P, c_int, c_int, _P] + [c_int] * 6 + [c_void_p]),
     "gs_colsum": (c_int, [_P, c_int, c_int] + [c_int] * 8 + [c_float, _F, _F, c_int, c_void_p]),
     "gs_stem_bn_bwd_wgrad": (c_int, [_P, _P, c_int, c_int, _F, _F, _F, _F, _F, _F, _F, c_int, _F, _F, c_int, c_int, c_int,

@@ -195,6 +195,45 @@ __global__ __launch_bounds__(256) void maxpool2x2_kernel(const unsigned short* _
         *reinterpret_cast<uint4*>(zp + (int64_t)(idx / nch) * C + ch * 8) = pack8<DT>(m);
     }
 }
+// The same on PAIRS (folded-BatchNorm inference of the pair forward): the pooled pair is the maximum of the pair VALUES hi + lo of
+// the window, split again; z_hi / z_lo share the pixel stride zs (two planes of one buffer), zp_hi / zp_lo the stride zps.
+template <int DT>
+__global__ __launch_bounds__(256) void maxpool2x2_pair_kernel(const unsigned short* __restrict__ z_hi, const unsigned short* __restrict__ z_lo,
+                                                              int zs, unsigned short* __restrict__ zp_hi, unsigned short* __restrict__ zp_lo,
+                                                              int zps, int N, int H, int W, int C) {
+    const int nch = C >> 3, PH = H / 2, PW = W / 2;
+    const int total = N * PH * PW * nch;                  // host guarantees < 2^31
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int ch = idx % nch;
+        int r = idx / nch;
+        const int px = r % PW; r /= PW;
+        const int py = r % PH;
+        const int n = r / PH;
+        const int64_t p00 = ((int64_t)n * H + 2 * py) * W + 2 * px;
+        const int64_t off[4] = {p00 * zs, (p00 + 1) * zs, (p00 + W) * zs, (p00 + W + 1) * zs};
+        uint4 vh[4], vl[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            vh[k] = *reinterpret_cast<const uint4*>(z_hi + off[k] + ch * 8);
+            vl[k] = *reinterpret_cast<const uint4*>(z_lo + off[k] + ch * 8);
+        }
+        float m[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m[i] = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v[8];
+            join8<DT>(vh[k], vl[k], v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], v[i]);
+        }
+        uint4 hi, lo;
+        split8<DT>(m, hi, lo);
+        const int64_t pp = (int64_t)(idx / nch) * zps + ch * 8;
+        *reinterpret_cast<uint4*>(zp_hi + pp) = hi;
+        if (zp_lo) *reinterpret_cast<uint4*>(zp_lo + pp) = lo;
+    }
+}
 }  // namespace
 
 extern "C" int gs_maxpool2x2_fwd(const void* z, int z_pix_stride, int z_coff, void* zp, int N, int H, int W, int C,
@@ -213,6 +252,26 @@ extern "C" int gs_maxpool2x2_fwd(const void* z, int z_pix_stride, int z_coff, vo
         maxpool2x2_kernel<GS_BF16><<<(int)nb, 256, 0, (hipStream_t)stream>>>((const unsigned short*)z, z_pix_stride, z_coff,
                                                                              (unsigned short*)zp, N, H, W, C);
     GS_CHECK_LAUNCH("gs_maxpool2x2_fwd");
+    return GS_OK;
+}
+
+extern "C" int gs_maxpool2x2_fwd_pair(const void* z_hi, const void* z_lo, int z_pix_stride, void* zp_hi, void* zp_lo, int zp_pix_stride,
+                                      int N, int H, int W, int C, int dtype, void* stream) {
+    GS_CHECK_ARG(z_hi && z_lo && zp_hi && N > 0 && H > 1 && W > 1 && C > 0 && C % 8 == 0, "gs_maxpool2x2_fwd_pair: bad arguments");
+    GS_CHECK_ARG(z_pix_stride >= C && z_pix_stride % 8 == 0 && zp_pix_stride >= C && zp_pix_stride % 8 == 0, "gs_maxpool2x2_fwd_pair: bad strides");
+    GS_CHECK_ARG(((uintptr_t)z_hi | (uintptr_t)z_lo | (uintptr_t)zp_hi | (uintptr_t)zp_lo) % 16 == 0, "gs_maxpool2x2_fwd_pair: planes must be 16-byte aligned");
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_maxpool2x2_fwd_pair: bad dtype");
+    const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 8);
+    GS_CHECK_ARG(total < 2147483000LL, "gs_maxpool2x2_fwd_pair: output too large for 32-bit indexing");
+    int64_t nb = cdiv64(total, 256);
+    if (nb > 16384) nb = 16384;
+    if (dtype == GS_F16)
+        maxpool2x2_pair_kernel<GS_F16><<<(int)nb, 256, 0, (hipStream_t)stream>>>((const unsigned short*)z_hi, (const unsigned short*)z_lo, z_pix_stride,
+                                                                                 (unsigned short*)zp_hi, (unsigned short*)zp_lo, zp_pix_stride, N, H, W, C);
+    else
+        maxpool2x2_pair_kernel<GS_BF16><<<(int)nb, 256, 0, (hipStream_t)stream>>>((const unsigned short*)z_hi, (const unsigned short*)z_lo, z_pix_stride,
+                                                                                  (unsigned short*)zp_hi, (unsigned short*)zp_lo, zp_pix_stride, N, H, W, C);
+    GS_CHECK_LAUNCH("gs_maxpool2x2_fwd_pair");
     return GS_OK;
 }
 

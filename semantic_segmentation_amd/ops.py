@@ -855,6 +855,15 @@ def maxpool2x2_fwd(z, zp, N, H, W, C, z_stride=None, z_coff=0):
               dt_code(z), _stream())
 
 
+def maxpool2x2_fwd_pair(z_hi, z_lo, z_stride, zp_hi, zp_lo, zp_stride, N, H, W, C):
+    """MaxPool2d(2) on pairs (folded-BatchNorm inference of the pair forward): z_hi / z_lo two planes with pixel stride z_stride,
+    pooled pair zp_hi / zp_lo (zp_lo may be None) with pixel stride zp_stride; the maximum is taken over the pair VALUES."""
+    _dev(z_hi)
+    if not (z_hi.dtype == z_lo.dtype == zp_hi.dtype):
+        raise TypeError("maxpool2x2_fwd_pair: the planes must share one 16-bit dtype")
+    _lib.call("gs_maxpool2x2_fwd_pair", _p(z_hi), _p(z_lo), z_stride, _p(zp_hi), _p(zp_lo), zp_stride, N, H, W, C, dt_code(z_hi), _stream())
+
+
 def maxpool3d_bwd(z, dzp, dres, dz, NB, D, H, W, C, z_stride=None, z_coff=0, res_stride=0, res_coff=0):
     _lib.call("gs_maxpool3d_bwd", _p(z), C if z_stride is None else z_stride, z_coff, _p(dzp), _p(dres), res_stride,
               res_coff, _p(dz), NB, D, H, W, C, dt_code(z), _stream())

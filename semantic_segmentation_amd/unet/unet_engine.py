@@ -603,6 +603,49 @@ class UNetEngine:
         for wkey, key, pack in fresh + qfresh:
             self._packs[wkey + "|segs"] = (key, pack)
 
+    def _prepack_segs_folded(self, params: Dict[str, torch.Tensor], bufs: Dict[str, torch.Tensor], eff: Dict[str, str]):
+        """Inference of the pair forward: BatchNorm(eval) folded into the segment packs -- w' = w * gamma / sqrt(var + eps) per output
+        channel (fp32, then split into the stage's hi / lo segments, so the folded weight keeps its ~22 bits) and the bias
+        beta - mean * gamma / sqrt(var + eps) that the conv epilogue adds before the ReLU.  Cached until a Parameter or a running
+        statistic changes; every stale pack in ONE launch.  Returns False when a BatchNorm has no running statistics."""
+        items, fresh = [], []
+        for st in STAGES:
+            if st.endswith(".up"):
+                continue
+            blk, idx = st.rsplit(".", 1)
+            prefix = blk if (blk == "inc" or blk.endswith(".conv")) else blk + ".maxpool_conv.1"
+            wkey, bnkey = f"{prefix}.double_conv.{idx}.weight", f"{prefix}.double_conv.{int(idx) + 1}"
+            w = params.get(wkey)
+            if w is None or w.dim() != 4 or w.shape[1] % 8 != 0:
+                continue                                   # (the image-end stem folds nothing: it is one pass already)
+            rm, rv = bufs.get(bnkey + ".running_mean"), bufs.get(bnkey + ".running_var")
+            if rm is None or rv is None:
+                return False
+            gamma, beta = params[bnkey + ".weight"], params[bnkey + ".bias"]
+            cin, cout = w.shape[1], w.shape[0]
+            lo_len = None
+            if (not all(v == "xw" for v in self.plan.values()) and st.endswith(".conv.0") and eff[st[:-len(".conv.0")] + ".up"] == "1"
+                    and not self.net.bilinear):
+                lo_len = cin // 2
+            eps = self.submodule(bnkey).eps
+            key = tuple(_pack_key(t) for t in (w, gamma, beta, rm, rv)) + (eps, eff[st], lo_len)
+            ent = self._packs.get(wkey + "|fsegs")
+            if ent is not None and ent[0] == key:
+                continue
+            with torch.no_grad():
+                sc = gamma.detach().float() * torch.rsqrt(rv.float() + eps)
+                w_eff = (w.detach().float() * sc.view(-1, 1, 1, 1)).contiguous()
+                bias = (beta.detach().float() - rm.float() * sc).contiguous()
+            segs, K, _ = _segs(eff[st], cin, lo_len)
+            pack = torch.empty((9, cout, K), dtype=self.tdt, device=w.device)
+            items.append((w_eff, pack, False, segs))
+            fresh.append((wkey, key, pack, bias))
+        if items:
+            ops.pack_weight_segs(items)
+        for wkey, key, pack, bias in fresh:
+            self._packs[wkey + "|fsegs"] = (key, pack, bias)
+        return True
+
     def _seg_pack(self, wkey: str):
         return self._packs[wkey + "|segs"][1]
 
@@ -663,6 +706,10 @@ class UNetEngine:
         if need_grad or not full:
             self._prepack(params, need_grad)               # the backward's data-gradient packs / the "1" up-convs' packs, one launch
         self._prepack_segs(params, eff)                    # the forward's segment packs, one launch per kind
+        # inference (eval mode, no graph): BatchNorm folded into the segment packs, conv + bias + ReLU write the z pair directly and
+        # the 2x2 pool of a Down block is a read-only pass over the skip pair (as the 16-bit engine does it, unet_engine.forward)
+        fold = (FOLD_BN_INFERENCE and not training and not need_grad and "q" not in eff.values()
+                and self._prepack_segs_folded(params, bufs, eff))
 
         def empty(*shape, dtype=tdt):
             return torch.empty(shape, dtype=dtype, device=dev)
@@ -733,6 +780,19 @@ class UNetEngine:
                 if need_grad:
                     recs.append(rec)
                 return rec
+            if fold and not image and not batch_stats:
+                _, fpack, fbias = self._packs[wkey + "|fsegs"]
+                _, K, wrap = _segs(plan[short], cin, lo_len)
+                if to_head:                                # the head reads a dense pair
+                    zd = empty(2, N, h, w, cout)
+                    ops.conv3x3_segs(inp, fpack, zd[0], zd[1], N, h, w, K, wrap, cin, cout, in_stride=2 * cin, bias=fbias, act=ACT_RELU)
+                    return zd
+                ops.conv3x3_segs(inp, fpack, zbuf, zbuf[..., z_stride // 2:], N, h, w, K, wrap, cin, cout, in_stride=2 * cin,
+                                 out_stride=z_stride, out_coff=0, bias=fbias, act=ACT_RELU)
+                if zp is not None:
+                    ops.maxpool2x2_fwd_pair(zbuf, zbuf[..., z_stride // 2:], z_stride, zp, zp[..., zp.shape[3] // 2:], zp.shape[3],
+                                            N, h, w, cout)
+                return None
             y_hi, y_lo = empty(N, h, w, cout), empty(N, h, w, cout)
             if image:
                 ops.conv_smallcin_fwd_split(inp, wparam.detach().contiguous(), y_hi, y_lo, partials, 3, 1)
@@ -854,6 +914,11 @@ class UNetEngine:
                 nxt_lo = True if bilinear else reads_lo(f"up{j + 1}.up")      # (the pair up-sampling interpolates both planes)
                 stage(prefix + ".conv", 3, zmid, cmid, cout3, H2, W2, zout, 2 * cout3, nxt_lo)
                 inp = zout
+            elif fold:                             # folded inference: the last stage leaves a dense z pair for the plain pair head
+                zl = stage(prefix + ".conv", 3, zmid, cmid, cout3, H2, W2, None, 0, False, to_head=True)
+                zl_hi, zl_lo = zl[0], zl[1]
+                last_rec = None
+                z_last = zl_hi
             elif not full and FUSED_HEAD_FWD and cout3 == 64 and net.n_classes <= 4:
                 # last stage: its activation has one reader, the head, which applies BatchNorm + ReLU on its own load path
                 last_rec, y_lo_last = stage(prefix + ".conv", 3, zmid, cmid, cout3, H2, W2, None, 0, False, to_head=True)

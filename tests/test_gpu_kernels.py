@@ -1501,3 +1501,25 @@ def test_q8_from_hi_and_stem_q8_planes():
     assert torch.equal(ch[..., 32:].reshape(2, 32, 40, 64).view(E4).float(), (hi * 0.25).clamp(-448, 448).to(E4).float())
     got_lo = ch[..., :32].reshape(2, 32, 40, 64).view(E4).float() / 512.0
     assert float((got_lo - lo).abs().max()) <= float(lo.abs().max()) / 16 + 2.0 ** -18          # e4m3 of (value - hi) * 2^9
+
+
+@pytest.mark.parametrize("N,H,W,C,coff", [(2, 16, 24, 64, 0), (1, 17, 31, 128, 0), (3, 8, 8, 8, 0)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_maxpool2x2_pair_matches_its_definition(N, H, W, C, coff, dtype):
+    """gs_maxpool2x2_fwd_pair (nn.MaxPool2d(2) of `Down`, unet_parts.py:34, on hi/lo pairs): the pooled pair is the maximum of the
+    window's pair VALUES hi + lo, split again -- bit-exact against that definition in torch; odd sizes drop the last row / column."""
+    from semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(5)
+    v = torch.randn(N, H, W, C, generator=g)
+    hi = v.to(dtype)
+    lo = (v - hi.float()).to(dtype)
+    buf = torch.empty(N, H, W, 2 * C + 16, dtype=dtype)
+    buf[..., :C], buf[..., C + 8:2 * C + 8] = hi, lo                       # two planes of one buffer, pixel stride 2C + 16
+    buf = buf.cuda()
+    zp = torch.zeros(N, H // 2, W // 2, 2 * C, dtype=dtype, device="cuda")
+    ops.maxpool2x2_fwd_pair(buf, buf[..., C + 8:], 2 * C + 16, zp, zp[..., C:], 2 * C, N, H, W, C)
+    val = (hi.float() + lo.float())[:, :H // 2 * 2, :W // 2 * 2]
+    m = val.reshape(N, H // 2, 2, W // 2, 2, C).amax(dim=(2, 4))
+    mh = m.to(dtype)
+    ml = (m - mh.float()).to(dtype)
+    assert torch.equal(zp[..., :C].cpu(), mh) and torch.equal(zp[..., C:].cpu(), ml)

@@ -295,6 +295,49 @@ def test_full_size_properties_bs32_256():
     assert float((got - ref_mean).abs().max()) < 2e-5 + 2e-3 * float(ref_mean.abs().max())
 
 
+@pytest.mark.parametrize("n_classes,bilinear,H,W", [(2, False, 64, 64), (1, True, 48, 80), (1, False, 33, 47), (2, False, 256, 256)])
+def test_pair_inference_folded_bn_matches_two_pass_and_oracle(n_classes, bilinear, H, W):
+    """The same for what `UNet()` builds (the pair forward): eval-mode forward with BatchNorm folded into the SEGMENT packs (conv +
+    bias + ReLU leave the z pair, `gs_maxpool2x2_fwd_pair` pools it) against the two-pass pair forward and against the oracle --
+    the north star's 1e-3 on logits holds for inference too (measured: folded vs two-pass <= 2.3e-6, vs oracle <= 3.5e-6: running
+    statistics two steps away from (0, 1) squash the activations)."""
+    from semantic_segmentation_amd.unet import unet_engine
+    net, sd = build_net(n_classes, seed=13, bilinear=bilinear, precise=None)
+    x, mask = oracle.synthetic_batch(3, max(H, W), seed=9)
+    x = x[:, :, :H, :W].contiguous().cuda()
+    net.train()
+    with torch.no_grad():
+        for _ in range(2):
+            net(x)                                       # move the running statistics away from (0, 1)
+    net.eval()
+    assert unet_engine.FOLD_BN_INFERENCE
+    with torch.no_grad():
+        folded = net(x)
+    assert any(k.endswith("|fsegs") for k in net.engine._packs), "the folded segment packs were not built"
+    unet_engine.FOLD_BN_INFERENCE = False
+    try:
+        with torch.no_grad():
+            two_pass = net(x)
+    finally:
+        unet_engine.FOLD_BN_INFERENCE = True
+    ref = oracle.unet_forward({k: v.detach().cpu() for k, v in net.state_dict().items()}, x.cpu(), False, {}, bilinear)
+    scale = max(1.0, float(ref.abs().max()))
+    REPORT[f"pair_folded_{n_classes}_{int(bilinear)}_{H}x{W}"] = {
+        "folded_vs_two_pass_max": float((folded - two_pass).abs().max()), "folded_vs_oracle_max": float((folded.cpu() - ref).abs().max()),
+        "two_pass_vs_oracle_max": float((two_pass.cpu() - ref).abs().max()), "logit_scale": scale}
+    assert float((folded - two_pass).abs().max()) < 4e-6 * scale
+    assert float((folded.cpu() - ref).abs().max()) < 6e-6 * scale
+    # another training step changes the running statistics: the folded packs must follow
+    net.train()
+    with torch.no_grad():
+        net(x)
+    net.eval()
+    with torch.no_grad():
+        again = net(x)
+    ref2 = oracle.unet_forward({k: v.detach().cpu() for k, v in net.state_dict().items()}, x.cpu(), False, {}, bilinear)
+    assert float((again.cpu() - ref2).abs().max()) < 1e-5 * max(1.0, float(ref2.abs().max()))
+
+
 @pytest.mark.parametrize("n_classes,bilinear,H,W", [(2, False, 64, 64), (1, True, 48, 80), (1, False, 33, 47)])
 def test_inference_folded_bn_matches_two_pass(n_classes, bilinear, H, W):
     """eval-mode forward with BatchNorm folded into the convs (one kernel per conv block, stand-alone
