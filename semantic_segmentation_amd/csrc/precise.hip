@@ -229,6 +229,116 @@ __global__ __launch_bounds__(256) void smallcin_split_kernel(const SCPArgs a) {
     }
 }
 
+// Cout == 32 (the first conv of UNet3D, GenSeg-3D/UNet3D/unet3d.py:28, run as a 2-D conv over three depth slices): ONE THREAD PER OUTPUT
+// PIXEL holding all 32 channels -- the [tap][32] weights come from LDS at wave-uniform addresses (8 broadcast ds_read_b128 + 32 FMAs per
+// tap) and the image value and its bounds test are formed once per tap, not once per (tap, 8-channel chunk) as in the generic
+// kernel above (334 us for the 128^3 volume, VALU-bound on index arithmetic).  The wave's 64 pixel rows (64 B of hi, 64 B of lo
+// each) are assembled in LDS (16-byte slot s of row r at s ^ ((r >> 2) & 3): conflict-free both ways) and leave as 1 KB stores of
+// complete lines.  BatchNorm partial sums through a padded LDS transpose, one row per SCP_TILE pixels as above.
+constexpr int SC32_PAD = 33, SC32_MAX_T = 64;
+template <int DT>
+__global__ __launch_bounds__(256) void smallcin_split32_kernel(const SCPArgs a) {
+    __shared__ float wl[SC32_MAX_T * 32];                       // [tap][32]
+    __shared__ __attribute__((aligned(16))) float stage[256 * SC32_PAD];     // output staging (4 waves x 8 KB), then the statistics transpose
+    const int T = a.Cin * a.k * a.k;
+    for (int i = threadIdx.x; i < T * 32; i += 256) {
+        const int co = i & 31, tap = i >> 5;
+        wl[i] = a.w[co * T + tap];
+    }
+    __syncthreads();
+    const int M = a.N * a.H * a.W;                               // host guarantees < 2^31
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned char* const wst = reinterpret_cast<unsigned char*>(stage) + wave * 8192;
+    for (int sub = 0; sub < SCP_TILE / 256; ++sub) {
+        const int m = blockIdx.x * SCP_TILE + sub * 256 + threadIdx.x;
+        const bool live = m < M;
+        const int mm = live ? m : M - 1;
+        const int ox = mm % a.W;
+        const int r = mm / a.W;
+        const int oy = r % a.H;
+        const int n = r / a.H;
+        float acc[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+        const float* xn = a.x + (int64_t)n * a.Cin * a.H * a.W;
+        int tap = 0;
+        for (int ci = 0; ci < a.Cin; ++ci)
+            for (int ky = 0; ky < a.k; ++ky) {
+                const int iy = oy - a.pad + ky;
+                for (int kx = 0; kx < a.k; ++kx, ++tap) {
+                    const int ix = ox - a.pad + kx;
+                    float xv = 0.f;
+                    if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) xv = xn[(ci * a.H + iy) * a.W + ix];
+                    const float4* wp = reinterpret_cast<const float4*>(wl + tap * 32);
+#pragma unroll
+                    for (int c4 = 0; c4 < 8; ++c4) {
+                        const float4 w4 = wp[c4];
+                        acc[4 * c4 + 0] += xv * w4.x;
+                        acc[4 * c4 + 1] += xv * w4.y;
+                        acc[4 * c4 + 2] += xv * w4.z;
+                        acc[4 * c4 + 3] += xv * w4.w;
+                    }
+                }
+            }
+        // the pair rows of the wave's 64 pixels -> LDS -> complete lines
+        {
+            const int sw = (lane >> 2) & 3;
+#pragma unroll
+            for (int c8 = 0; c8 < 4; ++c8) {
+                uint4 hi, lo;
+                float v8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v8[i] = acc[c8 * 8 + i];
+                split8<DT>(v8, hi, lo);
+                *reinterpret_cast<uint4*>(wst + lane * 64 + ((c8 ^ sw) << 4)) = hi;
+                *reinterpret_cast<uint4*>(wst + 4096 + lane * 64 + ((c8 ^ sw) << 4)) = lo;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int m_w = m - lane;                                   // the wave's first pixel
+            unsigned char* gh = reinterpret_cast<unsigned char*>(a.y_hi) + (int64_t)m_w * 64;
+            unsigned char* gl = reinterpret_cast<unsigned char*>(a.y_lo) + (int64_t)m_w * 64;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 16 + (lane >> 2);
+                const int off = row * 64 + (((lane & 3) ^ ((row >> 2) & 3)) << 4);
+                const uint4 vh = *reinterpret_cast<const uint4*>(wst + off);
+                const uint4 vl = *reinterpret_cast<const uint4*>(wst + 4096 + off);
+                if (m_w + row < M) {
+                    *reinterpret_cast<uint4*>(gh + it * 1024 + lane * 16) = vh;
+                    *reinterpret_cast<uint4*>(gl + it * 1024 + lane * 16) = vl;
+                }
+            }
+        }
+        if (a.bnp) {
+            // [256 pixels][33] transpose: lane (c, q) sums 32 pixels of channel c, then the eight pixel groups are added in order
+            const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
+            __syncthreads();                                            // every wave has left its output staging
+#pragma unroll
+            for (int i = 0; i < 32; ++i) stage[threadIdx.x * SC32_PAD + i] = live ? acc[i] : 0.f;
+            __syncthreads();
+            float t1 = 0.f, t2 = 0.f;
+            for (int i = 0; i < 32; ++i) {
+                const float v = stage[(q * 32 + i) * SC32_PAD + c];
+                t1 += v; t2 += v * v;
+            }
+            __syncthreads();
+            stage[q * 32 + c] = t1;
+            stage[256 + q * 32 + c] = t2;
+            __syncthreads();
+            if (threadIdx.x < 64) {
+                const int cc = threadIdx.x & 31, st = threadIdx.x >> 5;
+                const float* sp = stage + st * 256 + cc;
+                float t = 0.f;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) t += sp[g * 32];
+                float* dst = a.bnp + (int64_t)blockIdx.x * 64 + st * 32 + cc;
+                *dst = sub == 0 ? t : *dst + t;                          // same thread, same address on every pass
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---- BatchNorm apply + activation (+ 2x2 max-pool) on pairs ---------------------------------------------------------
 struct ApplySArgs {
     const unsigned short* y_hi; const unsigned short* y_lo;
@@ -543,6 +653,13 @@ extern "C" int gs_conv_smallcin_fwd_split(const float* x, const float* w, void* 
     SCPArgs a{x, w, (unsigned short*)y_hi, (unsigned short*)y_lo, bn_partials, N, Cin, H, W, Cout, k, pad};
     const int nb = (int)cdiv64((int64_t)N * H * W, SCP_TILE);
     hipStream_t s = (hipStream_t)stream;
+    if (Cout == 32 && Cin * k * k <= SC32_MAX_T && (int64_t)N * H * W < 2147483647LL && (((uintptr_t)y_hi | (uintptr_t)y_lo) & 15) == 0 &&
+        getenv("GSSEG_SC32_OFF") == nullptr) {       // one thread per pixel, complete-line stores (the UNet3D stem)
+        if (dtype == GS_F16) smallcin_split32_kernel<GS_F16><<<nb, 256, 0, s>>>(a);
+        else smallcin_split32_kernel<GS_BF16><<<nb, 256, 0, s>>>(a);
+        GS_CHECK_LAUNCH("gs_conv_smallcin_fwd_split");
+        return GS_OK;
+    }
     if (dtype == GS_F16) smallcin_split_kernel<GS_F16><<<nb, 256, 0, s>>>(a);
     else smallcin_split_kernel<GS_BF16><<<nb, 256, 0, s>>>(a);
     GS_CHECK_LAUNCH("gs_conv_smallcin_fwd_split");
