@@ -1039,3 +1039,58 @@ def test_q_plan_fp8_correction_segment_vs_golden(golden_dir, name):
     for k, p in net.named_parameters():
         ref = z["gsum/" + k]
         assert abs(grad_summary(p.grad.cpu())[1] - ref[1]) / max(ref[1], 1e-12) < 1.5e-2, k
+
+
+_CURVE_ORACLE = {}
+
+
+@pytest.mark.parametrize("mode", ["default", "fast"])
+def test_training_curve_tracks_the_fp32_oracle(mode):
+    """What the 16-bit backward (and, in the fast mode, the 16-bit forward) does to a TRAINING CURVE: 24 RMSprop
+    steps (the script's optimiser and learning rate: train_end2end_jsrt.py:69-70, lr 1e-5, momentum 0.9, weight decay 1e-8) of
+    UNet(1,2) on three alternating 64x64 batches of 4, this engine against the fp32 CPU oracle stepping the same initial weights
+    with the same optimiser, while the loss falls from 0.98 to 0.18.  The per-step losses must track (bounds = 1.5x the measured
+    maximum relative deviation, see the assert)."""
+    from semantic_segmentation_amd.losses import seg_loss
+    steps, lr = 24, 1e-5
+    net, sd = build_net(2, seed=23, precise=None if mode == "default" else False)
+    net.train()
+    batches = [oracle.synthetic_batch(4, 64, seed=100 + i) for i in range(3)]
+    opt = torch.optim.RMSprop(net.parameters(), lr=lr, weight_decay=1e-8, momentum=0.9, foreach=True)
+    got = []
+    for k in range(steps):
+        x, m = batches[k % 3]
+        opt.zero_grad(set_to_none=True)
+        loss = seg_loss(net(x.cuda()), m.cuda())
+        loss.backward()
+        opt.step()
+        got.append(float(loss.item()))
+    # the oracle: the same loop on the CPU in fp32 (once for both modes: ~20 s)
+    if "ref" not in _CURVE_ORACLE:
+        ref_sd = {k: v.clone() for k, v in sd.items()}
+        leaves = {k: v.clone().requires_grad_(True) for k, v in ref_sd.items() if v.is_floating_point() and "running" not in k}
+        ropt = torch.optim.RMSprop(list(leaves.values()), lr=lr, weight_decay=1e-8, momentum=0.9, foreach=True)
+        ref = []
+        for k in range(steps):
+            x, m = batches[k % 3]
+            cur = dict(ref_sd)
+            cur.update({kk: v.detach() for kk, v in leaves.items()})
+            _, loss, grads, updates = oracle.unet_step(cur, x, m, True)
+            for kk, v in leaves.items():
+                v.grad = grads[kk]
+            ropt.step()
+            ref_sd.update(updates)
+            ref.append(float(loss))
+        _CURVE_ORACLE["ref"], _CURVE_ORACLE["leaves"] = ref, leaves
+    ref, leaves = _CURVE_ORACLE["ref"], _CURVE_ORACLE["leaves"]
+    dev_ = max(abs(a - b) / abs(b) for a, b in zip(got, ref))
+    wrel = max(float((p.detach().cpu() - leaves[k].detach()).norm() / (leaves[k].detach().norm() + 1e-12))
+               for k, p in net.named_parameters() if p.dim() == 4)
+    REPORT["training_curve_" + mode] = {"loss_first": ref[0], "loss_last": ref[-1], "loss_last_engine": got[-1],
+                                        "max_rel_loss_deviation": dev_, "worst_conv_weight_rel_l2": wrel}
+    _dump()
+    assert ref[-1] < 0.3 * ref[0], "the oracle's loss did not move: the test would not see a broken backward"
+    # measured: default 1.9e-2 (final loss 0.1827 against 0.1807), fast 3.0e-2 (0.1843); final conv weights within 16 % / 18 % rel-L2 (RMSprop
+    # turns every gradient component, however small, into a step of ~lr: two fp32 runs with different summation orders drift apart too)
+    assert dev_ < (2.9e-2 if mode == "default" else 4.5e-2), REPORT["training_curve_" + mode]
+    assert abs(got[-1] - ref[-1]) < 0.03 * ref[-1]
