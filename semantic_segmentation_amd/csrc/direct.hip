@@ -207,10 +207,10 @@ __device__ __forceinline__ int sc_opaque(int x) { asm volatile("" : "+v"(x)); re
 // MODE 1: the partials ALONE -- they depend on the image and the weights only (tap sums + Gram matrix), y is not formed.
 // MODE 2: y * bn_scale + bn_shift, activation, stored: with MODE 1 in front (and gs_bn_finalize between) the stem's
 //         convolution output is never written -- train-mode BatchNorm without the 2 x 268 MB round trip of y at batch 32.
-extern __shared__ uint4 sc_line_stage[];            // MODE 2 with a.rows256: [4 waves][64 rows][256 B]
 template <int DT, int MODE>
 __global__ __launch_bounds__(256) void smallcin_fwd64_line_kernel(const SCArgs a) {
     constexpr int TT = 9, NG = TT * (TT + 1) / 2;
+    __shared__ uint4 sc_line_stage[MODE == 2 ? 4 * 64 * 16 : 1];      // MODE 2 with a.rows256: [4 waves][64 rows][256 B]
     __shared__ float wl[TT * 64];                   // [tap][co]
     __shared__ float part[4][TT + NG];              // per-wave tap sums and Gram entries
     __shared__ float bl[64];                        // bias (zeros without one): read per use -- as registers the 64 values spill
@@ -1485,19 +1485,11 @@ static int stem_fwd_bn_pair_impl(const float* x, const float* w, const float* bn
     SCArgs a{x, w, nullptr, (unsigned short*)z_hi, nullptr, N, 1, H, W, 64, H, W, 3, 1, 1, act};
     a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.y_lo = (unsigned short*)z_lo; a.ys = z_pix_stride; a.lo_q8 = lo_q8;
     const int nb = gs_conv_smallcin_mtiles(N, H, W);
+    const bool rows256_off = getenv("GSSEG_STEM_ROWS256_OFF") != nullptr;   // diagnostics: the lane-by-lane stores (read per call: tools/experiments/stem_pair_time.py switches in one process)
     a.rows256 = z_lo != nullptr && z_pix_stride == 128 && (unsigned short*)z_lo == (unsigned short*)z_hi + 64 &&
-                ((uintptr_t)z_hi & 15) == 0 && getenv("GSSEG_STEM_ROWS256_OFF") == nullptr;
-    const size_t lds = a.rows256 ? 4 * 64 * 256 : 0;
-    if (a.rows256) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)smallcin_fwd64_line_kernel<GS_F16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 256);
-            (void)hipFuncSetAttribute((const void*)smallcin_fwd64_line_kernel<GS_BF16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 256);
-            attr_done = true;
-        }
-    }
-    if (dtype == GS_F16) smallcin_fwd64_line_kernel<GS_F16, 2><<<nb, 256, lds, (hipStream_t)stream>>>(a);
-    else smallcin_fwd64_line_kernel<GS_BF16, 2><<<nb, 256, lds, (hipStream_t)stream>>>(a);
+                ((uintptr_t)z_hi & 15) == 0 && !rows256_off;
+    if (dtype == GS_F16) smallcin_fwd64_line_kernel<GS_F16, 2><<<nb, 256, 0, (hipStream_t)stream>>>(a);
+    else smallcin_fwd64_line_kernel<GS_BF16, 2><<<nb, 256, 0, (hipStream_t)stream>>>(a);
     GS_CHECK_LAUNCH("gs_stem_fwd_bn_pair");
     return GS_OK;
 }

@@ -654,7 +654,7 @@ extern "C" int gs_conv_smallcin_fwd_split(const float* x, const float* w, void* 
     const int nb = (int)cdiv64((int64_t)N * H * W, SCP_TILE);
     hipStream_t s = (hipStream_t)stream;
     if (Cout == 32 && Cin * k * k <= SC32_MAX_T && (int64_t)N * H * W < 2147483647LL && (((uintptr_t)y_hi | (uintptr_t)y_lo) & 15) == 0 &&
-        getenv("GSSEG_SC32_OFF") == nullptr) {       // one thread per pixel, complete-line stores (the UNet3D stem)
+        getenv("GSSEG_SC32_OFF") == nullptr) {       // (getenv per call: the kernel test switches forms in one process)       // one thread per pixel, complete-line stores (the UNet3D stem)
         if (dtype == GS_F16) smallcin_split32_kernel<GS_F16><<<nb, 256, 0, s>>>(a);
         else smallcin_split32_kernel<GS_BF16><<<nb, 256, 0, s>>>(a);
         GS_CHECK_LAUNCH("gs_conv_smallcin_fwd_split");
