@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 47
+#define GS_ABI_VERSION 48
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -384,6 +384,17 @@ int gs_isic_fake_trans(const float* x, float* out, void* ws, int N, int C, int H
  * engine this layer uses 1 of 64 N columns.  Needs (12*12*(Cin+8) + 64*Cout*Cin)*2 bytes <= 64 KB of LDS. */
 int gs_upconv8_image_fwd(const void* x, int in_pix_stride, int in_coff, const void* pack_fwd, int cpad, const float* bias,
                          float* out, void* u, int N, int h, int w, int Cin, int Cout, int act, int dtype, void* stream);
+/* Weight gradient of the same layer when it has ONE output channel (the JSRT generator, `output_nc = 1`): autograd of the merged
+ * `MixedOp_upconv` transposed conv of the outermost `UnetSkipConnectionBlock` (models_pix2pix/networks.py:486-511,588-593) w.r.t. its
+ * merged 8x8 kernel, written where gs_upconv_split_wgrad reads it: dwm[4 classes][16 taps][1][Cin] fp32 (un-scaled sums).
+ * x = the layer's input [N,h,w,*] (16-bit, pixel stride x_pix_stride, Cin channels from channel 0), du = the gradient w.r.t. the
+ * layer's pre-activation output [N,2h,2w,*] (16-bit, channel 0, pixel stride du_pix_stride).  Deterministic: per-block partials in
+ * ws (gs_upconv8_image_wgrad_ws_floats floats, no initialisation needed) summed in block order.  gs_upconv8_image_wgrad_ok: Cout == 1,
+ * Cin a multiple of 128 -- otherwise the caller takes gs_conv_wgrad_slabs_batch. */
+int gs_upconv8_image_wgrad_ok(int Cin, int Cout);
+int64_t gs_upconv8_image_wgrad_ws_floats(int N, int h, int w, int Cin);
+int gs_upconv8_image_wgrad(const void* x, int x_pix_stride, const void* du, int du_pix_stride, float* ws, float* dwm, int N, int h, int w,
+                           int Cin, int dtype, void* stream);
 
 /* ---- Pix2Pix mixed transposed convolution (networks.py:486-511, operations.py:14-39) ------------------
  * The softmax-weighted sum of ConvTranspose2d k4p1 / k6p2 / k8p3 (stride 2) equals ONE k8/s2/p3 transposed

@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 GS_F16, GS_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH = 0, 1, 2, 3
 GS_MAX_TAPS = 64
-ABI_VERSION = 47
+ABI_VERSION = 48
 
 
 class GsConvGeom(ctypes.Structure):
@@ -137,6 +137,9 @@ PROTOTYPES = {
                                    c_float, c_float, c_void_p]),
     "gs_fake_postprocess": (c_int, [_F, _F, _F, _F, c_int, c_int64, c_void_p]),
     "gs_upconv8_image_fwd": (c_int, [_P, c_int, c_int, _P, c_int, _F, _F, _P] + [c_int] * 7 + [c_void_p]),
+    "gs_upconv8_image_wgrad_ok": (c_int, [c_int, c_int]),
+    "gs_upconv8_image_wgrad_ws_floats": (c_int64, [c_int] * 4),
+    "gs_upconv8_image_wgrad": (c_int, [_P, c_int, _P, c_int, _F, _F] + [c_int] * 5 + [c_void_p]),
     "gs_upconv_split_wgrad": (c_int, [_F, _F, _F, _F, _F, c_float, _F, _F, _F, _F, c_int, c_int, c_void_p]),
     "gs_upconv_split_wgrad_det": (c_int, [_F, _F, _F, _F, _F, c_float, _F, _F, _F, _F, _F, c_int, c_int, c_void_p]),
     "gs_upconv_split_wgrad_ws_floats": (c_int64, [c_int, c_int]),

@@ -8,6 +8,7 @@ three architecture dot products (gs_upconv_split_wgrad); its data gradient is a 
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict
 
 import torch
@@ -17,6 +18,10 @@ from .._lib import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_TANH
 from .pix2pix_engine import cached_geom, g_tapw_identity
 
 TAPS64 = tuple((ky - 3, kx - 3) for ky in range(8) for kx in range(8))
+
+
+# the one-channel image layer's weight gradient on its direct kernel (GSSEG_IMAGE_WGRAD=0: the generic sub-pixel-class engine)
+IMAGE_WGRAD_DIRECT = os.environ.get("GSSEG_IMAGE_WGRAD", "1") != "0"
 
 
 def generator_backward(engine, ctx, arch, dout, need_dx):
@@ -71,21 +76,30 @@ def generator_backward(engine, ctx, arch, dout, need_dx):
         cin_t, cout_t, li, sm = info["cin"], info["cout"], info["li"], info["sm"]
         h, w = hs[d + 1], ws[d + 1]
         w4, w6, w8 = (cell._ops._ops[j].op.weight for j in range(3))
-        # weight gradient of the merged kernel, one sub-pixel class at a time
-        geoms = []
-        for cls in range(4):
-            geoms.append(cached_geom(ops.geom_convT_class, N, h, w, cin_t, cpad, 8, 3, cls >> 1, cls & 1, identity_slots=True))
-        # the four classes in ONE launch.  Few-pixel layers do not split K: every element is written exactly once, straight
-        # into dwm; otherwise the K parts go to slabs and one ordered sum over all classes follows (deterministic, no atomics)
-        nparts = ops.conv_wgrad_parts(geoms[0])
-        per = 4 * 16 * cpad * cin_t
-        wsl = empty(nparts * per, dtype=torch.float32) if nparts > 1 else None
-        # K-split layers: the split pass below sums the slabs itself (no separate ordered-sum pass over the merged gradient)
-        direct = nparts > 1 and cpad == cout_t and ops.upconv_split_wgrad_parts_ok(cin_t, cout_t)
-        dwm = None if direct else torch.empty((4, 16, cpad, cin_t), dtype=torch.float32, device=dev)
-        ops.conv_wgrad_det_batch(geoms, R[d + 1], du, wsl, dwm, reduce=not direct)
-        if not direct and cpad != cout_t:
-            dwm = dwm[:, :, :cout_t, :].contiguous()
+        xin = R[d + 1]
+        if (d == 0 and IMAGE_WGRAD_DIRECT and ops.upconv8_image_wgrad_ok(cin_t, cout_t) and xin.is_contiguous()
+                and xin.shape[3] == cin_t):
+            # the one-channel image layer: a GEMM with ONE output column -- the direct kernel (csrc/pix2pix.hip) instead of the
+            # engine's 8-cout-padded sub-pixel classes (1.7 ms at batch 32, 0.13 ms at batch 2)
+            nparts, wsl, direct = 1, None, False
+            dwm = torch.empty((4, 16, 1, cin_t), dtype=torch.float32, device=dev)
+            ops.upconv8_image_wgrad(xin, du, dwm, N, h, w, cin_t)
+        else:
+            # weight gradient of the merged kernel, one sub-pixel class at a time
+            geoms = []
+            for cls in range(4):
+                geoms.append(cached_geom(ops.geom_convT_class, N, h, w, cin_t, cpad, 8, 3, cls >> 1, cls & 1, identity_slots=True))
+            # the four classes in ONE launch.  Few-pixel layers do not split K: every element is written exactly once, straight
+            # into dwm; otherwise the K parts go to slabs and one ordered sum over all classes follows (deterministic, no atomics)
+            nparts = ops.conv_wgrad_parts(geoms[0])
+            per = 4 * 16 * cpad * cin_t
+            wsl = empty(nparts * per, dtype=torch.float32) if nparts > 1 else None
+            # K-split layers: the split pass below sums the slabs itself (no separate ordered-sum pass over the merged gradient)
+            direct = nparts > 1 and cpad == cout_t and ops.upconv_split_wgrad_parts_ok(cin_t, cout_t)
+            dwm = None if direct else torch.empty((4, 16, cpad, cin_t), dtype=torch.float32, device=dev)
+            ops.conv_wgrad_det_batch(geoms, xin, du, wsl, dwm, reduce=not direct)
+            if not direct and cpad != cout_t:
+                dwm = dwm[:, :, :cout_t, :].contiguous()
         dw4 = torch.empty_like(w4, memory_format=torch.contiguous_format)
         dw6 = torch.empty_like(w6, memory_format=torch.contiguous_format)
         dw8 = torch.empty_like(w8, memory_format=torch.contiguous_format)

@@ -1015,6 +1015,23 @@ def upconv8_image_fwd(x, pack_fwd, bias, out, u, N, h, w, Cin, Cout, act, in_str
               _p(out), _p(u), N, h, w, Cin, Cout, act, dt_code(x), _stream())
 
 
+def upconv8_image_wgrad_ok(Cin, Cout) -> bool:
+    return bool(_lib.load().gs_upconv8_image_wgrad_ok(int(Cin), int(Cout)))
+
+
+def upconv8_image_wgrad(x, du, dwm, N, h, w, Cin):
+    """Weight gradient of the merged 8x8/s2/p3 transposed conv to ONE image channel: x [N,h,w,>=Cin] 16-bit (channels from 0), du
+    [N,2h,2w,cpad] 16-bit (channel 0), dwm fp32 [4][16][1][Cin] (un-scaled sums, the layout upconv_split_wgrad reads)."""
+    _dev(x)
+    _f32(dwm, "dwm")
+    if x.dtype != du.dtype or x.dim() != 4 or du.dim() != 4 or tuple(x.shape[:3]) != (N, h, w) or tuple(du.shape[:3]) != (N, 2 * h, 2 * w):
+        raise ValueError("upconv8_image_wgrad: x [N,h,w,C] and du [N,2h,2w,cpad] of one 16-bit dtype")
+    if not (x.is_contiguous() and du.is_contiguous()) or dwm.numel() != 64 * Cin or not dwm.is_contiguous():
+        raise ValueError("upconv8_image_wgrad: dense x / du, dwm [4][16][1][Cin]")
+    ws = torch.empty(int(_lib.load().gs_upconv8_image_wgrad_ws_floats(N, h, w, Cin)), dtype=torch.float32, device=x.device)
+    _lib.call("gs_upconv8_image_wgrad", _p(x), x.shape[3], _p(du), du.shape[3], _p(ws), _p(dwm), N, h, w, Cin, dt_code(x), _stream())
+
+
 def upconv_split_wgrad_parts_ok(Cin, Cout) -> bool:
     return bool(_lib.load().gs_upconv_split_wgrad_parts_ok(int(Cin), int(Cout)))
 

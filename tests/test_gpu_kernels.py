@@ -1560,3 +1560,34 @@ def test_smallcin_split_cout32_thread_per_pixel_form(N, Cin, H, W, dtype):
     s_ref = torch.stack([ref.double().sum((0, 1, 2)), (ref.double() ** 2).sum((0, 1, 2))])
     for k in (True, False):
         assert float((out[k][2] - s_ref).abs().max()) < 1e-4 * float(s_ref.abs().max())
+
+
+@pytest.mark.parametrize("N,h,w,Cin", [(2, 16, 24, 128), (1, 9, 70, 128), (3, 8, 8, 256)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_upconv8_image_wgrad_matches_autograd(N, h, w, Cin, dtype):
+    """gs_upconv8_image_wgrad: weight gradient of the merged 8x8 / stride 2 / pad 3 transposed conv to ONE image channel (the
+    outermost up path of the JSRT generator, networks.py:486-511,588-593) against torch autograd of F.conv_transpose2d on the same
+    16-bit-rounded operands, in the [4 classes][16 taps][1][Cin] layout gs_upconv_split_wgrad reads; deterministic (two runs equal)."""
+    from semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, h, w, Cin, generator=g).to(dtype)
+    du = torch.zeros(N, 2 * h, 2 * w, 8, dtype=dtype)
+    du[..., 0] = torch.randn(N, 2 * h, 2 * w, generator=g).to(dtype)
+    du[..., 1:] = 7.0                                                   # the padding channels must not be read
+    assert ops.upconv8_image_wgrad_ok(Cin, 1) and not ops.upconv8_image_wgrad_ok(Cin, 3) and not ops.upconv8_image_wgrad_ok(64, 1)
+    outs = []
+    for _ in range(2):
+        dwm = torch.full((4, 16, 1, Cin), float("nan"), dtype=torch.float32, device="cuda")
+        ops.upconv8_image_wgrad(x.cuda(), du.cuda(), dwm, N, h, w, Cin)
+        outs.append(dwm.cpu())
+    assert torch.equal(outs[0], outs[1])
+    wm = torch.zeros(Cin, 1, 8, 8, dtype=torch.float64, requires_grad=True)
+    y = F.conv_transpose2d(x.permute(0, 3, 1, 2).double(), wm, stride=2, padding=3)
+    (y * du[..., 0].double().unsqueeze(1)).sum().backward()
+    ref = torch.empty(4, 16, 1, Cin, dtype=torch.float64)
+    for ky in range(8):
+        for kx in range(8):
+            cls, t16 = 2 * (1 - ky % 2) + (1 - kx % 2), 4 * (ky // 2) + kx // 2
+            ref[cls, t16, 0] = wm.grad[:, 0, ky, kx]
+    err = float((outs[0].double() - ref).abs().max())
+    assert err < 2e-4 * float(ref.abs().max()) + 1e-4, err
