@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 48
+#define GS_ABI_VERSION 49
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -541,6 +541,13 @@ int gs_conv3d_3x3x3_precise(const void* x, const void* w, void* y_hi, void* y_lo
                             int NB, int D, int H, int W, int K, int in_pix_stride, int in_coff, int in_wrap, int Cout,
                             int out_pix_stride, int out_coff, const int32_t* tap_dz, const int32_t* tap_dy,
                             const int32_t* tap_dx, int act, int dtype, void* stream);
+/* gs_conv3d_3x3x3_precise with the wrapped part of K continuing at input channel in_wrap_to (a multiple of 64; in_wrap_to + K - in_wrap <=
+ * in_wrap) instead of channel 0: the decoder-entry convs of UNet3D (unet3d.py:80-81, input torch.cat((up, residual), 1) stored as
+ * [up_h res_h | res_l]) run their w_lo segment over the residual channels only. */
+int gs_conv3d_3x3x3_precise_to(const void* x, const void* w, void* y_hi, void* y_lo, const float* bias, float* bn_partials, int NB, int D,
+                               int H, int W, int K, int in_pix_stride, int in_coff, int in_wrap, int in_wrap_to, int Cout, int out_pix_stride,
+                               int out_coff, const int32_t* tap_dz, const int32_t* tap_dy, const int32_t* tap_dx, int act, int dtype,
+                               void* stream);
 int gs_upconv2x2_fwd_precise(const void* x, const void* w, const float* bias, void* y_hi, void* y_lo, int N, int IH, int IW,
                              int K, int in_pix_stride, int in_coff, int in_wrap, int Cout, int OH, int OW,
                              int out_pix_stride, int out_coff, int ooy, int oox, int dtype, void* stream);

@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 GS_F16, GS_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH = 0, 1, 2, 3
 GS_MAX_TAPS = 64
-ABI_VERSION = 48
+ABI_VERSION = 49
 
 
 class GsConvGeom(ctypes.Structure):
@@ -169,6 +169,7 @@ PROTOTYPES = {
     "gs_stem_fwd_bn_pair_q8": (c_int, [_F, _F, _F, _F, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "gs_q8_from_hi": (c_int, [_P, _P, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "gs_conv3d_3x3x3_precise": (c_int, [_P, _P, _P, _P, _F, _F] + [c_int] * 11 + [POINTER(c_int32)] * 3 + [c_int, c_int, c_void_p]),
+    "gs_conv3d_3x3x3_precise_to": (c_int, [_P, _P, _P, _P, _F, _F] + [c_int] * 12 + [POINTER(c_int32)] * 3 + [c_int, c_int, c_void_p]),
     "gs_maxpool3d_fwd_pair_q8": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, c_int, c_int] + [c_int] * 6 + [c_void_p]),
     "gs_maxpool3d_fwd_pair": (c_int, [_P, _P, c_int, _P, _P] + [c_int] * 7 + [c_void_p]),
     "gs_upsample2x_bilinear_fwd_pair": (c_int, [_P, _P, _P, _P] + [c_int] * 13 + [c_void_p]),

@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_big_kernel(const C3Args a) {
         r.n = n + dz;
         r.kill = ((unsigned)(d + dz) < (unsigned)a.D) ? 0u : VOOB;
         int cx = c;                                               // input chunk of K chunk c
-        if (PREC && a.in_wrap > 0 && c >= a.in_wrap) cx = c - a.in_wrap;
+        if (PREC && a.in_wrap > 0 && c >= a.in_wrap) cx = c - a.in_wrap + a.in_wrap_to;
         r.sc = (unsigned)cx * 128u;                               // 64 channels x 2 bytes per chunk
         r.wsc = (unsigned)c * 128u + (unsigned)(dzi * 9) * tap_stride_c;
         r.ckill = (c * 64 + chunk * 8 < a.Cin) ? 0u : VOOB;       // Cin % 64 != 0: the tail chunk is zero padded
@@ -1106,7 +1106,7 @@ extern "C" int gs_conv3x3_stat_rows(int N, int H, int W, int Cin, int Cout, int 
 static int conv3x3_launch(const void* x, const void* w, void* y, const float* bias, float* bn_partials, int N, int H,
                           int W, int Cin, int in_pix_stride, int in_coff, int Cout, int out_pix_stride, int out_coff,
                           const int32_t* tap_dy, const int32_t* tap_dx, int act, int dtype, void* stream, int D, int ndz,
-                          const int32_t* tap_dz, void* y_lo = nullptr, int in_wrap = 0, const int* wexp = nullptr) {
+                          const int32_t* tap_dz, void* y_lo = nullptr, int in_wrap = 0, const int* wexp = nullptr, int in_wrap_to = 0) {
     GS_CHECK_ARG(x && w && y && tap_dy && tap_dx, "gs_conv3x3: null pointer");
     GS_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0 && Cout > 0, "gs_conv3x3: bad dims");
     const bool prec = y_lo != nullptr;
@@ -1133,7 +1133,9 @@ static int conv3x3_launch(const void* x, const void* w, void* y, const float* bi
         a.tap_dy[i] = tap_dy[i]; a.tap_dx[i] = tap_dx[i];
     }
     a.D = D; a.ndz = ndz;
-    a.y_lo = (unsigned short*)y_lo; a.in_wrap = in_wrap / 64; a.xcd_order = 0;
+    GS_CHECK_ARG(in_wrap_to == 0 || (prec && wexp == nullptr && in_wrap_to % 64 == 0 && in_wrap_to > 0 && in_wrap_to + (Cin - in_wrap) <= in_wrap),
+                 "gs_conv3x3_precise: the wrapped K chunks must stay inside the input (wrap_to %d + K %d - wrap %d <= wrap)", in_wrap_to, Cin, in_wrap);
+    a.y_lo = (unsigned short*)y_lo; a.in_wrap = in_wrap / 64; a.in_wrap_to = in_wrap_to / 64; a.xcd_order = 0;
     // "q" stages (gs_conv3x3_q8): Cin = K = 2 * (the layer's channels): the first half 16-bit stages, the second FP8 correction stages
     a.q8_c0 = wexp ? Cin / 64 : 0; a.wexp = wexp;
     for (int i = 0; i < 3; ++i) a.tap_dz[i] = (tap_dz && i < ndz) ? tap_dz[i] : 0;
@@ -1327,6 +1329,20 @@ extern "C" int gs_conv3d_3x3x3_precise(const void* x, const void* w, void* y_hi,
     GS_CHECK_ARG(c3_variant_get() == 2, "gs_conv3d_3x3x3_precise: needs the big-K-step kernel (GSSEG_C3=2)");
     return conv3x3_launch(x, w, y_hi, bias, bn_partials, NB * D, H, W, K, in_pix_stride, in_coff, Cout, out_pix_stride, out_coff,
                           tap_dy, tap_dx, act, dtype, stream, D, 3, tap_dz, y_lo, in_wrap);
+}
+
+// The same with the wrapped part of K continuing at input channel in_wrap_to (a multiple of 64) instead of channel 0: a decoder-entry conv
+// whose concat input is [up_h res_h | res_l] runs its w_lo segment over the residual channels only -- K = [hi (all) | res_l] then res_h.
+extern "C" int gs_conv3d_3x3x3_precise_to(const void* x, const void* w, void* y_hi, void* y_lo, const float* bias, float* bn_partials,
+                                          int NB, int D, int H, int W, int K, int in_pix_stride, int in_coff, int in_wrap, int in_wrap_to,
+                                          int Cout, int out_pix_stride, int out_coff, const int32_t* tap_dz, const int32_t* tap_dy,
+                                          const int32_t* tap_dx, int act, int dtype, void* stream) {
+    GS_CHECK_ARG(y_lo != nullptr, "gs_conv3d_3x3x3_precise_to: y_lo is NULL");
+    GS_CHECK_ARG(NB > 0 && D > 0 && tap_dz, "gs_conv3d_3x3x3_precise_to: bad depth arguments");
+    for (int i = 0; i < 3; ++i) GS_CHECK_ARG(tap_dz[i] >= -1 && tap_dz[i] <= 1, "gs_conv3d_3x3x3_precise_to: depth tap offsets must be in [-1,1]");
+    GS_CHECK_ARG(c3_variant_get() == 2, "gs_conv3d_3x3x3_precise_to: needs the big-K-step kernel (GSSEG_C3=2)");
+    return conv3x3_launch(x, w, y_hi, bias, bn_partials, NB * D, H, W, K, in_pix_stride, in_coff, Cout, out_pix_stride, out_coff,
+                          tap_dy, tap_dx, act, dtype, stream, D, 3, tap_dz, y_lo, in_wrap, nullptr, in_wrap_to);
 }
 
 extern "C" int gs_conv3d_3x3x3(const void* x, const void* w, void* y, const float* bias, float* bn_partials, int NB, int D,

@@ -20,6 +20,7 @@ struct C3Args {
     // hi/lo pair: hi at y, lo = 16-bit(value - hi) at y_lo (same stride / offset).
     unsigned short* y_lo;
     int in_wrap;                  // in 64-channel chunks; 0 = no wrap
+    int in_wrap_to = 0;           // the wrapped K chunks continue at this input chunk (64-channel chunks) instead of chunk 0
     int xcd_order;                // big kernel: XCD-aware item order (grid must be a multiple of 8)
     // "q" stages of the pair forward (conv3x3_dma_kernel<.., Q8>): per depth tap the first q8_c0 32-channel K stages are 16-bit
     // (x_hi . w_hi), the remaining ones FP8 correction stages reading the q planes of the input / of the pack (common.hpp); wexp[co]

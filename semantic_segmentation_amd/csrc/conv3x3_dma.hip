@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
     auto stage_src = [&](int n, int c) __attribute__((always_inline)) {
         Src r;
         r.n = n; r.sc = (unsigned)c * ROWB; r.wsc = r.sc; r.hkill = 0u;
-        if (PREC && a.in_wrap > 0 && c >= 2 * a.in_wrap) r.sc = (unsigned)(c - 2 * a.in_wrap) * ROWB;    // in_wrap counts 64-channel chunks
+        if (PREC && a.in_wrap > 0 && c >= 2 * a.in_wrap) r.sc = (unsigned)(c - 2 * a.in_wrap + 2 * a.in_wrap_to) * ROWB;    // in_wrap / in_wrap_to count 64-channel chunks
         if (a.ndz > 1) {
             const int dzi = c / nchunk, cc = c - dzi * nchunk;
             const int dz = a.tap_dz[dzi];
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv3x3_dma_kernel(const C3Args a
             r.n = inside ? n + dz : n;
             r.hkill = inside ? 0u : VOOB;
             // (pair forward: K chunk cc of a depth tap reads input chunk cc, wrapping once to the start of the input)
-            r.sc = (unsigned)((PREC && a.in_wrap > 0 && cc >= 2 * a.in_wrap) ? cc - 2 * a.in_wrap : cc) * ROWB;
+            r.sc = (unsigned)((PREC && a.in_wrap > 0 && cc >= 2 * a.in_wrap) ? cc - 2 * a.in_wrap + 2 * a.in_wrap_to : cc) * ROWB;
             r.wsc = (unsigned)(dzi * 9) * tap_stride + (unsigned)cc * ROWB;
         }
         return r;

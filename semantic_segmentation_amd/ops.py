@@ -1289,10 +1289,11 @@ def conv3x3_segs(x, w, y_hi, y_lo, N, H, W, K, wrap, Cin, Cout, in_stride, in_co
                    2.0 * (N * H * W * 2 * (Cin + Cout) + 9 * K * Cout))
 
 
-def conv3d3_segs(x, w, y_hi, y_lo, NB, D, H, W, K, wrap, Cin, Cout, in_stride, in_coff=0, bn_partials=None):
+def conv3d3_segs(x, w, y_hi, y_lo, NB, D, H, W, K, wrap, Cin, Cout, in_stride, in_coff=0, bn_partials=None, wrap_to=0):
     """Conv3d(k3, p1) of the pair forward (UNet3D): conv3x3_segs with depth -- x holds `wrap` channels per voxel ([hi | lo] planes or
     a part of them), K (a multiple of 64, wrap <= K <= 2*wrap) runs over them and wraps once, w = pack_weight_segs pack
-    [27][Cout][K]; Cin = the layer's channels (FLOP count only).  Result: dense pair y_hi / y_lo [NB*D, H, W, Cout]."""
+    [27][Cout][K]; Cin = the layer's channels (FLOP count only).  wrap_to: the wrapped part of K continues at this input channel (a
+    multiple of 64) instead of channel 0.  Result: dense pair y_hi / y_lo [NB*D, H, W, Cout]."""
     _dev(x)
     _f32(bn_partials, "bn_partials")
     if not (x.dtype == w.dtype == y_hi.dtype == y_lo.dtype):
@@ -1305,8 +1306,14 @@ def conv3d3_segs(x, w, y_hi, y_lo, NB, D, H, W, K, wrap, Cin, Cout, in_stride, i
     dy = (ctypes.c_int32 * 9)(*[k // 3 - 1 for k in range(9)])
     dx = (ctypes.c_int32 * 9)(*[k % 3 - 1 for k in range(9)])
     ev = TIMER.start() if TIMER is not None else None
-    _lib.call("gs_conv3d_3x3x3_precise", _p(x), _p(w), _p(y_hi), _p(y_lo), None, _p(bn_partials), NB, D, H, W, K, in_stride,
-              in_coff, wrap, Cout, Cout, 0, dz, dy, dx, ACT_NONE, dt_code(x), _stream())
+    if wrap_to:
+        if wrap_to % 64 != 0 or wrap_to + (K - wrap) > wrap:
+            raise ValueError("conv3d3_segs: wrap_to must be a multiple of 64 with wrap_to + K - wrap <= wrap")
+        _lib.call("gs_conv3d_3x3x3_precise_to", _p(x), _p(w), _p(y_hi), _p(y_lo), None, _p(bn_partials), NB, D, H, W, K, in_stride,
+                  in_coff, wrap, wrap_to, Cout, Cout, 0, dz, dy, dx, ACT_NONE, dt_code(x), _stream())
+    else:
+        _lib.call("gs_conv3d_3x3x3_precise", _p(x), _p(w), _p(y_hi), _p(y_lo), None, _p(bn_partials), NB, D, H, W, K, in_stride,
+                  in_coff, wrap, Cout, Cout, 0, dz, dy, dx, ACT_NONE, dt_code(x), _stream())
     if ev is not None:
         TIMER.stop("conv3x3_halo_precise", ev, 2.0 * NB * D * H * W * Cout * 27 * Cin,
                    2.0 * (NB * D * H * W * 2 * (Cin + Cout) + 27 * K * Cout))

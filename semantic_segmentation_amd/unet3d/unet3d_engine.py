@@ -10,6 +10,7 @@ the shift (eval), and its gradient is the column sum of the conv-output gradient
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List
 
 import torch
@@ -43,8 +44,14 @@ def resolve_plan3d(precise, dtype: str):
     elif precise in ("mixed", "auto"):
         from ..unet.unet_engine import MIXED_SEG      # "xw" (default) or "q": the FP8 correction segment (GSSEG_MIXED_SEG)
         plan = {s_: ("xw" if dtype != "f16" else (MIXED_SEG if s_ in MIXED3D_XW else "1")) for s_ in convs}
+        if dtype == "f16" and MIXED_SEG == "xw" and os.environ.get("GSSEG_MIXED3D_UPW", "res") == "res":
+            # the decoder-entry convs run their w_lo segment on the residual channels only ("xw-": the up half of their input has no
+            # lo plane either, so its weight rounding is of the size of the activation rounding the plan already accepts there):
+            # K = cin + 2 cr instead of 2 cin + cr -- 448 -> 320 / 896 -> 640 -- 21.3 -> 20.2 ms per 128^3 volume, max |dlogit| over the
+            # fixtures 5.4e-4 -> 4.7e-4 (16^3: 4.3e-4 -> 4.1e-4, 5.4e-4 -> 4.7e-4; 128^3: 3.7e-4 -> 4.3e-4).  GSSEG_MIXED3D_UPW=all: all channels.
+            plan["s_block2.conv1"] = plan["s_block1.conv1"] = "xw-"
     elif isinstance(precise, dict):
-        bad = [k for k, v in precise.items() if k not in STAGES3D or v not in ("1", "x", "w", "xw", "q")]
+        bad = [k for k, v in precise.items() if k not in STAGES3D or v not in ("1", "x", "w", "xw", "xw-", "q")]
         if bad:
             raise ValueError(f"precise plan: unknown stages / modes {bad}")
         plan = {s_: precise.get(s_, "1") for s_ in convs}
@@ -74,7 +81,11 @@ def segs3d(mode: str, cin: int, lo0: int = 0, lo_len=None):
             raise NotImplementedError(f"pair forward: cannot pad a {cin}-channel input to a multiple of 64 channels")
         segs.append((2, 0, pad))
         span += pad
-    if "w" in mode:
+    if mode == "xw-":                            # w_lo only on the channels whose x_lo is valid; the kernel wraps to channel lo0 (wrap_to)
+        if lo0 % 64 or ll % 64:
+            raise NotImplementedError("pair forward: the partial w_lo segment needs 64-channel-aligned residual channels")
+        segs.append((1, lo0, ll))
+    elif "w" in mode:
         segs.append((1, 0, cin))
         if cin % 64:
             segs.append((2, 0, 64 - cin % 64))
@@ -429,7 +440,8 @@ class UNet3DEngine:
                     qpack, wexp = packs[names[id(conv)]]
                     ops.conv3d3_q8(inp, qpack, wexp, y_hi, y_lo, NB, D, H, W, cin, cout, in_stride, 0, part)
                 else:
-                    ops.conv3d3_segs(inp, packs[names[id(conv)]], y_hi, y_lo, NB, D, H, W, K, wrap, cin, cout, in_stride, 0, part)
+                    wto = (conv.in_channels - (wrap - conv.in_channels)) if plan[names[id(conv)]] == "xw-" else 0     # lo0 = cin - lo_len
+                    ops.conv3d3_segs(inp, packs[names[id(conv)]], y_hi, y_lo, NB, D, H, W, K, wrap, cin, cout, in_stride, 0, part, wrap_to=wto)
                 st.halo = True
                 st.wd = dpacks.get(names[id(conv)])
             st.coef, st.stats = bn_coeffs(bn, conv.bias, part, nt, cout, NB * D * H * W)
