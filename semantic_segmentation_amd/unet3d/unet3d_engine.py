@@ -27,10 +27,12 @@ STAGES3D = ([f"a_block{k}.conv{c}" for k in (1, 2, 3) for c in (1, 2)] + ["bottl
             [s_ for k in (3, 2, 1) for s_ in (f"s_block{k}.upconv1", f"s_block{k}.conv1", f"s_block{k}.conv2")])
 # Where the 16-bit error of the UNet3D logits is made (tools/parity_fp8_sim.py --net unet3d, profiles/r04_fp8_sim_unet3d_32.json): the
 # two finest levels.  With K = 27 * C the rounding of the conv INPUTS (activations and weights) dominates -- pair storage alone
-# leaves 2.0e-3 -- so the "mixed" plan keeps pairs everywhere and runs the correction segments on the seven convs of levels 0 and 1
+# leaves 2.0e-3 -- so the "mixed" plan keeps pairs everywhere and runs the correction segments on the convs of levels 0 and 1
 # (a_block1.conv1 reads the fp32 volume on the direct kernel): simulated max |dlogit| 4.8e-4 (16-bit everywhere: 2.0e-3 .. 2.4e-3).
-MIXED3D_XW = ("a_block1.conv2", "a_block2.conv1", "a_block2.conv2", "s_block2.conv1", "s_block2.conv2", "s_block1.conv1",
-              "s_block1.conv2")
+# Round 4, measured on the MI355X (tools/experiments/plan3d_sweep.py; max |dlogit| on the two 16^3 fixtures / 128^3 step): all seven convs of
+# levels 0-1 4.7e-4 / 20.29 ms; without s_block2.conv1 (the level-1 decoder entry, K = 640 per tap) 5.2e-4 / 19.88 ms -- taken;
+# without both s_block2 convs 6.5e-4 / 19.55 ms; without a_block2 9.2e-4; level 0 only 9.7e-4.
+MIXED3D_XW = ("a_block1.conv2", "a_block2.conv1", "a_block2.conv2", "s_block2.conv2", "s_block1.conv1", "s_block1.conv2")
 
 
 def resolve_plan3d(precise, dtype: str):
@@ -49,7 +51,9 @@ def resolve_plan3d(precise, dtype: str):
             # lo plane either, so its weight rounding is of the size of the activation rounding the plan already accepts there):
             # K = cin + 2 cr instead of 2 cin + cr -- 448 -> 320 / 896 -> 640 -- 21.3 -> 20.2 ms per 128^3 volume, max |dlogit| over the
             # fixtures 5.4e-4 -> 4.7e-4 (16^3: 4.3e-4 -> 4.1e-4, 5.4e-4 -> 4.7e-4; 128^3: 3.7e-4 -> 4.3e-4).  GSSEG_MIXED3D_UPW=all: all channels.
-            plan["s_block2.conv1"] = plan["s_block1.conv1"] = "xw-"
+            for s_ in ("s_block2.conv1", "s_block1.conv1"):
+                if plan[s_] == "xw":
+                    plan[s_] = "xw-"
     elif isinstance(precise, dict):
         bad = [k for k, v in precise.items() if k not in STAGES3D or v not in ("1", "x", "w", "xw", "xw-", "q")]
         if bad:

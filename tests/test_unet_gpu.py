@@ -776,7 +776,7 @@ def test_mixed_plan_choices():
     from semantic_segmentation_amd.unet3d import unet3d_engine as u3
     m3 = u3.resolve_plan3d("auto", "f16")
     assert [k for k, v in m3.items() if v in ("xw", "xw-")] == [s_ for s_ in u3.STAGES3D if s_ in u3.MIXED3D_XW]
-    assert [k for k, v in m3.items() if v == "xw-"] == ["s_block2.conv1", "s_block1.conv1"]      # decoder entries: w_lo on the residual half
+    assert [k for k, v in m3.items() if v == "xw-"] == ["s_block1.conv1"]      # the level-0 decoder entry: w_lo on the residual half
     assert u3.segs3d("xw-", 192, lo0=128, lo_len=64) == ([(0, 0, 192), (0, 128, 64), (1, 128, 64)], 320, 256)
     assert u3.segs3d("xw", 32) == ([(0, 0, 32), (0, 0, 32), (1, 0, 32), (2, 0, 32)], 128, 64)      # the 32-channel conv: K padded to 128
     assert u3.segs3d("1", 32) == ([(0, 0, 32), (2, 0, 32)], 64, 64)
