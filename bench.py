@@ -69,10 +69,24 @@ def pmc_traffic(kind):
     (FETCH_SIZE x2 + WRITE_SIZE, launch-weighted over the class's template instances).  PMC counters cannot be
     collected from inside this process, so this is the figure of the profiled run of the same command."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))     # r01_v7 > r01_v4: newest by name
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")),      # newest by name, numbers compared as numbers (r04_v10 > r04_v2)
+                   key=lambda p: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(p))])
     pre = PMC_PREFIX.get(kind)
     if not files or pre is None:
         return None, None, None
+    # a summary taken with exactly these kernel sources wins over a newer-named one of other sources
+    cur = source_sha16()
+    pick = files[-1]
+    for p in reversed(files):
+        try:
+            with open(p) as f:
+                if json.load(f).get("_source_sha16") == cur:
+                    pick = p
+                    break
+        except (OSError, ValueError):
+            continue
+    files = [pick]
     with open(files[-1]) as f:
         d = json.load(f)
     sha = d.get("_source_sha16")
