@@ -313,12 +313,18 @@ def main():
     multi = world > 1 or args.rehearse_dp          # the data-parallel code path (rehearsal: one rank, the same calls)
     if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # RCCL's kernels on a high-priority stream: the persistent compute grids hold every CU until a kernel boundary; at the
+        # boundary a bucket's all-reduce must win the CUs against the next compute launch that is already queued
+        pg_opts = None
+        if os.environ.get("GSSEG_RCCL_HIGH_PRIORITY", "1") != "0" and hasattr(dist, "ProcessGroupNCCL"):
+            pg_opts = dist.ProcessGroupNCCL.Options()
+            pg_opts.is_high_priority_stream = True
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(free_port()))
-            dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+            dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1, pg_options=pg_opts)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, pg_options=pg_opts)
 
     from semantic_segmentation_amd import ops
     from semantic_segmentation_amd.harness import synthetic_batch
