@@ -40,6 +40,23 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_TAP_ARRAYS = {}
+
+
+def _tap_arrays(taps):
+    """(dy, dx) int32[9] ctypes arrays of a 3x3 tap list, built once per list (2.2 us per call otherwise: ~50 conv launches per
+    U-Net pass at the script's batch 2, where the host bounds the step)."""
+    key = tuple(taps)
+    r = _TAP_ARRAYS.get(key)
+    if r is None:
+        r = _TAP_ARRAYS[key] = ((ctypes.c_int32 * 9)(*[t[0] for t in key]), (ctypes.c_int32 * 9)(*[t[1] for t in key]))
+    return r
+
+
+_TAPS3D = {sgn: ((ctypes.c_int32 * 3)(*[sgn * (k - 1) for k in range(3)]), (ctypes.c_int32 * 9)(*[sgn * (k // 3 - 1) for k in range(9)]),
+                 (ctypes.c_int32 * 9)(*[sgn * (k % 3 - 1) for k in range(9)])) for sgn in (1, -1)}
+
+
 def _dev(t: torch.Tensor):
     if not t.is_cuda:
         raise RuntimeError("semantic_segmentation_amd ops need tensors on the MI355X (cuda) device; "
@@ -326,8 +343,7 @@ def conv3x3(x, w, y, N, H, W, Cin, Cout, taps=TAPS3_FWD, bias=None, bn_partials=
         raise TypeError("conv3x3: x, w, y must share one 16-bit dtype")
     if bn_partials is not None and bn_partials.numel() < bn_partials_numel(conv3x3_stat_rows(N, H, W, Cin, Cout), Cout):
         raise ValueError("conv3x3: bn_partials too small (conv3x3_stat_rows rows of [2][Cout])")
-    dy = (ctypes.c_int32 * 9)(*[t[0] for t in taps])
-    dx = (ctypes.c_int32 * 9)(*[t[1] for t in taps])
+    dy, dx = _tap_arrays(taps)
     ev = TIMER.start() if TIMER is not None else None
     _lib.call("gs_conv3x3", _p(x), _p(w), _p(y), _p(bias), _p(bn_partials), N, H, W, Cin,
               Cin if in_stride is None else in_stride, in_coff, Cout, Cout if out_stride is None else out_stride,
@@ -415,9 +431,7 @@ def conv3d3(x, w, y, NB, D, H, W, Cin, Cout, dgrad=False, bias=None, bn_partials
     if bn_partials is not None and bn_partials.numel() < bn_partials_numel(conv3d3_stat_rows(NB, D, H, W, Cin, Cout), Cout):
         raise ValueError("conv3d3: bn_partials too small")
     sgn = -1 if dgrad else 1
-    dz = (ctypes.c_int32 * 3)(*[sgn * (k - 1) for k in range(3)])
-    dy = (ctypes.c_int32 * 9)(*[sgn * (k // 3 - 1) for k in range(9)])
-    dx = (ctypes.c_int32 * 9)(*[sgn * (k % 3 - 1) for k in range(9)])
+    dz, dy, dx = _TAPS3D[sgn]
     ev = TIMER.start() if TIMER is not None else None
     _lib.call("gs_conv3d_3x3x3", _p(x), _p(w), _p(y), _p(bias), _p(bn_partials), NB, D, H, W, Cin,
               Cin if in_stride is None else in_stride, in_coff, Cout, Cout if out_stride is None else out_stride, out_coff,
@@ -1208,8 +1222,7 @@ def conv3x3_precise(x, w, y_hi, y_lo, N, H, W, Cin, Cout, in_stride, in_coff=0, 
         raise ValueError("conv3x3_precise: Cin must be a multiple of 64 and w the [9][Cout][3*Cin] split pack")
     if bn_partials is not None and bn_partials.numel() < bn_partials_numel(conv3x3_stat_rows(N, H, W, Cin, Cout, pair=True), Cout):
         raise ValueError("conv3x3_precise: bn_partials too small")
-    dy = (ctypes.c_int32 * 9)(*[t[0] for t in taps])
-    dx = (ctypes.c_int32 * 9)(*[t[1] for t in taps])
+    dy, dx = _tap_arrays(taps)
     ev = TIMER.start() if TIMER is not None else None
     _lib.call("gs_conv3x3_precise", _p(x), _p(w), _p(y_hi), _p(y_lo), _p(bias), _p(bn_partials), N, H, W, 3 * Cin,
               in_stride, in_coff, 2 * Cin, Cout, Cout if out_stride is None else out_stride, out_coff, dy, dx, act,
@@ -1278,8 +1291,7 @@ def conv3x3_segs(x, w, y_hi, y_lo, N, H, W, K, wrap, Cin, Cout, in_stride, in_co
         raise ValueError("conv3x3_segs: K / wrap must be multiples of 64 with wrap <= K <= 2*wrap and w the [9][Cout][K] pack")
     if bn_partials is not None and bn_partials.numel() < bn_partials_numel(conv3x3_stat_rows(N, H, W, Cin, Cout, pair=True), Cout):
         raise ValueError("conv3x3_segs: bn_partials too small (conv3x3_stat_rows(pair=True) rows of [2][Cout])")
-    dy = (ctypes.c_int32 * 9)(*[t[0] for t in taps])
-    dx = (ctypes.c_int32 * 9)(*[t[1] for t in taps])
+    dy, dx = _tap_arrays(taps)
     ev = TIMER.start() if TIMER is not None else None
     _lib.call("gs_conv3x3_precise", _p(x), _p(w), _p(y_hi), _p(y_lo), _p(bias), _p(bn_partials), N, H, W, K,
               in_stride, in_coff, wrap, Cout, Cout if out_stride is None else out_stride, out_coff, dy, dx, act,
@@ -1302,9 +1314,7 @@ def conv3d3_segs(x, w, y_hi, y_lo, NB, D, H, W, K, wrap, Cin, Cout, in_stride, i
         raise ValueError("conv3d3_segs: K / wrap must be multiples of 64 with wrap <= K <= 2*wrap and w the [27][Cout][K] pack")
     if bn_partials is not None and bn_partials.numel() < bn_partials_numel(conv3x3_stat_rows(NB * D, H, W, K, Cout, pair=True), Cout):
         raise ValueError("conv3d3_segs: bn_partials too small (conv3x3_stat_rows(NB*D, H, W, K, Cout, pair=True) rows)")
-    dz = (ctypes.c_int32 * 3)(*[k - 1 for k in range(3)])
-    dy = (ctypes.c_int32 * 9)(*[k // 3 - 1 for k in range(9)])
-    dx = (ctypes.c_int32 * 9)(*[k % 3 - 1 for k in range(9)])
+    dz, dy, dx = _TAPS3D[1]
     ev = TIMER.start() if TIMER is not None else None
     if wrap_to:
         if wrap_to % 64 != 0 or wrap_to + (K - wrap) > wrap:
