@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 49
+#define GS_ABI_VERSION 50
 
 enum GsDtype { GS_F16 = 0, GS_BF16 = 1 };
 enum GsStatus { GS_OK = 0, GS_EINVAL = -1, GS_ELAUNCH = -2, GS_EUNSUPPORTED = -3 };
@@ -556,6 +556,12 @@ int gs_conv_smallcin_fwd_split(const float* x, const float* w, void* y_hi, void*
 int gs_bn_act_apply_split(const void* y_hi, const void* y_lo, const float* scale, const float* shift, int act, void* z_hi,
                           void* z_lo, int z_pix_stride, int z_coff, void* zp_hi, void* zp_lo, int zp_pix_stride, int N,
                           int H, int W, int C, int dtype, void* stream);
+/* The same with MaxPool3d(2) (GenSeg-3D/UNet3D/unet3d.py:29-36: BatchNorm3d + ReLU + pooling of an analysis block): the z pair of the
+ * [NB*D, H, W] voxel grid (even D, H, W) AND the pooled pair [NB*D/2, H/2, W/2] (maximum of the stored pair values) in one pass --
+ * bit-identical to gs_bn_act_apply_split + gs_maxpool3d_fwd_pair without reading the z pair back.  z_lo / zp_lo may be NULL. */
+int gs_bn_act_apply_split_pool3d(const void* y_hi, const void* y_lo, const float* scale, const float* shift, int act, void* z_hi, void* z_lo,
+                                 int z_pix_stride, int z_coff, void* zp_hi, void* zp_lo, int zp_pix_stride, int NB, int D, int H, int W, int C,
+                                 int dtype, void* stream);
 int gs_head1x1_fwd_split(const void* x_hi, const void* x_lo, const float* w, const float* bias, float* y, int N, int H,
                          int W, int Cin, int Cout, int dtype, void* stream);
 /* Pair-forward forms of the "never stored" edge kernels (mixed mode; gs_stem_fwd_bn / gs_head1x1_bn_fwd of the default engine):

@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 GS_F16, GS_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH = 0, 1, 2, 3
 GS_MAX_TAPS = 64
-ABI_VERSION = 49
+ABI_VERSION = 50
 
 
 class GsConvGeom(ctypes.Structure):
@@ -177,6 +177,7 @@ PROTOTYPES = {
     "gs_upconv2x2_fwd_precise": (c_int, [_P, _P, _F, _P, _P] + [c_int] * 15 + [c_void_p]),
     "gs_conv_smallcin_fwd_split": (c_int, [_F, _F, _P, _P, _F] + [c_int] * 8 + [c_void_p]),
     "gs_bn_act_apply_split": (c_int, [_P, _P, _F, _F, c_int, _P, _P, c_int, c_int, _P, _P] + [c_int] * 6 + [c_void_p]),
+    "gs_bn_act_apply_split_pool3d": (c_int, [_P, _P, _F, _F, c_int, _P, _P, c_int, c_int, _P, _P] + [c_int] * 7 + [c_void_p]),
     "gs_head1x1_fwd_split": (c_int, [_P, _P, _F, _F, _F] + [c_int] * 6 + [c_void_p]),
     "gs_head1x1_bn_fwd_split": (c_int, [_P, _P, _F, _F, c_int, _F, _F, _F] + [c_int] * 6 + [c_void_p]),
     "gs_stem_fwd_bn_pair": (c_int, [_F, _F, _F, _F, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -496,6 +496,67 @@ __global__ __launch_bounds__(256) void bn_act_apply_split_pool_kernel(const Appl
     }
 }
 
+// 3-D form (UNet3D's analysis blocks, GenSeg-3D/UNet3D/unet3d.py:29-36: BatchNorm3d + ReLU + MaxPool3d(2)): units are 2x2x2 windows of
+// the [NB*D, H, W] voxel grid (even D, H, W: host-checked), the eight voxels of a window are loaded before the first use; the z pair is
+// stored as bn_act_apply_split_kernel stores it and the pooled pair is the maximum of the STORED pair values -- bit-identical to
+// gs_bn_act_apply_split followed by gs_maxpool3d_fwd_pair, without reading the z pair back (537 MB at 128^3).
+template <int DT, int LOF>
+__global__ __launch_bounds__(256) void bn_act_apply_split_pool3d_kernel(const ApplySArgs a, int D) {
+    constexpr bool LO = LOF == 1;
+    const float slope = a.act == GS_ACT_RELU ? 0.f : (a.act == GS_ACT_LEAKY02 ? 0.2f : 1.f);
+    const int nch = a.C >> 3;
+    const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int ch = (int)(gt % nch);
+    const int pl = (int)(gt / nch), npl = (int)(((int64_t)gridDim.x * 256) / nch);
+    const int c0 = ch * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sc[i] = a.scale ? a.scale[c0 + i] : 1.f; sh[i] = a.shift ? a.shift[c0 + i] : 0.f; }
+    const int PD = D / 2, PH = a.H / 2, PW = a.W / 2, NB = a.N / D;
+    const int units = NB * PD * PH * PW;                   // host guarantees < 2^31
+    for (int u = pl; u < units; u += npl) {
+        const int px = u % PW;
+        int r = u / PW;
+        const int py = r % PH; r /= PH;
+        const int pd = r % PD, nb = r / PD;
+        uint4 vh[8], vl[8];
+        int64_t pix[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            pix[q] = (((int64_t)nb * D + 2 * pd + (q >> 2)) * a.H + 2 * py + ((q >> 1) & 1)) * a.W + 2 * px + (q & 1);
+            vh[q] = *reinterpret_cast<const uint4*>(a.y_hi + pix[q] * a.C + c0);
+            vl[q] = *reinterpret_cast<const uint4*>(a.y_lo + pix[q] * a.C + c0);
+        }
+        float mx[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mx[i] = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float v[8];
+            join8<DT>(vh[q], vl[q], v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float t = v[i] * sc[i] + sh[i];
+                v[i] = t > 0.f ? t : t * slope;
+            }
+            uint4 hi, lo;
+            split8<DT>(v, hi, lo);
+            st16(a.z_hi + pix[q] * a.zs + a.zc + c0, hi);
+            if (LO) st16(a.z_lo + pix[q] * a.zs + a.zc + c0, lo);
+            float rr[8];
+            if (LO) join8<DT>(hi, lo, rr);
+            else unpack8<DT>(hi, rr);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mx[i] = fmaxf(mx[i], rr[i]);
+        }
+        const int64_t pp = (((int64_t)nb * PD + pd) * PH + py) * PW + px;
+        uint4 hi, lo;
+        split8<DT>(mx, hi, lo);
+        st16(a.zp_hi + pp * a.zps + c0, hi);
+        if (a.zp_lo) st16(a.zp_lo + pp * a.zps + c0, lo);
+    }
+}
+
 // ---- pointwise head, Cin == 64, on a pair of dense inputs: 8 lanes per pixel ---------------------------------------
 struct HeadSArgs {
     const unsigned short* x_hi; const unsigned short* x_lo; const float* w; const float* bias; float* y;
@@ -730,6 +791,37 @@ static int bn_act_apply_split_impl(const void* y_hi, const void* y_lo, const flo
     else GS_APPLY_SPLIT(GS_BF16);
 #undef GS_APPLY_SPLIT
     GS_CHECK_LAUNCH("gs_bn_act_apply_split");
+    return GS_OK;
+}
+
+extern "C" int gs_bn_act_apply_split_pool3d(const void* y_hi, const void* y_lo, const float* scale, const float* shift, int act,
+                                            void* z_hi, void* z_lo, int z_pix_stride, int z_coff, void* zp_hi, void* zp_lo,
+                                            int zp_pix_stride, int NB, int D, int H, int W, int C, int dtype, void* stream) {
+    GS_CHECK_ARG(y_hi && y_lo && z_hi && zp_hi && NB > 0 && D > 1 && H > 1 && W > 1 && C > 0 && C % 8 == 0, "gs_bn_act_apply_split_pool3d: bad arguments");
+    GS_CHECK_ARG(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "gs_bn_act_apply_split_pool3d: even volume dims only");
+    GS_CHECK_ARG(z_pix_stride >= z_coff + C && z_pix_stride % 8 == 0 && z_coff % 8 == 0 && zp_pix_stride >= C && zp_pix_stride % 8 == 0,
+                 "gs_bn_act_apply_split_pool3d: bad strides");
+    GS_CHECK_ARG((scale == nullptr) == (shift == nullptr), "gs_bn_act_apply_split_pool3d: scale/shift must both be given or NULL");
+    GS_CHECK_ARG(act == GS_ACT_NONE || act == GS_ACT_RELU || act == GS_ACT_LEAKY02, "gs_bn_act_apply_split_pool3d: activation %d", act);
+    GS_CHECK_ARG(dtype == GS_F16 || dtype == GS_BF16, "gs_bn_act_apply_split_pool3d: bad dtype");
+    GS_CHECK_ARG((int64_t)NB * D * H * W < 2147483000LL, "gs_bn_act_apply_split_pool3d: too many voxels");
+    ApplySArgs a{(const unsigned short*)y_hi, (const unsigned short*)y_lo, scale, shift, (unsigned short*)z_hi, (unsigned short*)z_lo,
+                 (unsigned short*)zp_hi, (unsigned short*)zp_lo, act, NB * D, H, W, C, z_pix_stride, z_coff, zp_pix_stride};
+    const int nch = C / 8;
+    int64_t blocks = cdiv64((int64_t)NB * (D / 2) * (H / 2) * (W / 2) * nch, 256);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    int bq = 1;                                            // smallest block multiple with nch | 256 * bq (a thread keeps its chunk)
+    while ((256 * bq) % nch != 0) ++bq;
+    blocks = cdiv64(blocks, bq) * bq;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GS_F16) {
+        if (z_lo) bn_act_apply_split_pool3d_kernel<GS_F16, 1><<<(int)blocks, 256, 0, s>>>(a, D);
+        else bn_act_apply_split_pool3d_kernel<GS_F16, 0><<<(int)blocks, 256, 0, s>>>(a, D);
+    } else {
+        if (z_lo) bn_act_apply_split_pool3d_kernel<GS_BF16, 1><<<(int)blocks, 256, 0, s>>>(a, D);
+        else bn_act_apply_split_pool3d_kernel<GS_BF16, 0><<<(int)blocks, 256, 0, s>>>(a, D);
+    }
+    GS_CHECK_LAUNCH("gs_bn_act_apply_split_pool3d");
     return GS_OK;
 }
 

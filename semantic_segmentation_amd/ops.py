@@ -1384,6 +1384,17 @@ def bn_act_apply_split(y_hi, y_lo, scale, shift, act, z_hi, z_lo, z_stride, z_co
               _p(zp_hi), _p(zp_lo), zp_stride, N, H, W, C, dt_code(y_hi), _stream())
 
 
+def bn_act_apply_split_pool3d(y_hi, y_lo, scale, shift, act, z_hi, z_lo, z_stride, z_coff, zp_hi, zp_lo, zp_stride, NB, D, H, W):
+    """bn_act_apply_split + MaxPool3d(2) of the pair in one pass: y_hi / y_lo dense [NB*D,H,W,C]; z pair as bn_act_apply_split; the
+    pooled pair zp_hi / zp_lo (views of the first channel of each plane, pixel stride zp_stride) = the maximum of the stored pair values."""
+    C = y_hi.shape[3]
+    if tuple(y_hi.shape) != (NB * D, H, W, C) or y_lo.shape != y_hi.shape or not (y_hi.is_contiguous() and y_lo.is_contiguous()):
+        raise ValueError("bn_act_apply_split_pool3d: y_hi / y_lo must be dense [NB*D,H,W,C]")
+    _f32(scale, "scale"); _f32(shift, "shift")
+    _lib.call("gs_bn_act_apply_split_pool3d", _p(y_hi), _p(y_lo), _p(scale), _p(shift), act, _p(z_hi), _p(z_lo), z_stride, z_coff,
+              _p(zp_hi), _p(zp_lo), zp_stride, NB, D, H, W, C, dt_code(y_hi), _stream())
+
+
 def head1x1_bn_fwd_split(y_hi, y_lo, scale, shift, act, w, bias, logits):
     """OutConv 1x1 on act(scale * (y_hi + y_lo) + shift) of a dense conv-output pair [N,H,W,64] -> fp32 NCHW logits."""
     _dev(y_hi)

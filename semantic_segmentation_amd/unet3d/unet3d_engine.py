@@ -32,6 +32,8 @@ STAGES3D = ([f"a_block{k}.conv{c}" for k in (1, 2, 3) for c in (1, 2)] + ["bottl
 # Round 4, measured on the MI355X (tools/experiments/plan3d_sweep.py; max |dlogit| on the two 16^3 fixtures / 128^3 step): all seven convs of
 # levels 0-1 4.7e-4 / 20.29 ms; without s_block2.conv1 (the level-1 decoder entry, K = 640 per tap) 5.2e-4 / 19.88 ms -- taken;
 # without both s_block2 convs 6.5e-4 / 19.55 ms; without a_block2 9.2e-4; level 0 only 9.7e-4.
+# BatchNorm + ReLU + MaxPool3d of an analysis block in one pass (GSSEG_POOL3D_FUSED=0: apply, then gs_maxpool3d_fwd_pair)
+FUSED_POOL3D = os.environ.get("GSSEG_POOL3D_FUSED", "1") != "0"
 MIXED3D_XW = ("a_block1.conv2", "a_block2.conv1", "a_block2.conv2", "s_block2.conv2", "s_block1.conv1", "s_block1.conv2")
 
 
@@ -419,9 +421,10 @@ class UNet3DEngine:
                                    coef[0], coef[1], coef[2], coef[3])
             return coef, batch
 
-        def stage(conv, bn, inp, in_stride, cin, D, H, W, z_hi, z_lo, z_stride, z_coff, first=False, z_q8=False):
+        def stage(conv, bn, inp, in_stride, cin, D, H, W, z_hi, z_lo, z_stride, z_coff, first=False, z_q8=False, zp=None):
             """conv (+ bias folded into BatchNorm) -> BN -> ReLU on pairs; the z pair goes to z_hi / z_lo (views; both take
-            z_coff) with pixel stride z_stride; z_lo None: not stored; z_q8: z_lo is the buffer's q plane (its byte 0)."""
+            z_coff) with pixel stride z_stride; z_lo None: not stored; z_q8: z_lo is the buffer's q plane (its byte 0); zp =
+            (zp_hi, zp_lo, zp_stride): MaxPool3d(2) of the z pair in the same pass (16-bit lo planes only)."""
             cout = conv.out_channels
             st = _Stage()
             st.conv, st.bn, st.cin, st.cout, st.D, st.H, st.W, st.first = conv, bn, cin, cout, D, H, W, first
@@ -451,6 +454,9 @@ class UNet3DEngine:
             st.coef, st.stats = bn_coeffs(bn, conv.bias, part, nt, cout, NB * D * H * W)
             if z_q8:
                 ops.bn_act_apply_split_q8(y_hi, y_lo, st.coef[0], st.coef[1], ACT_RELU, z_hi, z_lo, True, z_stride, z_coff)
+            elif zp is not None:
+                ops.bn_act_apply_split_pool3d(y_hi, y_lo, st.coef[0], st.coef[1], ACT_RELU, z_hi, z_lo, z_stride, z_coff, zp[0], zp[1], zp[2],
+                                              NB, D, H, W)
             else:
                 ops.bn_act_apply_split(y_hi, y_lo, st.coef[0], st.coef[1], ACT_RELU, z_hi, z_lo, z_stride, z_coff)
             st.y = y_hi
@@ -484,13 +490,16 @@ class UNet3DEngine:
             if cat_q8:
                 # residual: hi plane at channels [cup, ctot); the buffer's second half is the q plane of ALL ctot channels
                 s2 = stage(blk.conv2, blk.bn2, z1, 2 * cmid, cmid, D, H, W, cat, cat[..., ctot:], 2 * ctot, cup[k], z_q8=True)
-            else:
-                # residual: hi plane at channels [cup, ctot), 16-bit lo plane at [ctot, ctot + cout)
-                s2 = stage(blk.conv2, blk.bn2, z1, 2 * cmid, cmid, D, H, W, cat, cat[..., ctot - cup[k]:], 2 * ctot, cup[k])
             pooled = empty(NB * (D // 2), H // 2, W // 2, 2 * cout)
             nxt_conv = f"a_block{k + 1}.conv1" if k < 3 else "bottleNeck.conv1"
-            ops.maxpool3d_fwd_pair_q8(cat[..., cup[k]:], cat[..., ctot:], cat_q8, cup[k], 2 * ctot, pooled, pooled[..., cout:],
-                                      lo_fmt(nxt_conv) == 2, 2 * cout, NB, D, H, W, cout)
+            fused_pool = FUSED_POOL3D and not cat_q8 and lo_fmt(nxt_conv) != 2 and D % 2 == 0 and H % 2 == 0 and W % 2 == 0
+            if not cat_q8:
+                # residual: hi plane at channels [cup, ctot), 16-bit lo plane at [ctot, ctot + cout); the pooled pair in the same pass
+                s2 = stage(blk.conv2, blk.bn2, z1, 2 * cmid, cmid, D, H, W, cat, cat[..., ctot - cup[k]:], 2 * ctot, cup[k],
+                           zp=(pooled, pooled[..., cout:], 2 * cout) if fused_pool else None)
+            if not fused_pool:
+                ops.maxpool3d_fwd_pair_q8(cat[..., cup[k]:], cat[..., ctot:], cat_q8, cup[k], 2 * ctot, pooled, pooled[..., cout:],
+                                          lo_fmt(nxt_conv) == 2, 2 * cout, NB, D, H, W, cout)
             enc.append((s1, s2, pooled))
             inp, in_stride, cin = pooled, 2 * cout, cout
         D, H, W = dims[3]

@@ -1591,3 +1591,35 @@ def test_upconv8_image_wgrad_matches_autograd(N, h, w, Cin, dtype):
             ref[cls, t16, 0] = wm.grad[:, 0, ky, kx]
     err = float((outs[0].double() - ref).abs().max())
     assert err < 2e-4 * float(ref.abs().max()) + 1e-4, err
+
+
+@pytest.mark.parametrize("NB,D,H,W,C", [(1, 4, 6, 8, 64), (2, 2, 4, 10, 32), (1, 8, 8, 8, 128)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_bn_act_apply_split_pool3d_equals_apply_then_pool(NB, D, H, W, C, dtype):
+    """gs_bn_act_apply_split_pool3d (BatchNorm3d + ReLU + MaxPool3d(2) of a UNet3D analysis block, unet3d.py:29-36, on pairs) is
+    BIT-IDENTICAL to gs_bn_act_apply_split followed by gs_maxpool3d_fwd_pair: the z pair inside a wider concat buffer and the pooled pair."""
+    from semantic_segmentation_amd import ops
+    from semantic_segmentation_amd._lib import ACT_RELU
+    g = torch.Generator().manual_seed(2)
+    v = torch.randn(NB * D, H, W, C, generator=g)
+    yh = v.to(dtype)
+    yl = (v - yh.float()).to(dtype)
+    yh, yl = yh.cuda(), yl.cuda()
+    sc = (torch.rand(C, generator=g) + 0.5).cuda()
+    sh = (torch.randn(C, generator=g) * 0.2).cuda()
+    cu = 16                                                # the residual sits behind `cu` up channels: [up_h res_h | res_l]
+    res = []
+    for fused in (False, True):
+        cat = torch.zeros(NB * D, H, W, 2 * (cu + C), dtype=dtype, device="cuda")
+        pooled = torch.zeros(NB * D // 2, H // 2, W // 2, 2 * C, dtype=dtype, device="cuda")
+        if fused:
+            ops.bn_act_apply_split_pool3d(yh, yl, sc, sh, ACT_RELU, cat, cat[..., C:], 2 * (cu + C), cu, pooled, pooled[..., C:], 2 * C,
+                                          NB, D, H, W)
+        else:
+            ops.bn_act_apply_split(yh, yl, sc, sh, ACT_RELU, cat, cat[..., C:], 2 * (cu + C), cu)
+            ops.maxpool3d_fwd_pair(cat[..., cu:], cat[..., cu + C:], 2 * (cu + C), pooled, pooled[..., C:], 2 * C, NB, D, H, W, C)
+        torch.cuda.synchronize()
+        res.append((cat.cpu(), pooled.cpu()))
+    assert torch.equal(res[0][0].view(torch.int16), res[1][0].view(torch.int16))
+    assert torch.equal(res[0][1].view(torch.int16), res[1][1].view(torch.int16))
+    assert float(res[1][1].float().abs().max()) > 0

@@ -220,8 +220,10 @@ def test_unet3d_and_pix2pix_steps_replayed_from_hipgraphs_then_exchanged_over_rc
             n, c, d, h, w = lg.shape
             return seg_loss(lg.reshape(n, c, d * h, w), vmask.reshape(n, d * h, w))
         check(m3, in3, loss3)
-        # Pix2Pix generator (eval-mode dropout so that eager and replay draw no random numbers) and discriminator
-        nw.upconv_arch.data.zero_()
+        # Pix2Pix generator (eval-mode dropout so that eager and replay draw no random numbers) and discriminator; the architecture
+        # tensor must live on the device before a capture (a host-to-device copy is not capturable): this test must not depend on
+        # an earlier test of the session having moved the module global there
+        nw.upconv_arch = torch.zeros(8, 3, device=dev).requires_grad_(True)
         G = nw.define_G(1, 1, 64, "unet_256", "batch", False, "normal", 0.02, [0])
         D = nw.define_D(2, 64, "basic", 3, "batch", "normal", 0.02, [0])
 
