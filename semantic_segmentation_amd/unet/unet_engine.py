@@ -236,9 +236,11 @@ class UNetEngine:
         """Drop the cached 16-bit weight packs (they are otherwise reused until a Parameter changes)."""
         self._packs.clear()
 
-    def _prepack(self, params: Dict[str, torch.Tensor], need_dgrad: bool):
+    def _prepack(self, params: Dict[str, torch.Tensor], need_dgrad: bool, conv_fwd: bool = True):
         """Re-pack every stale 3x3 / k2-s2 conv weight of the network in ONE launch (after an optimiser step all of them are
-        stale: 21 pack launches of 5-8 us each were launch-bound); _packed() below then finds them cached."""
+        stale: 21 pack launches of 5-8 us each were launch-bound); _packed() below then finds them cached.  conv_fwd=False (the
+        pair forward, whose 3x3 convs read SEGMENT packs): the 3x3 convs get their data-gradient pack only -- half the launch's
+        bytes (a pack entry then holds None in the forward slot)."""
         items, fresh = [], []
         for name, w in params.items():
             if not name.endswith(".weight") or w.dim() != 4:
@@ -254,10 +256,13 @@ class UNetEngine:
                 cout, cin = w.shape[0], w.shape[1]
             key = _pack_key(w)
             ent = self._packs.get(name)
-            if ent is not None and ent[0] == key and (ent[2] is not None or not need_dgrad):
+            want_f = conv_fwd or transposed
+            if ent is not None and ent[0] == key and (ent[2] is not None or not need_dgrad) and (ent[1] is not None or not want_f):
+                continue
+            if not want_f and not need_dgrad:
                 continue
             taps = w.shape[2] * w.shape[3]
-            wf = torch.empty((taps, cout, cin), dtype=self.tdt, device=w.device)
+            wf = torch.empty((taps, cout, cin), dtype=self.tdt, device=w.device) if want_f else None
             wd = torch.empty((taps, cin, cout), dtype=self.tdt, device=w.device) if need_dgrad else None
             items.append((w.detach(), wf, wd, transposed))
             fresh.append((name, key, wf, wd))
@@ -266,11 +271,12 @@ class UNetEngine:
             for name, key, wf, wd in fresh:
                 self._packs[name] = (key, wf, wd)
 
-    def _packed(self, name: str, w: torch.Tensor, transposed: bool, need_dgrad: bool):
-        """16-bit K-major packs of a conv weight, cached until the Parameter is modified."""
+    def _packed(self, name: str, w: torch.Tensor, transposed: bool, need_dgrad: bool, need_fwd: bool = True):
+        """16-bit K-major packs of a conv weight, cached until the Parameter is modified (need_fwd=False: a cached entry without
+        its forward pack -- _prepack(conv_fwd=False) -- will do)."""
         key = _pack_key(w)
         ent = self._packs.get(name)
-        if ent is not None and ent[0] == key and (ent[2] is not None or not need_dgrad):
+        if ent is not None and ent[0] == key and (ent[2] is not None or not need_dgrad) and (ent[1] is not None or not need_fwd):
             return ent[1], ent[2]
         if transposed:
             cin, cout = w.shape[0], w.shape[1]
@@ -710,7 +716,7 @@ class UNetEngine:
                     eff[st_] = "xw"
         plan = eff
         if need_grad or not full:
-            self._prepack(params, need_grad)               # the backward's data-gradient packs / the "1" up-convs' packs, one launch
+            self._prepack(params, need_grad, conv_fwd=False)      # the backward's data-gradient packs / the "1" up-convs' packs, one launch
         self._prepack_segs(params, eff)                    # the forward's segment packs, one launch per kind
         # inference (eval mode, no graph): BatchNorm folded into the segment packs, conv + bias + ReLU write the z pair directly and
         # the 2x2 pool of a Down block is a read-only pass over the skip pair (as the 16-bit engine does it, unet_engine.forward)
@@ -811,7 +817,7 @@ class UNetEngine:
                                  bn_partials=partials)
             coef = bn_coef(bnkey, partials, ntiles, cout, N * h * w, batch_stats)
             rec.y, rec.coef = y_hi, coef
-            rec.wd = None if image else (self._packed(wkey, wparam, False, True)[1] if need_grad else None)
+            rec.wd = None if image else (self._packed(wkey, wparam, False, True, need_fwd=False)[1] if need_grad else None)
             if need_grad:
                 recs.append(rec)
             if to_head:
